@@ -1,0 +1,184 @@
+"""ctypes driver of the C oracle (oracle/rosdyn_oracle.c) -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+PARITY UNPINNED at the reference level (see rosdyn_oracle.c header): the reference is unbuildable in
+this image and its tests carry no golden vectors.  Only tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg may import this module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from . import urdf_model
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "_build", "liboracle.so")
+
+
+class _UJoint(C.Structure):
+    _fields_ = [("urdf_type", C.c_int), ("xyz", C.c_double * 3), ("quat", C.c_double * 4), ("axis", C.c_double * 3)]
+
+
+class _ULink(C.Structure):
+    _fields_ = [("has_inertial", C.c_int), ("mass", C.c_double), ("xyz", C.c_double * 3), ("quat", C.c_double * 4),
+                ("ixx", C.c_double), ("ixy", C.c_double), ("ixz", C.c_double),
+                ("iyy", C.c_double), ("iyz", C.c_double), ("izz", C.c_double)]
+
+
+def build(force=False):
+    if force or not os.path.exists(_LIB) or os.path.getmtime(_LIB) < os.path.getmtime(os.path.join(_HERE, "rosdyn_oracle.c")):
+        subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []))
+    return _LIB
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        l = C.CDLL(_LIB)
+        dp = C.POINTER(C.c_double)
+        l.orc_chain_create.restype = C.c_void_p
+        l.orc_chain_create.argtypes = [C.c_int, C.POINTER(_UJoint), C.POINTER(_ULink), dp, C.c_int, C.POINTER(C.c_int)]
+        l.orc_chain_destroy.argtypes = [C.c_void_p]
+        for name, nargs in (("orc_fk", 2), ("orc_jacobian", 2), ("orc_twist", 3), ("orc_dtwist", 6), ("orc_ddtwist", 5),
+                            ("orc_joint_torque", 6), ("orc_regressor", 4), ("orc_joint_inertia", 2),
+                            ("orc_nominal_parameters", 1)):
+            f = getattr(l, name)
+            f.restype = None
+            f.argtypes = [C.c_void_p] + [dp] * nargs
+        l.orc_batch_torque_regressor.restype = C.c_int
+        l.orc_batch_torque_regressor.argtypes = [C.c_void_p, C.c_long, dp, dp, dp, dp, dp, C.c_int]
+        l.orc_has_openmp.restype = C.c_int
+        _lib = l
+    return _lib
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _c(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+class OracleChain(object):
+    """Per-sample evaluation of the restated reference, looped over the batch on the host.
+
+    Shapes mirror the reference's Eigen return values: Y[s] is the (n x P) matrix of getRegressor,
+    J[s] the (6 x n) Jacobian, M[s] (n x n), T[s, l] the 3x4 [R|p] of T_bl[l], twists[s, l] = [lin; ang].
+    """
+
+    def __init__(self, urdf, base, tool, gravity=(0.0, 0.0, 0.0), input_joint_names=None):
+        self.spec = spec = urdf_model.load(urdf, base, tool, gravity, input_joint_names)
+        nj = spec.n_joints
+        uj = (_UJoint * max(nj, 1))()
+        for i, j in enumerate(spec.joints):
+            uj[i].urdf_type = j.urdf_type
+            uj[i].xyz[:] = j.xyz
+            uj[i].quat[:] = j.quat
+            uj[i].axis[:] = j.axis
+        ul = (_ULink * (nj + 1))()
+        for i, l in enumerate(spec.links):
+            ul[i].has_inertial = int(l.has_inertial)
+            ul[i].mass = l.mass
+            ul[i].xyz[:] = l.xyz
+            ul[i].quat[:] = l.quat
+            ul[i].ixx, ul[i].ixy, ul[i].ixz, ul[i].iyy, ul[i].iyz, ul[i].izz = l.inertia
+        g = (C.c_double * 3)(*spec.gravity)
+        idx = (C.c_int * max(spec.n_active, 1))(*spec.input_chain_index)
+        self._h = lib().orc_chain_create(nj, uj, ul, g, spec.n_active, idx)
+        if not self._h:
+            raise RuntimeError("oracle: chain too long")
+        self.n, self.nJ, self.L, self.P = spec.n_active, nj, nj + 1, 10 * nj
+
+    def __del__(self):
+        if getattr(self, "_h", None) and _lib is not None:
+            _lib.orc_chain_destroy(self._h)
+            self._h = None
+
+    def _in(self, *arrs):
+        out = [np.atleast_2d(_c(a)) for a in arrs]
+        for a in out:
+            assert a.shape == out[0].shape and a.shape[1] == self.n, "inputs must be (N, n_active)"
+        return out
+
+    def fk(self, q):
+        (q,) = self._in(q)
+        T = np.empty((len(q), self.L, 3, 4))
+        for s in range(len(q)):
+            lib().orc_fk(self._h, _p(q[s]), _p(T[s]))
+        return T
+
+    def jacobian(self, q):
+        (q,) = self._in(q)
+        J = np.empty((len(q), self.n, 6))
+        for s in range(len(q)):
+            lib().orc_jacobian(self._h, _p(q[s]), _p(J[s]))
+        return np.transpose(J, (0, 2, 1))  # (N, 6, n)
+
+    def twist(self, q, dq):
+        q, dq = self._in(q, dq)
+        tw = np.empty((len(q), self.L, 6))
+        for s in range(len(q)):
+            lib().orc_twist(self._h, _p(q[s]), _p(dq[s]), _p(tw[s]))
+        return tw
+
+    def dtwist(self, q, dq, ddq, parts=False):
+        q, dq, ddq = self._in(q, dq, ddq)
+        a = np.empty((len(q), self.L, 6))
+        al = np.empty_like(a) if parts else None
+        an = np.empty_like(a) if parts else None
+        for s in range(len(q)):
+            lib().orc_dtwist(self._h, _p(q[s]), _p(dq[s]), _p(ddq[s]), _p(a[s]),
+                             _p(al[s]) if parts else None, _p(an[s]) if parts else None)
+        return (a, al, an) if parts else a
+
+    def ddtwist(self, q, dq, ddq, dddq):
+        q, dq, ddq, dddq = self._in(q, dq, ddq, dddq)
+        j = np.empty((len(q), self.L, 6))
+        for s in range(len(q)):
+            lib().orc_ddtwist(self._h, _p(q[s]), _p(dq[s]), _p(ddq[s]), _p(dddq[s]), _p(j[s]))
+        return j
+
+    def joint_torque(self, q, dq, ddq, ext=None, wrenches=False):
+        q, dq, ddq = self._in(q, dq, ddq)
+        tau = np.empty((len(q), self.n))
+        w = np.empty((len(q), self.L, 6)) if wrenches else None
+        if ext is not None:
+            ext = _c(ext).reshape(len(q), self.L, 6)
+        for s in range(len(q)):
+            lib().orc_joint_torque(self._h, _p(q[s]), _p(dq[s]), _p(ddq[s]), _p(ext[s]) if ext is not None else None,
+                                   _p(tau[s]), _p(w[s]) if wrenches else None)
+        return (tau, w) if wrenches else tau
+
+    def regressor(self, q, dq, ddq):
+        q, dq, ddq = self._in(q, dq, ddq)
+        Y = np.empty((len(q), self.P, self.n))  # column-major n x P per sample
+        for s in range(len(q)):
+            lib().orc_regressor(self._h, _p(q[s]), _p(dq[s]), _p(ddq[s]), _p(Y[s]))
+        return np.transpose(Y, (0, 2, 1))  # (N, n, P)
+
+    def joint_inertia(self, q):
+        (q,) = self._in(q)
+        M = np.empty((len(q), self.n, self.n))
+        for s in range(len(q)):
+            lib().orc_joint_inertia(self._h, _p(q[s]), _p(M[s]))
+        return np.transpose(M, (0, 2, 1))
+
+    def nominal_parameters(self):
+        pi = np.zeros(self.P)
+        lib().orc_nominal_parameters(self._h, _p(pi))
+        return pi
+
+    def batch_torque_regressor(self, q, dq, ddq, threads=1, want_tau=True, want_Y=True):
+        """C-side batch loop (optionally OpenMP) -- the cpu_baseline leg.  Returns (tau, Y_colmajor_per_sample, threads)."""
+        q, dq, ddq = self._in(q, dq, ddq)
+        N = len(q)
+        tau = np.empty((N, self.n)) if want_tau else None
+        Y = np.empty((N, self.P, self.n)) if want_Y else None
+        used = lib().orc_batch_torque_regressor(self._h, N, _p(q), _p(dq), _p(ddq), _p(tau), _p(Y), int(threads))
+        return tau, (np.transpose(Y, (0, 2, 1)) if want_Y else None), used

@@ -1,0 +1,35 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+FIXTURES = os.path.join(ROOT, "tests", "fixtures")
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def golden_cases():
+    return sorted(f[:-4] for f in os.listdir(GOLDEN) if f.endswith(".npz"))
+
+
+def load_golden(name):
+    import numpy as np
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    d = {k: g[k] for k in g.files}
+    d["urdf_path"] = os.path.join(FIXTURES, str(d["urdf"]))
+    d["base"], d["tool"] = str(d["base"]), str(d["tool"])
+    d["inputs"] = [str(x) for x in d["inputs"]] or None
+    d["gravity"] = tuple(float(x) for x in d["gravity"])
+    return d
+
+
+@pytest.fixture(scope="session")
+def fixtures_dir():
+    return FIXTURES
