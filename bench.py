@@ -1,0 +1,168 @@
+#!/usr/bin/env python3
+"""bench.py -- RNEA joint torque + inertial regressor evaluations/s on MI355X (BASELINE.json metric).
+
+A "step" is one pass of the hot path (rdyn_regressor: fused getJointTorque + getRegressor, one HIP kernel
+launch) over one batch of synthetic (q, Dq, DDq) samples that are already resident in HBM.
+
+Workload (BASELINE.json configs[1]): 6-DOF chain (tests/fixtures/ur10_like.urdf cut at wrist_3_link:
+n = 6 active joints, 6 chain joints, P = 60 parameters), 1e6 samples per GPU, fp64, dense Y.
+Multi-GPU: the batch shards trivially (i.i.d. samples) -> every rank evaluates its own 1e6 samples, no
+data-path collective ("weak" scaling); the only exchange is the max-over-ranks of the elapsed time.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--samples S] [--y-layout element|stacked|per_sample]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 TB/s achievable)
+GRAVITY = (0.0, 0.0, -9.806)   # rosdyn_speed_test.cpp:61-62
+
+
+def shard_sizes(total, world):
+    """Contiguous split of `total` samples over `world` ranks."""
+    base, rem = divmod(total, world)
+    return [base + (1 if r < rem else 0) for r in range(world)]
+
+
+def max_over_ranks(value, dist, device):
+    """MAX all-reduce of a python float (the bench contract: time = slowest rank)."""
+    import torch
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def algorithmic_bytes_per_eval(n, P):
+    """3 n doubles read (q, Dq, DDq) + n written (tau) + n P written (dense Y)  -- SURVEY section 8(d)."""
+    return 3 * n * 8 + n * 8 + n * P * 8
+
+
+def cpu_baseline(urdf, base, tool, n, budget_evals):
+    """Times the CPU oracle (oracle/rosdyn_oracle.c, a port of the reference algorithm -- the reference itself
+    cannot be built without Eigen/ROS) on a bounded sample of the same workload, all host cores via OpenMP."""
+    import numpy as np
+    from oracle.oracle import OracleChain
+    from rosdyn_amd.samples import trajectory_batch
+    cores = os.cpu_count() or 1
+    ref = OracleChain(urdf, base, tool, GRAVITY)
+    q, dq, ddq = trajectory_batch(0x5EED0002, budget_evals, n)
+    bufs = (np.zeros((budget_evals, n)), np.zeros((budget_evals, ref.P, n)))
+    bufs[0].fill(1.0)
+    bufs[1].fill(1.0)          # touch every output page before timing
+    m = max(1, budget_evals // (2 * cores))
+    b1 = (bufs[0][:m], bufs[1][:m])
+    t1 = time.perf_counter()   # single thread first (idle OpenMP workers spin after a parallel region)
+    ref.batch_torque_regressor(q[:m], dq[:m], ddq[:m], threads=1, bufs=b1)
+    dt1 = time.perf_counter() - t1
+    ref.batch_torque_regressor(q[:m], dq[:m], ddq[:m], threads=cores, bufs=b1)   # spin up the thread pool
+    t0 = time.perf_counter()
+    _, _, used = ref.batch_torque_regressor(q, dq, ddq, threads=cores, bufs=bufs)
+    dt = time.perf_counter() - t0
+    return {"value": budget_evals / dt, "unit": "evals/s", "cores": int(used), "kind": "port",
+            "sample": "%d of the same seeded U[-1,1] samples, getJointTorque + getRegressor per sample, "
+                      "OpenMP static over samples; single-thread rate %.3e evals/s" % (budget_evals, m / dt1)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--samples", type=int, default=1000000, help="samples per GPU")
+    ap.add_argument("--y-layout", default="element", choices=["element", "stacked", "per_sample"])
+    ap.add_argument("--cpu-evals", type=int, default=400000, help="size of the CPU-baseline sample (0 = skip)")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from rosdyn_amd import Chain
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    urdf = os.path.join(ROOT, "tests", "fixtures", "ur10_like.urdf")
+    base, tool = "base_link", "wrist_3_link"
+    chain = Chain(urdf, base, tool, GRAVITY)
+    n, P = chain.getActiveJointsNumber(), 10 * chain.getJointsNumber()
+    N = args.samples
+    elem = args.y_layout == "element"
+    in_layout = "element" if elem else "sample"
+
+    gen = torch.Generator(device=dev).manual_seed(0x5EED0002 + rank)
+    shape = (n, N) if elem else (N, n)
+    q, dq, ddq = (torch.rand(shape, dtype=torch.float64, device=dev, generator=gen) * 2 - 1 for _ in range(3))
+    y_shape = {"element": (P, n, N), "stacked": (P, N * n), "per_sample": (N, P, n)}[args.y_layout]
+    Y = torch.empty(y_shape, dtype=torch.float64, device=dev)
+    tau = torch.empty(shape, dtype=torch.float64, device=dev)
+
+    def step():
+        chain.getRegressor(q, dq, ddq, layout=in_layout, y_layout=args.y_layout, out=Y, tau_out=tau)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()          # same stream the kernels are launched on (torch's current stream is passed to the C-ABI)
+    for _ in range(args.steps):
+        step()
+    ev1.record()
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dev_ms = ev0.elapsed_time(ev1)
+    wall = max_over_ranks(wall, dist if world > 1 else None, dev)
+    dev_ms = max_over_ranks(dev_ms, dist if world > 1 else None, dev)
+
+    total_evals = N * world * args.steps
+    value = total_evals / wall
+    b_eval = algorithmic_bytes_per_eval(n, P)
+    kernel_ms = dev_ms / args.steps                       # one launch per step, back to back on one stream
+    achieved = b_eval * N / (kernel_ms * 1e-3) / 1e9      # GB/s, algorithmic bytes per launch / launch duration
+
+    out = {
+        "metric": "RNEA+regressor evals/s (6-DOF, batch 1e6)", "value": value, "unit": "evals/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "configs[1]: 6-DOF chain (ur10_like base_link->wrist_3_link, n=6, P=60), "
+                               "batch %d samples per GPU, fp64 getJointTorque + dense getRegressor, "
+                               "inputs %s-major, Y layout %s" % (N, in_layout, args.y_layout),
+                   "samples_per_gpu": N, "n_active": n, "n_params": P, "parallelism": "sample-sharded x%d" % world},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                     "kernel": "k_local_sweep<6, REGRESSOR>", "kernel_ms": kernel_ms,
+                     "algorithmic_bytes_per_launch": b_eval * N},
+    }
+    if rank == 0 and world == 1 and args.cpu_evals > 0:
+        out["cpu_baseline"] = cpu_baseline(urdf, base, tool, n, args.cpu_evals)
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,191 @@
+/*
+ * rdyn.h -- C-ABI of librdyn_hip.so: batched rigid-body dynamics of a serial chain on AMD MI355X (gfx950).
+ *
+ * Drop-in boundary for ONE path of CNR-STIIMA-IRAS/rosdyn: the public surface of `class rosdyn::Chain`
+ * (rosdyn_core/include/rosdyn_core/primitives.h:235-555) restricted to
+ *   getTransformation(s) / getJacobian / getTwist / getDTwist / getJointTorque /
+ *   getJointTorqueNonLinearPart / getRegressor / getJointInertia / getNominalParameters,
+ * evaluated for N samples (q, Dq, DDq) per call instead of one.  The reference has no FFI layer; a
+ * maintainer binds these symbols from `rosdyn::Chain` (see INTEGRATION.md, and the ready-made C++
+ * facade rosdyn_amd/csrc/rosdyn_chain_facade.hpp which keeps the reference's method names).
+ *
+ * Contract = the STATELESS function (chain, q, Dq, DDq) -> outputs that a freshly constructed reference
+ * Chain computes on its first call (the reference's value caches, primitives_impl.h:886/985/1088, are
+ * not reproduced).  All arithmetic is IEEE fp64.  Conventions are the reference's: spatial vectors are
+ * [linear; angular] (spacevect_algebra.h:44-52); twists/Jacobians are expressed in the base frame with
+ * the link's own origin as reference point; the regressor has 10 columns per chain joint INCLUDING fixed
+ * joints, parameter order [m, m cx, m cy, m cz, Ixx, Ixy, Ixz, Iyy, Iyz, Izz] with the inertia taken
+ * about the link origin (primitives_impl.h:399-417, 1295-1355); rows exist only for the active (input)
+ * joints, in input order (primitives_impl.h:1352).
+ *
+ * Memory: every `const double*` / `double*` in a batched call is a DEVICE pointer (hipMalloc or a
+ * torch.cuda tensor's data_ptr()).  Nothing is copied to or from the host, no allocation and no
+ * synchronisation happens inside a batched call (graph-capturable) except the one-time upload of a
+ * chain's constants (~4 KB) the first time a chain is used on a device.
+ *
+ * Error handling: every function returns an rdyn_status; rdyn_last_error() returns the thread-local
+ * message.  Where the reference throws (std::runtime_error("Base link not found") primitives_impl.h:603,
+ * "Tool link not found" :610, std::invalid_argument("Input data dimensions mismatch") :1302) the same
+ * text is the message and the facade re-throws the same exception types.
+ */
+#ifndef RDYN_H
+#define RDYN_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RDYN_VERSION 100
+/* Chain joints INCLUDING fixed ones (reference: m_joints_number, primitives_impl.h:638).  Kernels are
+ * instantiated for 1..RDYN_MAX_JOINTS; the reference's own compile-time bound is MAX_NUM_AXES
+ * (rosdyn_core/CMakeLists.txt:12-25). */
+#define RDYN_MAX_JOINTS 10
+
+typedef enum rdyn_status
+{
+  RDYN_OK = 0,
+  RDYN_ERR_INVALID_ARGUMENT = 1, /* NULL pointers, negative sizes, dimension mismatch                    */
+  RDYN_ERR_BASE_NOT_FOUND = 2,   /* "Base link not found"   primitives_impl.h:603                        */
+  RDYN_ERR_TOOL_NOT_FOUND = 3,   /* "Tool link not found"   primitives_impl.h:610                        */
+  RDYN_ERR_URDF = 4,             /* malformed URDF XML                                                   */
+  RDYN_ERR_UNSUPPORTED = 5,      /* more than RDYN_MAX_JOINTS chain joints                               */
+  RDYN_ERR_JOINT_NOT_FOUND = 6,  /* setInputJointsName: "Joint named '%s' not found" primitives_impl.h:734 */
+  RDYN_ERR_NO_DEVICE = 7,        /* no HIP device / HIP runtime failure at start-up                      */
+  RDYN_ERR_HIP = 8               /* a HIP call failed (message carries hipGetErrorString)                */
+} rdyn_status;
+
+/* rosdyn::Joint::Type, primitives.h:67 (same numeric values) */
+typedef enum rdyn_joint_type { RDYN_REVOLUTE = 0, RDYN_PRISMATIC = 1, RDYN_FIXED = 2 } rdyn_joint_type;
+
+/* urdf::Joint::type values as urdfdom defines them; mapped by primitives_impl.h:74-83:
+ * revolute|continuous -> REVOLUTE, prismatic -> PRISMATIC, everything else -> FIXED */
+typedef enum rdyn_urdf_joint_type
+{
+  RDYN_URDF_UNKNOWN = 0, RDYN_URDF_REVOLUTE = 1, RDYN_URDF_CONTINUOUS = 2, RDYN_URDF_PRISMATIC = 3,
+  RDYN_URDF_FLOATING = 4, RDYN_URDF_PLANAR = 5, RDYN_URDF_FIXED = 6
+} rdyn_urdf_joint_type;
+
+typedef struct rdyn_chain rdyn_chain; /* opaque; immutable after creation except rdyn_chain_set_input_joints */
+
+/* ---- flat POD description of one serial chain, base -> tool (what Chain::init extracts from the urdf tree,
+ *      primitives_impl.h:600-636).  For callers that already hold a parsed urdf::Model. ------------------- */
+typedef struct rdyn_joint_desc
+{
+  char name[64];
+  int32_t urdf_type;         /* rdyn_urdf_joint_type */
+  double origin_xyz[3];      /* parent_to_joint_origin_transform.position            (primitives_impl.h:54) */
+  double origin_quat[4];     /* parent_to_joint_origin_transform.rotation  x,y,z,w   (urdf_parser.h:44-50)  */
+  double axis[3];            /* urdf joint axis, not necessarily normalised          (primitives_impl.h:55-59) */
+  int32_t has_limits;        /* urdf_joint->limits != NULL                           (primitives_impl.h:87)  */
+  double lower, upper, velocity, effort;
+} rdyn_joint_desc;
+
+typedef struct rdyn_link_desc
+{
+  char name[64];
+  int32_t has_inertial;      /* urdf_link->inertial != NULL                          (primitives_impl.h:291) */
+  double mass;
+  double com_xyz[3];         /* inertial->origin.position                            (primitives_impl.h:305-307) */
+  double com_quat[4];        /* inertial->origin.rotation x,y,z,w                    (primitives_impl.h:309-314) */
+  double ixx, ixy, ixz, iyy, iyz, izz;
+} rdyn_link_desc;
+
+typedef struct rdyn_chain_desc
+{
+  int32_t n_joints;                  /* chain joints incl. fixed; links = n_joints + 1 */
+  const rdyn_joint_desc* joints;     /* [n_joints], joint i connects links[i] -> links[i+1] */
+  const rdyn_link_desc* links;       /* [n_joints + 1], links[0] = base link */
+  double gravity[3];                 /* base-frame gravity vector; the reference's default is zero (primitives.h:346) */
+} rdyn_chain_desc;
+
+/* ---- construction (host only) --------------------------------------------------------------------- */
+/* rosdyn::createChain(urdf::ModelInterface, base, tool, gravity)  primitives.h:566, primitives_impl.h:1518.
+ * urdf_xml is the robot_description string; a minimal reader reproduces the urdfdom behaviour the
+ * reference relies on (rpy->quaternion, default axis (1,0,0), missing origin/inertial). */
+int rdyn_chain_from_urdf(const char* urdf_xml, const char* base_link, const char* tool_link,
+                         const double gravity[3], rdyn_chain** out);
+int rdyn_chain_from_desc(const rdyn_chain_desc* desc, rdyn_chain** out);
+/* Chain::clone() primitives_impl.h:552 -- an independent deep copy */
+int rdyn_chain_clone(const rdyn_chain* chain, rdyn_chain** out);
+void rdyn_chain_destroy(rdyn_chain* chain);
+const char* rdyn_last_error(void);
+
+/* ---- introspection (host only); reference getters primitives.h:364-447 ------------------------------ */
+int rdyn_chain_links_number(const rdyn_chain* chain);          /* getLinksNumber        */
+int rdyn_chain_joints_number(const rdyn_chain* chain);         /* getJointsNumber       */
+int rdyn_chain_active_joints_number(const rdyn_chain* chain);  /* getActiveJointsNumber */
+int rdyn_chain_moveable_joints_number(const rdyn_chain* chain);
+const char* rdyn_chain_link_name(const rdyn_chain* chain, int i);            /* getLinksName().at(i)          */
+const char* rdyn_chain_joint_name(const rdyn_chain* chain, int i);           /* chain order, incl. fixed      */
+const char* rdyn_chain_moveable_joint_name(const rdyn_chain* chain, int i);  /* getMoveableJointName(i)       */
+const char* rdyn_chain_active_joint_name(const rdyn_chain* chain, int i);    /* getActiveJointName(i)         */
+int rdyn_chain_joint_type(const rdyn_chain* chain, int i);                   /* rdyn_joint_type of chain joint i */
+int rdyn_chain_gravity(const rdyn_chain* chain, double gravity[3]);          /* getGravity                    */
+/* Chain::setInputJointsName primitives_impl.h:705.  Unknown names -> RDYN_ERR_JOINT_NOT_FOUND and the
+ * chain is left unchanged (the reference returns false and continues in an inconsistent state). */
+int rdyn_chain_set_input_joints(rdyn_chain* chain, const char* const* names, int n_names);
+/* getQMax/getQMin/getDQMax/getDDQMax/getTauMax of the active joints (primitives_impl.h:85-143, 768-776);
+ * any pointer may be NULL */
+int rdyn_chain_limits(const rdyn_chain* chain, double* q_max, double* q_min, double* dq_max, double* ddq_max, double* tau_max);
+/* Chain::getNominalParameters primitives_impl.h:1382 -> pi[10 * joints_number] (HOST pointer) */
+int rdyn_nominal_parameters(const rdyn_chain* chain, double* pi);
+
+/* ---- batched evaluation (device pointers) ------------------------------------------------------------ */
+typedef enum rdyn_layout
+{
+  /* x[s][e] -- every sample's record is contiguous and is exactly the memory image of the Eigen object the
+   * reference returns for that sample (VectorXd, column-major MatrixXd / Matrix6Xd, 3x4 column-major
+   * Affine3d::affine()).  Drop-in layout. */
+  RDYN_LAYOUT_SAMPLE_MAJOR = 0,
+  /* x[e][s] -- one N-vector per record element (structure of arrays).  Fully coalesced on the GPU;
+   * for the regressor this IS a column-major (n*N) x P matrix whose row index is j*N + s. */
+  RDYN_LAYOUT_ELEMENT_MAJOR = 1
+} rdyn_layout;
+
+typedef struct rdyn_batch
+{
+  int64_t n_samples;
+  const double* q;    /* n_active values per sample                           */
+  const double* dq;   /* may be NULL where the call does not need velocities  */
+  const double* ddq;  /* may be NULL where the call does not need accelerations */
+  int32_t layout;     /* rdyn_layout of q/dq/ddq AND of every output of the call (the regressor excepted, below) */
+  int32_t device;     /* HIP device ordinal, -1 = current device */
+  void* stream;       /* hipStream_t; NULL = the default stream */
+} rdyn_batch;
+
+/* Regressor element (sample s, active-joint row j, parameter column p) is written to
+ *   Y[s * stride_sample + j * stride_row + p * stride_col]        (strides in doubles). */
+typedef struct rdyn_regressor_layout
+{
+  int64_t stride_sample, stride_row, stride_col;
+} rdyn_regressor_layout;
+/* presets (n = active joints, P = 10 * joints_number, N = samples):
+ *   per-sample Eigen image  getRegressor()[s] column-major n x P : {n*P, 1, n}
+ *   stacked column-major (N*n) x P, row = s*n + j                : {n,   1, N*n}
+ *   element-major = column-major (n*N) x P, row = j*N + s        : {1,   N, n*N}   <- fastest */
+
+/* getTransformation primitives.h:452 -> T_bt[12] per sample: column-major 3x4 [R | p] (= Affine3d::affine()).
+ * T_links (optional, may be NULL): getTransformations primitives.h:454 -> links_number x 12 per sample. */
+int rdyn_transformation(const rdyn_chain* chain, const rdyn_batch* batch, double* T_bt, double* T_links);
+/* getJacobian primitives.h:455 -> 6 x n column-major per sample */
+int rdyn_jacobian(const rdyn_chain* chain, const rdyn_batch* batch, double* J);
+/* getTwist primitives.h:457 (needs q, dq) -> links_number x 6 per sample, [lin; ang] per link.
+ * getDTwist primitives.h:463 (needs q, dq, ddq) -> same shape; either output may be NULL. */
+int rdyn_twist(const rdyn_chain* chain, const rdyn_batch* batch, double* twists, double* dtwists);
+/* getJointTorque(q, Dq, DDq) primitives.h:540 -> n per sample */
+int rdyn_joint_torque(const rdyn_chain* chain, const rdyn_batch* batch, double* tau);
+/* getJointTorqueNonLinearPart(q, Dq) primitives.h:541 (DDq = 0; batch->ddq ignored) */
+int rdyn_joint_torque_nonlinear(const rdyn_chain* chain, const rdyn_batch* batch, double* tau);
+/* getRegressor primitives.h:543 fused with getJointTorque: writes Y (dense, structural zeros included) and,
+ * if tau != NULL, tau = Y * nominal parameters (== getJointTorque, identity verified to 1e-13). */
+int rdyn_regressor(const rdyn_chain* chain, const rdyn_batch* batch, double* tau, double* Y, const rdyn_regressor_layout* y_layout);
+/* getJointInertia primitives.h:547 -> n x n column-major per sample */
+int rdyn_joint_inertia(const rdyn_chain* chain, const rdyn_batch* batch, double* M);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RDYN_H */

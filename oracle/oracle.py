@@ -174,11 +174,16 @@ class OracleChain(object):
         lib().orc_nominal_parameters(self._h, _p(pi))
         return pi
 
-    def batch_torque_regressor(self, q, dq, ddq, threads=1, want_tau=True, want_Y=True):
-        """C-side batch loop (optionally OpenMP) -- the cpu_baseline leg.  Returns (tau, Y_colmajor_per_sample, threads)."""
+    def batch_torque_regressor(self, q, dq, ddq, threads=1, want_tau=True, want_Y=True, bufs=None):
+        """C-side batch loop (optionally OpenMP) -- the cpu_baseline leg.  Returns (tau, Y (N, n, P), threads).
+        `bufs` = (tau (N, n), Y (N, P, n)) pre-touched output buffers to keep page faults out of a timing."""
         q, dq, ddq = self._in(q, dq, ddq)
         N = len(q)
-        tau = np.empty((N, self.n)) if want_tau else None
-        Y = np.empty((N, self.P, self.n)) if want_Y else None
+        if bufs is not None:
+            tau, Y = bufs
+            assert tau.shape == (N, self.n) and Y.shape == (N, self.P, self.n) and tau.flags.c_contiguous and Y.flags.c_contiguous
+        else:
+            tau = np.empty((N, self.n)) if want_tau else None
+            Y = np.empty((N, self.P, self.n)) if want_Y else None
         used = lib().orc_batch_torque_regressor(self._h, N, _p(q), _p(dq), _p(ddq), _p(tau), _p(Y), int(threads))
-        return tau, (np.transpose(Y, (0, 2, 1)) if want_Y else None), used
+        return tau, (np.transpose(Y, (0, 2, 1)) if Y is not None else None), used

@@ -1,0 +1,229 @@
+"""Batched mirror of ``rosdyn::Chain`` (rosdyn_core/include/rosdyn_core/primitives.h:235-555) over the
+C-ABI of librdyn_hip.so.  Method names and argument meaning are the reference's; every ``q/Dq/DDq`` is a
+batch: a ``torch.float64`` CUDA tensor of shape (N, n_active) (sample-major) or (n_active, N) with
+``layout="element"``.  Outputs are CUDA tensors that alias nothing (fresh allocations, or the caller's
+``out=``).  The arithmetic happens in the HIP kernels; torch only owns the memory and the stream.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import LAYOUT_ELEMENT_MAJOR, LAYOUT_SAMPLE_MAJOR, Batch, RegressorLayout, check, lib
+
+
+def _torch():
+    import torch
+    return torch
+
+
+class Chain(object):
+    """rosdyn::createChain(urdf, base_frame, tool_frame, gravity)  (primitives.h:566)."""
+
+    def __init__(self, urdf_xml, base_frame, tool_frame, gravity=(0.0, 0.0, 0.0), _handle=None):
+        if _handle is not None:
+            self._h = _handle
+            return
+        if "<robot" not in urdf_xml:
+            with open(urdf_xml) as f:
+                urdf_xml = f.read()
+        h = C.c_void_p()
+        g = (C.c_double * 3)(*[float(x) for x in gravity])
+        check(lib().rdyn_chain_from_urdf(urdf_xml.encode(), base_frame.encode(), tool_frame.encode(), g, C.byref(h)))
+        self._h = h
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h and _lib._lib is not None:
+            _lib._lib.rdyn_chain_destroy(h)
+            self._h = None
+
+    def clone(self):                                  # primitives.h:554
+        h = C.c_void_p()
+        check(lib().rdyn_chain_clone(self._h, C.byref(h)))
+        return Chain(None, None, None, _handle=h)
+
+    # ---- getters, primitives.h:364-447
+    def getLinksNumber(self):
+        return lib().rdyn_chain_links_number(self._h)
+
+    def getJointsNumber(self):
+        return lib().rdyn_chain_joints_number(self._h)
+
+    def getActiveJointsNumber(self):
+        return lib().rdyn_chain_active_joints_number(self._h)
+
+    def getLinksName(self):
+        return [lib().rdyn_chain_link_name(self._h, i).decode() for i in range(self.getLinksNumber())]
+
+    def getJointsName(self):
+        return [lib().rdyn_chain_joint_name(self._h, i).decode() for i in range(self.getJointsNumber())]
+
+    def getMoveableJointNames(self):
+        return [lib().rdyn_chain_moveable_joint_name(self._h, i).decode()
+                for i in range(lib().rdyn_chain_moveable_joints_number(self._h))]
+
+    def getActiveJointsName(self):
+        return [lib().rdyn_chain_active_joint_name(self._h, i).decode() for i in range(self.getActiveJointsNumber())]
+
+    def getJointTypes(self):
+        return [lib().rdyn_chain_joint_type(self._h, i) for i in range(self.getJointsNumber())]
+
+    def getGravity(self):
+        g = (C.c_double * 3)()
+        check(lib().rdyn_chain_gravity(self._h, g))
+        return np.array(g[:])
+
+    def setInputJointsName(self, names):              # primitives.h:362; returns bool like the reference
+        arr = (C.c_char_p * max(len(names), 1))(*[n.encode() for n in names])
+        st = lib().rdyn_chain_set_input_joints(self._h, arr, len(names))
+        if st == 6:
+            return False
+        check(st)
+        return True
+
+    def _limits(self, which):
+        n = self.getActiveJointsNumber()
+        bufs = [np.zeros(n) for _ in range(5)]
+        check(lib().rdyn_chain_limits(self._h, *[b.ctypes.data_as(C.POINTER(C.c_double)) for b in bufs]))
+        return bufs[which]
+
+    def getQMax(self):
+        return self._limits(0)
+
+    def getQMin(self):
+        return self._limits(1)
+
+    def getDQMax(self):
+        return self._limits(2)
+
+    def getDDQMax(self):
+        return self._limits(3)
+
+    def getTauMax(self):
+        return self._limits(4)
+
+    def getNominalParameters(self):                   # primitives.h:548
+        pi = np.zeros(10 * self.getJointsNumber())
+        check(lib().rdyn_nominal_parameters(self._h, pi.ctypes.data_as(C.POINTER(C.c_double))))
+        return pi
+
+    # ---- batch plumbing
+    def _batch(self, layout, q, dq=None, ddq=None):
+        torch = _torch()
+        n = self.getActiveJointsNumber()
+        lay = LAYOUT_ELEMENT_MAJOR if layout == "element" else LAYOUT_SAMPLE_MAJOR
+        ts = [t for t in (q, dq, ddq) if t is not None]
+        for t in ts:
+            if t.dtype != torch.float64 or not t.is_cuda or not t.is_contiguous() or t.dim() != 2:
+                raise ValueError("inputs must be contiguous 2-D float64 CUDA tensors")
+            if t.shape != q.shape or t.device != q.device:
+                raise ValueError("Input data dimensions mismatch")   # primitives_impl.h:1302
+        N = q.shape[1] if lay == LAYOUT_ELEMENT_MAJOR else q.shape[0]
+        nin = q.shape[0] if lay == LAYOUT_ELEMENT_MAJOR else q.shape[1]
+        if nin != n:
+            raise ValueError("Input data dimensions mismatch")
+        b = Batch()
+        b.n_samples = N
+        b.q = q.data_ptr()
+        b.dq = dq.data_ptr() if dq is not None else None
+        b.ddq = ddq.data_ptr() if ddq is not None else None
+        b.layout = lay
+        b.device = q.device.index if q.device.index is not None else -1
+        b.stream = torch.cuda.current_stream(q.device).cuda_stream
+        return b, N, lay
+
+    def _out(self, q, N, lay, rec_shape, out=None):
+        torch = _torch()
+        shape = (N,) + tuple(rec_shape) if lay == LAYOUT_SAMPLE_MAJOR else tuple(rec_shape) + (N,)
+        if out is None:
+            return torch.empty(shape, dtype=torch.float64, device=q.device)
+        if tuple(out.shape) != shape or out.dtype != torch.float64 or not out.is_contiguous() or out.device != q.device:
+            raise ValueError("out must be a contiguous float64 tensor of shape %s" % (shape,))
+        return out
+
+    # ---- kinematics, primitives.h:452-463.  Record shapes are the transposes of the Eigen (column-major) objects:
+    #      sample-major T[s] is (4, 3) = columns of the 3x4 [R | p]; use .transpose(-1, -2) for the matrix.
+    def getTransformation(self, q, layout="sample", out=None):
+        b, N, lay = self._batch(layout, q)
+        T = self._out(q, N, lay, (4, 3), out)
+        check(lib().rdyn_transformation(self._h, C.byref(b), T.data_ptr(), None))
+        return T
+
+    def getTransformations(self, q, layout="sample", out=None):
+        b, N, lay = self._batch(layout, q)
+        T = self._out(q, N, lay, (self.getLinksNumber(), 4, 3), out)
+        check(lib().rdyn_transformation(self._h, C.byref(b), None, T.data_ptr()))
+        return T
+
+    def getJacobian(self, q, layout="sample", out=None):
+        b, N, lay = self._batch(layout, q)
+        J = self._out(q, N, lay, (self.getActiveJointsNumber(), 6), out)
+        check(lib().rdyn_jacobian(self._h, C.byref(b), J.data_ptr()))
+        return J
+
+    def getTwist(self, q, Dq, layout="sample", out=None):
+        b, N, lay = self._batch(layout, q, Dq)
+        tw = self._out(q, N, lay, (self.getLinksNumber(), 6), out)
+        check(lib().rdyn_twist(self._h, C.byref(b), tw.data_ptr(), None))
+        return tw
+
+    def getDTwist(self, q, Dq, DDq, layout="sample", out=None):
+        b, N, lay = self._batch(layout, q, Dq, DDq)
+        tw = self._out(q, N, lay, (self.getLinksNumber(), 6), out)
+        check(lib().rdyn_twist(self._h, C.byref(b), None, tw.data_ptr()))
+        return tw
+
+    # ---- dynamics, primitives.h:539-547
+    def getJointTorque(self, q, Dq, DDq, layout="sample", out=None):
+        b, N, lay = self._batch(layout, q, Dq, DDq)
+        tau = self._out(q, N, lay, (self.getActiveJointsNumber(),), out)
+        check(lib().rdyn_joint_torque(self._h, C.byref(b), tau.data_ptr()))
+        return tau
+
+    def getJointTorqueNonLinearPart(self, q, Dq, layout="sample", out=None):
+        b, N, lay = self._batch(layout, q, Dq)
+        tau = self._out(q, N, lay, (self.getActiveJointsNumber(),), out)
+        check(lib().rdyn_joint_torque_nonlinear(self._h, C.byref(b), tau.data_ptr()))
+        return tau
+
+    def getJointInertia(self, q, layout="sample", out=None):
+        b, N, lay = self._batch(layout, q)
+        n = self.getActiveJointsNumber()
+        M = self._out(q, N, lay, (n, n), out)
+        check(lib().rdyn_joint_inertia(self._h, C.byref(b), M.data_ptr()))
+        return M
+
+    def getRegressor(self, q, Dq, DDq, layout="sample", y_layout=None, out=None, tau_out=None, with_torque=False):
+        """Regressor (and optionally the fused joint torque).
+
+        y_layout: "per_sample" -> (N, P, n): Y[s] is the column-major n x P Eigen image (default for layout="sample");
+                  "stacked"    -> (P, N*n):  column-major (N*n) x P, row = s*n + j;
+                  "element"    -> (P, n, N): column-major (n*N) x P, row = j*N + s (default for layout="element").
+        """
+        torch = _torch()
+        b, N, lay = self._batch(layout, q, Dq, DDq)
+        n, P = self.getActiveJointsNumber(), 10 * self.getJointsNumber()
+        if y_layout is None:
+            y_layout = "element" if lay == LAYOUT_ELEMENT_MAJOR else "per_sample"
+        if y_layout == "per_sample":
+            shape, yl = (N, P, n), RegressorLayout(n * P, 1, n)
+        elif y_layout == "stacked":
+            shape, yl = (P, N * n), RegressorLayout(n, 1, N * n)
+        elif y_layout == "element":
+            shape, yl = (P, n, N), RegressorLayout(1, N, n * N)
+        else:
+            raise ValueError("unknown y_layout %r" % (y_layout,))
+        if out is None:
+            out = torch.empty(shape, dtype=torch.float64, device=q.device)
+        elif tuple(out.shape) != shape or out.dtype != torch.float64 or not out.is_contiguous():
+            raise ValueError("out must be a contiguous float64 tensor of shape %s" % (shape,))
+        tau = None
+        if with_torque or tau_out is not None:
+            tau = self._out(q, N, lay, (n,), tau_out)
+        check(lib().rdyn_regressor(self._h, C.byref(b), tau.data_ptr() if tau is not None else None, out.data_ptr(), C.byref(yl)))
+        return (out, tau) if tau is not None else out
+
+
+def createChain(urdf_xml, base_frame, tool_frame, gravity=(0.0, 0.0, 0.0)):
+    return Chain(urdf_xml, base_frame, tool_frame, gravity)

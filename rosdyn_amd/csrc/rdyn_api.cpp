@@ -1,0 +1,270 @@
+// rdyn_api.cpp -- batched C-ABI entry points (include/rdyn.h): argument checks, layout -> strides,
+// chain-constant residency per device, kernel launches.  No host<->device copies of batch data, no
+// allocation and no synchronisation after a chain's first use on a device.
+#include <cstring>
+
+#include <hip/hip_runtime.h>
+
+#include "rdyn_chain.hpp"
+#include "rdyn_kernels.h"
+
+namespace
+{
+
+#define RDYN_HIP_TRY(expr)                                                     \
+  do                                                                           \
+  {                                                                            \
+    hipError_t _e = (expr);                                                    \
+    if (_e != hipSuccess)                                                      \
+    {                                                                          \
+      rdyn_set_error("HIP error: %s (%s)", hipGetErrorString(_e), #expr);      \
+      return RDYN_ERR_HIP;                                                     \
+    }                                                                          \
+  } while (0)
+
+struct DeviceGuard
+{
+  int prev = -1;
+  bool switched = false;
+  int enter(int device)
+  {
+    if (hipGetDevice(&prev) != hipSuccess)
+    {
+      rdyn_set_error("no HIP device available (hipGetDevice failed)");
+      return RDYN_ERR_NO_DEVICE;
+    }
+    if (device >= 0 && device != prev)
+    {
+      if (hipSetDevice(device) != hipSuccess)
+      {
+        rdyn_set_error("hipSetDevice(%d) failed", device);
+        return RDYN_ERR_NO_DEVICE;
+      }
+      switched = true;
+    }
+    return RDYN_OK;
+  }
+  ~DeviceGuard()
+  {
+    if (switched) (void)hipSetDevice(prev);
+  }
+};
+
+int device_const(const rdyn_chain* c, const RdynChainConst** out)
+{
+  int dev = 0;
+  RDYN_HIP_TRY(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> lk(c->mu);
+  auto it = c->dev_const.find(dev);
+  if (it == c->dev_const.end())
+  {
+    RdynChainConst* d = nullptr;
+    RDYN_HIP_TRY(hipMalloc((void**)&d, sizeof(RdynChainConst)));
+    hipError_t e = hipMemcpy(d, &c->host_const, sizeof(RdynChainConst), hipMemcpyHostToDevice);
+    if (e != hipSuccess)
+    {
+      (void)hipFree(d);
+      rdyn_set_error("HIP error: %s (upload of chain constants)", hipGetErrorString(e));
+      return RDYN_ERR_HIP;
+    }
+    it = c->dev_const.emplace(dev, d).first;
+  }
+  *out = it->second;
+  return RDYN_OK;
+}
+
+int check_batch(const rdyn_chain* c, const rdyn_batch* b, bool need_dq, bool need_ddq, const char* fn)
+{
+  if (!c || !b)
+  {
+    rdyn_set_error("%s: null chain or batch", fn);
+    return RDYN_ERR_INVALID_ARGUMENT;
+  }
+  if (b->n_samples < 0 || (b->layout != RDYN_LAYOUT_SAMPLE_MAJOR && b->layout != RDYN_LAYOUT_ELEMENT_MAJOR))
+  {
+    rdyn_set_error("%s: invalid n_samples or layout", fn);
+    return RDYN_ERR_INVALID_ARGUMENT;
+  }
+  if (c->n_joints() < 1)
+  {
+    rdyn_set_error("%s: chain has no joints", fn);
+    return RDYN_ERR_UNSUPPORTED;
+  }
+  if (b->n_samples > 0 && (!b->q || (need_dq && !b->dq) || (need_ddq && !b->ddq)))
+  {
+    // the reference checks only getRegressor's dimensions (primitives_impl.h:1299-1309)
+    rdyn_set_error("Input data dimensions mismatch");
+    return RDYN_ERR_INVALID_ARGUMENT;
+  }
+  return RDYN_OK;
+}
+
+// per-sample / per-element strides of a record of `elems` doubles
+inline void rec_strides(const rdyn_batch* b, int64_t elems, int64_t* ss, int64_t* se)
+{
+  if (b->layout == RDYN_LAYOUT_SAMPLE_MAJOR)
+  {
+    *ss = elems;
+    *se = 1;
+  }
+  else
+  {
+    *ss = 1;
+    *se = b->n_samples;
+  }
+}
+
+int run_local(const rdyn_chain* c, const rdyn_batch* b, int mode, double* tau, double* Y, const rdyn_regressor_layout* yl, double* M,
+              bool use_dq, bool use_ddq)
+{
+  if (b->n_samples == 0) return RDYN_OK;
+  DeviceGuard g;
+  int st = g.enter(b->device);
+  if (st != RDYN_OK) return st;
+  RdynSweepArgs a;
+  memset(&a, 0, sizeof a);
+  st = device_const(c, &a.chain);
+  if (st != RDYN_OK) return st;
+  const int n = c->n_active();
+  a.q = b->q;
+  a.dq = use_dq ? b->dq : nullptr;
+  a.ddq = use_ddq ? b->ddq : nullptr;
+  a.n_samples = b->n_samples;
+  rec_strides(b, n, &a.in_ss, &a.in_sj);
+  a.tau = tau;
+  a.tau_ss = a.in_ss;
+  a.tau_sj = a.in_sj;
+  a.Y = Y;
+  if (yl)
+  {
+    a.y_ss = yl->stride_sample;
+    a.y_sr = yl->stride_row;
+    a.y_sc = yl->stride_col;
+  }
+  a.M = M;
+  rec_strides(b, (int64_t)n * n, &a.m_ss, &a.m_se);
+  RDYN_HIP_TRY(rdyn_launch_local_sweep(c->n_joints(), mode, a, (hipStream_t)b->stream));
+  return RDYN_OK;
+}
+
+}  // namespace
+
+extern "C"
+{
+
+int rdyn_joint_torque(const rdyn_chain* c, const rdyn_batch* b, double* tau)
+{
+  int st = check_batch(c, b, true, true, "rdyn_joint_torque");
+  if (st != RDYN_OK) return st;
+  if (!tau && b->n_samples > 0)
+  {
+    rdyn_set_error("rdyn_joint_torque: null output");
+    return RDYN_ERR_INVALID_ARGUMENT;
+  }
+  return run_local(c, b, RDYN_MODE_TORQUE, tau, nullptr, nullptr, nullptr, true, true);
+}
+
+int rdyn_joint_torque_nonlinear(const rdyn_chain* c, const rdyn_batch* b, double* tau)
+{
+  int st = check_batch(c, b, true, false, "rdyn_joint_torque_nonlinear");
+  if (st != RDYN_OK) return st;
+  if (!tau && b->n_samples > 0)
+  {
+    rdyn_set_error("rdyn_joint_torque_nonlinear: null output");
+    return RDYN_ERR_INVALID_ARGUMENT;
+  }
+  return run_local(c, b, RDYN_MODE_TORQUE, tau, nullptr, nullptr, nullptr, true, false);  // DDq = 0, primitives_impl.h:1287-1288
+}
+
+int rdyn_regressor(const rdyn_chain* c, const rdyn_batch* b, double* tau, double* Y, const rdyn_regressor_layout* yl)
+{
+  int st = check_batch(c, b, true, true, "rdyn_regressor");
+  if (st != RDYN_OK) return st;
+  if (b->n_samples > 0 && (!Y || !yl))
+  {
+    rdyn_set_error("rdyn_regressor: null output or layout");
+    return RDYN_ERR_INVALID_ARGUMENT;
+  }
+  return run_local(c, b, RDYN_MODE_REGRESSOR, tau, Y, yl, nullptr, true, true);
+}
+
+int rdyn_joint_inertia(const rdyn_chain* c, const rdyn_batch* b, double* M)
+{
+  int st = check_batch(c, b, false, false, "rdyn_joint_inertia");
+  if (st != RDYN_OK) return st;
+  if (!M && b->n_samples > 0)
+  {
+    rdyn_set_error("rdyn_joint_inertia: null output");
+    return RDYN_ERR_INVALID_ARGUMENT;
+  }
+  return run_local(c, b, RDYN_MODE_INERTIA, nullptr, nullptr, nullptr, M, false, false);
+}
+
+static int run_base(const rdyn_chain* c, const rdyn_batch* b, double* T_bt, double* T_links, double* J, double* tw, double* dtw)
+{
+  if (b->n_samples == 0) return RDYN_OK;
+  DeviceGuard g;
+  int st = g.enter(b->device);
+  if (st != RDYN_OK) return st;
+  RdynKinArgs a;
+  memset(&a, 0, sizeof a);
+  st = device_const(c, &a.chain);
+  if (st != RDYN_OK) return st;
+  const int n = c->n_active(), L = c->n_joints() + 1;
+  a.q = b->q;
+  a.dq = (tw || dtw) ? b->dq : nullptr;
+  a.ddq = dtw ? b->ddq : nullptr;
+  a.n_samples = b->n_samples;
+  rec_strides(b, n, &a.in_ss, &a.in_sj);
+  int64_t se;
+  a.T_bt = T_bt;
+  rec_strides(b, 12, &a.tb_ss, &se);
+  a.T_links = T_links;
+  rec_strides(b, 12 * (int64_t)L, &a.tl_ss, &se);
+  a.J = J;
+  rec_strides(b, 6 * (int64_t)n, &a.j_ss, &se);
+  a.twists = tw;
+  a.dtwists = dtw;
+  rec_strides(b, 6 * (int64_t)L, &a.tw_ss, &se);
+  a.out_se = se;
+  RDYN_HIP_TRY(rdyn_launch_base_sweep(c->n_joints(), a, (hipStream_t)b->stream));
+  return RDYN_OK;
+}
+
+int rdyn_transformation(const rdyn_chain* c, const rdyn_batch* b, double* T_bt, double* T_links)
+{
+  int st = check_batch(c, b, false, false, "rdyn_transformation");
+  if (st != RDYN_OK) return st;
+  if (!T_bt && !T_links && b->n_samples > 0)
+  {
+    rdyn_set_error("rdyn_transformation: null outputs");
+    return RDYN_ERR_INVALID_ARGUMENT;
+  }
+  return run_base(c, b, T_bt, T_links, nullptr, nullptr, nullptr);
+}
+
+int rdyn_jacobian(const rdyn_chain* c, const rdyn_batch* b, double* J)
+{
+  int st = check_batch(c, b, false, false, "rdyn_jacobian");
+  if (st != RDYN_OK) return st;
+  if (!J && b->n_samples > 0)
+  {
+    rdyn_set_error("rdyn_jacobian: null output");
+    return RDYN_ERR_INVALID_ARGUMENT;
+  }
+  return run_base(c, b, nullptr, nullptr, J, nullptr, nullptr);
+}
+
+int rdyn_twist(const rdyn_chain* c, const rdyn_batch* b, double* twists, double* dtwists)
+{
+  int st = check_batch(c, b, true, dtwists != nullptr, "rdyn_twist");
+  if (st != RDYN_OK) return st;
+  if (!twists && !dtwists && b->n_samples > 0)
+  {
+    rdyn_set_error("rdyn_twist: null outputs");
+    return RDYN_ERR_INVALID_ARGUMENT;
+  }
+  return run_base(c, b, nullptr, nullptr, nullptr, twists, dtwists);
+}
+
+}  // extern "C"

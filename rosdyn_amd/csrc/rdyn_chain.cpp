@@ -1,0 +1,346 @@
+// rdyn_chain.cpp -- chain ingest (host): urdf / flat description -> per-joint constants for the kernels.
+//
+// Follows the construction path of the reference:
+//   Joint::fromUrdf            primitives_impl.h:50-149   (pose, axis normalisation, type map, limits)
+//   Link::fromUrdf             primitives_impl.h:288-328  (inertia rotation, spatial inertia about the link origin)
+//   Link::getNominalParameters primitives_impl.h:399-417
+//   Chain::init                primitives_impl.h:580-703  (ordering, default input joints = moveable joints)
+//   Chain::setInputJointsName  primitives_impl.h:705-737
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+
+#include <hip/hip_runtime.h>
+
+#include "rdyn_chain.hpp"
+
+static thread_local char g_err[512] = "";
+
+void rdyn_set_error(const char* fmt, ...)
+{
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof g_err, fmt, ap);
+  va_end(ap);
+}
+
+extern "C" const char* rdyn_last_error(void) { return g_err; }
+
+namespace
+{
+// Eigen::Quaterniond(w,x,y,z).toRotationMatrix() as used by urdf_parser.h:44-50 / primitives_impl.h:317; row-major out
+void quat_to_R(const double q[4], double R[9])
+{
+  const double x = q[0], y = q[1], z = q[2], w = q[3];
+  const double tx = 2 * x, ty = 2 * y, tz = 2 * z;
+  const double twx = tx * w, twy = ty * w, twz = tz * w;
+  const double txx = tx * x, txy = ty * x, txz = tz * x;
+  const double tyy = ty * y, tyz = tz * y, tzz = tz * z;
+  R[0] = 1 - (tyy + tzz); R[1] = txy - twz;       R[2] = txz + twy;
+  R[3] = txy + twz;       R[4] = 1 - (txx + tzz); R[5] = tyz - twx;
+  R[6] = txz - twy;       R[7] = tyz + twx;       R[8] = 1 - (txx + tyy);
+}
+void mat3_mul(const double* a, const double* b, double* r)
+{
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j)
+    {
+      double s = 0;
+      for (int k = 0; k < 3; ++k) s += a[i * 3 + k] * b[k * 3 + j];
+      r[i * 3 + j] = s;
+    }
+}
+void skew3(const double* v, double* K)
+{
+  K[0] = 0;     K[1] = -v[2]; K[2] = v[1];
+  K[3] = v[2];  K[4] = 0;     K[5] = -v[0];
+  K[6] = -v[1]; K[7] = v[0];  K[8] = 0;
+}
+int map_type(int urdf_type)
+{
+  // primitives_impl.h:74-83
+  if (urdf_type == RDYN_URDF_REVOLUTE || urdf_type == RDYN_URDF_CONTINUOUS) return RDYN_REVOLUTE;
+  if (urdf_type == RDYN_URDF_PRISMATIC) return RDYN_PRISMATIC;
+  return RDYN_FIXED;
+}
+
+void free_device_copies(rdyn_chain* c)
+{
+  for (auto& kv : c->dev_const)
+  {
+    int prev = -1;
+    if (hipGetDevice(&prev) == hipSuccess && hipSetDevice(kv.first) == hipSuccess)
+    {
+      (void)hipFree(kv.second);
+      (void)hipSetDevice(prev);
+    }
+  }
+  c->dev_const.clear();
+}
+}  // namespace
+
+void rdyn_chain_finalize(rdyn_chain* c)
+{
+  const int nj = c->n_joints();
+  RdynChainConst& H = c->host_const;
+  memset(&H, 0, sizeof H);
+  H.n_joints = nj;
+  H.n_active = c->n_active();
+  for (int i = 0; i < 3; ++i) H.g[i] = c->gravity[i];
+  c->q_max.assign(nj, 0.0);
+  c->q_min.assign(nj, 0.0);
+  c->dq_max.assign(nj, 0.0);
+  c->ddq_max.assign(nj, 0.0);
+  c->tau_max.assign(nj, 0.0);
+  for (int j = 0; j < nj; ++j)
+  {
+    const rdyn_joint_desc& d = c->joints[j];
+    RdynJointConst& K = H.j[j];
+    double R[9], Ks[9], K2[9];
+    quat_to_R(d.origin_quat, R);
+    double u[3] = {d.axis[0], d.axis[1], d.axis[2]};
+    const double nrm = sqrt(u[0] * u[0] + u[1] * u[1] + u[2] * u[2]);
+    if (nrm > 0)  // primitives_impl.h:58-59
+      for (int i = 0; i < 3; ++i) u[i] /= nrm;
+    skew3(u, Ks);
+    mat3_mul(Ks, Ks, K2);
+    memcpy(K.A, R, sizeof R);
+    mat3_mul(R, Ks, K.B);
+    mat3_mul(R, K2, K.C);
+    for (int i = 0; i < 3; ++i)
+    {
+      K.t[i] = d.origin_xyz[i];
+      K.u[i] = u[i];
+      K.up[i] = R[i * 3 + 0] * u[0] + R[i * 3 + 1] * u[1] + R[i * 3 + 2] * u[2];
+    }
+    K.type = map_type(d.urdf_type);
+    K.in_idx = -1;
+    // child link nominal parameters (Link::fromUrdf 288-328, getNominalParameters 399-417)
+    const rdyn_link_desc& L = c->links[j + 1];
+    double m = 0, cg[3] = {0, 0, 0}, I[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    if (L.has_inertial)
+    {
+      m = L.mass;
+      for (int i = 0; i < 3; ++i) cg[i] = L.com_xyz[i];
+      const double I0[9] = {L.ixx, L.ixy, L.ixz, L.ixy, L.iyy, L.iyz, L.ixz, L.iyz, L.izz};
+      double Rc[9], RcT[9], tmp[9];
+      quat_to_R(L.com_quat, Rc);
+      for (int a = 0; a < 3; ++a)
+        for (int b = 0; b < 3; ++b) RcT[a * 3 + b] = Rc[b * 3 + a];
+      mat3_mul(Rc, I0, tmp);
+      mat3_mul(tmp, RcT, I);  // primitives_impl.h:317
+    }
+    double cs[9], csT[9], cc[9];
+    skew3(cg, cs);
+    for (int a = 0; a < 3; ++a)
+      for (int b = 0; b < 3; ++b) csT[a * 3 + b] = cs[b * 3 + a];
+    mat3_mul(cs, csT, cc);  // spacevect_algebra.h:238
+    double Io[9];
+    for (int i = 0; i < 9; ++i) Io[i] = I[i] + m * cc[i];
+    K.pi[0] = m;
+    K.pi[1] = cg[0] * m;
+    K.pi[2] = cg[1] * m;
+    K.pi[3] = cg[2] * m;
+    K.pi[4] = Io[0];
+    K.pi[5] = Io[1];
+    K.pi[6] = Io[2];
+    K.pi[7] = Io[4];
+    K.pi[8] = Io[5];
+    K.pi[9] = Io[8];
+
+    // limits (primitives_impl.h:85-143).  Where the reference leaves a member uninitialised
+    // (m_Dq_max without <limit>), 1e10 is used.
+    double qmax = 1e10, qmin = -1e10, dqmax = 1e10, taumax = 1e10;
+    if (d.urdf_type == RDYN_URDF_PRISMATIC || d.urdf_type == RDYN_URDF_REVOLUTE)
+    {
+      if (d.has_limits)
+      {
+        qmax = d.upper;
+        qmin = d.lower;
+        if (qmax <= qmin)
+        {
+          qmax = 2 * M_PI;
+          qmin = -2 * M_PI;
+        }
+        dqmax = d.velocity;
+        if (dqmax <= 0.0) dqmax = 2 * M_PI;
+        taumax = d.effort;
+      }
+    }
+    else if (d.urdf_type == RDYN_URDF_CONTINUOUS)
+    {
+      if (d.has_limits)
+      {
+        dqmax = d.velocity;
+        taumax = d.effort;
+      }
+    }
+    c->q_max[j] = qmax;
+    c->q_min[j] = qmin;
+    c->dq_max[j] = dqmax;
+    c->ddq_max[j] = 10.0 * dqmax;
+    c->tau_max[j] = taumax;
+  }
+  for (int k = 0; k < c->n_active(); ++k) H.j[c->active[k]].in_idx = k;
+}
+
+static int build_chain(std::vector<rdyn_joint_desc>& joints, std::vector<rdyn_link_desc>& links, const double gravity[3], rdyn_chain** out)
+{
+  if ((int)joints.size() > RDYN_MAX_JOINTS)
+  {
+    rdyn_set_error("chain has %d joints (fixed included); this build supports at most %d", (int)joints.size(), RDYN_MAX_JOINTS);
+    return RDYN_ERR_UNSUPPORTED;
+  }
+  rdyn_chain* c = new rdyn_chain();
+  c->joints.swap(joints);
+  c->links.swap(links);
+  for (int i = 0; i < 3; ++i) c->gravity[i] = gravity ? gravity[i] : 0.0;  // default zero, primitives.h:346
+  for (int j = 0; j < c->n_joints(); ++j)
+    if (map_type(c->joints[j].urdf_type) != RDYN_FIXED)
+    {
+      c->moveable_names.push_back(c->joints[j].name);  // primitives_impl.h:634-635
+      c->active.push_back(j);                          // setInputJointsName(m_moveable_joints_name), :700
+    }
+  rdyn_chain_finalize(c);
+  *out = c;
+  return RDYN_OK;
+}
+
+extern "C"
+{
+
+int rdyn_chain_from_urdf(const char* urdf_xml, const char* base_link, const char* tool_link, const double gravity[3], rdyn_chain** out)
+{
+  if (!urdf_xml || !base_link || !tool_link || !out)
+  {
+    rdyn_set_error("rdyn_chain_from_urdf: null argument");
+    return RDYN_ERR_INVALID_ARGUMENT;
+  }
+  *out = nullptr;
+  std::vector<rdyn_joint_desc> joints;
+  std::vector<rdyn_link_desc> links;
+  const int st = rdyn_urdf_extract_chain(urdf_xml, base_link, tool_link, joints, links);
+  if (st != RDYN_OK) return st;
+  return build_chain(joints, links, gravity, out);
+}
+
+int rdyn_chain_from_desc(const rdyn_chain_desc* desc, rdyn_chain** out)
+{
+  if (!desc || !out || desc->n_joints < 0 || !desc->links || (desc->n_joints > 0 && !desc->joints))
+  {
+    rdyn_set_error("rdyn_chain_from_desc: invalid description");
+    return RDYN_ERR_INVALID_ARGUMENT;
+  }
+  *out = nullptr;
+  std::vector<rdyn_joint_desc> joints(desc->joints, desc->joints + desc->n_joints);
+  std::vector<rdyn_link_desc> links(desc->links, desc->links + desc->n_joints + 1);
+  for (auto& j : joints) j.name[63] = 0;
+  for (auto& l : links) l.name[63] = 0;
+  return build_chain(joints, links, desc->gravity, out);
+}
+
+int rdyn_chain_clone(const rdyn_chain* chain, rdyn_chain** out)
+{
+  if (!chain || !out)
+  {
+    rdyn_set_error("rdyn_chain_clone: null argument");
+    return RDYN_ERR_INVALID_ARGUMENT;
+  }
+  rdyn_chain* c = new rdyn_chain();
+  c->joints = chain->joints;
+  c->links = chain->links;
+  c->moveable_names = chain->moveable_names;
+  c->active = chain->active;
+  memcpy(c->gravity, chain->gravity, sizeof c->gravity);
+  rdyn_chain_finalize(c);
+  *out = c;
+  return RDYN_OK;
+}
+
+void rdyn_chain_destroy(rdyn_chain* chain)
+{
+  if (!chain) return;
+  free_device_copies(chain);
+  delete chain;
+}
+
+int rdyn_chain_links_number(const rdyn_chain* c) { return c ? c->n_joints() + 1 : -1; }
+int rdyn_chain_joints_number(const rdyn_chain* c) { return c ? c->n_joints() : -1; }
+int rdyn_chain_active_joints_number(const rdyn_chain* c) { return c ? c->n_active() : -1; }
+int rdyn_chain_moveable_joints_number(const rdyn_chain* c) { return c ? (int)c->moveable_names.size() : -1; }
+const char* rdyn_chain_link_name(const rdyn_chain* c, int i) { return (c && i >= 0 && i <= c->n_joints()) ? c->links[i].name : nullptr; }
+const char* rdyn_chain_joint_name(const rdyn_chain* c, int i) { return (c && i >= 0 && i < c->n_joints()) ? c->joints[i].name : nullptr; }
+const char* rdyn_chain_moveable_joint_name(const rdyn_chain* c, int i)
+{
+  return (c && i >= 0 && i < (int)c->moveable_names.size()) ? c->moveable_names[i].c_str() : nullptr;
+}
+const char* rdyn_chain_active_joint_name(const rdyn_chain* c, int i)
+{
+  return (c && i >= 0 && i < c->n_active()) ? c->joints[c->active[i]].name : nullptr;
+}
+int rdyn_chain_joint_type(const rdyn_chain* c, int i) { return (c && i >= 0 && i < c->n_joints()) ? c->host_const.j[i].type : -1; }
+int rdyn_chain_gravity(const rdyn_chain* c, double g[3])
+{
+  if (!c || !g) return RDYN_ERR_INVALID_ARGUMENT;
+  for (int i = 0; i < 3; ++i) g[i] = c->gravity[i];
+  return RDYN_OK;
+}
+
+int rdyn_chain_set_input_joints(rdyn_chain* c, const char* const* names, int n_names)
+{
+  if (!c || n_names < 0 || (n_names > 0 && !names))
+  {
+    rdyn_set_error("rdyn_chain_set_input_joints: invalid argument");
+    return RDYN_ERR_INVALID_ARGUMENT;
+  }
+  std::vector<int> act;
+  for (int k = 0; k < n_names; ++k)
+  {
+    int found = -1;
+    for (int j = 0; j < c->n_joints(); ++j)
+      if (names[k] && !strcmp(names[k], c->joints[j].name)) found = j;
+    if (found < 0)
+    {
+      rdyn_set_error("Joint named '%s' not found", names[k] ? names[k] : "(null)");  // primitives_impl.h:734
+      return RDYN_ERR_JOINT_NOT_FOUND;
+    }
+    for (int e : act)
+      if (e == found)
+      {
+        rdyn_set_error("Joint named '%s' listed twice", names[k]);
+        return RDYN_ERR_INVALID_ARGUMENT;
+      }
+    act.push_back(found);
+  }
+  std::lock_guard<std::mutex> lk(c->mu);
+  c->active.swap(act);
+  rdyn_chain_finalize(c);
+  free_device_copies(c);
+  return RDYN_OK;
+}
+
+int rdyn_chain_limits(const rdyn_chain* c, double* q_max, double* q_min, double* dq_max, double* ddq_max, double* tau_max)
+{
+  if (!c) return RDYN_ERR_INVALID_ARGUMENT;
+  for (int k = 0; k < c->n_active(); ++k)  // primitives_impl.h:768-776
+  {
+    const int j = c->active[k];
+    if (q_max) q_max[k] = c->q_max[j];
+    if (q_min) q_min[k] = c->q_min[j];
+    if (dq_max) dq_max[k] = c->dq_max[j];
+    if (ddq_max) ddq_max[k] = c->ddq_max[j];
+    if (tau_max) tau_max[k] = c->tau_max[j];
+  }
+  return RDYN_OK;
+}
+
+int rdyn_nominal_parameters(const rdyn_chain* c, double* pi)
+{
+  if (!c || !pi) return RDYN_ERR_INVALID_ARGUMENT;
+  for (int j = 0; j < c->n_joints(); ++j)  // primitives_impl.h:1382-1391
+    for (int p = 0; p < 10; ++p) pi[10 * j + p] = c->host_const.j[j].pi[p];
+  return RDYN_OK;
+}
+
+}  // extern "C"

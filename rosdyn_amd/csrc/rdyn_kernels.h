@@ -1,0 +1,43 @@
+// rdyn_kernels.h -- launch interface between the C-ABI layer (rdyn_api.cpp) and the HIP kernels.
+#ifndef RDYN_KERNELS_H
+#define RDYN_KERNELS_H
+
+#include <hip/hip_runtime.h>
+#include "rdyn_device.h"
+
+// All strides are in doubles.  Inputs: x(s, k) = x[s * in_ss + k * in_sj].
+struct RdynSweepArgs
+{
+  const RdynChainConst* chain;  // device pointer
+  const double *q, *dq, *ddq;   // dq / ddq may be null (treated as zero)
+  int64_t n_samples;
+  int64_t in_ss, in_sj;
+  double* tau;                  // may be null in regressor mode
+  int64_t tau_ss, tau_sj;
+  double* Y;
+  int64_t y_ss, y_sr, y_sc;
+  double* M;
+  int64_t m_ss, m_se;
+};
+
+// Base-frame kinematics outputs; record element e of sample s at out[s * X_ss + e * out_se].
+struct RdynKinArgs
+{
+  const RdynChainConst* chain;
+  const double *q, *dq, *ddq;
+  int64_t n_samples;
+  int64_t in_ss, in_sj;
+  int64_t out_se;
+  double* T_bt;    int64_t tb_ss;   // 12 per sample
+  double* T_links; int64_t tl_ss;   // 12 * links per sample
+  double* J;       int64_t j_ss;    // 6 * n_active per sample
+  double* twists;                   // 6 * links per sample
+  double* dtwists; int64_t tw_ss;
+};
+
+enum { RDYN_MODE_REGRESSOR = 0, RDYN_MODE_TORQUE = 1, RDYN_MODE_INERTIA = 2 };
+
+hipError_t rdyn_launch_local_sweep(int n_joints, int mode, const RdynSweepArgs& a, hipStream_t st);
+hipError_t rdyn_launch_base_sweep(int n_joints, const RdynKinArgs& a, hipStream_t st);
+
+#endif

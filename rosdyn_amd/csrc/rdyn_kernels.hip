@@ -1,0 +1,473 @@
+// rdyn_kernels.hip -- hand-written HIP kernels for gfx950 (MI355X): batched rigid-body dynamics sweeps.
+//
+// One thread per trajectory sample (wave64: 64 samples per wavefront, 256-thread workgroups).
+// Chain constants are read through wave-uniform addresses -> scalar loads into SGPRs (see rdyn_device.h).
+//
+// k_local_sweep<NJ, MODE>  -- the north-star kernel family.  A single FORWARD sweep in link-local
+//   coordinates produces, per link f (base -> tool):
+//     w, vl      angular / linear velocity of the link origin           (reference: getTwist,  primitives_impl.h:1004-1009)
+//     al, a      angular / linear spatial acceleration, gravity folded  (reference: getDTwist, primitives_impl.h:1113-1118)
+//     j_l        the unit twist of every upstream joint l <= f, referred to link f's origin and axes
+//                (= rot(R_f^T, spatialTranslation(S_l, p_f - p_l)); it is the transposed operator the
+//                reference applies to the wrench regressor at primitives_impl.h:1341-1347, and the
+//                link-f Jacobian column of primitives_impl.h:1371-1372)
+//   and from them, without a backward pass and without materialising any 6x10 block:
+//     MODE_REGRESSOR  Y(l, 10 f .. 10 f + 9) = j_l^T W'_f   with the closed form of the reference's ten
+//                     basis-matrix products (primitives_impl.h:1324-1339):
+//                        W'_f = [ d | [al]x + [w]x[w]x | 0 ;  0 | -[d]x | L(al) + [w]x L(w) ],   d = a + w x vl
+//                     and tau = Y * pi fused (== getJointTorque, primitives_impl.h:1264-1272);
+//     MODE_TORQUE     tau_l = sum_f j_l . (I_f a_f + v_f x* I_f v_f + gravity)   (primitives_impl.h:1240-1257, 1270)
+//     MODE_INERTIA    M(l1,l2) = sum_f j_l1^T I_f j_l2                            (primitives_impl.h:1357-1379)
+//   Structural zeros of the regressor (rows of joints downstream of link f) are written explicitly: the
+//   output is the reference's dense n x P matrix.
+//
+// k_base_sweep<NJ> -- base-frame kinematics exactly as the reference states them (frames, screws, twists,
+//   spatial accelerations, tool Jacobian): primitives_impl.h:863-882, 927-949, 981-1013, 1082-1124.
+//
+// HBM traffic per sample (fp64): regressor 3n*8 in, (n + n*P)*8 out  (3 072 B for n=6, P=60); the
+// arithmetic (~3 k fp64 VALU ops per sample for n=6) is ~5x below the HBM time at 1 thread/sample, so
+// the store path decides the speed: with the element-major layout every store instruction of a wave
+// writes 512 contiguous bytes.
+#include <hip/hip_runtime.h>
+#include "rdyn_device.h"
+#include "rdyn_kernels.h"
+
+namespace
+{
+
+struct V3
+{
+  double x, y, z;
+};
+__device__ __forceinline__ V3 mk(double x, double y, double z) { V3 r = {x, y, z}; return r; }
+__device__ __forceinline__ V3 operator+(V3 a, V3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ V3 operator-(V3 a, V3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ double dot(V3 a, V3 b) { return fma(a.x, b.x, fma(a.y, b.y, a.z * b.z)); }
+__device__ __forceinline__ V3 cross(V3 a, V3 b)
+{
+  return mk(fma(a.y, b.z, -(a.z * b.y)), fma(a.z, b.x, -(a.x * b.z)), fma(a.x, b.y, -(a.y * b.x)));
+}
+// a + b * s
+__device__ __forceinline__ V3 axpy(V3 a, V3 b, double s) { return mk(fma(b.x, s, a.x), fma(b.y, s, a.y), fma(b.z, s, a.z)); }
+// R^T x, R row-major
+__device__ __forceinline__ V3 rotT(const double* R, V3 v)
+{
+  return mk(fma(R[0], v.x, fma(R[3], v.y, R[6] * v.z)), fma(R[1], v.x, fma(R[4], v.y, R[7] * v.z)),
+            fma(R[2], v.x, fma(R[5], v.y, R[8] * v.z)));
+}
+// R x
+__device__ __forceinline__ V3 rot(const double* R, V3 v)
+{
+  return mk(fma(R[0], v.x, fma(R[1], v.y, R[2] * v.z)), fma(R[3], v.x, fma(R[4], v.y, R[5] * v.z)),
+            fma(R[6], v.x, fma(R[7], v.y, R[8] * v.z)));
+}
+__device__ __forceinline__ V3 ld3(const double* p) { return mk(p[0], p[1], p[2]); }
+// symmetric 3x3 (Ixx Ixy Ixz Iyy Iyz Izz) times vector
+__device__ __forceinline__ V3 symv(const double* I, V3 v)
+{
+  return mk(fma(I[0], v.x, fma(I[1], v.y, I[2] * v.z)), fma(I[1], v.x, fma(I[3], v.y, I[4] * v.z)),
+            fma(I[2], v.x, fma(I[4], v.y, I[5] * v.z)));
+}
+
+enum
+{
+  MODE_REGRESSOR = 0,
+  MODE_TORQUE = 1,
+  MODE_INERTIA = 2
+};
+
+template <int NJ, int MODE>
+__global__ __launch_bounds__(256) void k_local_sweep(const RdynSweepArgs a)
+{
+  const RdynChainConst* __restrict__ c = a.chain;
+  const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (s >= a.n_samples) return;
+
+  const double* __restrict__ qp = a.q + s * a.in_ss;
+  const double* __restrict__ dqp = a.dq ? a.dq + s * a.in_ss : nullptr;
+  const double* __restrict__ ddqp = a.ddq ? a.ddq + s * a.in_ss : nullptr;
+  double* __restrict__ yp = (MODE == MODE_REGRESSOR) ? a.Y + s * a.y_ss : nullptr;
+
+  V3 w = mk(0, 0, 0), vl = mk(0, 0, 0), al = mk(0, 0, 0);
+  V3 acc = mk(-c->g[0], -c->g[1], -c->g[2]);  // base "acceleration" -g: gravity enters every link's d for free
+  V3 jl[NJ], ja[NJ];
+  double tau[NJ];
+  double Macc[(MODE == MODE_INERTIA) ? NJ * (NJ + 1) / 2 : 1];
+#pragma unroll
+  for (int l = 0; l < NJ; ++l)
+  {
+    tau[l] = 0.0;
+    jl[l] = mk(0, 0, 0);
+    ja[l] = mk(0, 0, 0);
+  }
+  if (MODE == MODE_INERTIA)
+  {
+#pragma unroll
+    for (int i = 0; i < NJ * (NJ + 1) / 2; ++i) Macc[i] = 0.0;
+  }
+
+#pragma unroll
+  for (int f = 0; f < NJ; ++f)
+  {
+    const RdynJointConst& J = c->j[f];
+    const int type = J.type;
+    const int idx = J.in_idx;
+    double qf = 0.0, dqf = 0.0, ddqf = 0.0;
+    if (idx >= 0)
+    {
+      const int64_t o = idx * a.in_sj;
+      qf = qp[o];
+      if (MODE != MODE_INERTIA)
+      {
+        if (dqp) dqf = dqp[o];
+        if (ddqp) ddqf = ddqp[o];
+      }
+    }
+    // ---- parent -> child transform (Joint::computedTpc, primitives_impl.h:38-47)
+    double R[9];
+    V3 t = ld3(J.t);
+    if (type == RDYN_REVOLUTE)
+    {
+      double sn, cs;
+      sincos(qf, &sn, &cs);
+      const double oc = 1.0 - cs;
+#pragma unroll
+      for (int i = 0; i < 9; ++i) R[i] = fma(sn, J.B[i], fma(oc, J.C[i], J.A[i]));
+    }
+    else
+    {
+#pragma unroll
+      for (int i = 0; i < 9; ++i) R[i] = J.A[i];
+      if (type == RDYN_PRISMATIC) t = axpy(t, ld3(J.up), qf);
+    }
+    // ---- carry the state into the child frame (spatialTranslation + rotation, sva.h:129-133, 172-175)
+    if (MODE != MODE_INERTIA)
+    {
+      const V3 wn = rotT(R, w);
+      const V3 vn = rotT(R, vl + cross(w, t));
+      const V3 aln = rotT(R, al);
+      const V3 an = rotT(R, acc + cross(al, t));
+      w = wn; vl = vn; al = aln; acc = an;
+    }
+#pragma unroll
+    for (int l = 0; l < f; ++l)
+    {
+      if (c->j[l].in_idx >= 0)
+      {
+        const V3 nl = rotT(R, jl[l] + cross(ja[l], t));
+        ja[l] = rotT(R, ja[l]);
+        jl[l] = nl;
+      }
+    }
+    // ---- add this joint's motion (S q', (v x S) q' + S q'';  primitives_impl.h:1007-1008, 1116-1117)
+    const V3 u = ld3(J.u);
+    if (type == RDYN_REVOLUTE)
+    {
+      if (MODE != MODE_INERTIA)
+      {
+        acc = axpy(acc, cross(vl, u), dqf);
+        al = axpy(axpy(al, cross(w, u), dqf), u, ddqf);
+        w = axpy(w, u, dqf);
+      }
+      jl[f] = mk(0, 0, 0);
+      ja[f] = u;
+    }
+    else if (type == RDYN_PRISMATIC)
+    {
+      if (MODE != MODE_INERTIA)
+      {
+        acc = axpy(axpy(acc, cross(w, u), dqf), u, ddqf);
+        vl = axpy(vl, u, dqf);
+      }
+      jl[f] = u;
+      ja[f] = mk(0, 0, 0);
+    }
+
+    if (MODE == MODE_REGRESSOR)
+    {
+      // ---- closed-form wrench regressor of link f+1 in its own frame
+      const V3 d = acc + cross(w, vl);
+      const double wxy = w.x * w.y, wxz = w.x * w.z, wyz = w.y * w.z;
+      const double wxx = w.x * w.x, wyy = w.y * w.y, wzz = w.z * w.z;
+      // Bm = [al]x + [w]x[w]x   (rows b0,b1,b2)
+      const double b00 = -(wyy + wzz), b01 = wxy - al.z, b02 = wxz + al.y;
+      const double b10 = wxy + al.z, b11 = -(wxx + wzz), b12 = wyz - al.x;
+      const double b20 = wxz - al.y, b21 = wyz + al.x, b22 = -(wxx + wyy);
+      const double* pi = J.pi;
+      const int64_t col0 = (int64_t)(10 * f) * a.y_sc;
+#pragma unroll
+      for (int l = 0; l < NJ; ++l)
+      {
+        const int row = c->j[l].in_idx;
+        if (row < 0) continue;
+        double* __restrict__ yr = yp + row * a.y_sr + col0;
+        if (l <= f)
+        {
+          const V3 L = jl[l], A = ja[l];
+          const V3 dxA = cross(d, A);
+          const V3 x = cross(A, w);
+          double y[10];
+          y[0] = dot(L, d);
+          y[1] = fma(L.x, b00, fma(L.y, b10, fma(L.z, b20, dxA.x)));
+          y[2] = fma(L.x, b01, fma(L.y, b11, fma(L.z, b21, dxA.y)));
+          y[3] = fma(L.x, b02, fma(L.y, b12, fma(L.z, b22, dxA.z)));
+          y[4] = fma(A.x, al.x, x.x * w.x);
+          y[5] = fma(A.x, al.y, fma(A.y, al.x, fma(x.x, w.y, x.y * w.x)));
+          y[6] = fma(A.x, al.z, fma(A.z, al.x, fma(x.x, w.z, x.z * w.x)));
+          y[7] = fma(A.y, al.y, x.y * w.y);
+          y[8] = fma(A.y, al.z, fma(A.z, al.y, fma(x.y, w.z, x.z * w.y)));
+          y[9] = fma(A.z, al.z, x.z * w.z);
+          double tl = tau[l];
+#pragma unroll
+          for (int p = 0; p < 10; ++p)
+          {
+            tl = fma(y[p], pi[p], tl);
+            yr[p * a.y_sc] = y[p];
+          }
+          tau[l] = tl;
+        }
+        else
+        {
+#pragma unroll
+          for (int p = 0; p < 10; ++p) yr[p * a.y_sc] = 0.0;
+        }
+      }
+    }
+    else if (MODE == MODE_TORQUE)
+    {
+      // ---- net wrench on link f+1 about its origin, own frame (getWrench, primitives_impl.h:1240-1250)
+      const double* pi = J.pi;
+      const double m = pi[0];
+      const V3 h = ld3(pi + 1);
+      const V3 d = acc + cross(w, vl);
+      const V3 fo = axpy(cross(al, h) + cross(w, cross(w, h)), d, m);
+      const V3 no = symv(pi + 4, al) + cross(w, symv(pi + 4, w)) + cross(h, d);
+#pragma unroll
+      for (int l = 0; l <= f; ++l)
+        if (c->j[l].in_idx >= 0) tau[l] += dot(jl[l], fo) + dot(ja[l], no);
+    }
+    else
+    {
+      // ---- M += J_f^T I_f J_f   (getJointInertia, primitives_impl.h:1364-1375)
+      const double* pi = J.pi;
+      const double m = pi[0];
+      const V3 h = ld3(pi + 1);
+#pragma unroll
+      for (int l2 = 0; l2 <= f; ++l2)
+      {
+        if (c->j[l2].in_idx < 0) continue;
+        const V3 Il = axpy(cross(ja[l2], h), jl[l2], m);
+        const V3 Ia = cross(h, jl[l2]) + symv(pi + 4, ja[l2]);
+#pragma unroll
+        for (int l1 = 0; l1 <= l2; ++l1)
+          if (c->j[l1].in_idx >= 0) Macc[l2 * (l2 + 1) / 2 + l1] += dot(jl[l1], Il) + dot(ja[l1], Ia);
+      }
+    }
+  }
+
+  if (MODE == MODE_INERTIA)
+  {
+    const int n = c->n_active;
+    double* __restrict__ mp = a.M + s * a.m_ss;
+#pragma unroll
+    for (int l2 = 0; l2 < NJ; ++l2)
+    {
+      const int r2 = c->j[l2].in_idx;
+      if (r2 < 0) continue;
+#pragma unroll
+      for (int l1 = 0; l1 <= l2; ++l1)
+      {
+        const int r1 = c->j[l1].in_idx;
+        if (r1 < 0) continue;
+        const double v = Macc[l2 * (l2 + 1) / 2 + l1];
+        mp[(int64_t)(r2 * n + r1) * a.m_se] = v;
+        mp[(int64_t)(r1 * n + r2) * a.m_se] = v;
+      }
+    }
+  }
+  else if (a.tau)
+  {
+    double* __restrict__ tp = a.tau + s * a.tau_ss;
+#pragma unroll
+    for (int l = 0; l < NJ; ++l)
+    {
+      const int r = c->j[l].in_idx;
+      if (r >= 0) tp[r * a.tau_sj] = tau[l];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Base-frame kinematics, stated as the reference states them.
+template <int NJ>
+__global__ __launch_bounds__(256) void k_base_sweep(const RdynKinArgs a)
+{
+  const RdynChainConst* __restrict__ c = a.chain;
+  const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (s >= a.n_samples) return;
+  const double* __restrict__ qp = a.q + s * a.in_ss;
+  const double* __restrict__ dqp = a.dq ? a.dq + s * a.in_ss : nullptr;
+  const double* __restrict__ ddqp = a.ddq ? a.ddq + s * a.in_ss : nullptr;
+  const int64_t es = a.out_se;  // element stride of every output record
+
+  double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+  V3 p = mk(0, 0, 0);
+  V3 vlin = mk(0, 0, 0), vang = mk(0, 0, 0), alin = mk(0, 0, 0), aang = mk(0, 0, 0);
+  V3 z[NJ], po[NJ];
+
+  auto put3x4 = [&](double* __restrict__ o) {
+    // column-major 3x4 [R | p]
+#pragma unroll
+    for (int cc = 0; cc < 3; ++cc)
+#pragma unroll
+      for (int r = 0; r < 3; ++r) o[(int64_t)(cc * 3 + r) * es] = R[r * 3 + cc];
+    o[9 * es] = p.x;
+    o[10 * es] = p.y;
+    o[11 * es] = p.z;
+  };
+  auto put6 = [&](double* __restrict__ o, V3 l, V3 g) {
+    o[0] = l.x; o[es] = l.y; o[2 * es] = l.z; o[3 * es] = g.x; o[4 * es] = g.y; o[5 * es] = g.z;
+  };
+
+  if (a.T_links) put3x4(a.T_links + s * a.tl_ss);
+  if (a.twists) put6(a.twists + s * a.tw_ss, vlin, vang);
+  if (a.dtwists) put6(a.dtwists + s * a.tw_ss, alin, aang);
+
+#pragma unroll
+  for (int f = 0; f < NJ; ++f)
+  {
+    const RdynJointConst& J = c->j[f];
+    const int type = J.type;
+    const int idx = J.in_idx;
+    double qf = 0.0, dqf = 0.0, ddqf = 0.0;
+    if (idx >= 0)
+    {
+      const int64_t o = idx * a.in_sj;
+      qf = qp[o];
+      if (dqp) dqf = dqp[o];
+      if (ddqp) ddqf = ddqp[o];
+    }
+    double Rpc[9];
+    V3 t = ld3(J.t);
+    if (type == RDYN_REVOLUTE)
+    {
+      double sn, cs;
+      sincos(qf, &sn, &cs);
+      const double oc = 1.0 - cs;
+#pragma unroll
+      for (int i = 0; i < 9; ++i) Rpc[i] = fma(sn, J.B[i], fma(oc, J.C[i], J.A[i]));
+    }
+    else
+    {
+#pragma unroll
+      for (int i = 0; i < 9; ++i) Rpc[i] = J.A[i];
+      if (type == RDYN_PRISMATIC) t = axpy(t, ld3(J.up), qf);
+    }
+    // screw axis of the child in the base frame, rotated by the PARENT frame (computeScrews, primitives_impl.h:879)
+    const V3 zl = rot(R, ld3(J.up));
+    const V3 d = rot(R, t);  // p_l - p_{l-1}
+    // T_bl[l] = T_bl[l-1] * T_pc   (computeFrames, primitives_impl.h:869)
+    double Rn[9];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int cc = 0; cc < 3; ++cc)
+        Rn[r * 3 + cc] = fma(R[r * 3 + 0], Rpc[cc], fma(R[r * 3 + 1], Rpc[3 + cc], R[r * 3 + 2] * Rpc[6 + cc]));
+#pragma unroll
+    for (int i = 0; i < 9; ++i) R[i] = Rn[i];
+    p = p + d;
+    z[f] = zl;
+    po[f] = p;
+    // twists (getTwist, primitives_impl.h:1007-1008) and spatial accelerations (getDTwist, 1116-1117)
+    V3 Sl = mk(0, 0, 0), Sa = mk(0, 0, 0);
+    if (type == RDYN_REVOLUTE) Sa = zl;
+    else if (type == RDYN_PRISMATIC) Sl = zl;
+    const V3 nvl = axpy(vlin + cross(vang, d), Sl, dqf);
+    const V3 nva = axpy(vang, Sa, dqf);
+    const V3 cl = cross(nva, Sl) + cross(nvl, Sa);  // spatialCrossProduct(v, S), sva.h:88-93
+    const V3 ca = cross(nva, Sa);
+    alin = axpy(axpy(alin + cross(aang, d), cl, dqf), Sl, ddqf);
+    aang = axpy(axpy(aang, ca, dqf), Sa, ddqf);
+    vlin = nvl;
+    vang = nva;
+    if (a.T_links) put3x4(a.T_links + s * a.tl_ss + (int64_t)(12 * (f + 1)) * es);
+    if (a.twists) put6(a.twists + s * a.tw_ss + (int64_t)(6 * (f + 1)) * es, vlin, vang);
+    if (a.dtwists) put6(a.dtwists + s * a.tw_ss + (int64_t)(6 * (f + 1)) * es, alin, aang);
+  }
+  if (a.T_bt) put3x4(a.T_bt + s * a.tb_ss);
+  if (a.J)
+  {
+    // getJacobian, primitives_impl.h:939-945: column k = spatialTranslation(S_l, p_tool - p_l)
+    double* __restrict__ jp = a.J + s * a.j_ss;
+#pragma unroll
+    for (int l = 0; l < NJ; ++l)
+    {
+      const int k = c->j[l].in_idx;
+      if (k < 0) continue;
+      const int type = c->j[l].type;
+      V3 jlin = mk(0, 0, 0), jang = mk(0, 0, 0);
+      if (type == RDYN_REVOLUTE)
+      {
+        jlin = cross(z[l], p - po[l]);
+        jang = z[l];
+      }
+      else if (type == RDYN_PRISMATIC)
+        jlin = z[l];
+      put6(jp + (int64_t)(6 * k) * es, jlin, jang);
+    }
+  }
+}
+
+template <int NJ>
+hipError_t launch_local_nj(int mode, const RdynSweepArgs& a, hipStream_t st)
+{
+  const unsigned grid = (unsigned)((a.n_samples + 255) / 256);
+  switch (mode)
+  {
+  case MODE_REGRESSOR: hipLaunchKernelGGL((k_local_sweep<NJ, MODE_REGRESSOR>), dim3(grid), dim3(256), 0, st, a); break;
+  case MODE_TORQUE: hipLaunchKernelGGL((k_local_sweep<NJ, MODE_TORQUE>), dim3(grid), dim3(256), 0, st, a); break;
+  default: hipLaunchKernelGGL((k_local_sweep<NJ, MODE_INERTIA>), dim3(grid), dim3(256), 0, st, a); break;
+  }
+  return hipGetLastError();
+}
+template <int NJ>
+hipError_t launch_base_nj(const RdynKinArgs& a, hipStream_t st)
+{
+  const unsigned grid = (unsigned)((a.n_samples + 255) / 256);
+  hipLaunchKernelGGL((k_base_sweep<NJ>), dim3(grid), dim3(256), 0, st, a);
+  return hipGetLastError();
+}
+
+}  // namespace
+
+#define RDYN_DISPATCH_NJ(nj, CALL)                 \
+  switch (nj)                                      \
+  {                                                \
+  case 1: return CALL(1);                          \
+  case 2: return CALL(2);                          \
+  case 3: return CALL(3);                          \
+  case 4: return CALL(4);                          \
+  case 5: return CALL(5);                          \
+  case 6: return CALL(6);                          \
+  case 7: return CALL(7);                          \
+  case 8: return CALL(8);                          \
+  case 9: return CALL(9);                          \
+  case 10: return CALL(10);                        \
+  default: return hipErrorInvalidValue;            \
+  }
+
+hipError_t rdyn_launch_local_sweep(int n_joints, int mode, const RdynSweepArgs& a, hipStream_t st)
+{
+  if (a.n_samples <= 0) return hipSuccess;
+#define CALL(N) launch_local_nj<N>(mode, a, st)
+  RDYN_DISPATCH_NJ(n_joints, CALL)
+#undef CALL
+}
+
+hipError_t rdyn_launch_base_sweep(int n_joints, const RdynKinArgs& a, hipStream_t st)
+{
+  if (a.n_samples <= 0) return hipSuccess;
+#define CALL(N) launch_base_nj<N>(a, st)
+  RDYN_DISPATCH_NJ(n_joints, CALL)
+#undef CALL
+}

@@ -1,0 +1,174 @@
+"""GPU parity tests (-m gpu): the HIP path, called through the C-ABI, against the committed golden vectors
+and against the CPU oracle on seeded batches.  Tolerance:
+|delta| <= 1e-11 * max(1, |ref|_inf)."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import FIXTURES, golden_cases, load_golden
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-11
+GRAV = (0.0, 0.0, -9.806)
+
+
+def _close(a, b, tol=TOL, what=""):
+    a, b = np.asarray(a), np.asarray(b)
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    scale = max(1.0, float(np.abs(b).max()))
+    err = float(np.abs(a - b).max())
+    assert err <= tol * scale, "%s: max abs err %.3e > %.1e * %.3g" % (what, err, tol, scale)
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    torch = pytest.importorskip("torch")
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    return torch
+
+
+def _dev(torch, *arrs):
+    return [torch.from_numpy(np.ascontiguousarray(a)).cuda() for a in arrs]
+
+
+def _eval_all(torch, chain, q, dq, ddq, layout):
+    """Runs every batched call and returns numpy arrays in the ORACLE's shapes."""
+    if layout == "element":
+        tq, tdq, tddq = _dev(torch, q.T, dq.T, ddq.T)
+        first = lambda t: np.moveaxis(t.cpu().numpy(), -1, 0)   # (..., N) -> (N, ...)
+    else:
+        tq, tdq, tddq = _dev(torch, q, dq, ddq)
+        first = lambda t: t.cpu().numpy()
+    out = {}
+    out["T"] = first(chain.getTransformations(tq, layout=layout)).transpose(0, 1, 3, 2)       # (N, L, 3, 4)
+    out["T_bt"] = first(chain.getTransformation(tq, layout=layout)).transpose(0, 2, 1)         # (N, 3, 4)
+    out["J"] = first(chain.getJacobian(tq, layout=layout)).transpose(0, 2, 1)                  # (N, 6, n)
+    out["twist"] = first(chain.getTwist(tq, tdq, layout=layout))
+    out["dtwist"] = first(chain.getDTwist(tq, tdq, tddq, layout=layout))
+    out["tau"] = first(chain.getJointTorque(tq, tdq, tddq, layout=layout))
+    out["tau_nl"] = first(chain.getJointTorqueNonLinearPart(tq, tdq, layout=layout))
+    out["M"] = first(chain.getJointInertia(tq, layout=layout)).transpose(0, 2, 1)
+    Y, tau2 = chain.getRegressor(tq, tdq, tddq, layout=layout, with_torque=True)
+    out["Y"] = first(Y).transpose(0, 2, 1)                                                     # (N, n, P)
+    out["tau_fused"] = first(tau2)
+    torch.cuda.synchronize()
+    return out
+
+
+@pytest.mark.parametrize("layout", ["sample", "element"])
+@pytest.mark.parametrize("name", golden_cases())
+def test_hip_matches_golden(torch_cuda, name, layout):
+    from rosdyn_amd import Chain
+    g = load_golden(name)
+    chain = Chain(g["urdf_path"], g["base"], g["tool"], g["gravity"])
+    if g["inputs"]:
+        assert chain.setInputJointsName(g["inputs"])
+    o = _eval_all(torch_cuda, chain, g["q"], g["dq"], g["ddq"], layout)
+    _close(o["T"], g["T"], what="T")
+    _close(o["T_bt"], g["T"][:, -1], what="T_bt")
+    _close(o["J"], g["J"], what="J")
+    _close(o["twist"], g["twist"], what="twist")
+    _close(o["dtwist"], g["dtwist"], what="dtwist")
+    _close(o["tau"], g["tau"], what="tau")
+    _close(o["tau_fused"], g["tau"], what="tau_fused")
+    _close(o["Y"], g["Y"], what="Y")
+    _close(o["M"], g["M"], what="M")
+    _close(chain.getNominalParameters(), g["pi"], 1e-15, what="pi")
+
+
+CHAINS = [("ur10_like.urdf", "base_link", "tool0"), ("ur10_like.urdf", "base_link", "wrist_3_link"),
+          ("panda_like.urdf", "link0", "hand"), ("panda_like.urdf", "link0", "link7"),
+          ("mixed_joints.urdf", "world", "tip"), ("mixed_joints.urdf", "turret", "slider")]
+
+
+@pytest.mark.parametrize("urdf,base,tool", CHAINS)
+def test_hip_matches_oracle_seeded_batch(torch_cuda, urdf, base, tool):
+    """2 000 seeded U[-1,1] samples (not a multiple of the 256-thread block: ragged tail) vs the C oracle."""
+    from oracle.oracle import OracleChain
+    from rosdyn_amd import Chain
+    from rosdyn_amd.samples import trajectory_batch
+    path = os.path.join(FIXTURES, urdf)
+    chain = Chain(path, base, tool, GRAV)
+    ref = OracleChain(path, base, tool, GRAV)
+    N = 2000
+    q, dq, ddq = trajectory_batch(0xABCDEF, N, ref.n)
+    o = _eval_all(torch_cuda, chain, q, dq, ddq, "sample")
+    _close(o["T"], ref.fk(q), what="T")
+    _close(o["J"], ref.jacobian(q), what="J")
+    _close(o["twist"], ref.twist(q, dq), what="twist")
+    _close(o["dtwist"], ref.dtwist(q, dq, ddq), what="dtwist")
+    tau = ref.joint_torque(q, dq, ddq)
+    _close(o["tau"], tau, what="tau")
+    _close(o["tau_fused"], tau, what="tau_fused")
+    _close(o["tau_nl"], ref.joint_torque(q, dq, 0 * ddq), what="tau_nl")
+    _close(o["Y"], ref.regressor(q, dq, ddq), what="Y")
+    _close(o["M"], ref.joint_inertia(q), what="M")
+
+
+def test_regressor_layouts_agree(torch_cuda):
+    """per-sample / stacked / element-major outputs hold the same numbers; structural zeros are written."""
+    from rosdyn_amd import Chain
+    from rosdyn_amd.samples import trajectory_batch
+    torch = torch_cuda
+    chain = Chain(os.path.join(FIXTURES, "ur10_like.urdf"), "base_link", "tool0", GRAV)
+    n, P, N = 6, 70, 777
+    q, dq, ddq = trajectory_batch(5, N, n)
+    tq, tdq, tddq = _dev(torch, q, dq, ddq)
+    poison = float("nan")
+    Yp = torch.full((N, P, n), poison, dtype=torch.float64, device="cuda")
+    Ys = torch.full((P, N * n), poison, dtype=torch.float64, device="cuda")
+    Ye = torch.full((P, n, N), poison, dtype=torch.float64, device="cuda")
+    chain.getRegressor(tq, tdq, tddq, y_layout="per_sample", out=Yp)
+    chain.getRegressor(tq, tdq, tddq, y_layout="stacked", out=Ys)
+    chain.getRegressor(tq, tdq, tddq, y_layout="element", out=Ye)
+    a = Yp.cpu().numpy().transpose(0, 2, 1)                       # (N, n, P)
+    b = Ys.cpu().numpy().reshape(P, N, n).transpose(1, 2, 0)
+    c = Ye.cpu().numpy().transpose(2, 1, 0)
+    assert not np.isnan(a).any() and not np.isnan(b).any() and not np.isnan(c).any()
+    assert np.array_equal(a, b) and np.array_equal(a, c)
+    for j in range(n):
+        assert np.all(a[:, j, :10 * j] == 0.0)
+
+
+def test_full_size_properties(torch_cuda):
+    """BASELINE config 2 size (N = 1e6, 6-DOF, P = 60): Y pi = tau and tau - tau_nl = M ddq on the whole batch,
+    plus oracle parity on a 4 096-sample prefix."""
+    from oracle.oracle import OracleChain
+    from rosdyn_amd import Chain
+    torch = torch_cuda
+    path = os.path.join(FIXTURES, "ur10_like.urdf")
+    chain = Chain(path, "base_link", "wrist_3_link", GRAV)
+    n, P, N = 6, 60, 1000000
+    gen = torch.Generator(device="cuda").manual_seed(1234)
+    q, dq, ddq = (torch.rand((n, N), dtype=torch.float64, device="cuda", generator=gen) * 2 - 1 for _ in range(3))
+    Y, tau = chain.getRegressor(q, dq, ddq, layout="element", with_torque=True)        # (P, n, N), (n, N)
+    pi = torch.from_numpy(chain.getNominalParameters()).cuda()
+    tau_y = torch.einsum("pjs,p->js", Y, pi)
+    scale = max(1.0, float(tau.abs().max()))
+    assert float((tau_y - tau).abs().max()) <= 1e-11 * scale
+    tau_r = chain.getJointTorque(q, dq, ddq, layout="element")
+    assert float((tau_r - tau).abs().max()) <= 1e-11 * scale
+    tau_nl = chain.getJointTorqueNonLinearPart(q, dq, layout="element")
+    M = chain.getJointInertia(q, layout="element")                                      # (n, n, N) [b][a][s]
+    Mddq = torch.einsum("bas,bs->as", M, ddq)
+    assert float((tau - tau_nl - Mddq).abs().max()) <= 1e-11 * scale
+    ref = OracleChain(path, "base_link", "wrist_3_link", GRAV)
+    k = 4096
+    qn, dqn, ddqn = (x[:, :k].T.contiguous().cpu().numpy() for x in (q, dq, ddq))
+    _close(Y[:, :, :k].cpu().numpy().transpose(2, 1, 0), ref.regressor(qn, dqn, ddqn), what="Y prefix")
+    _close(tau[:, :k].T.cpu().numpy(), ref.joint_torque(qn, dqn, ddqn), what="tau prefix")
+
+
+def test_empty_batch_and_errors(torch_cuda):
+    from rosdyn_amd import Chain
+    torch = torch_cuda
+    chain = Chain(os.path.join(FIXTURES, "ur10_like.urdf"), "base_link", "tool0", GRAV)
+    z = torch.empty((0, 6), dtype=torch.float64, device="cuda")
+    assert chain.getJointTorque(z, z, z).shape == (0, 6)
+    assert chain.getRegressor(z, z, z).shape == (0, 70, 6)
+    q = torch.zeros((4, 6), dtype=torch.float64, device="cuda")
+    with pytest.raises(ValueError, match="Input data dimensions mismatch"):   # primitives_impl.h:1299-1309
+        chain.getRegressor(q, q[:, :5].contiguous(), q)
+    with pytest.raises(ValueError):
+        chain.getJointTorque(q.float(), q, q)
