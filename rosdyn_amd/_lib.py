@@ -82,6 +82,13 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise ImportError("librdyn_hip.so not built (expected at %s); run __graft_entry__.build() -- "
                               "there is deliberately no CPU fallback" % LIB_PATH)
+        # One HIP runtime per process: torch wheels bundle their own libamdhip64.so.7 (same SONAME as
+        # /opt/rocm's).  Whichever is loaded first serves both; loading ours first and torch's second left
+        # this library without a device (hipGetDevice failed on MI355X/ROCm 7.2), so let torch load first.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         l = C.CDLL(LIB_PATH)
         for name, (res, args) in SYMBOLS.items():
             f = getattr(l, name)
