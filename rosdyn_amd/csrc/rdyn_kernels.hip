@@ -35,6 +35,21 @@
 namespace
 {
 
+// Chain constants are read through the CONSTANT address space: the loads are then known to be invariant,
+// so hipcc emits scalar loads (s_load_dwordx*, counted on lgkmcnt) into SGPRs.  Through a plain global
+// pointer the kernel's own Y stores make the compiler fall back to per-lane global_load (counted on
+// vmcnt, in order BEHIND the outstanding stores): measured 625 us -> see profiles/r1.
+#define RDYN_CONST_AS __attribute__((address_space(4)))
+typedef const RDYN_CONST_AS RdynChainConst* ChainPtr;
+typedef const RDYN_CONST_AS RdynJointConst& JointRef;
+__device__ __forceinline__ ChainPtr as_const(const RdynChainConst* p)
+{
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wold-style-cast"
+  return (ChainPtr)p;
+#pragma clang diagnostic pop
+}
+
 struct V3
 {
   double x, y, z;
@@ -61,9 +76,11 @@ __device__ __forceinline__ V3 rot(const double* R, V3 v)
   return mk(fma(R[0], v.x, fma(R[1], v.y, R[2] * v.z)), fma(R[3], v.x, fma(R[4], v.y, R[5] * v.z)),
             fma(R[6], v.x, fma(R[7], v.y, R[8] * v.z)));
 }
-__device__ __forceinline__ V3 ld3(const double* p) { return mk(p[0], p[1], p[2]); }
+template <class Ptr>
+__device__ __forceinline__ V3 ld3(Ptr p) { return mk(p[0], p[1], p[2]); }
 // symmetric 3x3 (Ixx Ixy Ixz Iyy Iyz Izz) times vector
-__device__ __forceinline__ V3 symv(const double* I, V3 v)
+template <class Ptr>
+__device__ __forceinline__ V3 symv(Ptr I, V3 v)
 {
   return mk(fma(I[0], v.x, fma(I[1], v.y, I[2] * v.z)), fma(I[1], v.x, fma(I[3], v.y, I[4] * v.z)),
             fma(I[2], v.x, fma(I[4], v.y, I[5] * v.z)));
@@ -79,14 +96,18 @@ enum
 template <int NJ, int MODE>
 __global__ __launch_bounds__(256) void k_local_sweep(const RdynSweepArgs a)
 {
-  const RdynChainConst* __restrict__ c = a.chain;
+  ChainPtr c = as_const(a.chain);
   const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (s >= a.n_samples) return;
 
   const double* __restrict__ qp = a.q + s * a.in_ss;
   const double* __restrict__ dqp = a.dq ? a.dq + s * a.in_ss : nullptr;
   const double* __restrict__ ddqp = a.ddq ? a.ddq + s * a.in_ss : nullptr;
-  double* __restrict__ yp = (MODE == MODE_REGRESSOR) ? a.Y + s * a.y_ss : nullptr;
+  // Y addressing = wave-uniform 64-bit base (SGPR pair) + 32-bit per-lane byte offset: the stores then use
+  // the saddr form (global_store_dwordx2 voff, data, s[base]) and need no per-store 64-bit VALU add.
+  char* const yblk = (MODE == MODE_REGRESSOR) ? (char*)(a.Y + (int64_t)blockIdx.x * 256 * a.y_ss) : nullptr;
+  const uint32_t yv = (uint32_t)threadIdx.x * (uint32_t)a.y_ss * 8u;
+  const int64_t y_sc_b = a.y_sc * 8;
 
   V3 w = mk(0, 0, 0), vl = mk(0, 0, 0), al = mk(0, 0, 0);
   V3 acc = mk(-c->g[0], -c->g[1], -c->g[2]);  // base "acceleration" -g: gravity enters every link's d for free
@@ -109,7 +130,7 @@ __global__ __launch_bounds__(256) void k_local_sweep(const RdynSweepArgs a)
 #pragma unroll
   for (int f = 0; f < NJ; ++f)
   {
-    const RdynJointConst& J = c->j[f];
+    JointRef J = c->j[f];
     const int type = J.type;
     const int idx = J.in_idx;
     double qf = 0.0, dqf = 0.0, ddqf = 0.0;
@@ -193,14 +214,14 @@ __global__ __launch_bounds__(256) void k_local_sweep(const RdynSweepArgs a)
       const double b00 = -(wyy + wzz), b01 = wxy - al.z, b02 = wxz + al.y;
       const double b10 = wxy + al.z, b11 = -(wxx + wzz), b12 = wyz - al.x;
       const double b20 = wxz - al.y, b21 = wyz + al.x, b22 = -(wxx + wyy);
-      const double* pi = J.pi;
+      const RDYN_CONST_AS double* pi = J.pi;
       const int64_t col0 = (int64_t)(10 * f) * a.y_sc;
 #pragma unroll
       for (int l = 0; l < NJ; ++l)
       {
         const int row = c->j[l].in_idx;
         if (row < 0) continue;
-        double* __restrict__ yr = yp + row * a.y_sr + col0;
+        char* const yr = yblk + (row * a.y_sr + col0) * 8;
         if (l <= f)
         {
           const V3 L = jl[l], A = ja[l];
@@ -222,21 +243,21 @@ __global__ __launch_bounds__(256) void k_local_sweep(const RdynSweepArgs a)
           for (int p = 0; p < 10; ++p)
           {
             tl = fma(y[p], pi[p], tl);
-            yr[p * a.y_sc] = y[p];
+            *(double*)(yr + p * y_sc_b + yv) = y[p];
           }
           tau[l] = tl;
         }
         else
         {
 #pragma unroll
-          for (int p = 0; p < 10; ++p) yr[p * a.y_sc] = 0.0;
+          for (int p = 0; p < 10; ++p) *(double*)(yr + p * y_sc_b + yv) = 0.0;
         }
       }
     }
     else if (MODE == MODE_TORQUE)
     {
       // ---- net wrench on link f+1 about its origin, own frame (getWrench, primitives_impl.h:1240-1250)
-      const double* pi = J.pi;
+      const RDYN_CONST_AS double* pi = J.pi;
       const double m = pi[0];
       const V3 h = ld3(pi + 1);
       const V3 d = acc + cross(w, vl);
@@ -249,7 +270,7 @@ __global__ __launch_bounds__(256) void k_local_sweep(const RdynSweepArgs a)
     else
     {
       // ---- M += J_f^T I_f J_f   (getJointInertia, primitives_impl.h:1364-1375)
-      const double* pi = J.pi;
+      const RDYN_CONST_AS double* pi = J.pi;
       const double m = pi[0];
       const V3 h = ld3(pi + 1);
 #pragma unroll
@@ -302,7 +323,7 @@ __global__ __launch_bounds__(256) void k_local_sweep(const RdynSweepArgs a)
 template <int NJ>
 __global__ __launch_bounds__(256) void k_base_sweep(const RdynKinArgs a)
 {
-  const RdynChainConst* __restrict__ c = a.chain;
+  ChainPtr c = as_const(a.chain);
   const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (s >= a.n_samples) return;
   const double* __restrict__ qp = a.q + s * a.in_ss;
@@ -336,7 +357,7 @@ __global__ __launch_bounds__(256) void k_base_sweep(const RdynKinArgs a)
 #pragma unroll
   for (int f = 0; f < NJ; ++f)
   {
-    const RdynJointConst& J = c->j[f];
+    JointRef J = c->j[f];
     const int type = J.type;
     const int idx = J.in_idx;
     double qf = 0.0, dqf = 0.0, ddqf = 0.0;
