@@ -185,6 +185,32 @@ int rdyn_regressor(const rdyn_chain* chain, const rdyn_batch* batch, double* tau
 /* getJointInertia primitives.h:547 -> n x n column-major per sample */
 int rdyn_joint_inertia(const rdyn_chain* chain, const rdyn_batch* batch, double* M);
 
+/* ---- normal equations of the stacked regressor (fp64 MFMA) ------------------------------------------------
+ * No counterpart inside rosdyn_core: the identification step that stacked getRegressor rows and solved the
+ * least-squares problem lived in the external rosdyn_identification (top-level README.md:15).  BASELINE.json's
+ * north star asks for the Gram reduction on the matrix cores, so it is part of this boundary.
+ *
+ * rdyn_gram: A is any column-major rows x n_cols DEVICE matrix (leading dimension lda >= rows), b a DEVICE
+ * vector of `rows` doubles or NULL.  Writes (accumulate == 0) or adds (accumulate != 0)
+ *   G  = A^T A   n_cols x n_cols column-major, both triangles      (device)
+ *   c  = A^T b   n_cols                                             (device, may be NULL)
+ *   bb = b^T b   1                                                  (device, may be NULL)
+ * with v_mfma_f64_16x16x4_f64; bitwise reproducible (fixed summation order, no atomics).
+ * workspace: rdyn_gram_workspace_bytes(n_cols) bytes of device memory. */
+size_t rdyn_gram_workspace_bytes(int n_cols);
+int rdyn_gram(const double* A, int64_t rows, int64_t lda, int n_cols, const double* b, double* G, double* c, double* bb,
+              int accumulate, void* workspace, size_t workspace_bytes, int device, void* stream);
+
+/* rdyn_regressor_gram: G, c, bb of the stacked regressor A (N*n x P) of the batch and measured torques
+ * tau_meas (same layout as batch->q) WITHOUT leaving the regressor in HBM: the batch is processed in chunks of
+ * `chunk_samples` (0 = default 32768) whose element-major regressor image (chunk * n * (P + 1) doubles, reused
+ * for every chunk, sized to stay resident in the 256 MiB Infinity Cache) is produced by the regressor kernel
+ * and consumed by the Gram kernel.  Multi-GPU: every rank calls this on its shard and all-reduces
+ * [G | c | bb] (P*P + P + 1 doubles) once -- rosdyn_amd/gram.py. */
+size_t rdyn_regressor_gram_workspace_bytes(const rdyn_chain* chain, int64_t chunk_samples);
+int rdyn_regressor_gram(const rdyn_chain* chain, const rdyn_batch* batch, const double* tau_meas, double* G, double* c,
+                        double* bb, int accumulate, int64_t chunk_samples, void* workspace, size_t workspace_bytes);
+
 #ifdef __cplusplus
 }
 #endif

@@ -71,6 +71,10 @@ SYMBOLS = {
     "rdyn_joint_torque_nonlinear": (_I, [_VP, _BP, _VP]),
     "rdyn_regressor": (_I, [_VP, _BP, _VP, _VP, _YP]),
     "rdyn_joint_inertia": (_I, [_VP, _BP, _VP]),
+    "rdyn_gram_workspace_bytes": (C.c_size_t, [_I]),
+    "rdyn_gram": (_I, [_VP, C.c_int64, C.c_int64, _I, _VP, _VP, _VP, _VP, _I, _VP, C.c_size_t, _I, _VP]),
+    "rdyn_regressor_gram_workspace_bytes": (C.c_size_t, [_VP, C.c_int64]),
+    "rdyn_regressor_gram": (_I, [_VP, _BP, _VP, _VP, _VP, _VP, _I, C.c_int64, _VP, C.c_size_t]),
 }
 
 _lib = None

@@ -225,5 +225,29 @@ class Chain(object):
         return (out, tau) if tau is not None else out
 
 
+    def getRegressorGram(self, q, Dq, DDq, tau_meas=None, layout="sample", chunk_samples=0, out=None, accumulate=False,
+                         workspace=None):
+        """Normal equations of the stacked regressor of this batch without leaving Y in HBM:
+        returns (G = A^T A (P, P), c = A^T tau_meas (P,), bb = tau_meas^T tau_meas (1,)).  include/rdyn.h: rdyn_regressor_gram."""
+        torch = _torch()
+        b, N, lay = self._batch(layout, q, Dq, DDq)
+        P = 10 * self.getJointsNumber()
+        if tau_meas is not None and (tau_meas.shape != q.shape or tau_meas.dtype != torch.float64 or not tau_meas.is_contiguous()):
+            raise ValueError("Input data dimensions mismatch")
+        if out is None:
+            out = (torch.empty((P, P), dtype=torch.float64, device=q.device), torch.empty((P,), dtype=torch.float64, device=q.device),
+                   torch.empty((1,), dtype=torch.float64, device=q.device))
+            if accumulate:
+                raise ValueError("accumulate needs out=")
+        G, c, bb = out
+        nbytes = lib().rdyn_regressor_gram_workspace_bytes(self._h, chunk_samples)
+        if workspace is None:
+            workspace = torch.empty((nbytes,), dtype=torch.uint8, device=q.device)
+        check(lib().rdyn_regressor_gram(self._h, C.byref(b), tau_meas.data_ptr() if tau_meas is not None else None,
+                                        G.data_ptr(), c.data_ptr(), bb.data_ptr(), 1 if accumulate else 0, chunk_samples,
+                                        workspace.data_ptr(), workspace.numel()))
+        return G, c, bb
+
+
 def createChain(urdf_xml, base_frame, tool_frame, gravity=(0.0, 0.0, 0.0)):
     return Chain(urdf_xml, base_frame, tool_frame, gravity)

@@ -231,6 +231,141 @@ static int run_base(const rdyn_chain* c, const rdyn_batch* b, double* T_bt, doub
   return RDYN_OK;
 }
 
+// ---- normal equations -----------------------------------------------------------------------------------
+static const int kGramBlocks = 512;  // 2 workgroups per CU; each owns one slab of the workspace
+
+static size_t gram_slab_bytes(int n_cols)
+{
+  const int nb = rdyn_gram_blocks_for(n_cols);
+  return (size_t)kGramBlocks * (size_t)(nb * (nb + 1) / 2) * 256 * sizeof(double);
+}
+
+size_t rdyn_gram_workspace_bytes(int n_cols) { return (n_cols < 1 || rdyn_gram_blocks_for(n_cols) > 7) ? 0 : gram_slab_bytes(n_cols); }
+
+static int gram_launch(const double* A, int64_t rows, int64_t lda, int n_cols, const double* bvec, double* G, double* cvec, double* bb,
+                       int slab_accumulate, bool finish, int add_to_output, void* workspace, hipStream_t st)
+{
+  RdynGramArgs a;
+  memset(&a, 0, sizeof a);
+  a.A = A;
+  a.b = bvec;
+  a.rows = rows;
+  a.lda = lda;
+  a.P = n_cols;
+  a.accumulate = slab_accumulate;
+  a.add_to_output = add_to_output;
+  a.slabs = (double*)workspace;
+  a.G = G;
+  a.c = cvec;
+  a.bb = bb;
+  RDYN_HIP_TRY(rdyn_launch_gram(a, kGramBlocks, st));
+  if (finish) RDYN_HIP_TRY(rdyn_launch_gram_finish(a, kGramBlocks, st));
+  return RDYN_OK;
+}
+
+int rdyn_gram(const double* A, int64_t rows, int64_t lda, int n_cols, const double* bvec, double* G, double* cvec, double* bb,
+              int accumulate, void* workspace, size_t workspace_bytes, int device, void* stream)
+{
+  if (!A || !G || rows < 0 || lda < rows || n_cols < 1 || !workspace)
+  {
+    rdyn_set_error("rdyn_gram: invalid argument");
+    return RDYN_ERR_INVALID_ARGUMENT;
+  }
+  if (rdyn_gram_blocks_for(n_cols) > 7)
+  {
+    rdyn_set_error("rdyn_gram: at most 111 columns are supported");
+    return RDYN_ERR_UNSUPPORTED;
+  }
+  if (workspace_bytes < gram_slab_bytes(n_cols))
+  {
+    rdyn_set_error("rdyn_gram: workspace too small (%zu < %zu bytes)", workspace_bytes, gram_slab_bytes(n_cols));
+    return RDYN_ERR_INVALID_ARGUMENT;
+  }
+  DeviceGuard g;
+  int st = g.enter(device);
+  if (st != RDYN_OK) return st;
+  return gram_launch(A, rows, lda, n_cols, bvec, G, cvec, bb, 0, true, accumulate ? 1 : 0, workspace, (hipStream_t)stream);
+}
+
+static int64_t default_chunk(int64_t chunk) { return chunk > 0 ? chunk : 32768; }
+
+size_t rdyn_regressor_gram_workspace_bytes(const rdyn_chain* c, int64_t chunk_samples)
+{
+  if (!c) return 0;
+  const int P = 10 * c->n_joints();
+  if (rdyn_gram_blocks_for(P) > 7) return 0;
+  const int64_t chunk = default_chunk(chunk_samples);
+  return gram_slab_bytes(P) + (size_t)chunk * c->n_active() * (P + 1) * sizeof(double);
+}
+
+int rdyn_regressor_gram(const rdyn_chain* c, const rdyn_batch* b, const double* tau_meas, double* G, double* cvec, double* bb,
+                        int accumulate, int64_t chunk_samples, void* workspace, size_t workspace_bytes)
+{
+  int st = check_batch(c, b, true, true, "rdyn_regressor_gram");
+  if (st != RDYN_OK) return st;
+  if (!G || !workspace)
+  {
+    rdyn_set_error("rdyn_regressor_gram: null output or workspace");
+    return RDYN_ERR_INVALID_ARGUMENT;
+  }
+  const int n = c->n_active(), P = 10 * c->n_joints();
+  if (rdyn_gram_blocks_for(P) > 7)
+  {
+    rdyn_set_error("rdyn_regressor_gram: at most 111 regressor columns are supported");
+    return RDYN_ERR_UNSUPPORTED;
+  }
+  const int64_t chunk = default_chunk(chunk_samples);
+  if (workspace_bytes < rdyn_regressor_gram_workspace_bytes(c, chunk))
+  {
+    rdyn_set_error("rdyn_regressor_gram: workspace too small");
+    return RDYN_ERR_INVALID_ARGUMENT;
+  }
+  DeviceGuard g;
+  st = g.enter(b->device);
+  if (st != RDYN_OK) return st;
+  const RdynChainConst* dc = nullptr;
+  st = device_const(c, &dc);
+  if (st != RDYN_OK) return st;
+  hipStream_t stream = (hipStream_t)b->stream;
+  double* slabs = (double*)workspace;
+  double* scratch = (double*)((char*)workspace + gram_slab_bytes(P));
+  const int64_t N = b->n_samples;
+  const int64_t in_step = (b->layout == RDYN_LAYOUT_SAMPLE_MAJOR) ? n : 1;  // pointer advance per sample
+  if (N == 0)
+  {
+    if (!accumulate)
+    {
+      RDYN_HIP_TRY(hipMemsetAsync(G, 0, sizeof(double) * P * P, stream));
+      if (cvec) RDYN_HIP_TRY(hipMemsetAsync(cvec, 0, sizeof(double) * P, stream));
+      if (bb) RDYN_HIP_TRY(hipMemsetAsync(bb, 0, sizeof(double), stream));
+    }
+    return RDYN_OK;
+  }
+  for (int64_t s0 = 0; s0 < N; s0 += chunk)
+  {
+    const int64_t cnt = (N - s0 < chunk) ? (N - s0) : chunk;
+    RdynSweepArgs a;
+    memset(&a, 0, sizeof a);
+    a.chain = dc;
+    a.q = b->q + s0 * in_step;
+    a.dq = b->dq + s0 * in_step;
+    a.ddq = b->ddq + s0 * in_step;
+    a.bcol = tau_meas ? tau_meas + s0 * in_step : nullptr;
+    a.n_samples = cnt;
+    rec_strides(b, n, &a.in_ss, &a.in_sj);  // element-major: joint stride stays the FULL batch's N
+    a.Y = scratch;                          // element-major image of this chunk: rows j * cnt + s, lda = n * cnt
+    a.y_ss = 1;
+    a.y_sr = cnt;
+    a.y_sc = (int64_t)n * cnt;
+    RDYN_HIP_TRY(rdyn_launch_local_sweep(c->n_joints(), RDYN_MODE_REGRESSOR, a, stream));
+    const bool last = (s0 + cnt >= N);
+    st = gram_launch(scratch, (int64_t)n * cnt, (int64_t)n * cnt, P, tau_meas ? scratch + (int64_t)P * n * cnt : nullptr, G, cvec, bb,
+                     s0 > 0 ? 1 : 0, last, accumulate ? 1 : 0, slabs, stream);
+    if (st != RDYN_OK) return st;
+  }
+  return RDYN_OK;
+}
+
 int rdyn_transformation(const rdyn_chain* c, const rdyn_batch* b, double* T_bt, double* T_links)
 {
   int st = check_batch(c, b, false, false, "rdyn_transformation");

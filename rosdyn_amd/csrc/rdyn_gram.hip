@@ -1,0 +1,189 @@
+// rdyn_gram.hip -- normal equations of the stacked regressor on the fp64 matrix cores (gfx950).
+//
+// No reference counterpart: rosdyn_core only produces getRegressor rows (primitives_impl.h:1295-1355); the
+// least-squares step that consumed them lived in the external rosdyn_identification (README.md:15).
+// BASELINE.json's north star asks for it: "MFMA used only for the final tall-skinny (N*ndof x 10*nlinks)
+// regressor Gram matrix".
+//
+//   Given A (rows x P, column-major, leading dimension lda) and b (rows), accumulate
+//       G = [A b]^T [A b]   ->  A^T A (P x P),  A^T b (P),  b^T b
+//   with v_mfma_f64_16x16x4_f64:  D(16x16) += Aop(16x4) * Bop(4x16),  Aop[i][k] = A[row k][16 rb + i],
+//   Bop[k][j] = A[row k][16 cb + j].  Only the NB(NB+1)/2 upper tiles are computed.
+//
+// Operand feed without any transposition: lane l (c = l & 15, g = l >> 4) loads FOUR CONSECUTIVE ROWS
+// (32 contiguous bytes) of column 16 cb + c starting at row r0 + 4 g; k-step t (t = 0..3) then uses element t of
+// every lane, i.e. rows {r0 + 4 g + t}: a permutation of which rows share a k-step, which a sum over rows does
+// not care about.  Per column the four lane groups read one full 128-byte line.
+//
+// Work split: each wave walks 16-row groups with stride (#waves * 16); per-wave tiles are summed over the block
+// in LDS, every block adds into ITS OWN slab of the workspace (no atomics, bitwise reproducible), and
+// k_gram_finish sums the slabs in fixed order and writes the symmetric result.
+#include <hip/hip_runtime.h>
+#include "rdyn_kernels.h"
+
+namespace
+{
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+typedef double d4u __attribute__((ext_vector_type(4), aligned(8)));
+
+template <int NB>
+__global__ __launch_bounds__(256) void k_gram(const RdynGramArgs a)
+{
+  constexpr int NT = NB * (NB + 1) / 2;
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int c = lane & 15, g = lane >> 4;
+  const int64_t R = a.rows;
+
+  // per-lane column base pointers (null -> column of zeros: padding beyond P + 1)
+  const double* col[NB];
+#pragma unroll
+  for (int cb = 0; cb < NB; ++cb)
+  {
+    const int p = 16 * cb + c;
+    col[cb] = (p < a.P) ? a.A + (int64_t)p * a.lda : ((p == a.P && a.b) ? a.b : nullptr);
+  }
+
+  d4 acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) acc[t] = (d4){0.0, 0.0, 0.0, 0.0};
+
+  const int64_t wstride = (int64_t)gridDim.x * 4 * 16;
+  int64_t r0 = ((int64_t)blockIdx.x * 4 + wave) * 16;
+
+  auto load = [&](int64_t rbase, d4* v) {
+    const int64_t r = rbase + 4 * g;
+#pragma unroll
+    for (int cb = 0; cb < NB; ++cb)
+    {
+      d4 x = (d4){0.0, 0.0, 0.0, 0.0};
+      if (col[cb])
+      {
+        if (r + 4 <= R)
+          x = *(const d4u*)(col[cb] + r);
+        else
+        {
+          if (r + 0 < R) x[0] = col[cb][r + 0];
+          if (r + 1 < R) x[1] = col[cb][r + 1];
+          if (r + 2 < R) x[2] = col[cb][r + 2];
+        }
+      }
+      v[cb] = x;
+    }
+  };
+
+  d4 cur[NB], nxt[NB];
+  if (r0 < R) load(r0, cur);
+  while (r0 < R)
+  {
+    const int64_t rn = r0 + wstride;
+    if (rn < R) load(rn, nxt);  // prefetch the next 16-row group behind this group's MFMAs
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+    {
+      int ti = 0;
+#pragma unroll
+      for (int cb = 0; cb < NB; ++cb)
+#pragma unroll
+        for (int rb = 0; rb <= cb; ++rb)
+        {
+          acc[ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(cur[rb][t], cur[cb][t], acc[ti], 0, 0, 0);
+          ++ti;
+        }
+    }
+#pragma unroll
+    for (int cb = 0; cb < NB; ++cb) cur[cb] = nxt[cb];
+    r0 = rn;
+  }
+
+  // ---- block reduction in LDS, then add into this block's slab
+  __shared__ double red[NT * 256];
+  for (int w = 0; w < 4; ++w)
+  {
+    if (wave == w)
+    {
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+        {
+          // C/D layout of v_mfma_f64_16x16x4_f64: row = (lane >> 4) + 4 * reg, col = lane & 15
+          const int idx = t * 256 + ((g + 4 * r) * 16 + c);
+          red[idx] = (w == 0) ? acc[t][r] : red[idx] + acc[t][r];
+        }
+    }
+    __syncthreads();
+  }
+  double* slab = a.slabs + (int64_t)blockIdx.x * (NT * 256);
+  for (int i = threadIdx.x; i < NT * 256; i += 256) slab[i] = a.accumulate ? slab[i] + red[i] : red[i];
+}
+
+// sums the per-block slabs (fixed order) and scatters the tiles into G (P x P, both triangles), c = A^T b, bb
+__global__ __launch_bounds__(256) void k_gram_finish(const RdynGramArgs a, int nb, int n_slabs)
+{
+  const int nt = nb * (nb + 1) / 2;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= nt * 256) return;
+  double s = 0.0;
+  for (int b = 0; b < n_slabs; ++b) s += a.slabs[(int64_t)b * nt * 256 + i];
+  const int t = i >> 8, e = i & 255;
+  // tile t -> (rb, cb): t = cb (cb + 1) / 2 + rb
+  int cb = 0;
+  while ((cb + 1) * (cb + 2) / 2 <= t) ++cb;
+  const int rb = t - cb * (cb + 1) / 2;
+  const int p1 = 16 * rb + (e >> 4), p2 = 16 * cb + (e & 15);
+  const int P = a.P;
+  const double prev_scale = a.add_to_output ? 1.0 : 0.0;
+  if (p1 < P && p2 < P)
+  {
+    if (rb != cb || p1 <= p2)
+    {
+      a.G[(int64_t)p2 * P + p1] = prev_scale * a.G[(int64_t)p2 * P + p1] + s;
+      if (p1 != p2) a.G[(int64_t)p1 * P + p2] = prev_scale * a.G[(int64_t)p1 * P + p2] + s;
+    }
+  }
+  else if (p2 == P && p1 < P)
+  {
+    if (a.c) a.c[p1] = prev_scale * a.c[p1] + s;
+  }
+  else if (p1 == P && p2 == P)
+  {
+    if (a.bb) a.bb[0] = prev_scale * a.bb[0] + s;
+  }
+}
+
+template <int NB>
+hipError_t launch_gram_nb(const RdynGramArgs& a, int blocks, hipStream_t st)
+{
+  hipLaunchKernelGGL((k_gram<NB>), dim3(blocks), dim3(256), 0, st, a);
+  return hipGetLastError();
+}
+
+}  // namespace
+
+int rdyn_gram_blocks_for(int P) { return (P + 1 + 15) / 16; }
+
+hipError_t rdyn_launch_gram(const RdynGramArgs& a, int blocks, hipStream_t st)
+{
+  const int nb = rdyn_gram_blocks_for(a.P);
+  switch (nb)
+  {
+  case 1: return launch_gram_nb<1>(a, blocks, st);
+  case 2: return launch_gram_nb<2>(a, blocks, st);
+  case 3: return launch_gram_nb<3>(a, blocks, st);
+  case 4: return launch_gram_nb<4>(a, blocks, st);
+  case 5: return launch_gram_nb<5>(a, blocks, st);
+  case 6: return launch_gram_nb<6>(a, blocks, st);
+  case 7: return launch_gram_nb<7>(a, blocks, st);
+  default: return hipErrorInvalidValue;
+  }
+}
+
+hipError_t rdyn_launch_gram_finish(const RdynGramArgs& a, int blocks, hipStream_t st)
+{
+  const int nb = rdyn_gram_blocks_for(a.P);
+  const int nt = nb * (nb + 1) / 2;
+  hipLaunchKernelGGL(k_gram_finish, dim3((nt * 256 + 255) / 256), dim3(256), 0, st, a, nb, blocks);
+  return hipGetLastError();
+}

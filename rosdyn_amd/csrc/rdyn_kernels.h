@@ -18,6 +18,9 @@ struct RdynSweepArgs
   int64_t y_ss, y_sr, y_sc;
   double* M;
   int64_t m_ss, m_se;
+  // regressor mode only: optional measured torque, copied into regressor column P (the "b" column of the
+  // normal equations) with the Y addressing; same layout as q.
+  const double* bcol;
 };
 
 // Base-frame kinematics outputs; record element e of sample s at out[s * X_ss + e * out_se].
@@ -34,6 +37,24 @@ struct RdynKinArgs
   double* twists;                   // 6 * links per sample
   double* dtwists; int64_t tw_ss;
 };
+
+// Gram / normal equations of a column-major rows x P matrix (rdyn_gram.hip)
+struct RdynGramArgs
+{
+  const double* A;
+  const double* b;     // may be null
+  int64_t rows, lda;
+  int P;
+  int accumulate;      // slabs += instead of slabs =
+  int add_to_output;   // finish: G/c/bb += instead of =
+  double* slabs;       // [blocks][NT * 256]
+  double* G;
+  double* c;
+  double* bb;
+};
+int rdyn_gram_blocks_for(int P);
+hipError_t rdyn_launch_gram(const RdynGramArgs& a, int blocks, hipStream_t st);
+hipError_t rdyn_launch_gram_finish(const RdynGramArgs& a, int blocks, hipStream_t st);
 
 enum { RDYN_MODE_REGRESSOR = 0, RDYN_MODE_TORQUE = 1, RDYN_MODE_INERTIA = 2 };
 

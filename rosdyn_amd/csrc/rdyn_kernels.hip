@@ -286,6 +286,18 @@ __global__ __launch_bounds__(256) void k_local_sweep(const RdynSweepArgs a)
     }
   }
 
+  if (MODE == MODE_REGRESSOR && a.bcol)
+  {
+    // measured torque -> column P of the regressor image (feeds the Gram kernel's A^T b)
+    const double* __restrict__ bp = a.bcol + s * a.in_ss;
+    const int64_t colP = (int64_t)(10 * NJ) * a.y_sc;
+#pragma unroll
+    for (int l = 0; l < NJ; ++l)
+    {
+      const int r = c->j[l].in_idx;
+      if (r >= 0) *(double*)(yblk + (r * a.y_sr + colP) * 8 + yv) = bp[r * a.in_sj];
+    }
+  }
   if (MODE == MODE_INERTIA)
   {
     const int n = c->n_active;

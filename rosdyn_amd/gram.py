@@ -1,0 +1,70 @@
+"""Normal equations of the stacked regressor: fp64-MFMA Gram reduction (librdyn_hip.so), the one multi-GPU
+exchange of the path (a single all-reduce of P*P + P + 2 doubles over RCCL/xGMI), and the small host-side
+least-squares solve.  No reference counterpart inside rosdyn_core (the identification step lived in the
+external rosdyn_identification, README.md:15); BASELINE.json's north star asks for it.
+"""
+import ctypes as C
+
+import numpy as np
+
+from ._lib import check, lib
+
+
+def gram(A, b=None, out=None, accumulate=False, workspace=None):
+    """A: (P, R) torch.float64 CUDA tensor = column-major R x P matrix (e.g. getRegressor(..., y_layout="element")
+    viewed as (P, n*N)); b: (R,) or None.  Returns (G (P, P), c (P,), bb (1,))."""
+    import torch
+    assert A.is_cuda and A.dtype == torch.float64 and A.dim() == 2 and A.is_contiguous()
+    P, R = A.shape
+    if out is None:
+        out = (torch.empty((P, P), dtype=torch.float64, device=A.device), torch.empty((P,), dtype=torch.float64, device=A.device),
+               torch.empty((1,), dtype=torch.float64, device=A.device))
+        assert not accumulate
+    G, c, bb = out
+    nbytes = lib().rdyn_gram_workspace_bytes(P)
+    if workspace is None:
+        workspace = torch.empty((nbytes,), dtype=torch.uint8, device=A.device)
+    if b is not None:
+        assert b.is_cuda and b.dtype == torch.float64 and b.numel() == R and b.is_contiguous()
+    check(lib().rdyn_gram(A.data_ptr(), R, R, P, b.data_ptr() if b is not None else None, G.data_ptr(), c.data_ptr(), bb.data_ptr(),
+                          1 if accumulate else 0, workspace.data_ptr(), workspace.numel(),
+                          A.device.index if A.device.index is not None else -1, torch.cuda.current_stream(A.device).cuda_stream))
+    return G, c, bb
+
+
+def pack_normal_equations(G, c, bb, count):
+    """[G | c | bb | count] as ONE flat fp64 buffer: the all-reduce payload."""
+    import torch
+    P = G.shape[0]
+    buf = torch.empty((P * P + P + 2,), dtype=torch.float64, device=G.device)
+    buf[:P * P] = G.reshape(-1)
+    buf[P * P:P * P + P] = c
+    buf[P * P + P] = bb.reshape(-1)[0]
+    buf[P * P + P + 1] = float(count)
+    return buf
+
+
+def unpack_normal_equations(buf, P):
+    return buf[:P * P].reshape(P, P), buf[P * P:P * P + P], buf[P * P + P:P * P + P + 1], float(buf[P * P + P + 1].item())
+
+
+def allreduce_normal_equations(G, c, bb, count, dist=None):
+    """Sum of every rank's accumulators: one all-reduce (RCCL over xGMI on GPUs, gloo in the CPU tests).
+    ~29 KB for P = 60: latency-bound, independent of the batch size."""
+    buf = pack_normal_equations(G, c, bb, count)
+    if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+    return unpack_normal_equations(buf, G.shape[0])
+
+
+def solve_base_parameters(G, c, rtol=1e-10):
+    """Minimum-norm least-squares solution of G x = c on the host (P <= 100): the stacked regressor is structurally
+    rank deficient (unobservable base-link parameters, fixed tail links), so the symmetric eigen-decomposition is
+    truncated at rtol * lambda_max.  Returns (x, rank)."""
+    Gh = np.asarray(G.detach().cpu() if hasattr(G, "detach") else G, dtype=np.float64)
+    ch = np.asarray(c.detach().cpu() if hasattr(c, "detach") else c, dtype=np.float64)
+    Gh = 0.5 * (Gh + Gh.T)
+    w, V = np.linalg.eigh(Gh)
+    keep = w > rtol * w.max()
+    x = V[:, keep] @ ((V[:, keep].T @ ch) / w[keep])
+    return x, int(keep.sum())

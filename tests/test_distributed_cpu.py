@@ -1,0 +1,61 @@
+"""world_size-2 gloo tests (CPU, no GPU): the only cross-rank exchanges of the path -- bench.py's max-over-ranks
+timing and the all-reduce of the packed normal-equation accumulators (rosdyn_amd/gram.py)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import bench
+    from rosdyn_amd.gram import allreduce_normal_equations
+    # sharding: contiguous, complete, balanced
+    sizes = bench.shard_sizes(1000003, world)
+    assert sum(sizes) == 1000003 and max(sizes) - min(sizes) <= 1
+    # time = slowest rank
+    t = bench.max_over_ranks(1.0 + rank, dist, torch.device("cpu"))
+    # accumulators: every rank holds the Gram of its own rows; the all-reduce must give the Gram of all rows
+    P, rows = 7, 50
+    rng = np.random.default_rng(1234)
+    A = rng.standard_normal((world * rows, P))
+    b = rng.standard_normal(world * rows)
+    Ar, br = A[rank * rows:(rank + 1) * rows], b[rank * rows:(rank + 1) * rows]
+    G, c, bb, cnt = allreduce_normal_equations(torch.from_numpy(Ar.T @ Ar), torch.from_numpy(Ar.T @ br),
+                                               torch.tensor([br @ br]), rows, dist)
+    ok = (np.allclose(G.numpy(), A.T @ A, rtol=1e-13, atol=1e-13) and np.allclose(c.numpy(), A.T @ b, rtol=1e-13, atol=1e-13)
+          and abs(float(bb.item()) - b @ b) < 1e-12 and cnt == world * rows and t == float(world))
+    q.put((rank, ok))
+    dist.destroy_process_group()
+
+
+def test_gloo_world2_allreduce_and_timing():
+    torch = pytest.importorskip("torch")
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(60)
+    assert res == [(0, True), (1, True)]

@@ -1,0 +1,95 @@
+"""GPU tests of the fp64-MFMA Gram path (rdyn_gram / rdyn_regressor_gram).  Oracle: numpy A.T @ A on the CPU
+oracle's regressor rows (extension row of SURVEY section 8c: no reference counterpart).
+Tolerance: ||dG||_F <= 1e-10 ||G||_F (reduction-order dependent), BASELINE.md section 3."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import FIXTURES
+
+pytestmark = pytest.mark.gpu
+GRAV = (0.0, 0.0, -9.806)
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    torch = pytest.importorskip("torch")
+    assert torch.cuda.is_available()
+    return torch
+
+
+def _fro(a, b):
+    return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300)
+
+
+@pytest.mark.parametrize("rows,P", [(16, 5), (1000, 15), (4099, 16), (12345, 60), (5000, 70), (3001, 80), (2000, 100)])
+def test_gram_exact_integers(torch_cuda, rows, P):
+    """Small-integer data: every product and partial sum is exactly representable, so G must be bit exact
+    (catches any lane/row/column mapping error of the MFMA tiles, incl. asymmetric content and ragged tails)."""
+    from rosdyn_amd.gram import gram
+    torch = torch_cuda
+    rng = np.random.default_rng(rows * 131 + P)
+    A = rng.integers(-3, 4, size=(rows, P)).astype(np.float64)
+    A[:, 0] += np.arange(rows) % 5            # asymmetric, column-dependent content
+    b = rng.integers(-2, 3, size=rows).astype(np.float64)
+    At = torch.from_numpy(np.ascontiguousarray(A.T)).cuda()   # (P, rows) = column-major rows x P
+    G, c, bb = gram(At, torch.from_numpy(b).cuda())
+    assert np.array_equal(G.cpu().numpy(), A.T @ A)
+    assert np.array_equal(c.cpu().numpy(), A.T @ b)
+    assert float(bb.item()) == float(b @ b)
+    G2, c2, bb2 = gram(At, torch.from_numpy(b).cuda(), out=(G, c, bb), accumulate=True)
+    assert np.array_equal(G2.cpu().numpy(), 2 * (A.T @ A))
+    assert float(bb2.item()) == 2 * float(b @ b)
+
+
+@pytest.mark.parametrize("urdf,base,tool,N,chunk", [("ur10_like.urdf", "base_link", "wrist_3_link", 5000, 2048),
+                                                    ("panda_like.urdf", "link0", "link7", 3000, 0),
+                                                    ("mixed_joints.urdf", "world", "tip", 2500, 1000)])
+def test_regressor_gram_matches_oracle(torch_cuda, urdf, base, tool, N, chunk):
+    from oracle.oracle import OracleChain
+    from rosdyn_amd import Chain
+    from rosdyn_amd.gram import solve_base_parameters
+    from rosdyn_amd.samples import trajectory_batch, uniform_pm1
+    torch = torch_cuda
+    path = os.path.join(FIXTURES, urdf)
+    chain, ref = Chain(path, base, tool, GRAV), OracleChain(path, base, tool, GRAV)
+    n, P = ref.n, ref.P
+    q, dq, ddq = trajectory_batch(77, N, n)
+    Y = ref.regressor(q, dq, ddq)                               # (N, n, P)
+    pi = ref.nominal_parameters()
+    tau_meas = Y @ pi + 1e-3 * uniform_pm1(99, (N, n))          # synthetic measurements
+    A = Y.reshape(N * n, P)
+    bvec = tau_meas.reshape(N * n)
+    G_ref, c_ref, bb_ref = A.T @ A, A.T @ bvec, bvec @ bvec
+    for layout in ("sample", "element"):
+        if layout == "element":
+            args = [torch.from_numpy(np.ascontiguousarray(x.T)).cuda() for x in (q, dq, ddq, tau_meas)]
+        else:
+            args = [torch.from_numpy(x).cuda() for x in (q, dq, ddq, tau_meas)]
+        G, c, bb = chain.getRegressorGram(args[0], args[1], args[2], args[3], layout=layout, chunk_samples=chunk)
+        assert _fro(G.cpu().numpy(), G_ref) <= 1e-10
+        assert _fro(c.cpu().numpy(), c_ref) <= 1e-10
+        assert abs(float(bb.item()) - bb_ref) <= 1e-10 * bb_ref
+        Gh = G.cpu().numpy()
+        assert np.array_equal(Gh, Gh.T)
+    # the recovered parameters reproduce the measured torques (base-parameter check)
+    x, rank = solve_base_parameters(G, c)
+    assert rank < P                                              # structurally rank deficient
+    assert np.abs(A @ x - bvec).max() <= 5e-3
+
+
+def test_gram_of_materialised_regressor_equals_fused(torch_cuda):
+    from rosdyn_amd import Chain
+    from rosdyn_amd.gram import gram
+    from rosdyn_amd.samples import trajectory_batch
+    torch = torch_cuda
+    chain = Chain(os.path.join(FIXTURES, "ur10_like.urdf"), "base_link", "tool0", GRAV)
+    n, P, N = 6, 70, 20000
+    q, dq, ddq = (torch.from_numpy(np.ascontiguousarray(x.T)).cuda() for x in trajectory_batch(3, N, n))
+    Y, tau = chain.getRegressor(q, dq, ddq, layout="element", with_torque=True)     # (P, n, N)
+    G1, c1, bb1 = gram(Y.reshape(P, n * N), tau.reshape(n * N))
+    G2, c2, bb2 = chain.getRegressorGram(q, dq, ddq, tau, layout="element", chunk_samples=N)   # one chunk: same order
+    assert torch.equal(G1, G2) and torch.equal(c1, c2) and torch.equal(bb1, bb2)
+    G3, _, _ = chain.getRegressorGram(q, dq, ddq, tau, layout="element", chunk_samples=4096)
+    assert float((G3 - G1).norm() / G1.norm()) <= 1e-12
