@@ -43,6 +43,33 @@ def max_over_ranks(value, dist, device):
     return float(t.item())
 
 
+def usable_cores():
+    """Host cores this process may actually use: min(CPU affinity, cgroup CPU quota).  The GPU boxes expose 256
+    logical CPUs but cap the container at 16 (cpu.max = 1600000 100000): 256 OpenMP threads there only thrash."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
+def measured_traffic(kernel_tag):
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/pmc_latest.json, written by
+    tools/summarize_prof.py from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this same command;
+    FETCH_SIZE doubled per the gfx950 correction of MI355X_MICROARCH.md section HBM).  None if no profile matches."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_latest.json")) as f:
+            d = json.load(f)
+        e = d.get(kernel_tag)
+        return float(e["traffic_bytes_per_launch"]) if e else None
+    except (OSError, ValueError, KeyError):
+        return None
+
+
 def algorithmic_bytes_per_eval(n, P):
     """3 n doubles read (q, Dq, DDq) + n written (tau) + n P written (dense Y)  -- SURVEY section 8(d)."""
     return 3 * n * 8 + n * 8 + n * P * 8
@@ -56,7 +83,7 @@ def cpu_baseline(urdf, base, tool, n, seconds, chunk=262144):
     import numpy as np
     from oracle.oracle import OracleChain
     from rosdyn_amd.samples import trajectory_batch
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     ref = OracleChain(urdf, base, tool, GRAVITY)
     q, dq, ddq = trajectory_batch(0x5EED0002, chunk, n)
     bufs = (np.ones((chunk, n)), np.ones((chunk, ref.P, n)))   # np.ones touches every output page
@@ -159,7 +186,7 @@ def main():
                                "inputs %s-major, Y layout %s" % (N, in_layout, args.y_layout),
                    "samples_per_gpu": N, "n_active": n, "n_params": P, "parallelism": "sample-sharded x%d" % world},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                     "frac": achieved / HBM_PEAK_GBPS, "traffic": measured_traffic("regressor_%s_n%d_P%d_N%d" % (args.y_layout, n, P, N)),
                      "kernel": "k_local_sweep<6, REGRESSOR>", "kernel_ms": kernel_ms,
                      "algorithmic_bytes_per_launch": b_eval * N},
     }

@@ -696,3 +696,54 @@ int orc_has_openmp(void)
   return 0;
 #endif
 }
+
+/* ------------------------------------------------------------------ harness restatement (BASELINE.json configs[0])
+ * rosdyn_core/test/rosdyn_speed_test.cpp:109-204: `ntrial` iterations; before EVERY timed call fresh q, Dq, DDq,
+ * DDDq ~ U[-1,1] (Eigen setRandom there, a seeded splitmix64 stream here); mean microseconds per call for, in the
+ * reference's order: pose, jacobian, twists, linear-acceleration twists, non-linear-acceleration twists,
+ * acceleration twists, jerk twists, joint torque, joint inertia -- plus getRegressor (not timed by the reference).
+ * Single thread.  out_us[10]. */
+#include <time.h>
+#include <stdint.h>
+static uint64_t sm64_state;
+static double sm64_pm1(void)
+{
+  uint64_t z = (sm64_state += 0x9E3779B97F4A7C15ULL);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+  z ^= z >> 31;
+  return (double)(z >> 11) * (1.0 / 4503599627370496.0) - 1.0;
+}
+static double now_us(void)
+{
+  struct timespec t;
+  clock_gettime(CLOCK_MONOTONIC, &t);
+  return t.tv_sec * 1e6 + t.tv_nsec * 1e-3;
+}
+double orc_speed_test(const orc_chain* c, int ntrial, uint64_t seed, double* out_us)
+{
+  int n = c->active_joints_number, L = c->links_number;
+  double q[ORC_MAX_LINKS], Dq[ORC_MAX_LINKS], DDq[ORC_MAX_LINKS], DDDq[ORC_MAX_LINKS];
+  double* buf = (double*)malloc(sizeof(double) * (size_t)(12 * L + 6 * n + 18 * L + n + n * n + 10 * n * c->joints_number + 64));
+  double sink = 0;
+  sm64_state = seed;
+  for (int k = 0; k < 10; k++) out_us[k] = 0;
+#define DRAW() for (int i = 0; i < n; i++) { q[i] = sm64_pm1(); Dq[i] = sm64_pm1(); DDq[i] = sm64_pm1(); DDDq[i] = sm64_pm1(); }
+#define TIMED(slot, call) { DRAW(); double t0 = now_us(); call; out_us[slot] += now_us() - t0; sink += buf[0]; }
+  for (int it = 0; it < ntrial; it++)
+  {
+    TIMED(0, orc_fk(c, q, buf));
+    TIMED(1, orc_jacobian(c, q, buf));
+    TIMED(2, orc_twist(c, q, Dq, buf));
+    { DRAW(); orc_state s; double t0 = now_us(); computeFrames(c, &s, q); computeScrews(c, &s); getDTwistLinearPart(c, &s, DDq); out_us[3] += now_us() - t0; sink += s.Dtw_lin[L - 1].v[0]; }
+    { DRAW(); orc_state s; double t0 = now_us(); computeFrames(c, &s, q); computeScrews(c, &s); getTwist(c, &s, Dq); getDTwistNonLinearPart(c, &s); out_us[4] += now_us() - t0; sink += s.Dtw_nonlin[L - 1].v[0]; }
+    TIMED(5, orc_dtwist(c, q, Dq, DDq, buf, NULL, NULL));
+    TIMED(6, orc_ddtwist(c, q, Dq, DDq, DDDq, buf));
+    TIMED(7, orc_joint_torque(c, q, Dq, DDq, NULL, buf, NULL));
+    TIMED(8, orc_joint_inertia(c, q, buf));
+    TIMED(9, orc_regressor(c, q, Dq, DDq, buf));
+  }
+  for (int k = 0; k < 10; k++) out_us[k] /= ntrial;
+  free(buf);
+  return sink;
+}

@@ -1,0 +1,116 @@
+// rdyn_speed_test.cpp -- the reference's harness (rosdyn_core/test/rosdyn_speed_test.cpp:38-211) written against
+// the C++ facade `rosdyn::Chain` of this repository (rosdyn_chain_facade.hpp), so it reads like the original:
+// 10 000 trials, fresh q/Dq/DDq ~ U[-1,1] before every timed call (seeded splitmix64 instead of the unseeded
+// Eigen setRandom of lines 111-114), mean microseconds per call, gravity (0, 0, -9.806) (lines 61-62).
+//  part 1: one sample per call through the GPU (host -> device -> kernel -> host latency; drop-in behaviour);
+//  part 2: the same 10 000 samples as ONE batched call per function on device-resident data.
+// The jerk / linear / non-linear acceleration calls of the reference are outside the accelerated path and not timed.
+// usage: rdyn_speed_test <urdf file> <base link> <tool link> [ntrial]
+#include <chrono>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <fstream>
+#include <sstream>
+
+#include <hip/hip_runtime_api.h>
+
+#include "rosdyn_chain_facade.hpp"
+
+static uint64_t g_state;
+static double pm1()
+{
+  uint64_t z = (g_state += 0x9E3779B97F4A7C15ULL);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+  z ^= z >> 31;
+  return (double)(z >> 11) * (1.0 / 4503599627370496.0) - 1.0;
+}
+static double now_us()
+{
+  return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+int main(int argc, char** argv)
+{
+  if (argc < 4)
+  {
+    std::fprintf(stderr, "usage: %s <urdf> <base> <tool> [ntrial]\n", argv[0]);
+    return 2;
+  }
+  std::ifstream f(argv[1]);
+  std::stringstream ss;
+  ss << f.rdbuf();
+  const int ntrial = argc > 4 ? std::atoi(argv[4]) : 10000;
+
+  rosdyn::ChainPtr chain = rosdyn::createChain(ss.str(), argv[2], argv[3], {0, 0, -9.806});
+  const unsigned int n_joints = chain->getActiveJointsNumber();
+  rosdyn::VectorXd q(n_joints), Dq(n_joints), DDq(n_joints);
+  auto draw = [&]() {
+    for (unsigned i = 0; i < n_joints; ++i)
+    {
+      q(i) = pm1();
+      Dq(i) = pm1();
+      DDq(i) = pm1();
+    }
+  };
+  g_state = 0x5EED0001ULL;
+  double t_pose = 0, t_jac = 0, t_vel = 0, t_acc = 0, t_torque = 0, t_inertia = 0, t_reg = 0, sink = 0;
+  chain->getJointTorque(q, Dq, DDq);  // first use uploads the chain constants
+  for (int idx = 0; idx < ntrial; idx++)
+  {
+    double t0;
+    draw(); t0 = now_us(); sink += chain->getTransformation(q)(0, 3); t_pose += now_us() - t0;
+    draw(); t0 = now_us(); sink += chain->getJacobian(q)(0, 0); t_jac += now_us() - t0;
+    draw(); t0 = now_us(); sink += chain->getTwist(q, Dq).back()(0); t_vel += now_us() - t0;
+    draw(); t0 = now_us(); sink += chain->getDTwist(q, Dq, DDq).back()(0); t_acc += now_us() - t0;
+    draw(); t0 = now_us(); sink += chain->getJointTorque(q, Dq, DDq)(0); t_torque += now_us() - t0;
+    draw(); t0 = now_us(); sink += chain->getJointInertia(q)(0, 0); t_inertia += now_us() - t0;
+    draw(); t0 = now_us(); sink += chain->getRegressor(q, Dq, DDq)(0, 0); t_reg += now_us() - t0;
+  }
+  std::printf("average on %d trials, ONE sample per call through the GPU (host round trip included):\n", ntrial);
+  std::printf("computation time pose                                  = %9.3f [us]\n", t_pose / ntrial);
+  std::printf("computation time jacobian                              = %9.3f [us]\n", t_jac / ntrial);
+  std::printf("computation time velocity twists for all links         = %9.3f [us]\n", t_vel / ntrial);
+  std::printf("computation time acceleration twists for all links     = %9.3f [us]\n", t_acc / ntrial);
+  std::printf("computation time joint torque                          = %9.3f [us]\n", t_torque / ntrial);
+  std::printf("computation time joint inertia                         = %9.3f [us]\n", t_inertia / ntrial);
+  std::printf("computation time regressor                             = %9.3f [us]\n", t_reg / ntrial);
+
+  // ---- part 2: the same number of samples as one batched call per function
+  const int N = ntrial, n = (int)n_joints, L = (int)chain->getLinksNumber(), P = 10 * (int)chain->getJointsNumber();
+  std::vector<double> h((size_t)3 * N * n);
+  for (auto& x : h) x = pm1();
+  double *d_in, *d_out;
+  (void)hipMalloc((void**)&d_in, h.size() * sizeof(double));
+  (void)hipMalloc((void**)&d_out, sizeof(double) * (size_t)N * (size_t)(n * P + n));
+  (void)hipMemcpy(d_in, h.data(), h.size() * sizeof(double), hipMemcpyHostToDevice);
+  rdyn_batch b;
+  std::memset(&b, 0, sizeof b);
+  b.n_samples = N;
+  b.q = d_in;
+  b.dq = d_in + (size_t)N * n;
+  b.ddq = d_in + (size_t)2 * N * n;
+  b.layout = RDYN_LAYOUT_ELEMENT_MAJOR;
+  b.device = -1;
+  auto timed = [&](const char* name, auto&& call) {
+    call();
+    (void)hipDeviceSynchronize();
+    const int reps = 20;
+    double t0 = now_us();
+    for (int r = 0; r < reps; ++r) call();
+    (void)hipDeviceSynchronize();
+    double us = (now_us() - t0) / reps;
+    std::printf("batched %-46s = %9.3f [us] per call of %d samples = %9.5f [us] per sample\n", name, us, N, us / N);
+  };
+  rdyn_regressor_layout yl = {1, N, (int64_t)n * N};
+  timed("pose (all links)", [&] { chain->getTransformationBatch(b, nullptr, d_out); });
+  timed("jacobian", [&] { chain->getJacobianBatch(b, d_out); });
+  timed("velocity + acceleration twists", [&] { chain->getTwistBatch(b, d_out, d_out + (size_t)6 * L * N); });
+  timed("joint torque", [&] { chain->getJointTorqueBatch(b, d_out); });
+  timed("joint inertia", [&] { chain->getJointInertiaBatch(b, d_out); });
+  timed("joint torque + regressor", [&] { chain->getRegressorBatch(b, d_out, d_out + (size_t)n * N, yl); });
+  (void)hipFree(d_in);
+  (void)hipFree(d_out);
+  return sink == 12345.678 ? 1 : 0;
+}

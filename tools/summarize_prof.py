@@ -42,3 +42,33 @@ for tag in ("fetch", "write"):
             acc[(name[:60], r.get("Counter_Name"))].append(float(r.get("Counter_Value", 0)))
     for (k, c), v in acc.items():
         print("pmc %-60s %s: n=%d avg=%.1f (KB units -> %.1f MB per launch)" % (k, c, len(v), sum(v) / len(v), sum(v) / len(v) / 1024.0))
+
+# ---- machine-readable PMC summary for bench.py's roofline.traffic (per launch, bytes)
+import json  # noqa: E402
+
+fetch, write = {}, {}
+for tag, store in (("fetch", fetch), ("write", write)):
+    acc = defaultdict(list)
+    for r in rows("pmc_%s/**/*counter_collection.csv" % tag):
+        name = r.get("Kernel_Name", "")
+        if "k_local_sweep" in name or "k_gram" in name:
+            acc[name].append(float(r.get("Counter_Value", 0)))
+    for k, v in acc.items():
+        store[k] = sum(v) / len(v)
+if len(sys.argv) > 2:
+    key = sys.argv[2]
+    names = [k for k in fetch if "k_local_sweep" in k and k in write]
+    if names:
+        k = names[0]
+        # FETCH_SIZE / WRITE_SIZE are in KB (1024 B).  gfx950: FETCH_SIZE reports 1/2 of the bytes of a coalesced
+        # streaming read (MI355X_MICROARCH.md, HBM section) -> doubled; WRITE_SIZE is exact.
+        traffic = 2.0 * fetch[k] * 1024.0 + write[k] * 1024.0
+        path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "pmc_latest.json")
+        try:
+            d = json.load(open(path))
+        except (OSError, ValueError):
+            d = {}
+        d[key] = {"kernel": k, "FETCH_SIZE_KB": fetch[k], "WRITE_SIZE_KB": write[k], "traffic_bytes_per_launch": traffic,
+                  "correction": "traffic = 2 * FETCH_SIZE * 1024 + WRITE_SIZE * 1024 (gfx950 FETCH_SIZE halving)"}
+        json.dump(d, open(path, "w"), indent=1, sort_keys=True)
+        print("wrote", path, key, traffic)
