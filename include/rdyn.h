@@ -185,6 +185,24 @@ int rdyn_regressor(const rdyn_chain* chain, const rdyn_batch* batch, double* tau
 /* getJointInertia primitives.h:547 -> n x n column-major per sample */
 int rdyn_joint_inertia(const rdyn_chain* chain, const rdyn_batch* batch, double* M);
 
+/* ---- mixed-chain batch (BASELINE.json configs[4]: 256 distinct 6-7-DOF chains x 4 096 samples) --------------
+ * One launch per group of chains with equal joint count evaluates rdyn_regressor for MANY (chain, batch) items:
+ * grid = (ceil(max samples / 256), items); every workgroup reads its item's descriptor and its chain's constants
+ * through scalar loads.  A plan freezes the items (device pointers, layouts) so that running it allocates and
+ * copies nothing (graph-capturable).  All items must live on the same device (items[0].batch.device). */
+typedef struct rdyn_multi_item
+{
+  const rdyn_chain* chain;
+  rdyn_batch batch;              /* stream field ignored */
+  double* tau;                   /* may be NULL */
+  double* Y;
+  rdyn_regressor_layout y_layout;
+} rdyn_multi_item;
+typedef struct rdyn_multi_plan rdyn_multi_plan;
+int rdyn_multi_plan_create(const rdyn_multi_item* items, int n_items, rdyn_multi_plan** out);
+int rdyn_multi_plan_regressor(const rdyn_multi_plan* plan, void* stream);
+void rdyn_multi_plan_destroy(rdyn_multi_plan* plan);
+
 /* ---- normal equations of the stacked regressor (fp64 MFMA) ------------------------------------------------
  * No counterpart inside rosdyn_core: the identification step that stacked getRegressor rows and solved the
  * least-squares problem lived in the external rosdyn_identification (top-level README.md:15).  BASELINE.json's

@@ -25,6 +25,10 @@ class RegressorLayout(C.Structure):
     _fields_ = [("stride_sample", C.c_int64), ("stride_row", C.c_int64), ("stride_col", C.c_int64)]
 
 
+class MultiItem(C.Structure):
+    _fields_ = [("chain", C.c_void_p), ("batch", Batch), ("tau", C.c_void_p), ("Y", C.c_void_p), ("y_layout", RegressorLayout)]
+
+
 class JointDesc(C.Structure):
     _fields_ = [("name", C.c_char * 64), ("urdf_type", C.c_int32), ("origin_xyz", C.c_double * 3),
                 ("origin_quat", C.c_double * 4), ("axis", C.c_double * 3), ("has_limits", C.c_int32),
@@ -71,6 +75,9 @@ SYMBOLS = {
     "rdyn_joint_torque_nonlinear": (_I, [_VP, _BP, _VP]),
     "rdyn_regressor": (_I, [_VP, _BP, _VP, _VP, _YP]),
     "rdyn_joint_inertia": (_I, [_VP, _BP, _VP]),
+    "rdyn_multi_plan_create": (_I, [_VP, _I, C.POINTER(_VP)]),
+    "rdyn_multi_plan_regressor": (_I, [_VP, _VP]),
+    "rdyn_multi_plan_destroy": (None, [_VP]),
     "rdyn_gram_workspace_bytes": (C.c_size_t, [_I]),
     "rdyn_gram": (_I, [_VP, C.c_int64, C.c_int64, _I, _VP, _VP, _VP, _VP, _I, _VP, C.c_size_t, _I, _VP]),
     "rdyn_regressor_gram_workspace_bytes": (C.c_size_t, [_VP, C.c_int64]),

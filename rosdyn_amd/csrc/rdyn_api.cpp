@@ -2,6 +2,9 @@
 // chain-constant residency per device, kernel launches.  No host<->device copies of batch data, no
 // allocation and no synchronisation after a chain's first use on a device.
 #include <cstring>
+#include <map>
+#include <memory>
+#include <vector>
 
 #include <hip/hip_runtime.h>
 
@@ -229,6 +232,103 @@ static int run_base(const rdyn_chain* c, const rdyn_batch* b, double* T_bt, doub
   a.out_se = se;
   RDYN_HIP_TRY(rdyn_launch_base_sweep(c->n_joints(), a, (hipStream_t)b->stream));
   return RDYN_OK;
+}
+
+// ---- mixed-chain batch ----------------------------------------------------------------------------------
+struct rdyn_multi_plan
+{
+  int device = 0;
+  struct Group
+  {
+    int n_joints = 0;
+    int n_items = 0;
+    int64_t max_samples = 0;
+    RdynSweepArgs* table = nullptr;  // device
+  };
+  std::vector<Group> groups;
+};
+
+int rdyn_multi_plan_create(const rdyn_multi_item* items, int n_items, rdyn_multi_plan** out)
+{
+  if (!items || n_items < 1 || !out)
+  {
+    rdyn_set_error("rdyn_multi_plan_create: invalid argument");
+    return RDYN_ERR_INVALID_ARGUMENT;
+  }
+  *out = nullptr;
+  DeviceGuard g;
+  int st = g.enter(items[0].batch.device);
+  if (st != RDYN_OK) return st;
+  std::unique_ptr<rdyn_multi_plan> plan(new rdyn_multi_plan());
+  RDYN_HIP_TRY(hipGetDevice(&plan->device));
+  std::map<int, std::vector<RdynSweepArgs>> by_nj;
+  std::map<int, int64_t> max_n;
+  for (int i = 0; i < n_items; ++i)
+  {
+    const rdyn_multi_item& it = items[i];
+    st = check_batch(it.chain, &it.batch, true, true, "rdyn_multi_plan_create");
+    if (st != RDYN_OK) return st;
+    if (it.batch.n_samples > 0 && !it.Y)
+    {
+      rdyn_set_error("rdyn_multi_plan_create: item %d has a null regressor output", i);
+      return RDYN_ERR_INVALID_ARGUMENT;
+    }
+    RdynSweepArgs a;
+    memset(&a, 0, sizeof a);
+    st = device_const(it.chain, &a.chain);
+    if (st != RDYN_OK) return st;
+    a.q = it.batch.q;
+    a.dq = it.batch.dq;
+    a.ddq = it.batch.ddq;
+    a.n_samples = it.batch.n_samples;
+    rec_strides(&it.batch, it.chain->n_active(), &a.in_ss, &a.in_sj);
+    a.tau = it.tau;
+    a.tau_ss = a.in_ss;
+    a.tau_sj = a.in_sj;
+    a.Y = it.Y;
+    a.y_ss = it.y_layout.stride_sample;
+    a.y_sr = it.y_layout.stride_row;
+    a.y_sc = it.y_layout.stride_col;
+    const int nj = it.chain->n_joints();
+    by_nj[nj].push_back(a);
+    if (a.n_samples > max_n[nj]) max_n[nj] = a.n_samples;
+  }
+  for (auto& kv : by_nj)
+  {
+    rdyn_multi_plan::Group grp;
+    grp.n_joints = kv.first;
+    grp.n_items = (int)kv.second.size();
+    grp.max_samples = max_n[kv.first];
+    RDYN_HIP_TRY(hipMalloc((void**)&grp.table, sizeof(RdynSweepArgs) * kv.second.size()));
+    plan->groups.push_back(grp);
+    RDYN_HIP_TRY(hipMemcpy(grp.table, kv.second.data(), sizeof(RdynSweepArgs) * kv.second.size(), hipMemcpyHostToDevice));
+  }
+  *out = plan.release();
+  return RDYN_OK;
+}
+
+int rdyn_multi_plan_regressor(const rdyn_multi_plan* plan, void* stream)
+{
+  if (!plan)
+  {
+    rdyn_set_error("rdyn_multi_plan_regressor: null plan");
+    return RDYN_ERR_INVALID_ARGUMENT;
+  }
+  DeviceGuard g;
+  int st = g.enter(plan->device);
+  if (st != RDYN_OK) return st;
+  for (const auto& grp : plan->groups)
+    RDYN_HIP_TRY(rdyn_launch_local_sweep_multi(grp.n_joints, RDYN_MODE_REGRESSOR, grp.table, grp.n_items, grp.max_samples, (hipStream_t)stream));
+  return RDYN_OK;
+}
+
+void rdyn_multi_plan_destroy(rdyn_multi_plan* plan)
+{
+  if (!plan) return;
+  DeviceGuard g;
+  if (g.enter(plan->device) == RDYN_OK)
+    for (auto& grp : plan->groups) (void)hipFree(grp.table);
+  delete plan;
 }
 
 // ---- normal equations -----------------------------------------------------------------------------------

@@ -93,11 +93,12 @@ enum
   MODE_INERTIA = 2
 };
 
-template <int NJ, int MODE>
-__global__ __launch_bounds__(256) void k_local_sweep(const RdynSweepArgs a)
+// `blk` = index of this 256-sample workgroup inside the batch described by `a` (blockIdx.x for both launch forms)
+template <int NJ, int MODE, class Args>
+__device__ __forceinline__ void local_sweep_body(const Args& a, const unsigned blk)
 {
   ChainPtr c = as_const(a.chain);
-  const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t s = (int64_t)blk * 256 + threadIdx.x;
   if (s >= a.n_samples) return;
 
   const double* __restrict__ qp = a.q + s * a.in_ss;
@@ -105,7 +106,7 @@ __global__ __launch_bounds__(256) void k_local_sweep(const RdynSweepArgs a)
   const double* __restrict__ ddqp = a.ddq ? a.ddq + s * a.in_ss : nullptr;
   // Y addressing = wave-uniform 64-bit base (SGPR pair) + 32-bit per-lane byte offset: the stores then use
   // the saddr form (global_store_dwordx2 voff, data, s[base]) and need no per-store 64-bit VALU add.
-  char* const yblk = (MODE == MODE_REGRESSOR) ? (char*)(a.Y + (int64_t)blockIdx.x * 256 * a.y_ss) : nullptr;
+  char* const yblk = (MODE == MODE_REGRESSOR) ? (char*)(a.Y + (int64_t)blk * 256 * a.y_ss) : nullptr;
   const uint32_t yv = (uint32_t)threadIdx.x * (uint32_t)a.y_ss * 8u;
   const int64_t y_sc_b = a.y_sc * 8;
 
@@ -330,6 +331,26 @@ __global__ __launch_bounds__(256) void k_local_sweep(const RdynSweepArgs a)
   }
 }
 
+// one chain, one batch: grid.x = ceil(N / 256)
+template <int NJ, int MODE>
+__global__ __launch_bounds__(256) void k_local_sweep(const RdynSweepArgs a)
+{
+  local_sweep_body<NJ, MODE>(a, blockIdx.x);
+}
+
+// mixed-chain batch (BASELINE.json configs[4]): blockIdx.y selects one (chain, batch) item of a device table;
+// the item descriptor and that chain's constants are wave-uniform, so both arrive by scalar loads -- the
+// per-block "re-stage" of the chain costs a few s_load_dwordx16, no LDS and no barrier.
+template <int NJ, int MODE>
+__global__ __launch_bounds__(256) void k_local_sweep_multi(const RdynSweepArgs* __restrict__ table)
+{
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wold-style-cast"
+  const RDYN_CONST_AS RdynSweepArgs* a = (const RDYN_CONST_AS RdynSweepArgs*)table + blockIdx.y;
+#pragma clang diagnostic pop
+  local_sweep_body<NJ, MODE>(*a, blockIdx.x);
+}
+
 // ---------------------------------------------------------------------------------------------------
 // Base-frame kinematics, stated as the reference states them.
 template <int NJ>
@@ -501,6 +522,31 @@ hipError_t rdyn_launch_base_sweep(int n_joints, const RdynKinArgs& a, hipStream_
 {
   if (a.n_samples <= 0) return hipSuccess;
 #define CALL(N) launch_base_nj<N>(a, st)
+  RDYN_DISPATCH_NJ(n_joints, CALL)
+#undef CALL
+}
+
+namespace
+{
+template <int NJ>
+hipError_t launch_local_multi_nj(int mode, const RdynSweepArgs* table, int n_items, int64_t max_samples, hipStream_t st)
+{
+  const dim3 grid((unsigned)((max_samples + 255) / 256), (unsigned)n_items);
+  switch (mode)
+  {
+  case MODE_REGRESSOR: hipLaunchKernelGGL((k_local_sweep_multi<NJ, MODE_REGRESSOR>), grid, dim3(256), 0, st, table); break;
+  case MODE_TORQUE: hipLaunchKernelGGL((k_local_sweep_multi<NJ, MODE_TORQUE>), grid, dim3(256), 0, st, table); break;
+  default: hipLaunchKernelGGL((k_local_sweep_multi<NJ, MODE_INERTIA>), grid, dim3(256), 0, st, table); break;
+  }
+  return hipGetLastError();
+}
+}  // namespace
+
+// `table` = device array of n_items descriptors, all for chains with `n_joints` joints; max_samples = largest batch
+hipError_t rdyn_launch_local_sweep_multi(int n_joints, int mode, const RdynSweepArgs* table, int n_items, int64_t max_samples, hipStream_t st)
+{
+  if (n_items <= 0 || max_samples <= 0) return hipSuccess;
+#define CALL(N) launch_local_multi_nj<N>(mode, table, n_items, max_samples, st)
   RDYN_DISPATCH_NJ(n_joints, CALL)
 #undef CALL
 }
