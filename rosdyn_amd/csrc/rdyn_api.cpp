@@ -146,7 +146,15 @@ int run_local(const rdyn_chain* c, const rdyn_batch* b, int mode, double* tau, d
   }
   a.M = M;
   rec_strides(b, (int64_t)n * n, &a.m_ss, &a.m_se);
-  RDYN_HIP_TRY(rdyn_launch_local_sweep(c->n_joints(), mode, a, (hipStream_t)b->stream));
+  // Row-contiguous regressor layouts (stacked column-major, per-sample Eigen image) with sample-major inputs:
+  // ceil(n/2) lanes per sample, 16-byte row-pair stores (k_rowpair_sweep) instead of 8-byte strided stores.
+  const bool rowpair = mode == RDYN_MODE_REGRESSOR && yl && yl->stride_row == 1 && n >= 2 && n <= 10 &&
+                       b->layout == RDYN_LAYOUT_SAMPLE_MAJOR && b->n_samples * ((n + 1) / 2) < (int64_t)0xFFFFFF00ll &&
+                       !getenv("RDYN_NO_ROWPAIR");
+  if (rowpair)
+    RDYN_HIP_TRY(rdyn_launch_rowpair_sweep(c->n_joints(), n, a, (hipStream_t)b->stream));
+  else
+    RDYN_HIP_TRY(rdyn_launch_local_sweep(c->n_joints(), mode, a, (hipStream_t)b->stream));
   return RDYN_OK;
 }
 

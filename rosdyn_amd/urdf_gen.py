@@ -17,10 +17,10 @@ def perturbed_urdf(base_xml, seed, amount=0.2):
             xyz = np.array([float(t) for t in e.get("xyz").split()])
             e.set("xyz", " ".join(repr(float(v)) for v in xyz * (1.0 + k[:3])))
         elif e.tag == "mass":
-            e.set("value", repr(float(e.get("value")) * (1.0 + k[0])))
+            e.set("value", repr(float(float(e.get("value")) * (1.0 + k[0]))))
         elif e.tag == "inertia":
             for a in ("ixx", "ixy", "ixz", "iyy", "iyz", "izz"):
-                e.set(a, repr(float(e.get(a, 0.0)) * (1.0 + k[0])))
+                e.set(a, repr(float(float(e.get(a, 0.0)) * (1.0 + k[0]))))
     return ET.tostring(root, encoding="unicode")
 
 

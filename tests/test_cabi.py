@@ -76,3 +76,18 @@ def test_too_many_joints_is_reported():
                      "<limit lower='-1' upper='1' effort='1' velocity='1'/></joint>" % (i, i, i + 1) for i in range(12))
     with pytest.raises(RdynError, match="at most"):
         Chain("<robot name='long'>%s%s</robot>" % (links, joints), "l0", "l12")
+
+
+def test_generated_chain_variants_ingest_identically():
+    """The perturbed URDFs of the mixed-chain workload parse the same way in the product reader and the oracle front end."""
+    from oracle.oracle import OracleChain
+    from rosdyn_amd import Chain
+    from rosdyn_amd.urdf_gen import mixed_chain_set
+    specs = mixed_chain_set(FIXTURES, n_chains=6)
+    pis = []
+    for xml, base, tool in specs:
+        c, o = Chain(xml, base, tool, (0, 0, -9.806)), OracleChain(xml, base, tool, (0, 0, -9.806))
+        assert c.getJointsName() == o.spec.joint_names
+        assert np.abs(c.getNominalParameters() - o.nominal_parameters()).max() <= 1e-15
+        pis.append(c.getNominalParameters())
+    assert not np.allclose(pis[0], pis[2]) and not np.allclose(pis[1], pis[3])   # variants differ
