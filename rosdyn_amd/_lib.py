@@ -5,7 +5,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librdyn_hip.so")
+LIB_PATH = os.environ.get("RDYN_LIB_PATH", os.path.join(_HERE, "librdyn_hip.so"))  # override: A/B builds only
 
 RDYN_MAX_JOINTS = 10
 LAYOUT_SAMPLE_MAJOR = 0

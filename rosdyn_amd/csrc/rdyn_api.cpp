@@ -152,7 +152,23 @@ int run_local(const rdyn_chain* c, const rdyn_batch* b, int mode, double* tau, d
                        b->layout == RDYN_LAYOUT_SAMPLE_MAJOR && b->n_samples * ((n + 1) / 2) < (int64_t)0xFFFFFF00ll &&
                        !getenv("RDYN_NO_ROWPAIR");
   if (rowpair)
-    RDYN_HIP_TRY(rdyn_launch_rowpair_sweep(c->n_joints(), n, a, (hipStream_t)b->stream));
+  {
+    // the kernel addresses Y with a 32-bit per-lane byte offset: split so that every launch spans < 4 GB of Y
+    const int64_t span = (a.y_ss > 0 ? a.y_ss : 1) * 8;
+    int64_t chunk = ((int64_t)0xF0000000ll / span) & ~(int64_t)255;
+    if (chunk < 256) chunk = 256;
+    for (int64_t s0 = 0; s0 < b->n_samples; s0 += chunk)
+    {
+      RdynSweepArgs p = a;
+      p.n_samples = (b->n_samples - s0 < chunk) ? b->n_samples - s0 : chunk;
+      p.q = a.q + s0 * a.in_ss;
+      p.dq = a.dq + s0 * a.in_ss;
+      p.ddq = a.ddq + s0 * a.in_ss;
+      p.Y = a.Y + s0 * a.y_ss;
+      if (a.tau) p.tau = a.tau + s0 * a.tau_ss;
+      RDYN_HIP_TRY(rdyn_launch_rowpair_sweep(c->n_joints(), n, p, (hipStream_t)b->stream));
+    }
+  }
   else
     RDYN_HIP_TRY(rdyn_launch_local_sweep(c->n_joints(), mode, a, (hipStream_t)b->stream));
   return RDYN_OK;

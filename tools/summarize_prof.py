@@ -26,7 +26,7 @@ dur = defaultdict(list)
 meta = {}
 for r in rows("trace/**/*kernel_trace.csv"):
     name = r.get("Kernel_Name", "")
-    if "k_local_sweep" in name or "k_base_sweep" in name or "k_gram" in name:
+    if any(k in name for k in ("k_local_sweep", "k_base_sweep", "k_gram", "k_rowpair")):
         dur[name].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
         meta[name] = (r.get("VGPR_Count"), r.get("Accum_VGPR_Count"), r.get("SGPR_Count"), r.get("LDS_Block_Size"), r.get("Scratch_Size"), r.get("Grid_Size"), r.get("Workgroup_Size"))
 for k, v in dur.items():
@@ -38,7 +38,7 @@ for tag in ("fetch", "write"):
     acc = defaultdict(list)
     for r in rows("pmc_%s/**/*counter_collection.csv" % tag):
         name = r.get("Kernel_Name", "")
-        if "k_local_sweep" in name or "k_base_sweep" in name or "k_gram" in name:
+        if any(k in name for k in ("k_local_sweep", "k_base_sweep", "k_gram", "k_rowpair")):
             acc[(name[:60], r.get("Counter_Name"))].append(float(r.get("Counter_Value", 0)))
     for (k, c), v in acc.items():
         print("pmc %-60s %s: n=%d avg=%.1f (KB units -> %.1f MB per launch)" % (k, c, len(v), sum(v) / len(v), sum(v) / len(v) / 1024.0))
