@@ -185,6 +185,29 @@ int rdyn_regressor(const rdyn_chain* chain, const rdyn_batch* batch, double* tau
 /* getJointInertia primitives.h:547 -> n x n column-major per sample */
 int rdyn_joint_inertia(const rdyn_chain* chain, const rdyn_batch* batch, double* M);
 
+/* ---- per-joint additive components: the extra regressor columns the identification step stacks next to
+ * getRegressor.  Reference: FirstOrderPolynomialFriction friction_polynomial1.h:45-52
+ * (columns [sign, omega]), SecondOrderPolynomialFriction friction_polynomial2.h:42-58 ([sign, omega, omega^2 sign]),
+ * IdealSpring ideal_spring.h:64-70 ([q, 1]); getTorque = regressor row * parameters.  `joint` is the index of the
+ * component's joint among the chain's ACTIVE joints (m_component_joint_number, base_component.h).
+ * Constants follow friction_polynomial1.h:72-86: min_velocity < 1e-6 -> 1e-6, max_velocity <= 0 -> 1e6. */
+typedef enum rdyn_component_type { RDYN_COMP_FRICTION1 = 0, RDYN_COMP_FRICTION2 = 1, RDYN_COMP_SPRING = 2 } rdyn_component_type;
+typedef struct rdyn_component
+{
+  int32_t type;           /* rdyn_component_type */
+  int32_t joint;          /* active-joint index */
+  double min_velocity;    /* friction/constants/min_velocity */
+  double max_velocity;    /* friction/constants/max_velocity */
+  double parameters[3];   /* nominal: {coloumb, viscous} | {coloumb, first_order_viscous, second_order_viscous} | {elasticity, offset_effort} */
+} rdyn_component;
+/* Number of regressor columns of a component list (2, 3, 2 per type). */
+int rdyn_components_columns(const rdyn_component* comps, int n_comps);
+/* C(s, j, k) -> C[s*stride_sample + j*stride_row + k*stride_col] for k < rdyn_components_columns (dense: zero outside a
+ * component's own joint row); pass Y + P*stride_col with Y's layout to append the columns to the inertial regressor.
+ * tau_add (optional, layout of batch->q): += component torques.  C or tau_add may be NULL.  At most 30 components. */
+int rdyn_components_regressor(const rdyn_component* comps, int n_comps, int n_active, const rdyn_batch* batch, double* C,
+                              const rdyn_regressor_layout* c_layout, double* tau_add);
+
 /* ---- mixed-chain batch (BASELINE.json configs[4]: 256 distinct 6-7-DOF chains x 4 096 samples) --------------
  * One launch per group of chains with equal joint count evaluates rdyn_regressor for MANY (chain, batch) items:
  * grid = (ceil(max samples / 256), items); every workgroup reads its item's descriptor and its chain's constants

@@ -25,6 +25,11 @@ class RegressorLayout(C.Structure):
     _fields_ = [("stride_sample", C.c_int64), ("stride_row", C.c_int64), ("stride_col", C.c_int64)]
 
 
+class Component(C.Structure):
+    _fields_ = [("type", C.c_int32), ("joint", C.c_int32), ("min_velocity", C.c_double), ("max_velocity", C.c_double),
+                ("parameters", C.c_double * 3)]
+
+
 class MultiItem(C.Structure):
     _fields_ = [("chain", C.c_void_p), ("batch", Batch), ("tau", C.c_void_p), ("Y", C.c_void_p), ("y_layout", RegressorLayout)]
 
@@ -75,6 +80,8 @@ SYMBOLS = {
     "rdyn_joint_torque_nonlinear": (_I, [_VP, _BP, _VP]),
     "rdyn_regressor": (_I, [_VP, _BP, _VP, _VP, _YP]),
     "rdyn_joint_inertia": (_I, [_VP, _BP, _VP]),
+    "rdyn_components_columns": (_I, [_VP, _I]),
+    "rdyn_components_regressor": (_I, [_VP, _I, _I, _BP, _VP, _YP, _VP]),
     "rdyn_multi_plan_create": (_I, [_VP, _I, C.POINTER(_VP)]),
     "rdyn_multi_plan_regressor": (_I, [_VP, _VP]),
     "rdyn_multi_plan_destroy": (None, [_VP]),

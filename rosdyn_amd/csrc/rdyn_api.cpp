@@ -258,6 +258,67 @@ static int run_base(const rdyn_chain* c, const rdyn_batch* b, double* T_bt, doub
   return RDYN_OK;
 }
 
+// ---- additive components ---------------------------------------------------------------------------------
+int rdyn_components_columns(const rdyn_component* comps, int n_comps)
+{
+  if (!comps || n_comps < 0) return -1;
+  int k = 0;
+  for (int i = 0; i < n_comps; ++i) k += (comps[i].type == RDYN_COMP_FRICTION2) ? 3 : 2;
+  return k;
+}
+
+int rdyn_components_regressor(const rdyn_component* comps, int n_comps, int n_active, const rdyn_batch* b, double* C,
+                              const rdyn_regressor_layout* cl, double* tau_add)
+{
+  if (!comps || n_comps < 1 || n_comps > RDYN_MAX_COMPONENTS || n_active < 1 || !b || (!C && !tau_add) || (C && !cl))
+  {
+    rdyn_set_error("rdyn_components_regressor: invalid argument (1..%d components, an output, a layout)", RDYN_MAX_COMPONENTS);
+    return RDYN_ERR_INVALID_ARGUMENT;
+  }
+  if (b->n_samples < 0 || (b->layout != RDYN_LAYOUT_SAMPLE_MAJOR && b->layout != RDYN_LAYOUT_ELEMENT_MAJOR) ||
+      (b->n_samples > 0 && (!b->q || !b->dq)))
+  {
+    rdyn_set_error("Input data dimensions mismatch");
+    return RDYN_ERR_INVALID_ARGUMENT;
+  }
+  RdynComponentArgs a;
+  memset(&a, 0, sizeof a);
+  for (int i = 0; i < n_comps; ++i)
+  {
+    const rdyn_component& c = comps[i];
+    if (c.type < RDYN_COMP_FRICTION1 || c.type > RDYN_COMP_SPRING || c.joint < 0 || c.joint >= n_active)
+    {
+      rdyn_set_error("rdyn_components_regressor: component %d has an invalid type or joint", i);
+      return RDYN_ERR_INVALID_ARGUMENT;
+    }
+    a.comps[i].type = c.type;
+    a.comps[i].joint = c.joint;
+    a.comps[i].min_velocity = c.min_velocity < 1e-6 ? 1e-6 : c.min_velocity;  // friction_polynomial1.h:73-78
+    a.comps[i].max_velocity = c.max_velocity <= 0 ? 1.0e6 : c.max_velocity;   // friction_polynomial1.h:81-86
+    for (int k = 0; k < 3; ++k) a.comps[i].parameters[k] = c.parameters[k];
+  }
+  if (b->n_samples == 0) return RDYN_OK;
+  DeviceGuard g;
+  int st = g.enter(b->device);
+  if (st != RDYN_OK) return st;
+  a.q = b->q;
+  a.dq = b->dq;
+  a.n_samples = b->n_samples;
+  rec_strides(b, n_active, &a.in_ss, &a.in_sj);
+  a.n_active = n_active;
+  a.n_comps = n_comps;
+  a.C = C;
+  if (cl)
+  {
+    a.c_ss = cl->stride_sample;
+    a.c_sr = cl->stride_row;
+    a.c_sc = cl->stride_col;
+  }
+  a.tau = tau_add;
+  RDYN_HIP_TRY(rdyn_launch_components(a, (hipStream_t)b->stream));
+  return RDYN_OK;
+}
+
 // ---- mixed-chain batch ----------------------------------------------------------------------------------
 struct rdyn_multi_plan
 {
@@ -367,10 +428,13 @@ static size_t gram_slab_bytes(int n_cols)
 size_t rdyn_gram_workspace_bytes(int n_cols) { return (n_cols < 1 || rdyn_gram_blocks_for(n_cols) > 7) ? 0 : gram_slab_bytes(n_cols); }
 
 static int gram_launch(const double* A, int64_t rows, int64_t lda, int n_cols, const double* bvec, double* G, double* cvec, double* bb,
-                       int slab_accumulate, bool finish, int add_to_output, void* workspace, hipStream_t st)
+                       int slab_accumulate, bool finish, int add_to_output, void* workspace, hipStream_t st,
+                       int64_t row_block = 0, const int* first_col = nullptr, int n_row_blocks = 0)
 {
   RdynGramArgs a;
   memset(&a, 0, sizeof a);
+  a.row_block = first_col ? row_block : 0;
+  for (int j = 0; first_col && j < n_row_blocks && j < RDYN_MAX_JOINTS; ++j) a.first_col[j] = first_col[j];
   a.A = A;
   a.b = bvec;
   a.rows = rows;
@@ -465,9 +529,21 @@ int rdyn_regressor_gram(const rdyn_chain* c, const rdyn_batch* b, const double* 
     }
     return RDYN_OK;
   }
+  // structural zero band of every row block (input joint j): columns < 10 * chain index of joint j
+  int first_col[RDYN_MAX_JOINTS];
+  for (int j = 0; j < n; ++j) first_col[j] = 10 * c->active[j];
+  int64_t prev_cnt = -1;
   for (int64_t s0 = 0; s0 < N; s0 += chunk)
   {
     const int64_t cnt = (N - s0 < chunk) ? (N - s0) : chunk;
+    if (cnt != prev_cnt)
+    {
+      // The sweep kernel does not store the zeros that k_gram never loads; where the image layout changes (first
+      // chunk, shorter last chunk) positions that are unwritten zeros must not hold stale data (16-row groups that
+      // straddle two row blocks read a few of them).
+      RDYN_HIP_TRY(hipMemsetAsync(scratch, 0, sizeof(double) * (size_t)cnt * n * (P + 1), stream));
+      prev_cnt = cnt;
+    }
     RdynSweepArgs a;
     memset(&a, 0, sizeof a);
     a.chain = dc;
@@ -481,10 +557,10 @@ int rdyn_regressor_gram(const rdyn_chain* c, const rdyn_batch* b, const double* 
     a.y_ss = 1;
     a.y_sr = cnt;
     a.y_sc = (int64_t)n * cnt;
-    RDYN_HIP_TRY(rdyn_launch_local_sweep(c->n_joints(), RDYN_MODE_REGRESSOR, a, stream));
+    RDYN_HIP_TRY(rdyn_launch_local_sweep(c->n_joints(), RDYN_MODE_REGRESSOR_GRAM, a, stream));
     const bool last = (s0 + cnt >= N);
     st = gram_launch(scratch, (int64_t)n * cnt, (int64_t)n * cnt, P, tau_meas ? scratch + (int64_t)P * n * cnt : nullptr, G, cvec, bb,
-                     s0 > 0 ? 1 : 0, last, accumulate ? 1 : 0, slabs, stream);
+                     s0 > 0 ? 1 : 0, last, accumulate ? 1 : 0, slabs, stream, cnt, first_col, n);
     if (st != RDYN_OK) return st;
   }
   return RDYN_OK;

@@ -15,6 +15,11 @@
 // every lane, i.e. rows {r0 + 4 g + t}: a permutation of which rows share a k-step, which a sum over rows does
 // not care about.  Per column the four lane groups read one full 128-byte line.
 //
+// Structure: in the element-major regressor image the rows of input joint j are exactly zero left of column
+// 10 * (chain index of j) (block upper-triangular Y, primitives_impl.h:1341-1347).  Column blocks that lie
+// entirely in that zero band are neither loaded nor multiplied: for n = 6 / P = 60 that removes 40 % of the MFMAs
+// and of the HBM reads, for n = 7 / P = 70 41 %.
+//
 // Work split: each wave walks 16-row groups with stride (#waves * 16); per-wave tiles are summed over the block
 // in LDS, every block adds into ITS OWN slab of the workspace (no atomics, bitwise reproducible), and
 // k_gram_finish sums the slabs in fixed order and writes the symmetric result.
@@ -27,12 +32,31 @@ namespace
 typedef double d4 __attribute__((ext_vector_type(4)));
 typedef double d4u __attribute__((ext_vector_type(4), aligned(8)));
 
+// the 4 k-steps of one 16-row group for all upper tiles (rb <= cb) whose column blocks are >= CBM
+template <int NB, int CBM>
+__device__ __forceinline__ void mfma_group(const d4* cur, d4* acc)
+{
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+  {
+    int ti = 0;
+#pragma unroll
+    for (int cb = 0; cb < NB; ++cb)
+#pragma unroll
+      for (int rb = 0; rb <= cb; ++rb)
+      {
+        if (rb >= CBM) acc[ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(cur[rb][t], cur[cb][t], acc[ti], 0, 0, 0);
+        ++ti;
+      }
+  }
+}
+
 template <int NB>
 __global__ __launch_bounds__(256) void k_gram(const RdynGramArgs a)
 {
   constexpr int NT = NB * (NB + 1) / 2;
   const int lane = threadIdx.x & 63;
-  const int wave = threadIdx.x >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // scalar: row bookkeeping stays on the SALU
   const int c = lane & 15, g = lane >> 4;
   const int64_t R = a.rows;
 
@@ -52,13 +76,29 @@ __global__ __launch_bounds__(256) void k_gram(const RdynGramArgs a)
   const int64_t wstride = (int64_t)gridDim.x * 4 * 16;
   int64_t r0 = ((int64_t)blockIdx.x * 4 + wave) * 16;
 
-  auto load = [&](int64_t rbase, d4* v) {
+  // first column block that can be non-zero for the 16-row group starting at r (wave-uniform)
+  // (rows only grow, so the row-block index is tracked incrementally: no 64-bit division per group)
+  int jb = 0;
+  int64_t bound = a.row_block;  // rows < bound belong to row block jb
+  auto cb_min_of = [&](int64_t r) -> int {
+    if (a.row_block <= 0) return 0;
+    while (r >= bound)
+    {
+      ++jb;
+      bound += a.row_block;
+    }
+    int fc = a.first_col[jb];
+    if (r + 15 >= bound && r + 15 < R && a.first_col[jb + 1] < fc) fc = a.first_col[jb + 1];
+    return fc >> 4;
+  };
+
+  auto load = [&](int64_t rbase, int cbm, d4* v) {
     const int64_t r = rbase + 4 * g;
 #pragma unroll
     for (int cb = 0; cb < NB; ++cb)
     {
       d4 x = (d4){0.0, 0.0, 0.0, 0.0};
-      if (col[cb])
+      if (cb >= cbm && col[cb])
       {
         if (r + 4 <= R)
           x = *(const d4u*)(col[cb] + r);
@@ -74,26 +114,34 @@ __global__ __launch_bounds__(256) void k_gram(const RdynGramArgs a)
   };
 
   d4 cur[NB], nxt[NB];
-  if (r0 < R) load(r0, cur);
+  int cbm = 0, cbm_n = 0;
+  if (r0 < R)
+  {
+    cbm = cb_min_of(r0);
+    load(r0, cbm, cur);
+  }
   while (r0 < R)
   {
     const int64_t rn = r0 + wstride;
-    if (rn < R) load(rn, nxt);  // prefetch the next 16-row group behind this group's MFMAs
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
+    if (rn < R)
     {
-      int ti = 0;
-#pragma unroll
-      for (int cb = 0; cb < NB; ++cb)
-#pragma unroll
-        for (int rb = 0; rb <= cb; ++rb)
-        {
-          acc[ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(cur[rb][t], cur[cb][t], acc[ti], 0, 0, 0);
-          ++ti;
-        }
+      cbm_n = cb_min_of(rn);
+      load(rn, cbm_n, nxt);  // prefetch the next 16-row group behind this group's MFMAs
+    }
+    // one straight-line MFMA block per possible zero band (wave-uniform switch, no per-tile branches)
+    switch (NB > 1 ? cbm : 0)
+    {
+    case 0: mfma_group<NB, 0>(cur, acc); break;
+    case 1: mfma_group<NB, 1>(cur, acc); break;
+    case 2: mfma_group<NB, 2>(cur, acc); break;
+    case 3: mfma_group<NB, 3>(cur, acc); break;
+    case 4: mfma_group<NB, 4>(cur, acc); break;
+    case 5: mfma_group<NB, 5>(cur, acc); break;
+    default: mfma_group<NB, 6>(cur, acc); break;
     }
 #pragma unroll
     for (int cb = 0; cb < NB; ++cb) cur[cb] = nxt[cb];
+    cbm = cbm_n;
     r0 = rn;
   }
 
@@ -119,14 +167,22 @@ __global__ __launch_bounds__(256) void k_gram(const RdynGramArgs a)
   for (int i = threadIdx.x; i < NT * 256; i += 256) slab[i] = a.accumulate ? slab[i] + red[i] : red[i];
 }
 
-// sums the per-block slabs (fixed order) and scatters the tiles into G (P x P, both triangles), c = A^T b, bb
+// sums the per-block slabs (fixed order) and scatters the tiles into G (P x P, both triangles), c = A^T b, bb.
+// One workgroup per 32 tile elements: 8 slab groups x 32 elements, slab groups reduced through LDS in fixed order.
 __global__ __launch_bounds__(256) void k_gram_finish(const RdynGramArgs a, int nb, int n_slabs)
 {
   const int nt = nb * (nb + 1) / 2;
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= nt * 256) return;
+  const int e_loc = threadIdx.x & 31, grp = threadIdx.x >> 5;
+  const int i = blockIdx.x * 32 + e_loc;
+  __shared__ double part[8][32];
   double s = 0.0;
-  for (int b = 0; b < n_slabs; ++b) s += a.slabs[(int64_t)b * nt * 256 + i];
+  if (i < nt * 256)
+    for (int b = grp; b < n_slabs; b += 8) s += a.slabs[(int64_t)b * nt * 256 + i];
+  part[grp][e_loc] = s;
+  __syncthreads();
+  if (grp != 0 || i >= nt * 256) return;
+  s = 0.0;
+  for (int k = 0; k < 8; ++k) s += part[k][e_loc];
   const int t = i >> 8, e = i & 255;
   // tile t -> (rb, cb): t = cb (cb + 1) / 2 + rb
   int cb = 0;
@@ -184,6 +240,6 @@ hipError_t rdyn_launch_gram_finish(const RdynGramArgs& a, int blocks, hipStream_
 {
   const int nb = rdyn_gram_blocks_for(a.P);
   const int nt = nb * (nb + 1) / 2;
-  hipLaunchKernelGGL(k_gram_finish, dim3((nt * 256 + 255) / 256), dim3(256), 0, st, a, nb, blocks);
+  hipLaunchKernelGGL(k_gram_finish, dim3((nt * 256 + 31) / 32), dim3(256), 0, st, a, nb, blocks);
   return hipGetLastError();
 }

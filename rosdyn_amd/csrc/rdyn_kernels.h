@@ -51,12 +51,37 @@ struct RdynGramArgs
   double* G;
   double* c;
   double* bb;
+  // Block structure of the element-major regressor image: rows [j * row_block, (j + 1) * row_block) belong to
+  // input joint j and are structurally zero in columns < first_col[j] (primitives_impl.h:690-691, 1341-1347).
+  // row_block == 0: no structure assumed.  Column blocks (16 wide) left of first_col[j] are neither loaded nor multiplied.
+  int64_t row_block;
+  int first_col[RDYN_MAX_JOINTS];
 };
 int rdyn_gram_blocks_for(int P);
 hipError_t rdyn_launch_gram(const RdynGramArgs& a, int blocks, hipStream_t st);
 hipError_t rdyn_launch_gram_finish(const RdynGramArgs& a, int blocks, hipStream_t st);
 
-enum { RDYN_MODE_REGRESSOR = 0, RDYN_MODE_TORQUE = 1, RDYN_MODE_INERTIA = 2 };
+// per-joint additive components (rdyn_components.hip); constants already sanitised by the API
+#define RDYN_MAX_COMPONENTS 30
+struct RdynComponent
+{
+  int type, joint;
+  double min_velocity, max_velocity;
+  double parameters[3];
+};
+struct RdynComponentArgs
+{
+  const double *q, *dq;
+  int64_t n_samples, in_ss, in_sj;
+  int n_active, n_comps;
+  double* C;            // may be null
+  int64_t c_ss, c_sr, c_sc;
+  double* tau;          // may be null; += component torque, same layout as q
+  RdynComponent comps[RDYN_MAX_COMPONENTS];
+};
+hipError_t rdyn_launch_components(const RdynComponentArgs& a, hipStream_t st);
+
+enum { RDYN_MODE_REGRESSOR = 0, RDYN_MODE_TORQUE = 1, RDYN_MODE_INERTIA = 2, RDYN_MODE_REGRESSOR_GRAM = 3 };
 
 hipError_t rdyn_launch_local_sweep(int n_joints, int mode, const RdynSweepArgs& a, hipStream_t st);
 hipError_t rdyn_launch_base_sweep(int n_joints, const RdynKinArgs& a, hipStream_t st);

@@ -40,8 +40,12 @@ enum
 {
   MODE_REGRESSOR = 0,
   MODE_TORQUE = 1,
-  MODE_INERTIA = 2
+  MODE_INERTIA = 2,
+  // regressor image that only the Gram kernel will read (rdyn_regressor_gram): structural zeros are stored only
+  // where k_gram still loads them, i.e. inside 16-column blocks that also hold non-zero columns of that row
+  MODE_REGRESSOR_GRAM = 3
 };
+#define RDYN_IS_REGRESSOR(MODE) ((MODE) == MODE_REGRESSOR || (MODE) == MODE_REGRESSOR_GRAM)
 
 // `blk` = index of this 256-sample workgroup inside the batch described by `a` (blockIdx.x for both launch forms)
 template <int NJ, int MODE, class Args>
@@ -56,7 +60,7 @@ __device__ __forceinline__ void local_sweep_body(const Args& a, const unsigned b
   const double* __restrict__ ddqp = a.ddq ? a.ddq + s * a.in_ss : nullptr;
   // Y addressing = wave-uniform 64-bit base (SGPR pair) + 32-bit per-lane byte offset: the stores then use
   // the saddr form (global_store_dwordx2 voff, data, s[base]) and need no per-store 64-bit VALU add.
-  char* const yblk = (MODE == MODE_REGRESSOR) ? (char*)(a.Y + (int64_t)blk * 256 * a.y_ss) : nullptr;
+  char* const yblk = RDYN_IS_REGRESSOR(MODE) ? (char*)(a.Y + (int64_t)blk * 256 * a.y_ss) : nullptr;
   const uint32_t yv = (uint32_t)threadIdx.x * (uint32_t)a.y_ss * 8u;
   const int64_t y_sc_b = a.y_sc * 8;
 
@@ -155,7 +159,7 @@ __device__ __forceinline__ void local_sweep_body(const Args& a, const unsigned b
       ja[f] = mk(0, 0, 0);
     }
 
-    if (MODE == MODE_REGRESSOR)
+    if (RDYN_IS_REGRESSOR(MODE))
     {
       // ---- closed-form wrench regressor of link f+1 in its own frame
       const V3 d = acc + cross(w, vl);
@@ -200,8 +204,11 @@ __device__ __forceinline__ void local_sweep_body(const Args& a, const unsigned b
         }
         else
         {
+          // structural zero block (row of a joint downstream of this link).  Gram image: the row's first
+          // non-zero column is 10 l, so k_gram never loads column blocks below (10 l) / 16 for it.
 #pragma unroll
-          for (int p = 0; p < 10; ++p) *(double*)(yr + p * y_sc_b + yv) = 0.0;
+          for (int p = 0; p < 10; ++p)
+            if (MODE == MODE_REGRESSOR || (10 * f + p) / 16 >= (10 * l) / 16) *(double*)(yr + p * y_sc_b + yv) = 0.0;
         }
       }
     }
@@ -237,7 +244,7 @@ __device__ __forceinline__ void local_sweep_body(const Args& a, const unsigned b
     }
   }
 
-  if (MODE == MODE_REGRESSOR && a.bcol)
+  if (RDYN_IS_REGRESSOR(MODE) && a.bcol)
   {
     // measured torque -> column P of the regressor image (feeds the Gram kernel's A^T b)
     const double* __restrict__ bp = a.bcol + s * a.in_ss;
@@ -429,6 +436,7 @@ hipError_t launch_local_nj(int mode, const RdynSweepArgs& a, hipStream_t st)
   switch (mode)
   {
   case MODE_REGRESSOR: hipLaunchKernelGGL((k_local_sweep<NJ, MODE_REGRESSOR>), dim3(grid), dim3(256), 0, st, a); break;
+  case MODE_REGRESSOR_GRAM: hipLaunchKernelGGL((k_local_sweep<NJ, MODE_REGRESSOR_GRAM>), dim3(grid), dim3(256), 0, st, a); break;
   case MODE_TORQUE: hipLaunchKernelGGL((k_local_sweep<NJ, MODE_TORQUE>), dim3(grid), dim3(256), 0, st, a); break;
   default: hipLaunchKernelGGL((k_local_sweep<NJ, MODE_INERTIA>), dim3(grid), dim3(256), 0, st, a); break;
   }
