@@ -175,8 +175,16 @@ int rdyn_jacobian(const rdyn_chain* chain, const rdyn_batch* batch, double* J);
 /* getTwist primitives.h:457 (needs q, dq) -> links_number x 6 per sample, [lin; ang] per link.
  * getDTwist primitives.h:463 (needs q, dq, ddq) -> same shape; either output may be NULL. */
 int rdyn_twist(const rdyn_chain* chain, const rdyn_batch* batch, double* twists, double* dtwists);
+/* getDTwistLinearPart (needs q, ddq) primitives.h:468, getDTwistNonLinearPart (q, dq) :473, getDDTwist (q, dq, ddq, dddq)
+ * :488 -> links_number x 6 per sample each; any output may be NULL; dddq (layout of q) only for ddtwists. */
+int rdyn_twist_parts(const rdyn_chain* chain, const rdyn_batch* batch, const double* dddq, double* dtwists_linear,
+                     double* dtwists_nonlinear, double* ddtwists);
 /* getJointTorque(q, Dq, DDq) primitives.h:540 -> n per sample */
 int rdyn_joint_torque(const rdyn_chain* chain, const rdyn_batch* batch, double* tau);
+/* getJointTorque(q, Dq, DDq, ext_wrenches_in_link_frame) primitives.h:539: ext_wrenches = links_number x 6 per sample
+ * ([force; torque] applied TO each link, in the link's frame; record layout = batch->layout).  The reference's
+ * twist-form transform of the wrench (primitives_impl.h:1255) is reproduced as it is. */
+int rdyn_joint_torque_ext(const rdyn_chain* chain, const rdyn_batch* batch, const double* ext_wrenches, double* tau);
 /* getJointTorqueNonLinearPart(q, Dq) primitives.h:541 (DDq = 0; batch->ddq ignored) */
 int rdyn_joint_torque_nonlinear(const rdyn_chain* chain, const rdyn_batch* batch, double* tau);
 /* getRegressor primitives.h:543 fused with getJointTorque: writes Y (dense, structural zeros included) and,

@@ -76,6 +76,8 @@ SYMBOLS = {
     "rdyn_transformation": (_I, [_VP, _BP, _VP, _VP]),
     "rdyn_jacobian": (_I, [_VP, _BP, _VP]),
     "rdyn_twist": (_I, [_VP, _BP, _VP, _VP]),
+    "rdyn_twist_parts": (_I, [_VP, _BP, _VP, _VP, _VP, _VP]),
+    "rdyn_joint_torque_ext": (_I, [_VP, _BP, _VP, _VP]),
     "rdyn_joint_torque": (_I, [_VP, _BP, _VP]),
     "rdyn_joint_torque_nonlinear": (_I, [_VP, _BP, _VP]),
     "rdyn_regressor": (_I, [_VP, _BP, _VP, _VP, _YP]),

@@ -174,6 +174,30 @@ class Chain(object):
         check(lib().rdyn_twist(self._h, C.byref(b), None, tw.data_ptr()))
         return tw
 
+    def _parts(self, q, Dq, DDq, DDDq, layout, which):
+        b, N, lay = self._batch(layout, q, Dq, DDq)
+        out = self._out(q, N, lay, (self.getLinksNumber(), 6))
+        ptrs = [None, None, None]
+        ptrs[which] = out.data_ptr()
+        check(lib().rdyn_twist_parts(self._h, C.byref(b), DDDq.data_ptr() if DDDq is not None else None, *ptrs))
+        return out
+
+    def getDTwistLinearPart(self, q, DDq, layout="sample"):            # primitives.h:468
+        return self._parts(q, None, DDq, None, layout, 0)
+
+    def getDTwistNonLinearPart(self, q, Dq, layout="sample"):          # primitives.h:473
+        return self._parts(q, Dq, None, None, layout, 1)
+
+    def getDDTwist(self, q, Dq, DDq, DDDq, layout="sample"):           # primitives.h:488
+        return self._parts(q, Dq, DDq, DDDq, layout, 2)
+
+    def getJointTorqueExt(self, q, Dq, DDq, ext_wrenches_in_link_frame, layout="sample", out=None):   # primitives.h:539
+        """ext: (N, L, 6) for layout="sample", (L, 6, N) for "element"."""
+        b, N, lay = self._batch(layout, q, Dq, DDq)
+        tau = self._out(q, N, lay, (self.getActiveJointsNumber(),), out)
+        check(lib().rdyn_joint_torque_ext(self._h, C.byref(b), ext_wrenches_in_link_frame.data_ptr(), tau.data_ptr()))
+        return tau
+
     # ---- dynamics, primitives.h:539-547
     def getJointTorque(self, q, Dq, DDq, layout="sample", out=None):
         b, N, lay = self._batch(layout, q, Dq, DDq)

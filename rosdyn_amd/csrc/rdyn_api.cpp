@@ -258,6 +258,69 @@ static int run_base(const rdyn_chain* c, const rdyn_batch* b, double* T_bt, doub
   return RDYN_OK;
 }
 
+// ---- split / jerk sweeps, external wrenches ---------------------------------------------------------------
+int rdyn_twist_parts(const rdyn_chain* c, const rdyn_batch* b, const double* dddq, double* dtw_lin, double* dtw_nonlin, double* ddtw)
+{
+  int st = check_batch(c, b, dtw_nonlin || ddtw, dtw_lin || ddtw, "rdyn_twist_parts");
+  if (st != RDYN_OK) return st;
+  if ((!dtw_lin && !dtw_nonlin && !ddtw) || (ddtw && !dddq && b->n_samples > 0))
+  {
+    rdyn_set_error("rdyn_twist_parts: no output, or ddtwists without dddq");
+    return RDYN_ERR_INVALID_ARGUMENT;
+  }
+  if (b->n_samples == 0) return RDYN_OK;
+  DeviceGuard g;
+  st = g.enter(b->device);
+  if (st != RDYN_OK) return st;
+  RdynKinExtArgs a;
+  memset(&a, 0, sizeof a);
+  st = device_const(c, &a.chain);
+  if (st != RDYN_OK) return st;
+  a.q = b->q;
+  a.dq = b->dq;
+  a.ddq = b->ddq;
+  a.dddq = dddq;
+  a.n_samples = b->n_samples;
+  rec_strides(b, c->n_active(), &a.in_ss, &a.in_sj);
+  rec_strides(b, 6 * (int64_t)(c->n_joints() + 1), &a.out_ss, &a.out_se);
+  a.dtw_lin = dtw_lin;
+  a.dtw_nonlin = dtw_nonlin;
+  a.ddtw = ddtw;
+  RDYN_HIP_TRY(rdyn_launch_base_ext(c->n_joints(), a, (hipStream_t)b->stream));
+  return RDYN_OK;
+}
+
+int rdyn_joint_torque_ext(const rdyn_chain* c, const rdyn_batch* b, const double* ext, double* tau)
+{
+  int st = check_batch(c, b, true, true, "rdyn_joint_torque_ext");
+  if (st != RDYN_OK) return st;
+  if ((!tau || !ext) && b->n_samples > 0)
+  {
+    rdyn_set_error("rdyn_joint_torque_ext: null argument");
+    return RDYN_ERR_INVALID_ARGUMENT;
+  }
+  if (b->n_samples == 0) return RDYN_OK;
+  DeviceGuard g;
+  st = g.enter(b->device);
+  if (st != RDYN_OK) return st;
+  RdynSweepArgs a;
+  memset(&a, 0, sizeof a);
+  st = device_const(c, &a.chain);
+  if (st != RDYN_OK) return st;
+  a.q = b->q;
+  a.dq = b->dq;
+  a.ddq = b->ddq;
+  a.n_samples = b->n_samples;
+  rec_strides(b, c->n_active(), &a.in_ss, &a.in_sj);
+  a.tau = tau;
+  a.tau_ss = a.in_ss;
+  a.tau_sj = a.in_sj;
+  a.ext = ext;
+  rec_strides(b, 6 * (int64_t)(c->n_joints() + 1), &a.ext_ss, &a.ext_se);
+  RDYN_HIP_TRY(rdyn_launch_local_sweep(c->n_joints(), RDYN_MODE_TORQUE, a, (hipStream_t)b->stream));
+  return RDYN_OK;
+}
+
 // ---- additive components ---------------------------------------------------------------------------------
 int rdyn_components_columns(const rdyn_component* comps, int n_comps)
 {

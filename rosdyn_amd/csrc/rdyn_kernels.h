@@ -21,7 +21,24 @@ struct RdynSweepArgs
   // regressor mode only: optional measured torque, copied into regressor column P (the "b" column of the
   // normal equations) with the Y addressing; same layout as q.
   const double* bcol;
+  // torque mode only: optional external wrenches, links x 6 per sample ([force; torque] in the link's own frame,
+  // applied TO the link; getWrench, primitives_impl.h:1225); element e of sample s at ext[s * ext_ss + e * ext_se]
+  const double* ext;
+  int64_t ext_ss, ext_se;
 };
+
+// split / jerk sweeps (rdyn_kin_ext.hip); every output record is links x 6
+struct RdynKinExtArgs
+{
+  const RdynChainConst* chain;
+  const double *q, *dq, *ddq, *dddq;
+  int64_t n_samples, in_ss, in_sj;
+  int64_t out_ss, out_se;
+  double* dtw_lin;
+  double* dtw_nonlin;
+  double* ddtw;
+};
+hipError_t rdyn_launch_base_ext(int n_joints, const RdynKinExtArgs& a, hipStream_t st);
 
 // Base-frame kinematics outputs; record element e of sample s at out[s * X_ss + e * out_se].
 struct RdynKinArgs

@@ -66,6 +66,7 @@ __device__ __forceinline__ void local_sweep_body(const Args& a, const unsigned b
 
   V3 w = mk(0, 0, 0), vl = mk(0, 0, 0), al = mk(0, 0, 0);
   V3 acc = mk(-c->g[0], -c->g[1], -c->g[2]);  // base "acceleration" -g: gravity enters every link's d for free
+  V3 pl = mk(0, 0, 0);  // link origin position, in link coordinates (external-wrench path only)
   V3 jl[NJ], ja[NJ];
   double tau[NJ];
   double Macc[(MODE == MODE_INERTIA) ? NJ * (NJ + 1) / 2 : 1];
@@ -219,8 +220,20 @@ __device__ __forceinline__ void local_sweep_body(const Args& a, const unsigned b
       const double m = pi[0];
       const V3 h = ld3(pi + 1);
       const V3 d = acc + cross(w, vl);
-      const V3 fo = axpy(cross(al, h) + cross(w, cross(w, h)), d, m);
-      const V3 no = symv(pi + 4, al) + cross(w, symv(pi + 4, w)) + cross(h, d);
+      V3 fo = axpy(cross(al, h) + cross(w, cross(w, h)), d, m);
+      V3 no = symv(pi + 4, al) + cross(w, symv(pi + 4, w)) + cross(h, d);
+      if (a.ext)
+      {
+        // external wrench applied TO link f+1, given in its own frame.  The reference adds
+        // spatialTranformation(-ext, T_bl) -- the TWIST-form transform with the link's absolute position
+        // (primitives_impl.h:1255, 1257); reproduced as is: in link coordinates [-(e.lin + e.ang x R^T p) ; -e.ang].
+        pl = rotT(R, pl + t);
+        const double* __restrict__ ep = a.ext + s * a.ext_ss + (int64_t)(6 * (f + 1)) * a.ext_se;
+        const V3 el = mk(ep[0], ep[a.ext_se], ep[2 * a.ext_se]);
+        const V3 ea = mk(ep[3 * a.ext_se], ep[4 * a.ext_se], ep[5 * a.ext_se]);
+        fo = fo - (el + cross(ea, pl));
+        no = no - ea;
+      }
 #pragma unroll
       for (int l = 0; l <= f; ++l)
         if (c->j[l].in_idx >= 0) tau[l] += dot(jl[l], fo) + dot(ja[l], no);
