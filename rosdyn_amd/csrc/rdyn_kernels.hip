@@ -47,265 +47,12 @@ enum
 };
 #define RDYN_IS_REGRESSOR(MODE) ((MODE) == MODE_REGRESSOR || (MODE) == MODE_REGRESSOR_GRAM)
 
-// `blk` = index of this 256-sample workgroup inside the batch described by `a` (blockIdx.x for both launch forms)
-template <int NJ, int MODE, class Args>
-__device__ __forceinline__ void local_sweep_body(const Args& a, const unsigned blk)
-{
-  ChainPtr c = as_const(a.chain);
-  const int64_t s = (int64_t)blk * 256 + threadIdx.x;
-  if (s >= a.n_samples) return;
-
-  const double* __restrict__ qp = a.q + s * a.in_ss;
-  const double* __restrict__ dqp = a.dq ? a.dq + s * a.in_ss : nullptr;
-  const double* __restrict__ ddqp = a.ddq ? a.ddq + s * a.in_ss : nullptr;
-  // Y addressing = wave-uniform 64-bit base (SGPR pair) + 32-bit per-lane byte offset: the stores then use
-  // the saddr form (global_store_dwordx2 voff, data, s[base]) and need no per-store 64-bit VALU add.
-  char* const yblk = RDYN_IS_REGRESSOR(MODE) ? (char*)(a.Y + (int64_t)blk * 256 * a.y_ss) : nullptr;
-  const uint32_t yv = (uint32_t)threadIdx.x * (uint32_t)a.y_ss * 8u;
-  const int64_t y_sc_b = a.y_sc * 8;
-
-  V3 w = mk(0, 0, 0), vl = mk(0, 0, 0), al = mk(0, 0, 0);
-  V3 acc = mk(-c->g[0], -c->g[1], -c->g[2]);  // base "acceleration" -g: gravity enters every link's d for free
-  V3 pl = mk(0, 0, 0);  // link origin position, in link coordinates (external-wrench path only)
-  V3 jl[NJ], ja[NJ];
-  double tau[NJ];
-  double Macc[(MODE == MODE_INERTIA) ? NJ * (NJ + 1) / 2 : 1];
-#pragma unroll
-  for (int l = 0; l < NJ; ++l)
-  {
-    tau[l] = 0.0;
-    jl[l] = mk(0, 0, 0);
-    ja[l] = mk(0, 0, 0);
-  }
-  if (MODE == MODE_INERTIA)
-  {
-#pragma unroll
-    for (int i = 0; i < NJ * (NJ + 1) / 2; ++i) Macc[i] = 0.0;
-  }
-
-#pragma unroll
-  for (int f = 0; f < NJ; ++f)
-  {
-    JointRef J = c->j[f];
-    const int type = J.type;
-    const int idx = J.in_idx;
-    double qf = 0.0, dqf = 0.0, ddqf = 0.0;
-    if (idx >= 0)
-    {
-      const int64_t o = idx * a.in_sj;
-      qf = qp[o];
-      if (MODE != MODE_INERTIA)
-      {
-        if (dqp) dqf = dqp[o];
-        if (ddqp) ddqf = ddqp[o];
-      }
-    }
-    // ---- parent -> child transform (Joint::computedTpc, primitives_impl.h:38-47)
-    double R[9];
-    V3 t = ld3(J.t);
-    if (type == RDYN_REVOLUTE)
-    {
-      double sn, cs;
-      sincos(qf, &sn, &cs);
-      const double oc = 1.0 - cs;
-#pragma unroll
-      for (int i = 0; i < 9; ++i) R[i] = fma(sn, J.B[i], fma(oc, J.C[i], J.A[i]));
-    }
-    else
-    {
-#pragma unroll
-      for (int i = 0; i < 9; ++i) R[i] = J.A[i];
-      if (type == RDYN_PRISMATIC) t = axpy(t, ld3(J.up), qf);
-    }
-    // ---- carry the state into the child frame (spatialTranslation + rotation, sva.h:129-133, 172-175)
-    if (MODE != MODE_INERTIA)
-    {
-      const V3 wn = rotT(R, w);
-      const V3 vn = rotT(R, vl + cross(w, t));
-      const V3 aln = rotT(R, al);
-      const V3 an = rotT(R, acc + cross(al, t));
-      w = wn; vl = vn; al = aln; acc = an;
-    }
-#pragma unroll
-    for (int l = 0; l < f; ++l)
-    {
-      if (c->j[l].in_idx >= 0)
-      {
-        const V3 nl = rotT(R, jl[l] + cross(ja[l], t));
-        ja[l] = rotT(R, ja[l]);
-        jl[l] = nl;
-      }
-    }
-    // ---- add this joint's motion (S q', (v x S) q' + S q'';  primitives_impl.h:1007-1008, 1116-1117)
-    const V3 u = ld3(J.u);
-    if (type == RDYN_REVOLUTE)
-    {
-      if (MODE != MODE_INERTIA)
-      {
-        acc = axpy(acc, cross(vl, u), dqf);
-        al = axpy(axpy(al, cross(w, u), dqf), u, ddqf);
-        w = axpy(w, u, dqf);
-      }
-      jl[f] = mk(0, 0, 0);
-      ja[f] = u;
-    }
-    else if (type == RDYN_PRISMATIC)
-    {
-      if (MODE != MODE_INERTIA)
-      {
-        acc = axpy(axpy(acc, cross(w, u), dqf), u, ddqf);
-        vl = axpy(vl, u, dqf);
-      }
-      jl[f] = u;
-      ja[f] = mk(0, 0, 0);
-    }
-
-    if (RDYN_IS_REGRESSOR(MODE))
-    {
-      // ---- closed-form wrench regressor of link f+1 in its own frame
-      const V3 d = acc + cross(w, vl);
-      const double wxy = w.x * w.y, wxz = w.x * w.z, wyz = w.y * w.z;
-      const double wxx = w.x * w.x, wyy = w.y * w.y, wzz = w.z * w.z;
-      // Bm = [al]x + [w]x[w]x   (rows b0,b1,b2)
-      const double b00 = -(wyy + wzz), b01 = wxy - al.z, b02 = wxz + al.y;
-      const double b10 = wxy + al.z, b11 = -(wxx + wzz), b12 = wyz - al.x;
-      const double b20 = wxz - al.y, b21 = wyz + al.x, b22 = -(wxx + wyy);
-      const RDYN_CONST_AS double* pi = J.pi;
-      const int64_t col0 = (int64_t)(10 * f) * a.y_sc;
-#pragma unroll
-      for (int l = 0; l < NJ; ++l)
-      {
-        const int row = c->j[l].in_idx;
-        if (row < 0) continue;
-        char* const yr = yblk + (row * a.y_sr + col0) * 8;
-        if (l <= f)
-        {
-          const V3 L = jl[l], A = ja[l];
-          const V3 dxA = cross(d, A);
-          const V3 x = cross(A, w);
-          double y[10];
-          y[0] = dot(L, d);
-          y[1] = fma(L.x, b00, fma(L.y, b10, fma(L.z, b20, dxA.x)));
-          y[2] = fma(L.x, b01, fma(L.y, b11, fma(L.z, b21, dxA.y)));
-          y[3] = fma(L.x, b02, fma(L.y, b12, fma(L.z, b22, dxA.z)));
-          y[4] = fma(A.x, al.x, x.x * w.x);
-          y[5] = fma(A.x, al.y, fma(A.y, al.x, fma(x.x, w.y, x.y * w.x)));
-          y[6] = fma(A.x, al.z, fma(A.z, al.x, fma(x.x, w.z, x.z * w.x)));
-          y[7] = fma(A.y, al.y, x.y * w.y);
-          y[8] = fma(A.y, al.z, fma(A.z, al.y, fma(x.y, w.z, x.z * w.y)));
-          y[9] = fma(A.z, al.z, x.z * w.z);
-          double tl = tau[l];
-#pragma unroll
-          for (int p = 0; p < 10; ++p)
-          {
-            tl = fma(y[p], pi[p], tl);
-            *(double*)(yr + p * y_sc_b + yv) = y[p];
-          }
-          tau[l] = tl;
-        }
-        else
-        {
-          // structural zero block (row of a joint downstream of this link).  Gram image: the row's first
-          // non-zero column is 10 l, so k_gram never loads column blocks below (10 l) / 16 for it.
-#pragma unroll
-          for (int p = 0; p < 10; ++p)
-            if (MODE == MODE_REGRESSOR || (10 * f + p) / 16 >= (10 * l) / 16) *(double*)(yr + p * y_sc_b + yv) = 0.0;
-        }
-      }
-    }
-    else if (MODE == MODE_TORQUE)
-    {
-      // ---- net wrench on link f+1 about its origin, own frame (getWrench, primitives_impl.h:1240-1250)
-      const RDYN_CONST_AS double* pi = J.pi;
-      const double m = pi[0];
-      const V3 h = ld3(pi + 1);
-      const V3 d = acc + cross(w, vl);
-      V3 fo = axpy(cross(al, h) + cross(w, cross(w, h)), d, m);
-      V3 no = symv(pi + 4, al) + cross(w, symv(pi + 4, w)) + cross(h, d);
-      if (a.ext)
-      {
-        // external wrench applied TO link f+1, given in its own frame.  The reference adds
-        // spatialTranformation(-ext, T_bl) -- the TWIST-form transform with the link's absolute position
-        // (primitives_impl.h:1255, 1257); reproduced as is: in link coordinates [-(e.lin + e.ang x R^T p) ; -e.ang].
-        pl = rotT(R, pl + t);
-        const double* __restrict__ ep = a.ext + s * a.ext_ss + (int64_t)(6 * (f + 1)) * a.ext_se;
-        const V3 el = mk(ep[0], ep[a.ext_se], ep[2 * a.ext_se]);
-        const V3 ea = mk(ep[3 * a.ext_se], ep[4 * a.ext_se], ep[5 * a.ext_se]);
-        fo = fo - (el + cross(ea, pl));
-        no = no - ea;
-      }
-#pragma unroll
-      for (int l = 0; l <= f; ++l)
-        if (c->j[l].in_idx >= 0) tau[l] += dot(jl[l], fo) + dot(ja[l], no);
-    }
-    else
-    {
-      // ---- M += J_f^T I_f J_f   (getJointInertia, primitives_impl.h:1364-1375)
-      const RDYN_CONST_AS double* pi = J.pi;
-      const double m = pi[0];
-      const V3 h = ld3(pi + 1);
-#pragma unroll
-      for (int l2 = 0; l2 <= f; ++l2)
-      {
-        if (c->j[l2].in_idx < 0) continue;
-        const V3 Il = axpy(cross(ja[l2], h), jl[l2], m);
-        const V3 Ia = cross(h, jl[l2]) + symv(pi + 4, ja[l2]);
-#pragma unroll
-        for (int l1 = 0; l1 <= l2; ++l1)
-          if (c->j[l1].in_idx >= 0) Macc[l2 * (l2 + 1) / 2 + l1] += dot(jl[l1], Il) + dot(ja[l1], Ia);
-      }
-    }
-  }
-
-  if (RDYN_IS_REGRESSOR(MODE) && a.bcol)
-  {
-    // measured torque -> column P of the regressor image (feeds the Gram kernel's A^T b)
-    const double* __restrict__ bp = a.bcol + s * a.in_ss;
-    const int64_t colP = (int64_t)(10 * NJ) * a.y_sc;
-#pragma unroll
-    for (int l = 0; l < NJ; ++l)
-    {
-      const int r = c->j[l].in_idx;
-      if (r >= 0) *(double*)(yblk + (r * a.y_sr + colP) * 8 + yv) = bp[r * a.in_sj];
-    }
-  }
-  if (MODE == MODE_INERTIA)
-  {
-    const int n = c->n_active;
-    double* __restrict__ mp = a.M + s * a.m_ss;
-#pragma unroll
-    for (int l2 = 0; l2 < NJ; ++l2)
-    {
-      const int r2 = c->j[l2].in_idx;
-      if (r2 < 0) continue;
-#pragma unroll
-      for (int l1 = 0; l1 <= l2; ++l1)
-      {
-        const int r1 = c->j[l1].in_idx;
-        if (r1 < 0) continue;
-        const double v = Macc[l2 * (l2 + 1) / 2 + l1];
-        mp[(int64_t)(r2 * n + r1) * a.m_se] = v;
-        mp[(int64_t)(r1 * n + r2) * a.m_se] = v;
-      }
-    }
-  }
-  else if (a.tau)
-  {
-    double* __restrict__ tp = a.tau + s * a.tau_ss;
-#pragma unroll
-    for (int l = 0; l < NJ; ++l)
-    {
-      const int r = c->j[l].in_idx;
-      if (r >= 0) tp[r * a.tau_sj] = tau[l];
-    }
-  }
-}
-
 // one chain, one batch: grid.x = ceil(N / 256)
 template <int NJ, int MODE>
 __global__ __launch_bounds__(256) void k_local_sweep(const RdynSweepArgs a)
 {
-  local_sweep_body<NJ, MODE>(a, blockIdx.x);
+  const unsigned blk = blockIdx.x;
+#include "rdyn_local_sweep_body.inc"
 }
 
 // mixed-chain batch (BASELINE.json configs[4]): blockIdx.y selects one (chain, batch) item of a device table;
@@ -316,9 +63,10 @@ __global__ __launch_bounds__(256) void k_local_sweep_multi(const RdynSweepArgs* 
 {
 #pragma clang diagnostic push
 #pragma clang diagnostic ignored "-Wold-style-cast"
-  const RDYN_CONST_AS RdynSweepArgs* a = (const RDYN_CONST_AS RdynSweepArgs*)table + blockIdx.y;
+  const RDYN_CONST_AS RdynSweepArgs& a = *((const RDYN_CONST_AS RdynSweepArgs*)table + blockIdx.y);
 #pragma clang diagnostic pop
-  local_sweep_body<NJ, MODE>(*a, blockIdx.x);
+  const unsigned blk = blockIdx.x;
+#include "rdyn_local_sweep_body.inc"
 }
 
 // ---------------------------------------------------------------------------------------------------

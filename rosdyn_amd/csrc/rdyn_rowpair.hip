@@ -186,14 +186,11 @@ __global__ __launch_bounds__(256) void k_rowpair_sweep(const RdynSweepArgs a, co
       if (pair)
       {
         d2u v = {y0[p], y1[p]};
-        *(d2u*)dst = v;
+        __builtin_nontemporal_store(v, (d2u*)dst);  // streaming output, never re-read here
       }
       else
-        dst[0] = y0[p];
+        __builtin_nontemporal_store(y0[p], dst);
     }
-    // keep hipcc from overlapping the next link's sincos/transform with this link's row blocks: without the
-    // fence the live set exceeds 256 VGPRs (1 wave per SIMD); with it the links are scheduled one after the other
-    __builtin_amdgcn_sched_barrier(0);
   }
   if (a.tau)
   {
