@@ -10,4 +10,4 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o bench -- p
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o bench -- python3 bench.py --steps 5 --warmup 1 --cpu-seconds 0 "$@" > /dev/null 2> $OUT/pmc_fetch.log
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o bench -- python3 bench.py --steps 5 --warmup 1 --cpu-seconds 0 "$@" > /dev/null 2> $OUT/pmc_write.log
 find $OUT -name "*.csv" | head -20
-python3 tools/summarize_prof.py $OUT | tee $OUT/summary.txt
+python3 tools/summarize_prof.py $OUT ${PMC_KEY:-} | tee $OUT/summary.txt
