@@ -75,7 +75,9 @@ __global__ __launch_bounds__(256) void k_rowpair_sweep(const RdynSweepArgs a, co
   V3 L0 = mk(0, 0, 0), A0 = mk(0, 0, 0), L1 = mk(0, 0, 0), A1 = mk(0, 0, 0);
   double tau0 = 0.0, tau1 = 0.0;
 
-#pragma unroll
+  // No per-link arrays here.  Stacked layout (NT): a ROLLED loop keeps the live set to one link (137 VGPRs, 3 waves per SIMD;
+  // fully unrolled it needs > 256) and measured 527 vs 539 us; the per-sample image measured better unrolled (671 vs 810 us).
+#pragma unroll(NT ? 1 : NJ)
   for (int f = 0; f < NJ; ++f)
   {
     JointRef J = c->j[f];
