@@ -54,6 +54,42 @@ int main(int argc, char** argv)
       DDq(i) = pm1();
     }
   };
+  if (argc > 5 && std::string(argv[5]) == "dump")
+  {
+    // numerical dump of single-sample facade calls for the parity test (tests/test_facade.py):
+    // q = 0.1 (i+1), Dq = -0.05 (i+1), DDq = 0.3 - 0.02 i
+    for (unsigned i = 0; i < n_joints; ++i)
+    {
+      q(i) = 0.1 * (i + 1);
+      Dq(i) = -0.05 * (i + 1);
+      DDq(i) = 0.3 - 0.02 * i;
+    }
+    const rosdyn::VectorXd& tau = chain->getJointTorque(q, Dq, DDq);
+    std::printf("tau");
+    for (unsigned i = 0; i < n_joints; ++i) std::printf(" %.17g", tau(i));
+    std::printf("\n");
+    rosdyn::MatrixXd Y = chain->getRegressor(q, Dq, DDq);
+    std::printf("Y");
+    for (int c = 0; c < Y.cols(); ++c)
+      for (int r = 0; r < Y.rows(); ++r) std::printf(" %.17g", Y(r, c));
+    std::printf("\n");
+    const rosdyn::MatrixXd& M = chain->getJointInertia(q);
+    std::printf("M");
+    for (int c = 0; c < M.cols(); ++c)
+      for (int r = 0; r < M.rows(); ++r) std::printf(" %.17g", M(r, c));
+    std::printf("\n");
+    const rosdyn::Affine3d& T = chain->getTransformation(q);
+    std::printf("T");
+    for (int c = 0; c < 4; ++c)
+      for (int r = 0; r < 3; ++r) std::printf(" %.17g", T(r, c));
+    std::printf("\n");
+    const rosdyn::Matrix6Xd& J = chain->getJacobian(q);
+    std::printf("J");
+    for (int c = 0; c < (int)n_joints; ++c)
+      for (int r = 0; r < 6; ++r) std::printf(" %.17g", J(r, c));
+    std::printf("\n");
+    return 0;
+  }
   g_state = 0x5EED0001ULL;
   double t_pose = 0, t_jac = 0, t_vel = 0, t_acc = 0, t_torque = 0, t_inertia = 0, t_reg = 0, sink = 0;
   chain->getJointTorque(q, Dq, DDq);  // first use uploads the chain constants

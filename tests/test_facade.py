@@ -35,3 +35,27 @@ def test_harness_runs_on_gpu():
 def test_facade_reports_reference_errors():
     r = subprocess.run([BIN, os.path.join(FIXTURES, "ur10_like.urdf"), "nope", "tool0", "1"], capture_output=True, text=True)
     assert r.returncode != 0 and "Base link not found" in r.stderr
+
+
+@pytest.mark.gpu
+def test_facade_single_sample_values_match_oracle():
+    """The C++ facade's one-sample getters (host -> device -> kernel -> host) against the CPU oracle."""
+    import numpy as np
+    from oracle.oracle import OracleChain
+    urdf = os.path.join(FIXTURES, "ur10_like.urdf")
+    r = subprocess.run([BIN, urdf, "base_link", "tool0", "1", "dump"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    vals = {l.split()[0]: np.array([float(x) for x in l.split()[1:]]) for l in r.stdout.splitlines() if l and l[0] in "tYMTJ"}
+    ref = OracleChain(urdf, "base_link", "tool0", (0.0, 0.0, -9.806))
+    n = ref.n
+    q = np.array([[0.1 * (i + 1) for i in range(n)]])
+    dq = np.array([[-0.05 * (i + 1) for i in range(n)]])
+    ddq = np.array([[0.3 - 0.02 * i for i in range(n)]])
+
+    def close(a, b):
+        assert np.abs(a - b).max() <= 1e-11 * max(1.0, np.abs(b).max())
+    close(vals["tau"], ref.joint_torque(q, dq, ddq)[0])
+    close(vals["Y"], ref.regressor(q, dq, ddq)[0].T.reshape(-1))          # column-major n x P
+    close(vals["M"], ref.joint_inertia(q)[0].T.reshape(-1))
+    close(vals["T"], ref.fk(q)[0, -1].T.reshape(-1))                       # column-major 3 x 4
+    close(vals["J"], ref.jacobian(q)[0].T.reshape(-1))                     # column-major 6 x n
