@@ -225,6 +225,44 @@ public:
     return fill6(m_Dtwists);
   }
   const Vector6d& getDTwistTool(const VectorXd& q, const VectorXd& Dq, const VectorXd& DDq) { return getDTwist(q, Dq, DDq).back(); }
+  // split / jerk sweeps, primitives.h:468-488
+  const VectorOfVector6d& getDTwistLinearPart(const VectorXd& q, const VectorXd& DDq)
+  {
+    stage(&q, nullptr, &DDq);
+    run(rdyn_twist_parts(m_h, &m_b, nullptr, out(0), nullptr, nullptr), 6 * m_links_number);
+    return fill6(m_Dtwists_linear_part);
+  }
+  const VectorOfVector6d& getDTwistNonLinearPart(const VectorXd& q, const VectorXd& Dq)
+  {
+    stage(&q, &Dq, nullptr);
+    run(rdyn_twist_parts(m_h, &m_b, nullptr, nullptr, out(0), nullptr), 6 * m_links_number);
+    return fill6(m_Dtwists_nonlinear_part);
+  }
+  const VectorOfVector6d& getDDTwist(const VectorXd& q, const VectorXd& Dq, const VectorXd& DDq, const VectorXd& DDDq)
+  {
+    stage(&q, &Dq, &DDq);
+    const size_t n = m_active_joints_number;
+    if ((size_t)DDDq.rows() != n) throw std::invalid_argument("Input data dimensions mismatch");
+    // DDDq travels behind the output area of the staging buffer (the jerk record is 6 L doubles)
+    double* d_dddq = out(6 * (size_t)m_links_number);
+    hip(hipMemcpyAsync(d_dddq, DDDq.data(), n * sizeof(double), hipMemcpyHostToDevice, nullptr));
+    run(rdyn_twist_parts(m_h, &m_b, d_dddq, nullptr, nullptr, out(0)), 6 * m_links_number);
+    return fill6(m_DDtwists);
+  }
+  // getJointTorque with external wrenches applied TO the links, in link frames (primitives.h:539)
+  const VectorXd& getJointTorque(const VectorXd& q, const VectorXd& Dq, const VectorXd& DDq, const VectorOfVector6d& ext_wrenches_in_link_frame)
+  {
+    if (ext_wrenches_in_link_frame.size() != m_links_number) throw std::invalid_argument("Input data dimensions mismatch");
+    stage(&q, &Dq, &DDq);
+    std::vector<double> e(6 * (size_t)m_links_number);
+    for (unsigned l = 0; l < m_links_number; ++l)
+      for (int i = 0; i < 6; ++i) e[6 * l + i] = ext_wrenches_in_link_frame[l](i);
+    double* d_ext = out(m_active_joints_number);
+    hip(hipMemcpyAsync(d_ext, e.data(), e.size() * sizeof(double), hipMemcpyHostToDevice, nullptr));
+    hip(hipStreamSynchronize(nullptr));  // `e` is pageable stack-owned memory
+    run(rdyn_joint_torque_ext(m_h, &m_b, d_ext, out(0)), m_active_joints_number);
+    return fillv(m_active_joint_torques);
+  }
   const VectorXd& getJointTorque(const VectorXd& q, const VectorXd& Dq, const VectorXd& DDq)
   {
     stage(&q, &Dq, &DDq);
@@ -279,7 +317,7 @@ private:
   Affine3d m_T_bt;
   VectorOfAffine3d m_T_bl;
   Matrix6Xd m_jacobian;
-  VectorOfVector6d m_twists, m_Dtwists;
+  VectorOfVector6d m_twists, m_Dtwists, m_Dtwists_linear_part, m_Dtwists_nonlinear_part, m_DDtwists;
   MatrixXd m_joint_inertia;
   // staging: pinned host + device buffers for ONE sample
   double* m_dev = nullptr;

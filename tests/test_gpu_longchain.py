@@ -17,12 +17,12 @@ def _chain_xml(nj, seed):
         typ = "prismatic" if (i % 4 == 3) else "revolute"
         joints.append(
             "<joint name='j%d' type='%s'><parent link='l%d'/><child link='l%d'/>"
-            "<origin xyz='%r %r %r' rpy='%r %r %r'/><axis xyz='%r %r %r'/>"
+            "<origin xyz='%.17g %.17g %.17g' rpy='%.17g %.17g %.17g'/><axis xyz='%.17g %.17g %.17g'/>"
             "<limit lower='-3' upper='3' effort='10' velocity='2'/></joint>"
             % (i, typ, i, i + 1, 0.2 * k[0], 0.2 * k[1], 0.15 + 0.1 * k[2], k[3], k[4], k[5], k[6], k[7], 1.0 + 0.5 * k[8]))
         links.append(
-            "<link name='l%d'><inertial><origin xyz='%r %r %r' rpy='%r %r 0'/><mass value='%r'/>"
-            "<inertia ixx='%r' ixy='%r' ixz='%r' iyy='%r' iyz='%r' izz='%r'/></inertial></link>"
+            "<link name='l%d'><inertial><origin xyz='%.17g %.17g %.17g' rpy='%.17g %.17g 0'/><mass value='%.17g'/>"
+            "<inertia ixx='%.17g' ixy='%.17g' ixz='%.17g' iyy='%.17g' iyz='%.17g' izz='%.17g'/></inertial></link>"
             % (i + 1, 0.05 * k[9], 0.05 * k[10], 0.05 * k[11], 0.3 * k[12], 0.3 * k[13], 1.5 + k[14],
                0.02, 0.002 * k[15], -0.001, 0.03, 0.0015, 0.025))
     return "<robot name='gen%d'>%s%s</robot>" % (nj, "".join(links), "".join(joints))
