@@ -91,3 +91,43 @@ def test_generated_chain_variants_ingest_identically():
         assert np.abs(c.getNominalParameters() - o.nominal_parameters()).max() <= 1e-15
         pis.append(c.getNominalParameters())
     assert not np.allclose(pis[0], pis[2]) and not np.allclose(pis[1], pis[3])   # variants differ
+
+
+def test_chain_from_desc_equals_chain_from_urdf():
+    """rdyn_chain_from_desc (for callers that already hold a parsed urdf::Model) builds the same chain as the XML path."""
+    import ctypes as C
+    from oracle import urdf_model
+    from rosdyn_amd import Chain, _lib
+    path = os.path.join(FIXTURES, "mixed_joints.urdf")
+    spec = urdf_model.load(path, "world", "tip", (0.1, 0.2, -9.0))
+    types = {0: 1, 1: 2, 2: 3, 3: 6, 4: 4, 5: 5, 6: 0}       # oracle urdf_type -> rdyn_urdf_joint_type
+    nj = spec.n_joints
+    joints = (_lib.JointDesc * nj)()
+    links = (_lib.LinkDesc * (nj + 1))()
+    for i, j in enumerate(spec.joints):
+        joints[i].name = j.name.encode()
+        joints[i].urdf_type = types[j.urdf_type]
+        joints[i].origin_xyz[:] = j.xyz
+        joints[i].origin_quat[:] = j.quat
+        joints[i].axis[:] = j.axis
+        if j.limits:
+            joints[i].has_limits = 1
+            joints[i].lower, joints[i].upper = j.limits["lower"], j.limits["upper"]
+            joints[i].velocity, joints[i].effort = j.limits["velocity"], j.limits["effort"]
+    for i, l in enumerate(spec.links):
+        links[i].name = l.name.encode()
+        links[i].has_inertial = int(l.has_inertial)
+        links[i].mass = l.mass
+        links[i].com_xyz[:] = l.xyz
+        links[i].com_quat[:] = l.quat
+        links[i].ixx, links[i].ixy, links[i].ixz, links[i].iyy, links[i].iyz, links[i].izz = l.inertia
+    desc = _lib.ChainDesc(nj, joints, links, (C.c_double * 3)(0.1, 0.2, -9.0))
+    h = C.c_void_p()
+    _lib.check(_lib.lib().rdyn_chain_from_desc(C.byref(desc), C.byref(h)))
+    a = Chain(None, None, None, _handle=h)
+    b = Chain(path, "world", "tip", (0.1, 0.2, -9.0))
+    assert a.getJointsName() == b.getJointsName() and a.getLinksName() == b.getLinksName()
+    assert a.getActiveJointsName() == b.getActiveJointsName() and a.getJointTypes() == b.getJointTypes()
+    assert np.array_equal(a.getNominalParameters(), b.getNominalParameters())
+    assert np.array_equal(a.getQMax(), b.getQMax()) and np.array_equal(a.getTauMax(), b.getTauMax())
+    assert np.array_equal(a.getGravity(), b.getGravity())
