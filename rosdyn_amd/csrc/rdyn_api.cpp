@@ -539,6 +539,10 @@ int rdyn_gram(const double* A, int64_t rows, int64_t lda, int n_cols, const doub
 }
 
 static int64_t default_chunk(int64_t chunk) { return chunk > 0 ? chunk : 32768; }
+// Fused regressor->Gram kernel: persistent workgroups, each with its own 256-sample tile image (rewritten per tile, so
+// it stays in L2 / Infinity Cache): 256 workgroups x 256 samples x n x (P + 1) doubles = 192 MB at n = 6, P = 60.
+static int fused_blocks_env() { const char* e = getenv("RDYN_FUSED_BLOCKS"); return e ? atoi(e) : 256; }
+static const int kFusedBlocks = 256;  // upper bound used for the workspace size; the launch uses fused_blocks_env()
 
 size_t rdyn_regressor_gram_workspace_bytes(const rdyn_chain* c, int64_t chunk_samples)
 {
@@ -546,7 +550,9 @@ size_t rdyn_regressor_gram_workspace_bytes(const rdyn_chain* c, int64_t chunk_sa
   const int P = 10 * c->n_joints();
   if (rdyn_gram_blocks_for(P) > 7) return 0;
   const int64_t chunk = default_chunk(chunk_samples);
-  return gram_slab_bytes(P) + (size_t)chunk * c->n_active() * (P + 1) * sizeof(double);
+  const size_t chunked = (size_t)chunk * c->n_active() * (P + 1) * sizeof(double);
+  const size_t fused = (size_t)kFusedBlocks * 256 * c->n_active() * (P + 1) * sizeof(double);  // one tile image per workgroup
+  return gram_slab_bytes(P) + (chunked > fused ? chunked : fused);
 }
 
 int rdyn_regressor_gram(const rdyn_chain* c, const rdyn_batch* b, const double* tau_meas, double* G, double* cvec, double* bb,
@@ -595,6 +601,42 @@ int rdyn_regressor_gram(const rdyn_chain* c, const rdyn_batch* b, const double* 
   // structural zero band of every row block (input joint j): columns < 10 * chain index of joint j
   int first_col[RDYN_MAX_JOINTS];
   for (int j = 0; j < n; ++j) first_col[j] = 10 * c->active[j];
+  if (chunk_samples <= 0 && !getenv("RDYN_GRAM_UNFUSED"))
+  {
+    // default: ONE persistent kernel, the regressor image never goes through HBM (rdyn_fused_gram.hip).
+    // chunk_samples > 0 selects the two-kernel chunked path below (kept for A/B and as the reference ordering).
+    RdynFusedGramArgs fa;
+    memset(&fa, 0, sizeof fa);
+    fa.sweep.chain = dc;
+    fa.sweep.q = b->q;
+    fa.sweep.dq = b->dq;
+    fa.sweep.ddq = b->ddq;
+    fa.sweep.bcol = tau_meas;
+    fa.sweep.n_samples = N;
+    rec_strides(b, n, &fa.sweep.in_ss, &fa.sweep.in_sj);
+    fa.n_active = n;
+    for (int j = 0; j < n; ++j) fa.first_col[j] = first_col[j];
+    fa.images = scratch;
+    fa.slabs = slabs;
+    if (const char* dbg = getenv("RDYN_FUSED_DEBUG")) fa.debug = atoi(dbg);
+    const int64_t tiles = (N + 255) / 256;
+    int want = fused_blocks_env();
+    if (want < 1 || want > kFusedBlocks) want = kFusedBlocks;
+    const int blocks = (int)(tiles < want ? tiles : want);
+    // structural zeros that the sweep never stores but the Gram still loads must read as zero
+    RDYN_HIP_TRY(hipMemsetAsync(scratch, 0, sizeof(double) * (size_t)blocks * 256 * n * (P + 1), stream));
+    RDYN_HIP_TRY(rdyn_launch_regressor_gram_fused(c->n_joints(), fa, blocks, stream));
+    RdynGramArgs ga;
+    memset(&ga, 0, sizeof ga);
+    ga.P = P;
+    ga.add_to_output = accumulate ? 1 : 0;
+    ga.slabs = slabs;
+    ga.G = G;
+    ga.c = cvec;  // without tau_meas the image's column P stays zero: c = 0, bb = 0
+    ga.bb = bb;
+    RDYN_HIP_TRY(rdyn_launch_gram_finish(ga, blocks, stream));
+    return RDYN_OK;
+  }
   int64_t prev_cnt = -1;
   for (int64_t s0 = 0; s0 < N; s0 += chunk)
   {

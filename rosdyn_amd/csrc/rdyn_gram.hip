@@ -25,31 +25,10 @@
 // k_gram_finish sums the slabs in fixed order and writes the symmetric result.
 #include <hip/hip_runtime.h>
 #include "rdyn_kernels.h"
+#include "rdyn_gram_common.h"
 
 namespace
 {
-
-typedef double d4 __attribute__((ext_vector_type(4)));
-typedef double d4u __attribute__((ext_vector_type(4), aligned(8)));
-
-// the 4 k-steps of one 16-row group for all upper tiles (rb <= cb) whose column blocks are >= CBM
-template <int NB, int CBM>
-__device__ __forceinline__ void mfma_group(const d4* cur, d4* acc)
-{
-#pragma unroll
-  for (int t = 0; t < 4; ++t)
-  {
-    int ti = 0;
-#pragma unroll
-    for (int cb = 0; cb < NB; ++cb)
-#pragma unroll
-      for (int rb = 0; rb <= cb; ++rb)
-      {
-        if (rb >= CBM) acc[ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(cur[rb][t], cur[cb][t], acc[ti], 0, 0, 0);
-        ++ti;
-      }
-  }
-}
 
 template <int NB>
 __global__ __launch_bounds__(256) void k_gram(const RdynGramArgs a)

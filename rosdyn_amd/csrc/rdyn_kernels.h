@@ -74,6 +74,17 @@ struct RdynGramArgs
   int64_t row_block;
   int first_col[RDYN_MAX_JOINTS];
 };
+// fused regressor -> Gram persistent kernel (rdyn_fused_gram.hip)
+struct RdynFusedGramArgs
+{
+  RdynSweepArgs sweep;   // chain, q/dq/ddq/bcol, n_samples, input strides (Y fields ignored)
+  int n_active;
+  int first_col[RDYN_MAX_JOINTS];
+  double* images;        // [blocks][(P + 1) * n * 256] per-workgroup tile images
+  double* slabs;         // [blocks][NT * 256] per-workgroup Gram slabs
+  int debug;             // timing experiments only (RDYN_FUSED_DEBUG): bit 0 skip phase 1 after the first tile, bit 1 skip phase 2
+};
+hipError_t rdyn_launch_regressor_gram_fused(int n_joints, const RdynFusedGramArgs& a, int blocks, hipStream_t st);
 int rdyn_gram_blocks_for(int P);
 hipError_t rdyn_launch_gram(const RdynGramArgs& a, int blocks, hipStream_t st);
 hipError_t rdyn_launch_gram_finish(const RdynGramArgs& a, int blocks, hipStream_t st);

@@ -46,6 +46,7 @@ enum
   MODE_REGRESSOR_GRAM = 3
 };
 #define RDYN_IS_REGRESSOR(MODE) ((MODE) == MODE_REGRESSOR || (MODE) == MODE_REGRESSOR_GRAM)
+#define RDYN_BODY_EXIT return
 
 // one chain, one batch: grid.x = ceil(N / 256)
 template <int NJ, int MODE>
