@@ -108,6 +108,39 @@ def cpu_baseline(urdf, base, tool, n, seconds, chunk=262144):
                       "single-thread rate %.3e evals/s" % (passes, chunk, dt, used, m / dt1)}
 
 
+def gram_extras(chain, q, dq, ddq, tau, in_layout, N, n, P, world, dist, dev):
+    """Outside the timed region, informational only (BASELINE.json configs[3]: normal equations of every rank's shard
+    on the fp64 matrix cores + ONE all-reduce of [G | c | bb | count] = P*P + P + 2 doubles).  Never fails the bench."""
+    import torch
+    try:
+        from rosdyn_amd._lib import lib
+        from rosdyn_amd.gram import allreduce_normal_equations
+        ws = torch.empty((lib().rdyn_regressor_gram_workspace_bytes(chain._h, 0),), dtype=torch.uint8, device=dev)
+        acc = chain.getRegressorGram(q, dq, ddq, tau, layout=in_layout, workspace=ws)
+        torch.cuda.synchronize()
+        reps = 5
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            chain.getRegressorGram(q, dq, ddq, tau, layout=in_layout, out=acc, workspace=ws)
+        torch.cuda.synchronize()
+        t_gram = (time.perf_counter() - t0) / reps
+        ex = {"regressor_gram_ms_per_rank": t_gram * 1e3, "regressor_gram_evals_per_s": N * world / max_over_ranks(t_gram, dist, dev),
+              "gram_flop_per_eval_dense_syrk": n * P * (P + 1) + 2 * n * P,
+              "allreduce_doubles": P * P + P + 2, "allreduce_us": None}
+        if dist is not None:
+            for _ in range(3):
+                allreduce_normal_equations(acc[0], acc[1], acc[2], N, dist)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(20):
+                allreduce_normal_equations(acc[0], acc[1], acc[2], N, dist)
+            torch.cuda.synchronize()
+            ex["allreduce_us"] = max_over_ranks((time.perf_counter() - t0) / 20, dist, dev) * 1e6
+        return ex
+    except Exception as e:   # informational leg: report, do not fail the run
+        return {"error": repr(e)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -116,6 +149,7 @@ def main():
     ap.add_argument("--samples", type=int, default=1000000, help="samples per GPU")
     ap.add_argument("--y-layout", default="element", choices=["element", "stacked", "per_sample"])
     ap.add_argument("--cpu-seconds", type=float, default=8.0, help="wall time of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the informational Gram/all-reduce leg after the timed region")
     args = ap.parse_args()
 
     import torch
@@ -187,9 +221,11 @@ def main():
                    "samples_per_gpu": N, "n_active": n, "n_params": P, "parallelism": "sample-sharded x%d" % world},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBPS, "traffic": measured_traffic("regressor_%s_n%d_P%d_N%d" % (args.y_layout, n, P, N)),
-                     "kernel": "k_local_sweep<6, REGRESSOR>", "kernel_ms": kernel_ms,
+                     "kernel": "k_local_sweep<6, REGRESSOR>" if elem else "k_rowpair_sweep<6>", "kernel_ms": kernel_ms,
                      "algorithmic_bytes_per_launch": b_eval * N},
     }
+    if not args.no_extras:
+        out["extras"] = gram_extras(chain, q, dq, ddq, tau, in_layout, N, n, P, world, dist if world > 1 else None, dev)
     if rank == 0 and world == 1 and args.cpu_seconds > 0:
         out["cpu_baseline"] = cpu_baseline(urdf, base, tool, n, args.cpu_seconds)
     if rank == 0:
