@@ -601,7 +601,65 @@ int rdyn_regressor_gram(const rdyn_chain* c, const rdyn_batch* b, const double* 
   // structural zero band of every row block (input joint j): columns < 10 * chain index of joint j
   int first_col[RDYN_MAX_JOINTS];
   for (int j = 0; j < n; ++j) first_col[j] = 10 * c->active[j];
-  if (chunk_samples <= 0 && !getenv("RDYN_GRAM_UNFUSED"))
+  const char* path_env = getenv("RDYN_GRAM_PATH");  // A/B only: "lds" (default when eligible), "image", "two"
+  const bool want_lds = !path_env || !strcmp(path_env, "lds");
+  if (chunk_samples <= 0 && !getenv("RDYN_GRAM_UNFUSED") && want_lds && n >= 2 && n <= 8)
+  {
+    // LDS-resident path (rdyn_lds_gram.hip): needs input joints in chain order (rows of a link's columns are a prefix)
+    // and four tiles inside 160 KB of LDS.
+    bool monotonic = true;
+    for (int j = 1; j < n; ++j) monotonic = monotonic && c->active[j] > c->active[j - 1];
+    RdynLdsGramArgs la;
+    memset(&la, 0, sizeof la);
+    const int nJ = c->n_joints();
+    int off = 0;
+    for (int f = 0; f < nJ; ++f)
+    {
+      int m = 0;
+      for (int j = 0; j < n; ++j) m += (c->active[j] <= f) ? 1 : 0;
+      la.lds_m[f] = m;
+      la.lds_stride[f] = (16 * m + 4) * 8;
+      la.lds_off[f] = off;
+      off += 10 * la.lds_stride[f];
+    }
+    la.lds_off_b = off;
+    off += (16 * n + 4) * 8;
+    la.tile_bytes = (off + 255) & ~255;
+    const int nb = rdyn_gram_blocks_for(P);
+    size_t lds_bytes = 4 * (size_t)la.tile_bytes;
+    const size_t red_bytes = (size_t)(nb * (nb + 1) / 2) * 256 * sizeof(double);
+    if (lds_bytes < red_bytes) lds_bytes = red_bytes;
+    if (monotonic && lds_bytes <= 160 * 1024)
+    {
+      la.chain = dc;
+      la.q = b->q;
+      la.dq = b->dq;
+      la.ddq = b->ddq;
+      la.bcol = tau_meas;
+      la.n_samples = N;
+      rec_strides(b, n, &la.in_ss, &la.in_sj);
+      la.n_active = n;
+      for (int j = 0; j < n; ++j) la.first_col[j] = first_col[j];
+      la.slabs = slabs;
+      if (const char* dbg = getenv("RDYN_FUSED_DEBUG")) la.debug = atoi(dbg);
+      const int64_t tiles = (N + 15) / 16;
+      int want = fused_blocks_env();
+      if (want < 1 || want > kFusedBlocks) want = kFusedBlocks;
+      const int blocks = (int)((tiles + 3) / 4 < want ? (tiles + 3) / 4 : want);
+      RDYN_HIP_TRY(rdyn_launch_regressor_gram_lds(P, la, blocks, lds_bytes, stream));
+      RdynGramArgs ga;
+      memset(&ga, 0, sizeof ga);
+      ga.P = P;
+      ga.add_to_output = accumulate ? 1 : 0;
+      ga.slabs = slabs;
+      ga.G = G;
+      ga.c = cvec;
+      ga.bb = bb;
+      RDYN_HIP_TRY(rdyn_launch_gram_finish(ga, blocks, stream));
+      return RDYN_OK;
+    }
+  }
+  if (chunk_samples <= 0 && !getenv("RDYN_GRAM_UNFUSED") && (!path_env || strcmp(path_env, "two")))
   {
     // default: ONE persistent kernel, the regressor image never goes through HBM (rdyn_fused_gram.hip).
     // chunk_samples > 0 selects the two-kernel chunked path below (kept for A/B and as the reference ordering).

@@ -85,6 +85,24 @@ struct RdynFusedGramArgs
   int debug;             // timing experiments only (RDYN_FUSED_DEBUG): bit 0 skip phase 1 after the first tile, bit 1 skip phase 2
 };
 hipError_t rdyn_launch_regressor_gram_fused(int n_joints, const RdynFusedGramArgs& a, int blocks, hipStream_t st);
+
+// LDS-resident regressor -> Gram kernel (rdyn_lds_gram.hip): 16 samples per wave, packed column-major tile in LDS
+struct RdynLdsGramArgs
+{
+  const RdynChainConst* chain;
+  const double *q, *dq, *ddq, *bcol;   // bcol may be null
+  int64_t n_samples, in_ss, in_sj;
+  int n_active;
+  int first_col[RDYN_MAX_JOINTS];      // per input joint: 10 * chain index
+  int lds_off[RDYN_MAX_JOINTS];        // per link: byte offset of its first column in the tile
+  int lds_stride[RDYN_MAX_JOINTS];     // per link: bytes between its columns = (16 m_f + 4) * 8
+  int lds_m[RDYN_MAX_JOINTS];          // per link: number of input joints whose rows can be non-zero (stored rows = 16 m_f)
+  int lds_off_b;                       // byte offset of column P (measured torque), 16 n rows
+  int tile_bytes;                      // one wave's tile
+  double* slabs;
+  int debug;                           // timing experiments only (RDYN_FUSED_DEBUG): bit 0 sweep only the first tile, bit 1 no Gram phase
+};
+hipError_t rdyn_launch_regressor_gram_lds(int n_cols, const RdynLdsGramArgs& a, int blocks, size_t lds_bytes, hipStream_t st);
 int rdyn_gram_blocks_for(int P);
 hipError_t rdyn_launch_gram(const RdynGramArgs& a, int blocks, hipStream_t st);
 hipError_t rdyn_launch_gram_finish(const RdynGramArgs& a, int blocks, hipStream_t st);

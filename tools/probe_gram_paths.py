@@ -19,7 +19,8 @@ for name, urdf, base, tool, N in (("cfg2", "ur10_like.urdf", "base_link", "wrist
     ref = None
     # (a third variant -- the two kernels software-pipelined over two images and a helper stream -- measured 1.50 ms vs
     #  1.41 ms serial vs 1.12 ms fused at n = 6, N = 1e6 and was removed)
-    for label, chunk, env in (("fused", 0, {}), ("two kernels chunk=131072", 131072, {}), ("two kernels chunk=262144", 262144, {})):
+    for label, chunk, env in (("lds tile (default)", 0, {}), ("global image", 0, {"RDYN_GRAM_PATH": "image"}),
+                              ("two kernels chunk=262144", 262144, {})):
         for k, v in env.items():
             os.environ[k] = v
         ws = torch.empty((lib().rdyn_regressor_gram_workspace_bytes(chain._h, chunk),), dtype=torch.uint8, device="cuda")
