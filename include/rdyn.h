@@ -172,6 +172,13 @@ typedef struct rdyn_regressor_layout
 int rdyn_transformation(const rdyn_chain* chain, const rdyn_batch* batch, double* T_bt, double* T_links);
 /* getJacobian primitives.h:455 -> 6 x n column-major per sample */
 int rdyn_jacobian(const rdyn_chain* chain, const rdyn_batch* batch, double* J);
+/* getJacobianLink primitives.h:456 / primitives_impl.h:951-979 -> 6 x n column-major per sample, referred to the origin
+ * of chain link `link_index` (0 = base .. joints_number = tool; names via rdyn_chain_link_name).  As in the
+ * reference only the first `up` input columns are filled (up = input joints upstream of the link, :965-972), the rest
+ * are zero; with the default chain-ordered input list those are exactly the link's parent joints.  (The by-name getters getTransformationLink / getTwistLink are the record
+ * `link_index` of rdyn_transformation's T_links / rdyn_twist's twists.)  Stateless: evaluated at the given q, whereas
+ * the reference's getJacobianLink ignores its q and uses the frames of the previous call (primitives_impl.h:953). */
+int rdyn_jacobian_link(const rdyn_chain* chain, const rdyn_batch* batch, int link_index, double* J);
 /* getTwist primitives.h:457 (needs q, dq) -> links_number x 6 per sample, [lin; ang] per link.
  * getDTwist primitives.h:463 (needs q, dq, ddq) -> same shape; either output may be NULL. */
 int rdyn_twist(const rdyn_chain* chain, const rdyn_batch* batch, double* twists, double* dtwists);

@@ -44,7 +44,7 @@ def lib():
         l.orc_chain_create.restype = C.c_void_p
         l.orc_chain_create.argtypes = [C.c_int, C.POINTER(_UJoint), C.POINTER(_ULink), dp, C.c_int, C.POINTER(C.c_int)]
         l.orc_chain_destroy.argtypes = [C.c_void_p]
-        for name, nargs in (("orc_fk", 2), ("orc_jacobian", 2), ("orc_twist", 3), ("orc_dtwist", 6), ("orc_ddtwist", 5),
+        for name, nargs in (("orc_fk", 2), ("orc_jacobian", 2), ("orc_jacobian_link", 3),("orc_twist", 3), ("orc_dtwist", 6), ("orc_ddtwist", 5),
                             ("orc_joint_torque", 6), ("orc_regressor", 4), ("orc_joint_inertia", 2),
                             ("orc_nominal_parameters", 1)):
             f = getattr(l, name)
@@ -118,6 +118,14 @@ class OracleChain(object):
         J = np.empty((len(q), self.n, 6))
         for s in range(len(q)):
             lib().orc_jacobian(self._h, _p(q[s]), _p(J[s]))
+        return np.transpose(J, (0, 2, 1))  # (N, 6, n)
+
+    def jacobian_link(self, q, link_index):
+        (q,) = self._in(q)
+        J = np.empty((len(q), self.n, 6))
+        li = np.array([float(link_index)])
+        for s in range(len(q)):
+            lib().orc_jacobian_link(self._h, _p(q[s]), _p(li), _p(J[s]))
         return np.transpose(J, (0, 2, 1))  # (N, 6, n)
 
     def twist(self, q, dq):

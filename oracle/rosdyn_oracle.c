@@ -500,6 +500,31 @@ void orc_jacobian(const orc_chain* c, const double* q, double* J)
     }
   }
 }
+/* getJacobianLink impl.h:951-979, evaluated on the frames of q (the reference uses the frames of the previous call, :953).
+ * m_parent_moveable_joints_of_link.at(link) (impl.h:798-827) lists the input positions of the active joints found while
+ * walking the chain joints up to the one whose child is the link; only its SIZE is used (:970), the column index and the
+ * joint both come from the loop counter (:972, :975). */
+void orc_jacobian_link(const orc_chain* c, const double* q, const double* link_idx_as_double, double* J)
+{
+  orc_state s;
+  computeFrames(c, &s, q);
+  computeScrews(c, &s);
+  int link_idx = (int)link_idx_as_double[0];
+  int n_parent = 0; /* joints.size(), impl.h:808-821: chain joints 0 .. link_idx-1 that are active */
+  for (int ijnt = 0; ijnt < link_idx; ijnt++)
+    for (int k = 0; k < c->active_joints_number; k++)
+      if (c->active_joints[k] == ijnt) { n_parent++; break; }
+  memset(J, 0, sizeof(double) * 6 * c->active_joints_number); /* :969 */
+  for (int idx = 0; idx < n_parent; idx++)
+  {
+    int nj = c->active_joints[idx], nl = nj + 1;
+    if (c->joints[nj].type != ORC_FIXED)
+    {
+      v6 col = spatialTranslation(s.screws[nl], v3_sub(T_p(&s.T_bl[link_idx]), T_p(&s.T_bl[nl])));
+      for (int i = 0; i < 6; i++) J[idx * 6 + i] = col.v[i];
+    }
+  }
+}
 /* getTwist impl.h:981 : twists = L x 6 */
 void orc_twist(const orc_chain* c, const double* q, const double* Dq, double* twists)
 {

@@ -75,6 +75,7 @@ SYMBOLS = {
     "rdyn_nominal_parameters": (_I, [_VP, _DP]),
     "rdyn_transformation": (_I, [_VP, _BP, _VP, _VP]),
     "rdyn_jacobian": (_I, [_VP, _BP, _VP]),
+    "rdyn_jacobian_link": (_I, [_VP, _BP, _I, _VP]),
     "rdyn_twist": (_I, [_VP, _BP, _VP, _VP]),
     "rdyn_twist_parts": (_I, [_VP, _BP, _VP, _VP, _VP, _VP]),
     "rdyn_joint_torque_ext": (_I, [_VP, _BP, _VP, _VP]),

@@ -162,6 +162,28 @@ class Chain(object):
         check(lib().rdyn_jacobian(self._h, C.byref(b), J.data_ptr()))
         return J
 
+    def _link_index(self, link_name):
+        names = self.getLinksName()
+        if link_name not in names:
+            raise ValueError("link " + link_name + " is not member of the chain")     # primitives_impl.h:920, 960, 1022
+        return names.index(link_name)
+
+    def getJacobianLink(self, q, link_name, layout="sample", out=None):              # primitives.h:456
+        b, N, lay = self._batch(layout, q)
+        J = self._out(q, N, lay, (self.getActiveJointsNumber(), 6), out)
+        check(lib().rdyn_jacobian_link(self._h, C.byref(b), self._link_index(link_name), J.data_ptr()))
+        return J
+
+    def getTransformationLink(self, q, link_name, layout="sample"):                  # primitives.h:453
+        T = self.getTransformations(q, layout=layout)
+        i = self._link_index(link_name)
+        return T[:, i] if layout != "element" else T[i]
+
+    def getTwistLink(self, q, Dq, link_name, layout="sample"):                       # primitives.h:458
+        tw = self.getTwist(q, Dq, layout=layout)
+        i = self._link_index(link_name)
+        return tw[:, i] if layout != "element" else tw[i]
+
     def getTwist(self, q, Dq, layout="sample", out=None):
         b, N, lay = self._batch(layout, q, Dq)
         tw = self._out(q, N, lay, (self.getLinksNumber(), 6), out)

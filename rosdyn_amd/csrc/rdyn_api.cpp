@@ -227,7 +227,8 @@ int rdyn_joint_inertia(const rdyn_chain* c, const rdyn_batch* b, double* M)
   return run_local(c, b, RDYN_MODE_INERTIA, nullptr, nullptr, nullptr, M, false, false);
 }
 
-static int run_base(const rdyn_chain* c, const rdyn_batch* b, double* T_bt, double* T_links, double* J, double* tw, double* dtw)
+static int run_base(const rdyn_chain* c, const rdyn_batch* b, double* T_bt, double* T_links, double* J, double* tw, double* dtw,
+                    int j_link = -1)
 {
   if (b->n_samples == 0) return RDYN_OK;
   DeviceGuard g;
@@ -249,6 +250,7 @@ static int run_base(const rdyn_chain* c, const rdyn_batch* b, double* T_bt, doub
   a.T_links = T_links;
   rec_strides(b, 12 * (int64_t)L, &a.tl_ss, &se);
   a.J = J;
+  a.j_link = j_link < 0 ? c->n_joints() : j_link;
   rec_strides(b, 6 * (int64_t)n, &a.j_ss, &se);
   a.twists = tw;
   a.dtwists = dtw;
@@ -751,6 +753,23 @@ int rdyn_jacobian(const rdyn_chain* c, const rdyn_batch* b, double* J)
     return RDYN_ERR_INVALID_ARGUMENT;
   }
   return run_base(c, b, nullptr, nullptr, J, nullptr, nullptr);
+}
+
+int rdyn_jacobian_link(const rdyn_chain* c, const rdyn_batch* b, int link_index, double* J)
+{
+  int st = check_batch(c, b, false, false, "rdyn_jacobian_link");
+  if (st != RDYN_OK) return st;
+  if (link_index < 0 || link_index > c->n_joints())
+  {
+    rdyn_set_error("link index %d is not member of the chain", link_index);  // primitives_impl.h:960
+    return RDYN_ERR_INVALID_ARGUMENT;
+  }
+  if (!J && b->n_samples > 0)
+  {
+    rdyn_set_error("rdyn_jacobian_link: null output");
+    return RDYN_ERR_INVALID_ARGUMENT;
+  }
+  return run_base(c, b, nullptr, nullptr, J, nullptr, nullptr, link_index);
 }
 
 int rdyn_twist(const rdyn_chain* c, const rdyn_batch* b, double* twists, double* dtwists)

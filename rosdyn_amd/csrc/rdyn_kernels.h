@@ -51,6 +51,7 @@ struct RdynKinArgs
   double* T_bt;    int64_t tb_ss;   // 12 per sample
   double* T_links; int64_t tl_ss;   // 12 * links per sample
   double* J;       int64_t j_ss;    // 6 * n_active per sample
+  int j_link;                       // Jacobian reference link (chain link index); n_joints = the tool (getJacobian)
   double* twists;                   // 6 * links per sample
   double* dtwists; int64_t tw_ss;
 };

@@ -170,8 +170,21 @@ __global__ __launch_bounds__(256) void k_base_sweep(const RdynKinArgs a)
   if (a.T_bt) put3x4(a.T_bt + s * a.tb_ss);
   if (a.J)
   {
-    // getJacobian, primitives_impl.h:939-945: column k = spatialTranslation(S_l, p_tool - p_l)
+    // getJacobian, primitives_impl.h:939-945: column k = spatialTranslation(S_l, p_tool - p_l);
+    // getJacobianLink, primitives_impl.h:951-979: the same referred to the origin of link j_link; only the FIRST
+    // `up` input columns are filled, up = number of input joints upstream of the link (the reference's loop runs over
+    // idx < joints.size() and reads m_active_joints.at(idx), :970-972) -- for the default, chain-ordered input list
+    // these are exactly the link's parent joints.  j_link == NJ is the tool (up = n_active: plain getJacobian).
     double* __restrict__ jp = a.J + s * a.j_ss;
+    V3 pref = p;
+    int up = 0;
+#pragma unroll
+    for (int l = 0; l < NJ; ++l)
+    {
+      if (a.j_link == l + 1) pref = po[l];
+      if (l < a.j_link && c->j[l].in_idx >= 0) ++up;
+    }
+    if (a.j_link == 0) pref = mk(0, 0, 0);
 #pragma unroll
     for (int l = 0; l < NJ; ++l)
     {
@@ -179,13 +192,16 @@ __global__ __launch_bounds__(256) void k_base_sweep(const RdynKinArgs a)
       if (k < 0) continue;
       const int type = c->j[l].type;
       V3 jlin = mk(0, 0, 0), jang = mk(0, 0, 0);
-      if (type == RDYN_REVOLUTE)
+      if (k < up)
       {
-        jlin = cross(z[l], p - po[l]);
-        jang = z[l];
+        if (type == RDYN_REVOLUTE)
+        {
+          jlin = cross(z[l], pref - po[l]);
+          jang = z[l];
+        }
+        else if (type == RDYN_PRISMATIC)
+          jlin = z[l];
       }
-      else if (type == RDYN_PRISMATIC)
-        jlin = z[l];
       put6(jp + (int64_t)(6 * k) * es, jlin, jang);
     }
   }

@@ -218,6 +218,33 @@ public:
     return fill6(m_twists);
   }
   const Vector6d& getTwistTool(const VectorXd& q, const VectorXd& Dq) { return getTwist(q, Dq).back(); }
+  // ---- by-name getters (primitives.h:453, 456, 458); same exception type and text as primitives_impl.h:920, 960, 1022
+  unsigned int linkIndex(const std::string& link_name) const
+  {
+    for (unsigned int l = 0; l < m_links_number; ++l)
+      if (m_links_name[l] == link_name) return l;
+    throw std::invalid_argument("link " + link_name + " is not member of the chain");
+  }
+  const Affine3d& getTransformationLink(const VectorXd& q, const std::string& link_name)
+  {
+    const unsigned int l = linkIndex(link_name);
+    return getTransformations(q).at(l);
+  }
+  Matrix6Xd getJacobianLink(const VectorXd& q, const std::string& link_name)
+  {
+    const unsigned int l = linkIndex(link_name);
+    stage(&q, nullptr, nullptr);
+    run(rdyn_jacobian_link(m_h, &m_b, (int)l, out(0)), 6 * m_active_joints_number);
+    Matrix6Xd jac;
+    jac.resize(6, (int)m_active_joints_number);
+    std::memcpy(jac.data(), m_host.data(), sizeof(double) * 6 * m_active_joints_number);
+    return jac;
+  }
+  const Vector6d& getTwistLink(const VectorXd& q, const VectorXd& Dq, const std::string& link_name)
+  {
+    const unsigned int l = linkIndex(link_name);
+    return getTwist(q, Dq).at(l);
+  }
   const VectorOfVector6d& getDTwist(const VectorXd& q, const VectorXd& Dq, const VectorXd& DDq)
   {
     stage(&q, &Dq, &DDq);

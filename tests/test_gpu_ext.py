@@ -45,3 +45,42 @@ def test_parts_jerk_and_ext_wrench(urdf, base, tool, layout):
     # zero external wrenches == plain getJointTorque
     z = torch.zeros_like(text)
     assert torch.equal(chain.getJointTorqueExt(tq, tdq, tddq, z, layout=layout), chain.getJointTorque(tq, tdq, tddq, layout=layout))
+
+
+@pytest.mark.parametrize("urdf,base,tool,inputs", [
+    ("ur10_like.urdf", "base_link", "tool0", None),
+    ("mixed_joints.urdf", "world", "tip", None),
+    # permuted subset of the moveable joints: the reference fills the first joints.size() input columns
+    ("panda_like.urdf", "link0", "hand", ["joint5", "joint2", "joint7", "joint1"])])
+@pytest.mark.parametrize("layout", ["sample", "element"])
+def test_by_link_getters(urdf, base, tool, inputs, layout):
+    """getJacobianLink / getTransformationLink / getTwistLink (primitives_impl.h:914-925, 951-979, 1016-1027)."""
+    torch = pytest.importorskip("torch")
+    from oracle.oracle import OracleChain
+    from rosdyn_amd import Chain
+    from rosdyn_amd.samples import trajectory_batch
+    path = os.path.join(FIXTURES, urdf)
+    chain, ref = Chain(path, base, tool, GRAV), OracleChain(path, base, tool, GRAV, input_joint_names=inputs)
+    if inputs:
+        names = [j for j in inputs if j in chain.getMoveableJointNames()]
+        assert names == inputs and chain.setInputJointsName(inputs)
+    N, n = 777, ref.n
+    q, dq, _ = trajectory_batch(99, N, n)
+    if layout == "element":
+        dev = lambda x: torch.from_numpy(np.ascontiguousarray(np.moveaxis(x, 0, -1))).cuda()
+        host = lambda t: np.moveaxis(t.cpu().numpy(), -1, 0)
+    else:
+        dev = lambda x: torch.from_numpy(np.ascontiguousarray(x)).cuda()
+        host = lambda t: t.cpu().numpy()
+    tq, tdq = dev(q), dev(dq)
+    T, tw = ref.fk(q), ref.twist(q, dq)
+    links = chain.getLinksName()
+    for i, name in enumerate(links):
+        J = host(chain.getJacobianLink(tq, name, layout=layout)).transpose(0, 2, 1)
+        _close(J, ref.jacobian_link(q, i), "J link %s" % name)
+        _close(host(chain.getTransformationLink(tq, name, layout=layout)).transpose(0, 2, 1), T[:, i], "T link %s" % name)
+        _close(host(chain.getTwistLink(tq, tdq, name, layout=layout)), tw[:, i], "twist link %s" % name)
+    # the tool link's Jacobian is getJacobian, bit for bit
+    assert torch.equal(chain.getJacobianLink(tq, links[-1], layout=layout), chain.getJacobian(tq, layout=layout))
+    with pytest.raises(ValueError, match="is not member of the chain"):
+        chain.getJacobianLink(tq, "no_such_link", layout=layout)
