@@ -200,6 +200,22 @@ int rdyn_regressor(const rdyn_chain* chain, const rdyn_batch* batch, double* tau
 /* getJointInertia primitives.h:547 -> n x n column-major per sample */
 int rdyn_joint_inertia(const rdyn_chain* chain, const rdyn_batch* batch, double* M);
 
+/* ---- batched local inverse kinematics.
+ * computeLocalIk primitives.h:510 / primitives_impl.h:1398-1433 (weight == NULL) and computeWeigthedLocalIk
+ * primitives.h:526 / primitives_impl.h:1436-1468 (weight = 6 HOST doubles), one pose per batch entry:
+ *   repeat: e = getFrameDistance(T_target, getTransformation(sol)) (frame_distance.h:44-49); if |weight o e| < toll -> converged;
+ *           dq = argmin 1/2 dq'(J'WJ)dq - (J'We)'dq  s.t.  q_min <= sol + dq <= q_max  (Eigen::solve_quadprog);  sol += dq.
+ * batch->q = the seeds (n_active per pose, batch->layout); T_target = 12 per pose, the column-major 3x4 [R|p] record
+ * rdyn_transformation writes, same layout; sol = like the seeds (may alias them).  The reference bounds the loop by
+ * wall-clock time (max_time, default 5 ms); here by max_iterations QP updates.  Per-pose results (device int32, either
+ * may be NULL): status 1 = converged (the reference's `true`), 0 = not within max_iterations (`false`), -1 = J'WJ not
+ * positive definite (a Cholesky pivot <= 1e-10 trace: more than 6 input joints or a singular pose; the reference's
+ * Cholesky-based QP is undefined there),
+ * -2 = bounds infeasible (q_min > q_max), -3 = QP iteration guard; iterations = QP updates performed.  On a failure
+ * sol holds the last iterate. */
+int rdyn_local_ik(const rdyn_chain* chain, const rdyn_batch* batch, const double* T_target, const double* weight, double toll,
+                  int max_iterations, double* sol, int32_t* status, int32_t* iterations);
+
 /* ---- per-joint additive components: the extra regressor columns the identification step stacks next to
  * getRegressor.  Reference: FirstOrderPolynomialFriction friction_polynomial1.h:45-52
  * (columns [sign, omega]), SecondOrderPolynomialFriction friction_polynomial2.h:42-58 ([sign, omega, omega^2 sign]),

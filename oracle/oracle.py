@@ -27,7 +27,7 @@ class _ULink(C.Structure):
 
 
 def build(force=False):
-    if force or not os.path.exists(_LIB) or os.path.getmtime(_LIB) < os.path.getmtime(os.path.join(_HERE, "rosdyn_oracle.c")):
+    if force or not os.path.exists(_LIB) or os.path.getmtime(_LIB) < max(os.path.getmtime(os.path.join(_HERE, f)) for f in ("rosdyn_oracle.c", "components_oracle.c", "ik_oracle.c")):
         subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []))
     return _LIB
 
@@ -53,8 +53,29 @@ def lib():
         l.orc_batch_torque_regressor.restype = C.c_int
         l.orc_batch_torque_regressor.argtypes = [C.c_void_p, C.c_long, dp, dp, dp, dp, dp, C.c_int]
         l.orc_has_openmp.restype = C.c_int
+        l.orc_frame_distance.restype = None
+        l.orc_frame_distance.argtypes = [dp, dp, dp]
+        l.orc_solve_quadprog.restype = C.c_int
+        l.orc_solve_quadprog.argtypes = [C.c_int, C.c_int, dp, dp, dp, dp, dp]
+        l.orc_local_ik.restype = C.c_int
+        l.orc_local_ik.argtypes = [C.c_void_p, C.c_int, C.c_int, dp, dp, dp, dp, dp, C.c_double, C.c_int, dp, C.POINTER(C.c_int)]
         _lib = l
     return _lib
+
+
+def frame_distance(T_wa, T_wb):
+    """getFrameDistance (frame_distance.h:44-49) for one pair of 3x4 [R|p] frames."""
+    a, b, d = _c(T_wa).reshape(12), _c(T_wb).reshape(12), np.empty(6)
+    lib().orc_frame_distance(_p(a), _p(b), _p(d))
+    return d
+
+
+def solve_quadprog(G, g0, CI, ci0):
+    """min 1/2 x'Gx + g0'x  s.t.  CI'x + ci0 >= 0  (Goldfarb-Idnani); returns (status, x)."""
+    G, g0, CI, ci0 = _c(G), _c(g0), _c(CI), _c(ci0)
+    x = np.empty(len(g0))
+    st = lib().orc_solve_quadprog(len(g0), len(ci0), _p(G), _p(g0), _p(CI), _p(ci0), _p(x))
+    return st, x
 
 
 def _p(a):
@@ -127,6 +148,22 @@ class OracleChain(object):
         for s in range(len(q)):
             lib().orc_jacobian_link(self._h, _p(q[s]), _p(li), _p(J[s]))
         return np.transpose(J, (0, 2, 1))  # (N, 6, n)
+
+    def local_ik(self, T_target, seed, weight=None, toll=1e-4, max_iter=100):
+        """computeLocalIk / computeWeigthedLocalIk per sample.  T_target (N, 3, 4); returns (sol (N, n), status (N,), iterations (N,))."""
+        (seed,) = self._in(seed)
+        T = _c(T_target).reshape(len(seed), 12)
+        w = None if weight is None else _c(weight)
+        lo, hi = _c(self.spec.q_min), _c(self.spec.q_max)
+        sol = np.empty_like(seed)
+        status = np.empty(len(seed), dtype=np.int32)
+        iters = np.empty(len(seed), dtype=np.int32)
+        it = C.c_int(0)
+        for s in range(len(seed)):
+            status[s] = lib().orc_local_ik(self._h, self.n, self.L, _p(T[s]), _p(seed[s]), _p(w), _p(lo), _p(hi), float(toll),
+                                           int(max_iter), _p(sol[s]), C.byref(it))
+            iters[s] = it.value
+        return sol, status, iters
 
     def twist(self, q, dq):
         q, dq = self._in(q, dq)

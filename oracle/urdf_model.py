@@ -160,6 +160,17 @@ class ChainSpec(object):
         self.n_links = len(links)
         self.n_active = len(self.input_chain_index)
         self.n_params = 10 * self.n_joints
+        # position limits of the input joints (Joint::fromUrdf, primitives_impl.h:85-143; Chain, :768-776)
+        self.q_min, self.q_max = [], []
+        for c in self.input_chain_index:
+            j = joints[c]
+            lo, hi = -1e10, 1e10
+            if j.urdf_type in (0, 2) and j.limits is not None:
+                lo, hi = j.limits["lower"], j.limits["upper"]
+                if hi <= lo:
+                    lo, hi = -2 * math.pi, 2 * math.pi
+            self.q_min.append(lo)
+            self.q_max.append(hi)
 
 
 def load(path_or_xml, base, tool, gravity=(0.0, 0.0, 0.0), input_joint_names=None):

@@ -184,6 +184,65 @@ class Chain(object):
         i = self._link_index(link_name)
         return tw[:, i] if layout != "element" else tw[i]
 
+    # ---- local inverse kinematics, primitives.h:510, 526 (batched: one pose per batch entry)
+    def computeLocalIk(self, T_b_t, seed, toll=1e-4, max_iterations=100, weight=None, layout="sample", out=None):
+        """Returns (sol, status, iterations); status 1 = the reference's `true`, 0 = `false` (iteration cap instead of
+        the reference's max_time), < 0 = the QP of that pose failed (see include/rdyn.h).  T_b_t: the record
+        getTransformation returns ((N, 4, 3) sample-major / (4, 3, N) element-major)."""
+        torch = _torch()
+        b, N, lay = self._batch(layout, seed)
+        shape = (N, 4, 3) if lay == LAYOUT_SAMPLE_MAJOR else (4, 3, N)
+        if (tuple(T_b_t.shape) != shape or T_b_t.dtype != torch.float64 or not T_b_t.is_contiguous()
+                or T_b_t.device != seed.device):
+            raise ValueError("T_b_t must be a contiguous float64 tensor of shape %s" % (shape,))
+        sol = self._out(seed, N, lay, (self.getActiveJointsNumber(),), out)
+        status = torch.empty(N, dtype=torch.int32, device=seed.device)
+        iters = torch.empty(N, dtype=torch.int32, device=seed.device)
+        w = None
+        if weight is not None:
+            w = (C.c_double * 6)(*[float(v) for v in weight])
+        check(lib().rdyn_local_ik(self._h, C.byref(b), T_b_t.data_ptr(), w, float(toll), int(max_iterations), sol.data_ptr(),
+                                  status.data_ptr(), iters.data_ptr()))
+        return sol, status, iters
+
+    def computeWeigthedLocalIk(self, T_b_t, weight, seed, toll=1e-4, max_iterations=100, layout="sample", out=None):
+        return self.computeLocalIk(T_b_t, seed, toll, max_iterations, weight=weight, layout=layout, out=out)
+
+    def getMultiplicity(self, q):                                                    # primitives_impl.h:1470-1516
+        """Host-side: every joint vector equal to q up to whole turns of the revolute input joints within the limits."""
+        q = np.asarray(q, dtype=np.float64)
+        qmax, qmin = self.getQMax(), self.getQMin()
+        names, types = self.getJointsName(), self.getJointTypes()
+        axes = []
+        for idx, name in enumerate(self.getActiveJointsName()):
+            vals = [q[idx]]
+            if types[names.index(name)] == 0:   # REVOLUTE (continuous included, primitives_impl.h:74-77)
+                if qmax[idx] - qmin[idx] > 2 * np.pi * 1e4:
+                    # the reference enumerates every turn up to the 1e10 default limit; refuse instead of exhausting memory
+                    raise ValueError("getMultiplicity: joint %s has no finite position limits" % name)
+                tmp = q[idx]
+                while True:
+                    tmp += 2 * np.pi
+                    if tmp > qmax[idx]:
+                        break
+                    vals.append(tmp)
+                tmp = q[idx]
+                while True:
+                    tmp -= 2 * np.pi
+                    if tmp < qmin[idx]:
+                        break
+                    vals.append(tmp)
+            axes.append(vals)
+        multiturn = [q.copy()]
+        for idx, vals in enumerate(axes):
+            size = len(multiturn)
+            for v in vals[1:]:
+                for im in range(size):
+                    new_q = multiturn[im].copy()
+                    new_q[idx] = v
+                    multiturn.append(new_q)
+        return multiturn
+
     def getTwist(self, q, Dq, layout="sample", out=None):
         b, N, lay = self._batch(layout, q, Dq)
         tw = self._out(q, N, lay, (self.getLinksNumber(), 6), out)

@@ -260,6 +260,50 @@ static int run_base(const rdyn_chain* c, const rdyn_batch* b, double* T_bt, doub
   return RDYN_OK;
 }
 
+// ---- batched local inverse kinematics -------------------------------------------------------------------------
+int rdyn_local_ik(const rdyn_chain* c, const rdyn_batch* b, const double* T_target, const double* weight, double toll,
+                  int max_iterations, double* sol, int32_t* status, int32_t* iterations)
+{
+  int st = check_batch(c, b, false, false, "rdyn_local_ik");  // batch->q = the seeds
+  if (st != RDYN_OK) return st;
+  if (b->n_samples > 0 && (!T_target || !sol))
+  {
+    rdyn_set_error("rdyn_local_ik: null target or solution pointer");
+    return RDYN_ERR_INVALID_ARGUMENT;
+  }
+  if (max_iterations < 0 || !(toll >= 0.0))
+  {
+    rdyn_set_error("rdyn_local_ik: negative iteration cap or tolerance");
+    return RDYN_ERR_INVALID_ARGUMENT;
+  }
+  if (b->n_samples == 0) return RDYN_OK;
+  DeviceGuard g;
+  st = g.enter(b->device);
+  if (st != RDYN_OK) return st;
+  RdynIkArgs a;
+  memset(&a, 0, sizeof a);
+  st = device_const(c, &a.chain);
+  if (st != RDYN_OK) return st;
+  a.T_target = T_target;
+  rec_strides(b, 12, &a.tt_ss, &a.tt_se);
+  a.seed = b->q;
+  a.sol = sol;
+  a.n_samples = b->n_samples;
+  rec_strides(b, c->n_active(), &a.in_ss, &a.in_sj);
+  for (int i = 0; i < 6; ++i) a.weight[i] = weight ? weight[i] : 1.0;
+  for (int j = 0; j < c->n_joints(); ++j)
+  {
+    a.q_min[j] = c->q_min[j];
+    a.q_max[j] = c->q_max[j];
+  }
+  a.toll = toll;
+  a.max_iter = max_iterations;
+  a.status = status;
+  a.iterations = iterations;
+  RDYN_HIP_TRY(rdyn_launch_local_ik(c->n_joints(), a, (hipStream_t)b->stream));
+  return RDYN_OK;
+}
+
 // ---- split / jerk sweeps, external wrenches ---------------------------------------------------------------
 int rdyn_twist_parts(const rdyn_chain* c, const rdyn_batch* b, const double* dddq, double* dtw_lin, double* dtw_nonlin, double* ddtw)
 {

@@ -40,6 +40,25 @@ struct RdynKinExtArgs
 };
 hipError_t rdyn_launch_base_ext(int n_joints, const RdynKinExtArgs& a, hipStream_t st);
 
+// batched local inverse kinematics (rdyn_ik.hip)
+struct RdynIkArgs
+{
+  const RdynChainConst* chain;
+  const double* T_target;            // 12 per pose, column-major 3x4 [R | p]; element e of pose s at [s * tt_ss + e * tt_se]
+  int64_t tt_ss, tt_se;
+  const double* seed;                // n_active per pose, x(s, k) = seed[s * in_ss + k * in_sj]
+  double* sol;                       // same addressing as seed (may alias it)
+  int64_t n_samples, in_ss, in_sj;
+  double weight[6];                  // all 1 for computeLocalIk
+  double q_min[RDYN_MAX_JOINTS];     // per CHAIN joint
+  double q_max[RDYN_MAX_JOINTS];
+  double toll;
+  int max_iter;
+  int* status;                       // per pose, may be null: 1 converged, 0 not within max_iter, < 0 QP failure
+  int* iterations;                   // per pose, may be null: QP updates performed
+};
+hipError_t rdyn_launch_local_ik(int n_joints, const RdynIkArgs& a, hipStream_t st);
+
 // Base-frame kinematics outputs; record element e of sample s at out[s * X_ss + e * out_se].
 struct RdynKinArgs
 {

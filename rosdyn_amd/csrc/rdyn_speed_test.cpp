@@ -88,6 +88,20 @@ int main(int argc, char** argv)
     for (int c = 0; c < (int)n_joints; ++c)
       for (int r = 0; r < 6; ++r) std::printf(" %.17g", J(r, c));
     std::printf("\n");
+    // the README's IK usage (rosdyn_core/README.md:78-84): T_base_tool of q, seed moved away from q
+    rosdyn::Affine3d T_base_tool = T;
+    rosdyn::VectorXd seed = q, sol;
+    for (unsigned i = 0; i < n_joints; ++i) seed(i) += (i % 2 ? -0.15 : 0.2);
+    const bool found = chain->computeLocalIk(sol, T_base_tool, seed, 1e-8, 50);
+    std::printf("IK %d", found ? 1 : 0);
+    for (unsigned i = 0; i < n_joints; ++i) std::printf(" %.17g", sol(i));
+    std::printf("\n");
+    const std::string mid = chain->getLinksName().at(chain->getLinksNumber() / 2);
+    rosdyn::Matrix6Xd Jl = chain->getJacobianLink(q, mid);
+    std::printf("L");
+    for (int c = 0; c < (int)n_joints; ++c)
+      for (int r = 0; r < 6; ++r) std::printf(" %.17g", Jl(r, c));
+    std::printf("\n");
     return 0;
   }
   g_state = 0x5EED0001ULL;

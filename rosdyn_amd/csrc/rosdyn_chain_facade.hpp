@@ -324,6 +324,25 @@ public:
     return m_joint_inertia;
   }
 
+  // ---- local inverse kinematics (primitives.h:510, 526).  The reference's wall-clock budget `max_time` becomes an
+  // iteration cap; returns the reference's bool (false also when the QP of an iterate is not positive definite).
+  bool computeLocalIk(VectorXd& sol, const Affine3d& T_b_t, const VectorXd& seed, const double& toll = 1e-4, int max_iterations = 100)
+  {
+    return localIk(sol, T_b_t, nullptr, seed, toll, max_iterations);
+  }
+  bool computeWeigthedLocalIk(VectorXd& sol, const Affine3d& T_b_t, const Vector6d& weight, const VectorXd& seed, const double& toll = 1e-4,
+                              int max_iterations = 100)
+  {
+    double w[6];
+    for (int i = 0; i < 6; ++i) w[i] = weight(i);
+    return localIk(sol, T_b_t, w, seed, toll, max_iterations);
+  }
+  void computeLocalIkBatch(const rdyn_batch& seeds, const double* T_target, const double* weight, double toll, int max_iterations, double* sol,
+                           int32_t* status, int32_t* iterations) const
+  {
+    chk(rdyn_local_ik(m_h, &seeds, T_target, weight, toll, max_iterations, sol, status, iterations));
+  }
+
   // ---- batched evaluation on device pointers (what the kernels are for); see include/rdyn.h for layouts
   void getJointTorqueBatch(const rdyn_batch& b, double* tau) const { chk(rdyn_joint_torque(m_h, &b, tau)); }
   void getRegressorBatch(const rdyn_batch& b, double* tau, double* Y, const rdyn_regressor_layout& yl) const
@@ -424,6 +443,30 @@ private:
     hip(hipMemcpyAsync(m_pin + 3 * (size_t)m_active_joints_number, out(0), n_out * sizeof(double), hipMemcpyDeviceToHost, nullptr));
     hip(hipStreamSynchronize(nullptr));
     std::memcpy(m_host.data(), m_pin + 3 * (size_t)m_active_joints_number, n_out * sizeof(double));
+  }
+  bool localIk(VectorXd& sol, const Affine3d& T_b_t, const double* weight, const VectorXd& seed, double toll, int max_iterations)
+  {
+    const size_t n = m_active_joints_number;
+    stage(&seed, nullptr, nullptr);
+    // device record after the inputs: target (12) | sol (n) | status, iterations (2 x int32 in one double)
+    double* pin = m_pin + 3 * n;
+    for (int c = 0; c < 4; ++c)
+      for (int r = 0; r < 3; ++r)
+#ifdef RDYN_FACADE_HAS_EIGEN
+        pin[c * 3 + r] = T_b_t.matrix()(r, c);
+#else
+        pin[c * 3 + r] = T_b_t(r, c);
+#endif
+    hip(hipMemcpyAsync(out(0), pin, 12 * sizeof(double), hipMemcpyHostToDevice, nullptr));
+    int32_t* flags = reinterpret_cast<int32_t*>(out(12 + n));
+    chk(rdyn_local_ik(m_h, &m_b, out(0), weight, toll, max_iterations, out(12), flags, flags + 1));
+    hip(hipMemcpyAsync(pin + 12, out(12), (n + 1) * sizeof(double), hipMemcpyDeviceToHost, nullptr));
+    hip(hipStreamSynchronize(nullptr));
+    sol.resize((int)n);
+    for (size_t i = 0; i < n; ++i) sol((int)i) = pin[12 + i];
+    int32_t st;
+    std::memcpy(&st, pin + 12 + n, sizeof st);
+    return st == 1;
   }
   const VectorOfVector6d& fill6(VectorOfVector6d& dst)
   {

@@ -45,7 +45,7 @@ def test_facade_single_sample_values_match_oracle():
     urdf = os.path.join(FIXTURES, "ur10_like.urdf")
     r = subprocess.run([BIN, urdf, "base_link", "tool0", "1", "dump"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr
-    vals = {l.split()[0]: np.array([float(x) for x in l.split()[1:]]) for l in r.stdout.splitlines() if l and l[0] in "tYMTJ"}
+    vals = {l.split()[0]: np.array([float(x) for x in l.split()[1:]]) for l in r.stdout.splitlines() if l and l[0] in "tYMTJIL"}
     ref = OracleChain(urdf, "base_link", "tool0", (0.0, 0.0, -9.806))
     n = ref.n
     q = np.array([[0.1 * (i + 1) for i in range(n)]])
@@ -59,3 +59,9 @@ def test_facade_single_sample_values_match_oracle():
     close(vals["M"], ref.joint_inertia(q)[0].T.reshape(-1))
     close(vals["T"], ref.fk(q)[0, -1].T.reshape(-1))                       # column-major 3 x 4
     close(vals["J"], ref.jacobian(q)[0].T.reshape(-1))                     # column-major 6 x n
+    close(vals["L"], ref.jacobian_link(q, ref.L // 2)[0].T.reshape(-1))    # getJacobianLink of the middle link
+    # computeLocalIk as in rosdyn_core/README.md:78-84: back to q from a displaced seed
+    seed = q + np.array([[0.2 if i % 2 == 0 else -0.15 for i in range(n)]])
+    rsol, rst, _ = ref.local_ik(ref.fk(q)[:, -1], seed, toll=1e-8, max_iter=50)
+    assert vals["IK"][0] == 1.0 and rst[0] == 1
+    assert np.abs(vals["IK"][1:] - rsol[0]).max() < 1e-9
