@@ -440,6 +440,12 @@ struct rdyn_multi_plan
     RdynSweepArgs* table = nullptr;  // device
   };
   std::vector<Group> groups;
+  ~rdyn_multi_plan()  // also runs when creation fails half-way
+  {
+    DeviceGuard g;
+    if (g.enter(device) == RDYN_OK)
+      for (auto& grp : groups) (void)hipFree(grp.table);
+  }
 };
 
 int rdyn_multi_plan_create(const rdyn_multi_item* items, int n_items, rdyn_multi_plan** out)
@@ -518,11 +524,7 @@ int rdyn_multi_plan_regressor(const rdyn_multi_plan* plan, void* stream)
 
 void rdyn_multi_plan_destroy(rdyn_multi_plan* plan)
 {
-  if (!plan) return;
-  DeviceGuard g;
-  if (g.enter(plan->device) == RDYN_OK)
-    for (auto& grp : plan->groups) (void)hipFree(grp.table);
-  delete plan;
+  delete plan;  // the destructor releases the device tables
 }
 
 // ---- normal equations -----------------------------------------------------------------------------------

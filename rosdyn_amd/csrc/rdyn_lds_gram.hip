@@ -18,6 +18,8 @@
 // Requirements (else rdyn_regressor_gram falls back to rdyn_fused_gram.hip): 2 <= n_active <= 7, input joints in
 // chain order (row prefix property), LDS tile x 4 waves <= 160 KB.
 #include <hip/hip_runtime.h>
+#include <atomic>
+#include <cstdint>
 #include "rdyn_device.h"
 #include "rdyn_devmath.h"
 #include "rdyn_kernels.h"
@@ -325,12 +327,17 @@ __global__ __launch_bounds__(256) void k_regressor_gram_lds(const RdynLdsGramArg
 template <int NB>
 hipError_t launch_lds_nb(const RdynLdsGramArgs& a, int blocks, size_t lds_bytes, hipStream_t st)
 {
-  static bool attr_set = false;  // > 64 KB of dynamic LDS needs the opt-in attribute (once per instantiation)
-  if (!attr_set)
+  // > 64 KB of dynamic LDS needs the opt-in attribute, once per instantiation AND device (one bit per device ordinal)
+  static std::atomic<uint64_t> attr_set{0};
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  const uint64_t bit = 1ull << (dev & 63);
+  if (!(attr_set.load(std::memory_order_acquire) & bit))
   {
-    hipError_t e = hipFuncSetAttribute((const void*)k_regressor_gram_lds<NB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    e = hipFuncSetAttribute((const void*)k_regressor_gram_lds<NB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
-    attr_set = true;
+    attr_set.fetch_or(bit, std::memory_order_release);
   }
   hipLaunchKernelGGL((k_regressor_gram_lds<NB>), dim3(blocks), dim3(256), lds_bytes, st, a);
   return hipGetLastError();

@@ -57,6 +57,36 @@ def allreduce_normal_equations(G, c, bb, count, dist=None):
     return unpack_normal_equations(buf, G.shape[0])
 
 
+def r_factor(G, rtol=1e-10):
+    """Rank-revealing R factor of the stacked regressor A from its Gram G = A'A (what a tall-skinny QR of A returns, up to
+    the signs of the rows): pivoted Cholesky on the host, R'R = G[perm][:, perm] restricted to the numerical rank.
+    Returns (R (rank x P, upper trapezoidal in the permuted column order), perm, rank).  Going through the Gram squares
+    the condition number (CholeskyQR): fine for cond(A) << 1e8 in fp64, which identification trajectories satisfy after
+    the rank truncation; BASELINE.json configs[2] names this factor."""
+    Gh = np.array(G.detach().cpu() if hasattr(G, "detach") else G, dtype=np.float64)
+    Gh = 0.5 * (Gh + Gh.T)
+    P = Gh.shape[0]
+    perm = np.arange(P)
+    R = np.zeros((P, P))
+    d = np.diag(Gh).copy()
+    dmax = d.max() if P else 0.0
+    rank = 0
+    for k in range(P):
+        j = k + int(np.argmax(d[k:]))
+        if d[j] <= rtol * dmax:
+            break
+        if j != k:
+            perm[[k, j]] = perm[[j, k]]
+            d[[k, j]] = d[[j, k]]
+            R[:, [k, j]] = R[:, [j, k]]
+        R[k, k] = np.sqrt(d[k])
+        row = Gh[perm[k], perm[k + 1:]] - R[:k, k] @ R[:k, k + 1:]
+        R[k, k + 1:] = row / R[k, k]
+        d[k + 1:] -= R[k, k + 1:] ** 2
+        rank += 1
+    return R[:rank], perm, rank
+
+
 def solve_base_parameters(G, c, rtol=1e-10):
     """Minimum-norm least-squares solution of G x = c on the host (P <= 100): the stacked regressor is structurally
     rank deficient (unobservable base-link parameters, fixed tail links), so the symmetric eigen-decomposition is
