@@ -28,9 +28,15 @@
 namespace
 {
 
-template <int NB>
+// NJ = chain joints; the number of 16-column blocks follows from it (P + 1 = 10 NJ + 1 columns).  The link loop is
+// unrolled (registers are not the constraint at the one wave per SIMD the LDS tiles allow): a rolled loop has ~8
+// dependent scalar-load round trips per link for the chain constants, unrolled hipcc hoists them across links.
+// Measured gain is small (sweep phase 566 -> 554 us per 1e6 samples): the phase is bound by the dependent fp64 chains of
+// ONE wave per SIMD, not by the constants.
+template <int NJ>
 __global__ __launch_bounds__(256) void k_regressor_gram_lds(const RdynLdsGramArgs fa)
 {
+  constexpr int NB = (10 * NJ + 1 + 15) / 16;
   constexpr int NT = NB * (NB + 1) / 2;
   extern __shared__ __attribute__((aligned(32))) char lds_raw[];
   ChainPtr c = as_const(fa.chain);
@@ -39,7 +45,8 @@ __global__ __launch_bounds__(256) void k_regressor_gram_lds(const RdynLdsGramArg
   char* const tile = lds_raw + (size_t)wave * fa.tile_bytes;  // this wave's private tile
   const int s_loc = lane >> 2, k = lane & 3;                 // sweep role: sample within the tile, row pair
   const int cl = lane & 15, g = lane >> 4;                   // MFMA role: column within a block, row quad
-  const int n = fa.n_active, NJ = c->n_joints, P = 10 * NJ;
+  const int n = fa.n_active;
+  constexpr int P = 10 * NJ;
   const int r0 = 2 * k, r1 = 2 * k + 1;
 
   // MFMA role: LDS byte offset of my column in every column block and the number of joint row-groups it stores
@@ -114,8 +121,10 @@ __global__ __launch_bounds__(256) void k_regressor_gram_lds(const RdynLdsGramArg
     V3 lin = mk(-c->g[0], -c->g[1], -c->g[2]);
     V3 L0 = mk(0, 0, 0), A0 = mk(0, 0, 0), L1 = mk(0, 0, 0), A1 = mk(0, 0, 0);
 
-#pragma nounroll
-    for (int f = 0; f < ((fa.debug & 1) && tl != t_first ? 0 : NJ); ++f)  // debug bit 0: sweep only the first tile (timing)
+    const bool skip_sweep = (fa.debug & 1) && tl != t_first;  // debug bit 0: sweep only the first tile (timing)
+    if (!skip_sweep)
+#pragma unroll(NJ <= 7 ? NJ : 1)  // longer chains: rolled (unrolled, NJ = 10 needs scratch)
+    for (int f = 0; f < NJ; ++f)
     {
       JointRef J = c->j[f];
       const int type = J.type;
@@ -324,8 +333,8 @@ __global__ __launch_bounds__(256) void k_regressor_gram_lds(const RdynLdsGramArg
   for (int i = threadIdx.x; i < NT * 256; i += 256) slab[i] = red[i];
 }
 
-template <int NB>
-hipError_t launch_lds_nb(const RdynLdsGramArgs& a, int blocks, size_t lds_bytes, hipStream_t st)
+template <int NJ>
+hipError_t launch_lds_nj(const RdynLdsGramArgs& a, int blocks, size_t lds_bytes, hipStream_t st)
 {
   // > 64 KB of dynamic LDS needs the opt-in attribute, once per instantiation AND device (one bit per device ordinal)
   static std::atomic<uint64_t> attr_set{0};
@@ -335,26 +344,28 @@ hipError_t launch_lds_nb(const RdynLdsGramArgs& a, int blocks, size_t lds_bytes,
   const uint64_t bit = 1ull << (dev & 63);
   if (!(attr_set.load(std::memory_order_acquire) & bit))
   {
-    e = hipFuncSetAttribute((const void*)k_regressor_gram_lds<NB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    e = hipFuncSetAttribute((const void*)k_regressor_gram_lds<NJ>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
     attr_set.fetch_or(bit, std::memory_order_release);
   }
-  hipLaunchKernelGGL((k_regressor_gram_lds<NB>), dim3(blocks), dim3(256), lds_bytes, st, a);
+  hipLaunchKernelGGL((k_regressor_gram_lds<NJ>), dim3(blocks), dim3(256), lds_bytes, st, a);
   return hipGetLastError();
 }
 }  // namespace
 
 hipError_t rdyn_launch_regressor_gram_lds(int n_cols, const RdynLdsGramArgs& a, int blocks, size_t lds_bytes, hipStream_t st)
 {
-  switch (rdyn_gram_blocks_for(n_cols))
+  switch (n_cols / 10)  // chain joints
   {
-  case 1: return launch_lds_nb<1>(a, blocks, lds_bytes, st);
-  case 2: return launch_lds_nb<2>(a, blocks, lds_bytes, st);
-  case 3: return launch_lds_nb<3>(a, blocks, lds_bytes, st);
-  case 4: return launch_lds_nb<4>(a, blocks, lds_bytes, st);
-  case 5: return launch_lds_nb<5>(a, blocks, lds_bytes, st);
-  case 6: return launch_lds_nb<6>(a, blocks, lds_bytes, st);
-  case 7: return launch_lds_nb<7>(a, blocks, lds_bytes, st);
+  case 2: return launch_lds_nj<2>(a, blocks, lds_bytes, st);
+  case 3: return launch_lds_nj<3>(a, blocks, lds_bytes, st);
+  case 4: return launch_lds_nj<4>(a, blocks, lds_bytes, st);
+  case 5: return launch_lds_nj<5>(a, blocks, lds_bytes, st);
+  case 6: return launch_lds_nj<6>(a, blocks, lds_bytes, st);
+  case 7: return launch_lds_nj<7>(a, blocks, lds_bytes, st);
+  case 8: return launch_lds_nj<8>(a, blocks, lds_bytes, st);
+  case 9: return launch_lds_nj<9>(a, blocks, lds_bytes, st);
+  case 10: return launch_lds_nj<10>(a, blocks, lds_bytes, st);
   default: return hipErrorInvalidValue;
   }
 }
