@@ -66,8 +66,12 @@ __global__ __launch_bounds__(256) void k_gram(const RdynGramArgs a)
       ++jb;
       bound += a.row_block;
     }
+    // the group may straddle several row blocks (row_block < 16: short last chunk) and first_col is not monotonic
+    // when the input joints are not in chain order: take the minimum over every row block the 16 rows touch
     int fc = a.first_col[jb];
-    if (r + 15 >= bound && r + 15 < R && a.first_col[jb + 1] < fc) fc = a.first_col[jb + 1];
+    int j2 = jb + 1;
+    for (int64_t b2 = bound; b2 <= r + 15 && b2 < R && j2 < RDYN_MAX_JOINTS; b2 += a.row_block, ++j2)
+      if (a.first_col[j2] < fc) fc = a.first_col[j2];
     return fc >> 4;
   };
 

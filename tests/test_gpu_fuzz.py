@@ -1,0 +1,134 @@
+"""Seeded structural fuzz (-m gpu): random serial chains with every joint kind the reference maps (revolute, continuous,
+prismatic, fixed, floating/planar -> fixed, primitives_impl.h:74-83), optional <origin>/<axis>/<inertial>/<limit>
+elements, side branches that are not on the chain, random permuted subsets of input joints -- every batched entry point
+against the CPU oracle.  The URDF text goes through two independent readers (rdyn_urdf.cpp vs oracle/urdf_model.py)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-11
+
+
+def _fmt(v):
+    return " ".join("%.17g" % float(x) for x in v)
+
+
+def random_chain_xml(seed):
+    rng = np.random.default_rng(seed)
+    nj = int(rng.integers(1, 11))
+    kinds = ["revolute", "continuous", "prismatic", "fixed", "floating", "planar"]
+    probs = [0.45, 0.15, 0.15, 0.15, 0.05, 0.05]
+    links, joints = ["<link name='L0'/>"], []
+    n_moving = 0
+    for i in range(nj):
+        kind = str(rng.choice(kinds, p=probs))
+        if i == nj - 1 and n_moving == 0:
+            kind = "revolute"                                   # at least one moveable joint
+        n_moving += kind in ("revolute", "continuous", "prismatic")
+        origin = ""
+        if rng.random() < 0.85:
+            origin = "<origin xyz='%s' rpy='%s'/>" % (_fmt(0.3 * rng.uniform(-1, 1, 3)), _fmt(rng.uniform(-3.1, 3.1, 3)))
+            if rng.random() < 0.15:
+                origin = "<origin xyz='%s'/>" % _fmt(0.3 * rng.uniform(-1, 1, 3))       # rpy missing
+        axis = ""
+        if rng.random() < 0.8:
+            axis = "<axis xyz='%s'/>" % _fmt(rng.uniform(-1, 1, 3) * rng.choice([1.0, 2.5]))   # not normalised
+        limit = ""
+        if kind in ("revolute", "prismatic") or rng.random() < 0.3:
+            limit = "<limit lower='%.17g' upper='%.17g' effort='50' velocity='2'/>" % (-rng.uniform(1.5, 3), rng.uniform(1.5, 3))
+        joints.append("<joint name='J%d' type='%s'><parent link='L%d'/><child link='L%d'/>%s%s%s</joint>"
+                      % (i, kind, i, i + 1, origin, axis, limit))
+        inertial = ""
+        if rng.random() < 0.85:
+            B = rng.normal(size=(3, 3))
+            I = B @ B.T * 0.01 + 0.01 * np.eye(3)
+            io = "<origin xyz='%s' rpy='%s'/>" % (_fmt(0.1 * rng.uniform(-1, 1, 3)), _fmt(rng.uniform(-3, 3, 3))) if rng.random() < 0.8 else ""
+            inertial = ("<inertial>%s<mass value='%.17g'/><inertia ixx='%.17g' ixy='%.17g' ixz='%.17g' iyy='%.17g' iyz='%.17g' "
+                        "izz='%.17g'/></inertial>" % (io, rng.uniform(0.2, 5), I[0, 0], I[0, 1], I[0, 2], I[1, 1], I[1, 2], I[2, 2]))
+        links.append("<link name='L%d'>%s</link>" % (i + 1, inertial))
+        if rng.random() < 0.25:                                  # a side branch hanging off the chain
+            links.append("<link name='S%d'><inertial><mass value='1'/><inertia ixx='1' ixy='0' ixz='0' iyy='1' iyz='0' izz='1'/></inertial></link>" % i)
+            joints.append("<joint name='B%d' type='revolute'><parent link='L%d'/><child link='S%d'/><axis xyz='0 1 0'/>"
+                          "<limit lower='-1' upper='1' effort='1' velocity='1'/></joint>" % (i, i, i))
+    order = rng.permutation(len(links) + len(joints))           # element order in the file must not matter
+    elems = links + joints
+    body = "".join(elems[k] for k in order)
+    lo = int(rng.integers(0, max(1, nj // 3 + 1)))               # chain = a sub-path of the tree
+    hi = nj
+    return "<robot name='fuzz%d'>%s</robot>" % (seed, body), "L%d" % lo, "L%d" % hi, rng
+
+
+@pytest.mark.parametrize("seed", range(64))
+def test_fuzzed_chain_all_entry_points(seed):
+    torch = pytest.importorskip("torch")
+    from oracle.oracle import OracleChain
+    from rosdyn_amd import Chain
+    from rosdyn_amd.samples import trajectory_batch, uniform_pm1
+    xml, base, tool, rng = random_chain_xml(1000 + seed)
+    grav = tuple(rng.uniform(-10, 10, 3))
+    chain = Chain(xml, base, tool, grav)
+    ref0 = OracleChain(xml, base, tool, grav)
+    if ref0.n == 0:
+        pytest.skip("sub-path without a moveable joint")
+    inputs = None
+    if seed % 2 == 1 and ref0.n >= 2:                            # permuted subset of the moveable joints
+        names = list(ref0.spec.moveable)
+        k = int(rng.integers(1, len(names) + 1))
+        inputs = [names[i] for i in rng.permutation(len(names))[:k]]
+        assert chain.setInputJointsName(inputs)
+    ref = OracleChain(xml, base, tool, grav, input_joint_names=inputs)
+    assert chain.getActiveJointsNumber() == ref.n and chain.getLinksNumber() == ref.L and chain.getLinksName() == ref.spec.link_names
+    assert np.array_equal(chain.getQMax(), np.array(ref.spec.q_max)) and np.array_equal(chain.getQMin(), np.array(ref.spec.q_min))
+    N, n, L, P = 257, ref.n, ref.L, ref.P
+    q, dq, ddq, dddq = trajectory_batch(seed, N, n, order=4)
+    ext = 3.0 * uniform_pm1(seed + 99, (N, L, 6))
+    layout = "element" if seed % 3 == 0 else "sample"
+    if layout == "element":
+        dev = lambda x: torch.from_numpy(np.ascontiguousarray(np.moveaxis(x, 0, -1))).cuda()
+        host = lambda t: np.moveaxis(t.cpu().numpy(), -1, 0)
+    else:
+        dev = lambda x: torch.from_numpy(np.ascontiguousarray(x)).cuda()
+        host = lambda t: t.cpu().numpy()
+    tq, tdq, tddq, tdddq, text = dev(q), dev(dq), dev(ddq), dev(dddq), dev(ext)
+
+    def close(a, b, what, tol=TOL):
+        a, b = np.asarray(a), np.asarray(b)
+        assert a.shape == b.shape, (what, a.shape, b.shape)
+        assert np.abs(a - b).max() <= tol * max(1.0, np.abs(b).max()), "%s: %.3e" % (what, np.abs(a - b).max())
+
+    pi = chain.getNominalParameters()
+    close(host(chain.getTransformations(tq, layout=layout)).transpose(0, 1, 3, 2), ref.fk(q), "T")
+    close(host(chain.getJacobian(tq, layout=layout)).transpose(0, 2, 1), ref.jacobian(q), "J")
+    mid = chain.getLinksName()[L // 2]
+    close(host(chain.getJacobianLink(tq, mid, layout=layout)).transpose(0, 2, 1), ref.jacobian_link(q, L // 2), "J link")
+    close(host(chain.getTwist(tq, tdq, layout=layout)), ref.twist(q, dq), "twist")
+    a, al, an = ref.dtwist(q, dq, ddq, parts=True)
+    close(host(chain.getDTwist(tq, tdq, tddq, layout=layout)), a, "dtwist")
+    close(host(chain.getDTwistLinearPart(tq, tddq, layout=layout)), al, "dtwist linear")
+    close(host(chain.getDTwistNonLinearPart(tq, tdq, layout=layout)), an, "dtwist non-linear")
+    close(host(chain.getDDTwist(tq, tdq, tddq, tdddq, layout=layout)), ref.ddtwist(q, dq, ddq, dddq), "jerk")
+    tau = ref.joint_torque(q, dq, ddq)
+    close(host(chain.getJointTorque(tq, tdq, tddq, layout=layout)), tau, "tau")
+    close(host(chain.getJointTorqueNonLinearPart(tq, tdq, layout=layout)), ref.joint_torque(q, dq, 0 * ddq), "tau nl")
+    close(host(chain.getJointTorqueExt(tq, tdq, tddq, text, layout=layout)), ref.joint_torque(q, dq, ddq, ext=ext), "tau ext")
+    close(host(chain.getJointInertia(tq, layout=layout)).transpose(0, 2, 1), ref.joint_inertia(q), "M")
+    Yr = ref.regressor(q, dq, ddq)
+    Y, tau2 = chain.getRegressor(tq, tdq, tddq, layout=layout, with_torque=True)
+    close(host(Y).transpose(0, 2, 1), Yr, "Y")
+    close(host(tau2), tau, "tau fused")
+    close(np.einsum("snp,p->sn", Yr, pi), tau, "Y pi = tau (oracle, product parameters)", 1e-10)
+    if layout == "sample":
+        Ys = chain.getRegressor(tq, tdq, tddq, y_layout="stacked")
+        close(Ys.cpu().numpy().reshape(P, N, n).transpose(1, 2, 0), Yr, "Y stacked")
+    if P + 1 <= 111:
+        eq, edq, eddq = (torch.from_numpy(np.ascontiguousarray(x.T)).cuda() for x in (q, dq, ddq))
+        etau = torch.from_numpy(np.ascontiguousarray(tau.T)).cuda()
+        A = Yr.transpose(1, 0, 2).reshape(n * N, P)
+        Gr, cr = A.T @ A, A.T @ tau.T.reshape(-1)
+        # fused path (LDS tile or global image), then the two-kernel path with row blocks of 128, 100 and 7 rows (the
+        # last two are not multiples of the 16-row MFMA group: groups straddle row blocks)
+        for chunk in (0, 128, 100, 7):
+            G, c, bb = chain.getRegressorGram(eq, edq, eddq, etau, layout="element", chunk_samples=chunk)
+            assert np.linalg.norm(G.cpu().numpy() - Gr) <= 1e-10 * max(np.linalg.norm(Gr), 1e-300), ("G", chunk)
+            assert np.linalg.norm(c.cpu().numpy() - cr) <= 1e-10 * max(np.linalg.norm(cr), 1e-300), ("c", chunk)
+            assert abs(bb.item() - (tau ** 2).sum()) <= 1e-10 * max((tau ** 2).sum(), 1e-300)
