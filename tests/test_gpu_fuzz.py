@@ -132,3 +132,72 @@ def test_fuzzed_chain_all_entry_points(seed):
             assert np.linalg.norm(G.cpu().numpy() - Gr) <= 1e-10 * max(np.linalg.norm(Gr), 1e-300), ("G", chunk)
             assert np.linalg.norm(c.cpu().numpy() - cr) <= 1e-10 * max(np.linalg.norm(cr), 1e-300), ("c", chunk)
             assert abs(bb.item() - (tau ** 2).sum()) <= 1e-10 * max((tau ** 2).sum(), 1e-300)
+
+
+@pytest.mark.parametrize("N", [1, 2, 15, 16, 17, 63, 64, 65, 255, 256, 257, 1023])
+def test_ragged_batch_sizes(N):
+    """Batch sizes around every tiling boundary (16-sample LDS tiles, 64-lane waves, 256-thread blocks, row-pair lanes)."""
+    torch = pytest.importorskip("torch")
+    import os
+    from conftest import FIXTURES
+    from oracle.oracle import OracleChain
+    from rosdyn_amd import Chain
+    from rosdyn_amd.samples import trajectory_batch
+    path = os.path.join(FIXTURES, "panda_like.urdf")
+    grav = (0.0, 0.0, -9.806)
+    chain, ref = Chain(path, "link0", "hand", grav), OracleChain(path, "link0", "hand", grav)
+    n, P = ref.n, ref.P
+    q, dq, ddq = trajectory_batch(N, N, n)
+    Yr, tau = ref.regressor(q, dq, ddq), ref.joint_torque(q, dq, ddq)
+    tq, tdq, tddq = (torch.from_numpy(x).cuda() for x in (q, dq, ddq))
+    eq, edq, eddq = (torch.from_numpy(np.ascontiguousarray(x.T)).cuda() for x in (q, dq, ddq))
+
+    def close(a, b, what):
+        assert np.abs(a - b).max() <= TOL * max(1.0, np.abs(b).max()), what
+    Y, t2 = chain.getRegressor(tq, tdq, tddq, with_torque=True)
+    close(Y.cpu().numpy().transpose(0, 2, 1), Yr, "per-sample")
+    close(t2.cpu().numpy(), tau, "tau")
+    close(chain.getRegressor(tq, tdq, tddq, y_layout="stacked").cpu().numpy().reshape(P, N, n).transpose(1, 2, 0), Yr, "stacked")
+    close(chain.getRegressor(eq, edq, eddq, layout="element").cpu().numpy().transpose(2, 1, 0), Yr, "element")
+    close(chain.getJointTorque(tq, tdq, tddq).cpu().numpy(), tau, "torque")
+    close(chain.getJointInertia(tq).cpu().numpy().transpose(0, 2, 1), ref.joint_inertia(q), "M")
+    etau = torch.from_numpy(np.ascontiguousarray(tau.T)).cuda()
+    A = Yr.transpose(1, 0, 2).reshape(n * N, P)
+    Gr = A.T @ A
+    for chunk in (0, 64):
+        G, c, bb = chain.getRegressorGram(eq, edq, eddq, etau, layout="element", chunk_samples=chunk)
+        assert np.linalg.norm(G.cpu().numpy() - Gr) <= 1e-10 * np.linalg.norm(Gr), chunk
+    T = chain.getTransformation(tq)
+    sol, st, it = chain.computeLocalIk(T, tq, toll=1e-9, max_iterations=3)      # seeds = goals: converged, untouched
+    assert (st.cpu().numpy() == -1).all() or ((st.cpu().numpy() == 1).all() and torch.equal(sol, tq))
+
+
+def test_mixed_plan_with_fuzzed_chains_and_ragged_items():
+    """rdyn_multi_plan over random chains of different joint counts, items of different (also zero) sample counts."""
+    torch = pytest.importorskip("torch")
+    from oracle.oracle import OracleChain
+    from rosdyn_amd import Chain
+    from rosdyn_amd.multi import MultiChainRegressor
+    from rosdyn_amd.samples import trajectory_batch
+    chains, refs, batches = [], [], []
+    for k, seed in enumerate(range(2000, 2012)):
+        xml, base, tool, rng = random_chain_xml(seed)
+        grav = (0.0, 0.0, -9.806)
+        ref = OracleChain(xml, base, tool, grav)
+        if ref.n == 0:
+            continue
+        chains.append(Chain(xml, base, tool, grav))
+        refs.append(ref)
+        N = [0, 1, 77, 256, 300, 513][k % 6]
+        batches.append(trajectory_batch(seed, max(N, 1), ref.n) if N else tuple(np.zeros((0, ref.n)) for _ in range(3)))
+    dev = [tuple(torch.from_numpy(np.ascontiguousarray(x.T)).cuda() for x in b) for b in batches]
+    mc = MultiChainRegressor([(c,) + d for c, d in zip(chains, dev)])
+    mc.run()
+    torch.cuda.synchronize()
+    for ref, b, Y, tau in zip(refs, batches, mc.Y, mc.tau):
+        if b[0].shape[0] == 0:
+            continue
+        Yr = ref.regressor(*b)
+        assert np.abs(Y.cpu().numpy().transpose(2, 1, 0) - Yr).max() <= TOL * max(1.0, np.abs(Yr).max())
+        tr = ref.joint_torque(*b)
+        assert np.abs(tau.cpu().numpy().T - tr).max() <= TOL * max(1.0, np.abs(tr).max())
