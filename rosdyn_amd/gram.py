@@ -63,7 +63,7 @@ def r_factor(G, rtol=1e-10):
     Returns (R (rank x P, upper trapezoidal in the permuted column order), perm, rank).  Going through the Gram squares
     the condition number (CholeskyQR): fine for cond(A) << 1e8 in fp64, which identification trajectories satisfy after
     the rank truncation; BASELINE.json configs[2] names this factor."""
-    Gh = np.array(G.detach().cpu() if hasattr(G, "detach") else G, dtype=np.float64)
+    Gh = np.array(G.detach().cpu().numpy() if hasattr(G, "detach") else G, dtype=np.float64)
     Gh = 0.5 * (Gh + Gh.T)
     P = Gh.shape[0]
     perm = np.arange(P)

@@ -115,3 +115,46 @@ def test_regressor_gram_with_permuted_subset_of_input_joints(torch_cuda):
     G, c, bb = chain.getRegressorGram(*args, layout="element")
     assert _fro(G.cpu().numpy(), A.T @ A) <= 1e-10
     assert _fro(c.cpu().numpy(), A.T @ bvec) <= 1e-10
+
+
+def test_config3_full_size_properties(torch_cuda):
+    """BASELINE configs[2] size (Panda-like 7-DOF cut at link7: n = 7, P = 70, N = 4e6, measured torque = Y pi + noise):
+    the Gram is additive over a split of the batch (second half accumulated onto the first), every path gives the same
+    normal equations, the recovered base parameters predict the torques of an oracle-evaluated subset to the noise level,
+    and bb = |tau_meas|^2."""
+    from oracle.oracle import OracleChain
+    from rosdyn_amd import Chain
+    from rosdyn_amd.gram import r_factor, solve_base_parameters
+    torch = torch_cuda
+    path = os.path.join(FIXTURES, "panda_like.urdf")
+    chain, ref = Chain(path, "link0", "link7", GRAV), OracleChain(path, "link0", "link7", GRAV)
+    n, P, N = 7, 70, 4000000
+    gen = torch.Generator(device="cuda").manual_seed(0x5EED0003)
+    q, dq, ddq = (torch.rand((n, N), dtype=torch.float64, device="cuda", generator=gen) * 2 - 1 for _ in range(3))
+    tau = chain.getJointTorque(q, dq, ddq, layout="element")
+    sigma = 1e-3
+    tau_meas = tau + sigma * torch.randn((n, N), dtype=torch.float64, device="cuda", generator=gen)
+    G, c, bb = chain.getRegressorGram(q, dq, ddq, tau_meas, layout="element")
+    Gh, ch = G.cpu().numpy(), c.cpu().numpy()
+    assert abs(bb.item() - float((tau_meas ** 2).sum())) <= 1e-10 * bb.item()
+    assert np.array_equal(Gh, Gh.T)
+    # additivity: halves, the second accumulated onto the first (element-major halves are strided views -> copy)
+    h = N // 2
+    first = [t[:, :h].contiguous() for t in (q, dq, ddq, tau_meas)]
+    second = [t[:, h:].contiguous() for t in (q, dq, ddq, tau_meas)]
+    out = chain.getRegressorGram(*first, layout="element")
+    G2, c2, bb2 = chain.getRegressorGram(*second, layout="element", out=out, accumulate=True)
+    assert _fro(G2.cpu().numpy(), Gh) <= 1e-11 and _fro(c2.cpu().numpy(), ch) <= 1e-11
+    assert abs(bb2.item() - bb.item()) <= 1e-11 * bb.item()
+    # the two-kernel path (regressor image through HBM in chunks) gives the same normal equations
+    G3, c3, _ = chain.getRegressorGram(q, dq, ddq, tau_meas, layout="element", chunk_samples=262144)
+    assert _fro(G3.cpu().numpy(), Gh) <= 1e-11 and _fro(c3.cpu().numpy(), ch) <= 1e-11
+    # parameter recovery, checked on an oracle-evaluated subset
+    x, rank = solve_base_parameters(G, c)
+    R, perm, rank_r = r_factor(G, rtol=1e-10)
+    assert rank == rank_r < P
+    sub = slice(0, 2000)
+    qs, dqs, ddqs = (t[:, sub].T.contiguous().cpu().numpy() for t in (q, dq, ddq))
+    Ys = ref.regressor(qs, dqs, ddqs)
+    pred, truth = Ys @ x, ref.joint_torque(qs, dqs, ddqs)
+    assert np.abs(pred - truth).max() <= 20 * sigma / np.sqrt(N / 1000.0) + 1e-9 * np.abs(truth).max()
