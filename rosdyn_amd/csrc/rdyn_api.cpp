@@ -650,7 +650,7 @@ int rdyn_regressor_gram(const rdyn_chain* c, const rdyn_batch* b, const double* 
   int first_col[RDYN_MAX_JOINTS];
   for (int j = 0; j < n; ++j) first_col[j] = 10 * c->active[j];
   const char* path_env = getenv("RDYN_GRAM_PATH");  // A/B only: "lds" (default when eligible), "image", "two"
-  const bool want_lds = !path_env || !strcmp(path_env, "lds");
+  const bool want_lds = !path_env || !strcmp(path_env, "lds") || !strcmp(path_env, "lds0");
   if (chunk_samples <= 0 && !getenv("RDYN_GRAM_UNFUSED") && want_lds && n >= 2 && n <= 8)
   {
     // LDS-resident path (rdyn_lds_gram.hip): needs input joints in chain order (rows of a link's columns are a prefix)
@@ -672,6 +672,11 @@ int rdyn_regressor_gram(const rdyn_chain* c, const rdyn_batch* b, const double* 
     }
     la.lds_off_b = off;
     off += (16 * n + 4) * 8;
+    // software-pipelined variant (rdyn_pipe_gram.hip) where its register budget allows; RDYN_GRAM_PATH=lds0 keeps the
+    // two-phase kernel (A/B)
+    const bool pipe = rdyn_regressor_gram_pipe_supported(P) && !(path_env && !strcmp(path_env, "lds0"));
+    la.lds_dummy_off = off;
+    if (pipe) off += 64 * 8;
     la.tile_bytes = (off + 255) & ~255;
     const int nb = rdyn_gram_blocks_for(P);
     size_t lds_bytes = 4 * (size_t)la.tile_bytes;
@@ -694,7 +699,10 @@ int rdyn_regressor_gram(const rdyn_chain* c, const rdyn_batch* b, const double* 
       int want = fused_blocks_env();
       if (want < 1 || want > kFusedBlocks) want = kFusedBlocks;
       const int blocks = (int)((tiles + 3) / 4 < want ? (tiles + 3) / 4 : want);
-      RDYN_HIP_TRY(rdyn_launch_regressor_gram_lds(P, la, blocks, lds_bytes, stream));
+      if (pipe)
+        RDYN_HIP_TRY(rdyn_launch_regressor_gram_pipe(P, la, blocks, lds_bytes, stream));
+      else
+        RDYN_HIP_TRY(rdyn_launch_regressor_gram_lds(P, la, blocks, lds_bytes, stream));
       RdynGramArgs ga;
       memset(&ga, 0, sizeof ga);
       ga.P = P;

@@ -118,11 +118,15 @@ struct RdynLdsGramArgs
   int lds_stride[RDYN_MAX_JOINTS];     // per link: bytes between its columns = (16 m_f + 4) * 8
   int lds_m[RDYN_MAX_JOINTS];          // per link: number of input joints whose rows can be non-zero (stored rows = 16 m_f)
   int lds_off_b;                       // byte offset of column P (measured torque), 16 n rows
+  int lds_dummy_off;                   // pipelined kernel only: 64 x 8 bytes where lanes drop rows a link does not store
   int tile_bytes;                      // one wave's tile
   double* slabs;
   int debug;                           // timing experiments only (RDYN_FUSED_DEBUG): bit 0 sweep only the first tile, bit 1 no Gram phase
 };
 hipError_t rdyn_launch_regressor_gram_lds(int n_cols, const RdynLdsGramArgs& a, int blocks, size_t lds_bytes, hipStream_t st);
+// the same kernel software-pipelined inside the wave (rdyn_pipe_gram.hip): chains of 2..6 joints
+bool rdyn_regressor_gram_pipe_supported(int n_cols);
+hipError_t rdyn_launch_regressor_gram_pipe(int n_cols, const RdynLdsGramArgs& a, int blocks, size_t lds_bytes, hipStream_t st);
 int rdyn_gram_blocks_for(int P);
 hipError_t rdyn_launch_gram(const RdynGramArgs& a, int blocks, hipStream_t st);
 hipError_t rdyn_launch_gram_finish(const RdynGramArgs& a, int blocks, hipStream_t st);

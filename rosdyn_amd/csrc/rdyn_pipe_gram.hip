@@ -1,0 +1,336 @@
+// rdyn_pipe_gram.hip -- the LDS-tile regressor -> Gram kernel (rdyn_lds_gram.hip) software-pipelined INSIDE the wave.
+//
+// rdyn_lds_gram.hip runs two phases per 16-sample tile, one after the other on the same wave: the fp64 VALU sweep that
+// fills the LDS tile, then the fp64 MFMA k-steps that consume it.  LDS capacity (one 30 KB tile per wave, four waves per
+// CU) rules out a second wave per SIMD, so each phase runs with the dependency stalls of a single wave: sweep 0.55 ms +
+// Gram 0.47 ms per 1e6 samples at n = 6.  Here the two phases share ONE instruction stream:
+//   * row group j of tile t (the 16 samples of input joint j) is consumed DURING THE SWEEP OF TILE t + 1, at link j: its
+//     rows only exist in the columns of links >= j, which that sweep has not rewritten yet (link j's own columns are
+//     written at the end of link j's block), so the operands are read from LDS just in time -- one group (<= NB quads)
+//     in registers at a time, zero band skipped at compile time ((10 j) >> 4, input joints in chain order);
+//   * __builtin_amdgcn_sched_group_barrier interleaves the group's MFMAs with the VALU stream of the link, one
+//     v_mfma_f64_16x16x4_f64 per RDYN_PIPE_VALU_PER_MFMA VALU instructions, so each fills the other's dependency stalls;
+//   * to give the scheduler one large straight-line region per link the sweep is written branch-free after the sincos:
+//     joint kinds are handled by selects / zero factors (a non-revolute joint takes sincos(0): R = A exactly), rows that
+//     are not stored for a link are written to a per-lane dummy slot instead of being branched around;
+//   * the chain pointer is laundered once per tile: hoisted out of the tile loop the unrolled links' constants need ~450
+//     SGPRs and come back as v_readlane traffic.
+// Measured (same box, n = 6 / P = 60 / N = 1e6): 0.82-0.86 ms vs 0.98-1.01 ms for the two-phase kernel (+18 %).
+// What it cannot do: run the matrix pipe BEHIND the VALU.  On gfx950 fp64 MFMA and fp64 VALU do not overlap
+// (tools/mfma_valu_overlap.hip: MFMA-only 5.10 ms, FMA-only 2.63 ms, interleaved 7.49 ms = the sum), and the ratio of
+// VALU instructions per MFMA makes no difference (5, 10, 16: same time): the gain is stall filling, the floor is the SUM
+// of the two instruction streams (~18 k cycles per tile; the kernel runs at ~31 k, PMC in profiles/r1/pipe_gram_pmc.txt).
+// Same tile layout, arguments, accumulation order and epilogue as rdyn_lds_gram.hip: results are bit-identical to it.
+// Instantiated for up to 4 column blocks (chains of up to 6 joints).
+#include <hip/hip_runtime.h>
+#include <atomic>
+#include <cstdint>
+#include "rdyn_device.h"
+#include "rdyn_devmath.h"
+#include "rdyn_kernels.h"
+#include "rdyn_gram_common.h"
+
+#ifndef RDYN_PIPE_VALU_PER_MFMA
+#define RDYN_PIPE_VALU_PER_MFMA 10  // VALU instructions scheduled behind every MFMA (A/B: tools/probe_pipe.py)
+#endif
+
+namespace
+{
+
+// one k-step (element t of the operand quads) of one 16-row group: all upper tiles with both column blocks >= cbm
+template <int NB>
+__device__ __forceinline__ void mfma_kstep(const d4* op, int t, int cbm, d4* acc)
+{
+  int ti = 0;
+#pragma unroll
+  for (int cb = 0; cb < NB; ++cb)
+#pragma unroll
+    for (int rb = 0; rb <= cb; ++rb)
+    {
+      if (rb >= cbm) acc[ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(op[rb][t], op[cb][t], acc[ti], 0, 0, 0);
+      ++ti;
+    }
+}
+__device__ __forceinline__ constexpr int tiles_from(int nb, int cbm) { return (nb - cbm) * (nb - cbm + 1) / 2; }
+template <int NJ>
+__global__ __launch_bounds__(256) void k_regressor_gram_pipe(const RdynLdsGramArgs fa)
+{
+  constexpr int NB = (10 * NJ + 1 + 15) / 16;
+  constexpr int NT = NB * (NB + 1) / 2;
+  constexpr int P = 10 * NJ;
+  extern __shared__ __attribute__((aligned(32))) char lds_raw[];
+  ChainPtr c = as_const(fa.chain);  // re-laundered per tile, see below
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  char* const tile = lds_raw + (size_t)wave * fa.tile_bytes;  // this wave's private tile
+  char* const dummy = tile + fa.lds_dummy_off + lane * 8;     // where rows that a link does not store are dropped
+  const int s_loc = lane >> 2, k = lane & 3;                 // sweep role: sample within the tile, row pair
+  const int cl = lane & 15, g = lane >> 4;                   // MFMA role: column within a block, row quad
+  const int n = fa.n_active;
+  const int r0 = 2 * k, r1 = 2 * k + 1;
+
+  int colbase[NB], colm[NB];
+#pragma unroll
+  for (int cb = 0; cb < NB; ++cb)
+  {
+    const int p = 16 * cb + cl;
+    const int f = p < P ? p / 10 : 0;
+    colbase[cb] = p < P ? fa.lds_off[f] + (p - 10 * f) * fa.lds_stride[f] : (p == P ? fa.lds_off_b : 0);
+    colm[cb] = p < P ? fa.lds_m[f] : (p == P ? n : 0);
+  }
+
+  d4 acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) acc[t] = (d4){0.0, 0.0, 0.0, 0.0};
+  // operands of row group j (the 16 samples of input joint j) out of this wave's tile: column blocks >= (10 j) >> 4
+  auto lds_group = [&](int j, d4* op) {
+#pragma unroll
+    for (int cb = 0; cb < NB; ++cb)
+    {
+      d4 x = (d4){0.0, 0.0, 0.0, 0.0};
+      if (cb >= ((10 * j) >> 4) && j < colm[cb]) x = *(const d4*)(tile + colbase[cb] + j * 128 + g * 32);
+      op[cb] = x;
+    }
+  };
+  // before the first tile the "previous tile" is all zeros
+  for (int i = lane * 8; i < fa.tile_bytes; i += 64 * 8) *(double*)(tile + i) = 0.0;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+  // inputs one tile ahead, as in rdyn_lds_gram.hip: lane k of a sample's quad holds input joints k and k + 4
+  double nqa = 0.0, ndqa = 0.0, nddqa = 0.0, nqb = 0.0, ndqb = 0.0, nddqb = 0.0, nb0 = 0.0, nb1 = 0.0;
+  auto fetch = [&](int64_t tile_index) {
+    int64_t sx = tile_index * 16 + s_loc;
+    if (sx >= fa.n_samples) sx = fa.n_samples - 1;
+    const int64_t o = sx * fa.in_ss;
+    if (fa.bcol)
+    {
+      if (r0 < n) nb0 = fa.bcol[o + r0 * fa.in_sj];
+      if (r1 < n) nb1 = fa.bcol[o + r1 * fa.in_sj];
+    }
+    if (k < n)
+    {
+      nqa = fa.q[o + k * fa.in_sj];
+      ndqa = fa.dq[o + k * fa.in_sj];
+      nddqa = fa.ddq[o + k * fa.in_sj];
+    }
+    if (k + 4 < n)
+    {
+      nqb = fa.q[o + (k + 4) * fa.in_sj];
+      ndqb = fa.dq[o + (k + 4) * fa.in_sj];
+      nddqb = fa.ddq[o + (k + 4) * fa.in_sj];
+    }
+  };
+  const int64_t n_tiles = (fa.n_samples + 15) / 16;
+  const int64_t t_first = (int64_t)blockIdx.x * 4 + wave, t_step = (int64_t)gridDim.x * 4;
+  if (t_first < n_tiles) fetch(t_first);
+  for (int64_t tl = t_first; tl < n_tiles; tl += t_step)
+  {
+    // keep the chain constants' scalar loads inside the iteration: hoisted out of the tile loop they need ~450 SGPRs,
+    // which end up as v_writelane / v_readlane traffic in the VALU stream
+    asm volatile("" : "+s"(c));
+    const double zmask = (tl * 16 + s_loc < fa.n_samples) ? 1.0 : 0.0;
+    const double qa = nqa, dqa = ndqa, ddqa = nddqa, qb = nqb, dqb = ndqb, ddqb = nddqb;
+    const double tb0 = nb0 * zmask, tb1 = nb1 * zmask;
+
+    V3 w = mk(0, 0, 0), vl = mk(0, 0, 0), al = mk(0, 0, 0);
+    V3 lin = mk(-c->g[0], -c->g[1], -c->g[2]);
+    V3 L0 = mk(0, 0, 0), A0 = mk(0, 0, 0), L1 = mk(0, 0, 0), A1 = mk(0, 0, 0);
+
+#pragma unroll
+    for (int f = 0; f < NJ; ++f)
+    {
+      JointRef J = c->j[f];
+      const int type = J.type;
+      const int idx = J.in_idx;
+      const bool act = idx >= 0, rev = type == RDYN_REVOLUTE, pri = type == RDYN_PRISMATIC;
+      // input joint idx lives in lane (idx & 3) of my sample's quad, first or second slot (all wave-uniform choices)
+      const int sidx = act ? idx : 0;
+      const int src = (lane & ~3) | (sidx & 3);
+      const bool second = sidx >= 4;
+      const double qs = __shfl(second ? qb : qa, src), dqs = __shfl(second ? dqb : dqa, src), ddqs = __shfl(second ? ddqb : ddqa, src);
+      const double qf = act ? qs : 0.0, dqf = act ? dqs : 0.0, ddqf = act ? ddqs : 0.0;
+      // revolute: R = A + sin q B + (1 - cos q) C; every other kind takes the angle 0: sin = 0, 1 - cos = 0, R = A exactly
+      double sn, cs;
+      sincos(rev ? qf : 0.0, &sn, &cs);
+      const double oc = 1.0 - cs;
+      // ---------- from here to the end of the link: ONE basic block (selects, no branches)
+      double R[9];
+#pragma unroll
+      for (int i = 0; i < 9; ++i) R[i] = fma(sn, J.B[i], fma(oc, J.C[i], J.A[i]));
+      const V3 tt = axpy(ld3(J.t), ld3(J.up), pri ? qf : 0.0);
+      {
+        const V3 wn = rotT(R, w);
+        const V3 vn = rotT(R, vl + cross(w, tt));
+        const V3 aln = rotT(R, al);
+        const V3 an = rotT(R, lin + cross(al, tt));
+        w = wn; vl = vn; al = aln; lin = an;
+        const V3 nL0 = rotT(R, L0 + cross(A0, tt));
+        A0 = rotT(R, A0);
+        L0 = nL0;
+        const V3 nL1 = rotT(R, L1 + cross(A1, tt));
+        A1 = rotT(R, A1);
+        L1 = nL1;
+      }
+      const V3 u = ld3(J.u);
+      {
+        // revolute: lin += (vl x u) dq, al += (w x u) dq + u ddq, w += u dq;  prismatic: lin += (w x u) dq + u ddq, vl += u dq
+        const double dqr = rev ? dqf : 0.0, ddqr = rev ? ddqf : 0.0, dqp = pri ? dqf : 0.0, ddqp = pri ? ddqf : 0.0;
+        const V3 wxu = cross(w, u);
+        lin = axpy(axpy(axpy(lin, cross(vl, u), dqr), wxu, dqp), u, ddqp);
+        al = axpy(axpy(al, wxu, dqr), u, ddqr);
+        w = axpy(w, u, dqr);
+        vl = axpy(vl, u, dqp);
+      }
+      {
+        const V3 sl = mk(pri ? u.x : 0.0, pri ? u.y : 0.0, pri ? u.z : 0.0), sa = mk(rev ? u.x : 0.0, rev ? u.y : 0.0, rev ? u.z : 0.0);
+        const bool m0 = act && (idx == r0), m1 = act && (idx == r1);
+        L0 = mk(m0 ? sl.x : L0.x, m0 ? sl.y : L0.y, m0 ? sl.z : L0.z);
+        A0 = mk(m0 ? sa.x : A0.x, m0 ? sa.y : A0.y, m0 ? sa.z : A0.z);
+        L1 = mk(m1 ? sl.x : L1.x, m1 ? sl.y : L1.y, m1 ? sl.z : L1.z);
+        A1 = mk(m1 ? sa.x : A1.x, m1 ? sa.y : A1.y, m1 ? sa.z : A1.z);
+      }
+
+      // The PREVIOUS tile's row group f, read from LDS just in time: its rows only exist in the columns of links >= f,
+      // which this sweep has not rewritten yet (link f's own columns are written at the end of this block).  Its four
+      // k-steps are executed by the matrix pipe behind the VALU work of this block.
+      {
+        d4 op[NB];
+        lds_group(f, op);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) mfma_kstep<NB>(op, t, (10 * f) >> 4, acc);
+      }
+
+      const V3 d = lin + cross(w, vl);
+      const double wxy = w.x * w.y, wxz = w.x * w.z, wyz = w.y * w.z;
+      const double wxx = w.x * w.x, wyy = w.y * w.y, wzz = w.z * w.z;
+      const double b00 = -(wyy + wzz), b01 = wxy - al.z, b02 = wxz + al.y;
+      const double b10 = wxy + al.z, b11 = -(wxx + wzz), b12 = wyz - al.x;
+      const double b20 = wxz - al.y, b21 = wyz + al.x, b22 = -(wxx + wyy);
+      double y0[10], y1[10];
+      {
+        const V3 dxA = cross(d, A0), x = cross(A0, w);
+        y0[0] = dot(L0, d);
+        y0[1] = fma(L0.x, b00, fma(L0.y, b10, fma(L0.z, b20, dxA.x)));
+        y0[2] = fma(L0.x, b01, fma(L0.y, b11, fma(L0.z, b21, dxA.y)));
+        y0[3] = fma(L0.x, b02, fma(L0.y, b12, fma(L0.z, b22, dxA.z)));
+        y0[4] = fma(A0.x, al.x, x.x * w.x);
+        y0[5] = fma(A0.x, al.y, fma(A0.y, al.x, fma(x.x, w.y, x.y * w.x)));
+        y0[6] = fma(A0.x, al.z, fma(A0.z, al.x, fma(x.x, w.z, x.z * w.x)));
+        y0[7] = fma(A0.y, al.y, x.y * w.y);
+        y0[8] = fma(A0.y, al.z, fma(A0.z, al.y, fma(x.y, w.z, x.z * w.y)));
+        y0[9] = fma(A0.z, al.z, x.z * w.z);
+      }
+      {
+        const V3 dxA = cross(d, A1), x = cross(A1, w);
+        y1[0] = dot(L1, d);
+        y1[1] = fma(L1.x, b00, fma(L1.y, b10, fma(L1.z, b20, dxA.x)));
+        y1[2] = fma(L1.x, b01, fma(L1.y, b11, fma(L1.z, b21, dxA.y)));
+        y1[3] = fma(L1.x, b02, fma(L1.y, b12, fma(L1.z, b22, dxA.z)));
+        y1[4] = fma(A1.x, al.x, x.x * w.x);
+        y1[5] = fma(A1.x, al.y, fma(A1.y, al.x, fma(x.x, w.y, x.y * w.x)));
+        y1[6] = fma(A1.x, al.z, fma(A1.z, al.x, fma(x.x, w.z, x.z * w.x)));
+        y1[7] = fma(A1.y, al.y, x.y * w.y);
+        y1[8] = fma(A1.y, al.z, fma(A1.z, al.y, fma(x.y, w.z, x.z * w.y)));
+        y1[9] = fma(A1.z, al.z, x.z * w.z);
+      }
+      // rows j < m_f are stored for the columns of link f (row = 16 j + sample); the others go to the dummy slot
+      const int mf = fa.lds_m[f], stride = fa.lds_stride[f];
+      char* const lf = tile + fa.lds_off[f] + s_loc * 8;
+      char* const p0 = r0 < mf ? lf + r0 * 128 : dummy;
+      char* const p1 = r1 < mf ? lf + r1 * 128 : dummy;
+      const int st0 = r0 < mf ? stride : 0, st1 = r1 < mf ? stride : 0;
+#pragma unroll
+      for (int p = 0; p < 10; ++p)
+      {
+        *(double*)(p0 + p * st0) = y0[p] * zmask;
+        *(double*)(p1 + p * st1) = y1[p] * zmask;
+      }
+      // scheduling pipeline for this block: one MFMA, then ten VALU instructions, for every MFMA of the link
+#pragma unroll
+      for (int i = 0; i < (RDYN_PIPE_VALU_PER_MFMA > 0 ? 4 * tiles_from(NB, (10 * f) >> 4) : 0); ++i)
+      {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, RDYN_PIPE_VALU_PER_MFMA, 0);
+      }
+    }
+    // measured torque -> column P
+    {
+      char* const lb = tile + fa.lds_off_b + s_loc * 8;
+      *(double*)(r0 < n ? lb + r0 * 128 : dummy) = tb0;
+      *(double*)(r1 < n ? lb + r1 * 128 : dummy) = tb1;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+    if (tl + t_step < n_tiles) fetch(tl + t_step);
+
+  }
+  // the last tile's row groups (all zero if this wave had no tile)
+#pragma unroll
+  for (int j = 0; j < NJ; ++j)
+  {
+    d4 op[NB];
+    lds_group(j, op);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) mfma_kstep<NB>(op, t, (10 * j) >> 4, acc);
+  }
+
+  // ================= epilogue: block reduction through LDS (the tiles are dead now), this block's Gram slab
+  __syncthreads();
+  double* red = (double*)lds_raw;
+  for (int wv = 0; wv < 4; ++wv)
+  {
+    if (wave == wv)
+    {
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+        {
+          const int idx = t * 256 + ((g + 4 * r) * 16 + cl);
+          red[idx] = (wv == 0) ? acc[t][r] : red[idx] + acc[t][r];
+        }
+    }
+    __syncthreads();
+  }
+  double* slab = fa.slabs + (int64_t)blockIdx.x * (NT * 256);
+  for (int i = threadIdx.x; i < NT * 256; i += 256) slab[i] = red[i];
+}
+
+template <int NJ>
+hipError_t launch_pipe_nj(const RdynLdsGramArgs& a, int blocks, size_t lds_bytes, hipStream_t st)
+{
+  // > 64 KB of dynamic LDS needs the opt-in attribute, once per instantiation AND device (one bit per device ordinal)
+  static std::atomic<uint64_t> attr_set{0};
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  const uint64_t bit = 1ull << (dev & 63);
+  if (!(attr_set.load(std::memory_order_acquire) & bit))
+  {
+    e = hipFuncSetAttribute((const void*)k_regressor_gram_pipe<NJ>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
+    attr_set.fetch_or(bit, std::memory_order_release);
+  }
+  hipLaunchKernelGGL((k_regressor_gram_pipe<NJ>), dim3(blocks), dim3(256), lds_bytes, st, a);
+  return hipGetLastError();
+}
+}  // namespace
+
+bool rdyn_regressor_gram_pipe_supported(int n_cols) { return n_cols >= 20 && n_cols <= 60; }
+
+hipError_t rdyn_launch_regressor_gram_pipe(int n_cols, const RdynLdsGramArgs& a, int blocks, size_t lds_bytes, hipStream_t st)
+{
+  switch (n_cols / 10)  // chain joints
+  {
+  case 2: return launch_pipe_nj<2>(a, blocks, lds_bytes, st);
+  case 3: return launch_pipe_nj<3>(a, blocks, lds_bytes, st);
+  case 4: return launch_pipe_nj<4>(a, blocks, lds_bytes, st);
+  case 5: return launch_pipe_nj<5>(a, blocks, lds_bytes, st);
+  case 6: return launch_pipe_nj<6>(a, blocks, lds_bytes, st);
+  default: return hipErrorInvalidValue;
+  }
+}
