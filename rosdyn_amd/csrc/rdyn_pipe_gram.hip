@@ -21,7 +21,8 @@
 // VALU instructions per MFMA makes no difference (5, 10, 16: same time): the gain is stall filling, the floor is the SUM
 // of the two instruction streams (~18 k cycles per tile; the kernel runs at ~31 k, PMC in profiles/r1/pipe_gram_pmc.txt).
 // Same tile layout, arguments, accumulation order and epilogue as rdyn_lds_gram.hip: results are bit-identical to it.
-// Instantiated for up to 4 column blocks (chains of up to 6 joints).
+// Instantiated for up to 4 column blocks (chains of up to 6 joints): with 5 blocks (15 accumulator tiles) hipcc spills
+// (352 B of scratch at NJ = 7) and the kernel is slower than the two-phase one (6.33 vs 5.14 ms at n = 7, N = 4e6).
 #include <hip/hip_runtime.h>
 #include <atomic>
 #include <cstdint>
