@@ -215,6 +215,11 @@ int rdyn_joint_inertia(const rdyn_chain* chain, const rdyn_batch* batch, double*
  * sol holds the last iterate. */
 int rdyn_local_ik(const rdyn_chain* chain, const rdyn_batch* batch, const double* T_target, const double* weight, double toll,
                   int max_iterations, double* sol, int32_t* status, int32_t* iterations);
+/* The same iteration with a Levenberg term: damping^2 is added to the diagonal of J'WJ before the QP (damping = 0 is
+ * rdyn_local_ik).  No counterpart in the reference; it is what makes the loop usable where the reference's QP is singular
+ * (7-DOF arms: J'J is 7 x 7 of rank 6) and near singular poses. */
+int rdyn_local_ik_damped(const rdyn_chain* chain, const rdyn_batch* batch, const double* T_target, const double* weight, double toll,
+                         double damping, int max_iterations, double* sol, int32_t* status, int32_t* iterations);
 
 /* ---- per-joint additive components: the extra regressor columns the identification step stacks next to
  * getRegressor.  Reference: FirstOrderPolynomialFriction friction_polynomial1.h:45-52

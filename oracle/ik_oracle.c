@@ -244,8 +244,9 @@ int orc_solve_quadprog(int n, int m, const double* G_in, const double* g0, const
  * returns 1 converged (the reference's `true`), 0 not converged within max_iter updates (`false` after max_time),
  * -1 / -2 / -3 the QP failed (see orc_solve_quadprog) -- sol then holds the last iterate. */
 int orc_local_ik(const orc_chain* c, int n_active, int n_links, const double* T_target, const double* seed, const double* weight,
-                 const double* q_min, const double* q_max, double toll, int max_iter, double* sol, int* iterations)
+                 const double* q_min, const double* q_max, double toll, double damping, int max_iter, double* sol, int* iterations)
 {
+  /* damping: not in the reference -- the product's Levenberg option (rdyn_local_ik_damped), damping^2 on the diagonal of H */
   const int n = n_active, m = 2 * n_active;
   double T_all[IK_MAX_N * 12 + 12], J[6 * IK_MAX_N], e[6], H[IK_MAX_N * IK_MAX_N], f[IK_MAX_N], CI[IK_MAX_N * IK_MAX_M], ci0[IK_MAX_M],
       dq[IK_MAX_N];
@@ -272,6 +273,7 @@ int orc_local_ik(const orc_chain* c, int n_active, int n_links, const double* T_
         for (int i = 0; i < 6; i++) v += J[a * 6 + i] * (weight ? weight[i] : 1.0) * J[b * 6 + i];   /* :1414, :1451 */
         H[a * n + b] = v;
       }
+      H[a * n + a] += damping * damping;
     }
     for (int i = 0; i < n; i++) { ci0[i] = sol[i] - q_min[i]; ci0[n + i] = q_max[i] - sol[i]; }        /* :1417-1418 */
     int st = orc_solve_quadprog(n, m, H, f, CI, ci0, dq);                  /* :1421-1427 */

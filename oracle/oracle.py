@@ -58,7 +58,8 @@ def lib():
         l.orc_solve_quadprog.restype = C.c_int
         l.orc_solve_quadprog.argtypes = [C.c_int, C.c_int, dp, dp, dp, dp, dp]
         l.orc_local_ik.restype = C.c_int
-        l.orc_local_ik.argtypes = [C.c_void_p, C.c_int, C.c_int, dp, dp, dp, dp, dp, C.c_double, C.c_int, dp, C.POINTER(C.c_int)]
+        l.orc_local_ik.argtypes = [C.c_void_p, C.c_int, C.c_int, dp, dp, dp, dp, dp, C.c_double, C.c_double, C.c_int, dp,
+                                   C.POINTER(C.c_int)]
         _lib = l
     return _lib
 
@@ -149,7 +150,7 @@ class OracleChain(object):
             lib().orc_jacobian_link(self._h, _p(q[s]), _p(li), _p(J[s]))
         return np.transpose(J, (0, 2, 1))  # (N, 6, n)
 
-    def local_ik(self, T_target, seed, weight=None, toll=1e-4, max_iter=100):
+    def local_ik(self, T_target, seed, weight=None, toll=1e-4, max_iter=100, damping=0.0):
         """computeLocalIk / computeWeigthedLocalIk per sample.  T_target (N, 3, 4); returns (sol (N, n), status (N,), iterations (N,))."""
         (seed,) = self._in(seed)
         T = _c(T_target).reshape(len(seed), 12)
@@ -161,7 +162,7 @@ class OracleChain(object):
         it = C.c_int(0)
         for s in range(len(seed)):
             status[s] = lib().orc_local_ik(self._h, self.n, self.L, _p(T[s]), _p(seed[s]), _p(w), _p(lo), _p(hi), float(toll),
-                                           int(max_iter), _p(sol[s]), C.byref(it))
+                                           float(damping), int(max_iter), _p(sol[s]), C.byref(it))
             iters[s] = it.value
         return sol, status, iters
 

@@ -185,7 +185,7 @@ class Chain(object):
         return tw[:, i] if layout != "element" else tw[i]
 
     # ---- local inverse kinematics, primitives.h:510, 526 (batched: one pose per batch entry)
-    def computeLocalIk(self, T_b_t, seed, toll=1e-4, max_iterations=100, weight=None, layout="sample", out=None):
+    def computeLocalIk(self, T_b_t, seed, toll=1e-4, max_iterations=100, weight=None, layout="sample", out=None, damping=0.0):
         """Returns (sol, status, iterations); status 1 = the reference's `true`, 0 = `false` (iteration cap instead of
         the reference's max_time), < 0 = the QP of that pose failed (see include/rdyn.h).  T_b_t: the record
         getTransformation returns ((N, 4, 3) sample-major / (4, 3, N) element-major)."""
@@ -201,12 +201,13 @@ class Chain(object):
         w = None
         if weight is not None:
             w = (C.c_double * 6)(*[float(v) for v in weight])
-        check(lib().rdyn_local_ik(self._h, C.byref(b), T_b_t.data_ptr(), w, float(toll), int(max_iterations), sol.data_ptr(),
-                                  status.data_ptr(), iters.data_ptr()))
+        # damping > 0: Levenberg term (no reference counterpart; what 7-DOF arms need, see include/rdyn.h)
+        check(lib().rdyn_local_ik_damped(self._h, C.byref(b), T_b_t.data_ptr(), w, float(toll), float(damping), int(max_iterations),
+                                         sol.data_ptr(), status.data_ptr(), iters.data_ptr()))
         return sol, status, iters
 
-    def computeWeigthedLocalIk(self, T_b_t, weight, seed, toll=1e-4, max_iterations=100, layout="sample", out=None):
-        return self.computeLocalIk(T_b_t, seed, toll, max_iterations, weight=weight, layout=layout, out=out)
+    def computeWeigthedLocalIk(self, T_b_t, weight, seed, toll=1e-4, max_iterations=100, layout="sample", out=None, damping=0.0):
+        return self.computeLocalIk(T_b_t, seed, toll, max_iterations, weight=weight, layout=layout, out=out, damping=damping)
 
     def getMultiplicity(self, q):                                                    # primitives_impl.h:1470-1516
         """Host-side: every joint vector equal to q up to whole turns of the revolute input joints within the limits."""

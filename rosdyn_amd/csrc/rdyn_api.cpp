@@ -1,6 +1,15 @@
 // rdyn_api.cpp -- batched C-ABI entry points (include/rdyn.h): argument checks, layout -> strides,
 // chain-constant residency per device, kernel launches.  No host<->device copies of batch data, no
 // allocation and no synchronisation after a chain's first use on a device.
+//
+// Diagnostic environment switches (A/B measurements only -- tools/probe_*.py; never needed for correct results, re-read
+// on every call so that a probe can flip them inside one process):
+//   RDYN_NO_ROWPAIR=1       regressor in row-contiguous layouts through the one-thread-per-sample kernel
+//   RDYN_GRAM_PATH=lds0|image|two   regressor->Gram kernel: two-phase LDS tile / global image / two kernels
+//                           (default: software-pipelined LDS tile where eligible, then LDS tile, then global image)
+//   RDYN_GRAM_UNFUSED=1     same as RDYN_GRAM_PATH=two
+//   RDYN_FUSED_BLOCKS=n     persistent workgroups of the fused Gram kernels (default 256 = one per CU)
+//   RDYN_FUSED_DEBUG=bits   phase ablation of the fused Gram kernels (timing only: results are then wrong)
 #include <cstring>
 #include <map>
 #include <memory>
@@ -264,6 +273,12 @@ static int run_base(const rdyn_chain* c, const rdyn_batch* b, double* T_bt, doub
 int rdyn_local_ik(const rdyn_chain* c, const rdyn_batch* b, const double* T_target, const double* weight, double toll,
                   int max_iterations, double* sol, int32_t* status, int32_t* iterations)
 {
+  return rdyn_local_ik_damped(c, b, T_target, weight, toll, 0.0, max_iterations, sol, status, iterations);
+}
+
+int rdyn_local_ik_damped(const rdyn_chain* c, const rdyn_batch* b, const double* T_target, const double* weight, double toll,
+                         double damping, int max_iterations, double* sol, int32_t* status, int32_t* iterations)
+{
   int st = check_batch(c, b, false, false, "rdyn_local_ik");  // batch->q = the seeds
   if (st != RDYN_OK) return st;
   if (b->n_samples > 0 && (!T_target || !sol))
@@ -271,9 +286,9 @@ int rdyn_local_ik(const rdyn_chain* c, const rdyn_batch* b, const double* T_targ
     rdyn_set_error("rdyn_local_ik: null target or solution pointer");
     return RDYN_ERR_INVALID_ARGUMENT;
   }
-  if (max_iterations < 0 || !(toll >= 0.0))
+  if (max_iterations < 0 || !(toll >= 0.0) || !(damping >= 0.0))
   {
-    rdyn_set_error("rdyn_local_ik: negative iteration cap or tolerance");
+    rdyn_set_error("rdyn_local_ik: negative iteration cap, tolerance or damping");
     return RDYN_ERR_INVALID_ARGUMENT;
   }
   if (b->n_samples == 0) return RDYN_OK;
@@ -297,6 +312,7 @@ int rdyn_local_ik(const rdyn_chain* c, const rdyn_batch* b, const double* T_targ
     a.q_max[j] = c->q_max[j];
   }
   a.toll = toll;
+  a.damping = damping;
   a.max_iter = max_iterations;
   a.status = status;
   a.iterations = iterations;

@@ -251,7 +251,11 @@ __global__ __launch_bounds__(64) void k_local_ik(const RdynIkArgs a)
       g[i] = -(dot(wjl, el) + dot(wja, ea));
 #pragma unroll
       for (int j = 0; j <= i; ++j) H[TRI(i, j)] = dot(wjl, jl[j]) + dot(wja, ja[j]);
-      if (!((perm >> i) & 1u)) c1 += H[TRI(i, i)];
+      if (!((perm >> i) & 1u))
+      {
+        H[TRI(i, i)] += a.damping * a.damping;  // 0 unless the caller asked for a damped step (rdyn_local_ik_damped)
+        c1 += H[TRI(i, i)];
+      }
       lo[i] = a.q_min[i] - sol[i];  // dq_i >= lo_i  <=>  ci0 = sol - q_min (:1417)
       hi[i] = a.q_max[i] - sol[i];  // dq_i <= hi_i  <=>  ci0 = q_max - sol (:1418)
     }

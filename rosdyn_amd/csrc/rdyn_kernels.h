@@ -53,6 +53,7 @@ struct RdynIkArgs
   double q_min[RDYN_MAX_JOINTS];     // per CHAIN joint
   double q_max[RDYN_MAX_JOINTS];
   double toll;
+  double damping;                    // Levenberg term: damping^2 is added to the diagonal of J'WJ (0 = the reference's QP)
   int max_iter;
   int* status;                       // per pose, may be null: 1 converged, 0 not within max_iter, < 0 QP failure
   int* iterations;                   // per pose, may be null: QP updates performed

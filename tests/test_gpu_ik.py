@@ -115,3 +115,23 @@ def test_get_multiplicity_matches_reference_enumeration():
     for v in m:
         assert (v <= qmax).all() and (v >= qmin).all()
         assert np.allclose(((v - q) / (2 * np.pi)) - np.round((v - q) / (2 * np.pi)), 0, atol=1e-12)
+
+
+def test_damped_ik_makes_the_seven_dof_arm_solvable():
+    """rdyn_local_ik_damped: with a Levenberg term the 7-DOF Panda-like arm (singular J'J) converges; pose-by-pose
+    agreement with the oracle's damped loop on the poses it solves quickly."""
+    torch = pytest.importorskip("torch")
+    chain, ref, q_goal, seeds, T = _setup("panda_like.urdf", "link0", "hand", 1500, 0.2, seed=21)
+    sol, st, it = _run(torch, chain, T, seeds, "sample", toll=1e-6, max_iterations=40, damping=1e-3)
+    rsol, rst, rit = ref.local_ik(T, seeds, toll=1e-6, max_iter=40, damping=1e-3)
+    assert (st == 1).mean() > 0.9 and (rst == 1).mean() > 0.9
+    conv = (rst == 1) & (rit <= 10)
+    assert conv.mean() > 0.5 and (st[conv] == 1).all()
+    assert (np.abs(it[conv] - rit[conv]) <= 1).all()
+    # a redundant arm: the damped step is unique, so the iterates (not only the reached pose) agree
+    assert np.abs(sol[conv] - rsol[conv]).max() < 1e-6
+    from oracle.oracle import frame_distance
+    Ts = ref.fk(sol[st == 1][:200])[:, -1]
+    assert max(np.linalg.norm(frame_distance(a, b)) for a, b in zip(T[st == 1][:200], Ts)) < 1e-6
+    lo, hi = np.array(ref.spec.q_min), np.array(ref.spec.q_max)
+    assert (sol[st >= 0] >= lo - 1e-12).all() and (sol[st >= 0] <= hi + 1e-12).all()
