@@ -4,7 +4,7 @@
 // Eigen setRandom of lines 111-114), mean microseconds per call, gravity (0, 0, -9.806) (lines 61-62).
 //  part 1: one sample per call through the GPU (host -> device -> kernel -> host latency; drop-in behaviour);
 //  part 2: the same 10 000 samples as ONE batched call per function on device-resident data.
-// The jerk / linear / non-linear acceleration calls of the reference are outside the accelerated path and not timed.
+// All nine timed calls of the reference (lines 109-192) plus getRegressor; the *Tool getters of lines 187-191 are called too.
 // usage: rdyn_speed_test <urdf file> <base link> <tool link> [ntrial]
 #include <chrono>
 #include <cstdint>
@@ -45,13 +45,14 @@ int main(int argc, char** argv)
 
   rosdyn::ChainPtr chain = rosdyn::createChain(ss.str(), argv[2], argv[3], {0, 0, -9.806});
   const unsigned int n_joints = chain->getActiveJointsNumber();
-  rosdyn::VectorXd q(n_joints), Dq(n_joints), DDq(n_joints);
+  rosdyn::VectorXd q(n_joints), Dq(n_joints), DDq(n_joints), DDDq(n_joints);
   auto draw = [&]() {
     for (unsigned i = 0; i < n_joints; ++i)
     {
       q(i) = pm1();
       Dq(i) = pm1();
       DDq(i) = pm1();
+      DDDq(i) = pm1();
     }
   };
   if (argc > 5 && std::string(argv[5]) == "dump")
@@ -105,7 +106,7 @@ int main(int argc, char** argv)
     return 0;
   }
   g_state = 0x5EED0001ULL;
-  double t_pose = 0, t_jac = 0, t_vel = 0, t_acc = 0, t_torque = 0, t_inertia = 0, t_reg = 0, sink = 0;
+  double t_pose = 0, t_jac = 0, t_vel = 0, t_linacc = 0, t_nonlinacc = 0, t_acc = 0, t_jerk = 0, t_torque = 0, t_inertia = 0, t_reg = 0, sink = 0;
   chain->getJointTorque(q, Dq, DDq);  // first use uploads the chain constants
   for (int idx = 0; idx < ntrial; idx++)
   {
@@ -113,16 +114,25 @@ int main(int argc, char** argv)
     draw(); t0 = now_us(); sink += chain->getTransformation(q)(0, 3); t_pose += now_us() - t0;
     draw(); t0 = now_us(); sink += chain->getJacobian(q)(0, 0); t_jac += now_us() - t0;
     draw(); t0 = now_us(); sink += chain->getTwist(q, Dq).back()(0); t_vel += now_us() - t0;
+    draw(); t0 = now_us(); sink += chain->getDTwistLinearPart(q, DDq).back()(0); t_linacc += now_us() - t0;
+    draw(); t0 = now_us(); sink += chain->getDTwistNonLinearPart(q, Dq).back()(0); t_nonlinacc += now_us() - t0;
     draw(); t0 = now_us(); sink += chain->getDTwist(q, Dq, DDq).back()(0); t_acc += now_us() - t0;
+    draw(); t0 = now_us(); sink += chain->getDDTwist(q, Dq, DDq, DDDq).back()(0); t_jerk += now_us() - t0;
     draw(); t0 = now_us(); sink += chain->getJointTorque(q, Dq, DDq)(0); t_torque += now_us() - t0;
     draw(); t0 = now_us(); sink += chain->getJointInertia(q)(0, 0); t_inertia += now_us() - t0;
     draw(); t0 = now_us(); sink += chain->getRegressor(q, Dq, DDq)(0, 0); t_reg += now_us() - t0;
+    if (idx == 0)  // the tool-link shortcuts the reference calls untimed (lines 187-191)
+      sink += chain->getTwistTool(q, Dq)(0) + chain->getDTwistLinearPartTool(q, DDq)(0) + chain->getDTwistNonLinearPartTool(q, Dq)(0) +
+              chain->getDTwistTool(q, Dq, DDq)(0) + chain->getDDTwistTool(q, Dq, DDq, DDDq)(0);
   }
   std::printf("average on %d trials, ONE sample per call through the GPU (host round trip included):\n", ntrial);
   std::printf("computation time pose                                  = %9.3f [us]\n", t_pose / ntrial);
   std::printf("computation time jacobian                              = %9.3f [us]\n", t_jac / ntrial);
   std::printf("computation time velocity twists for all links         = %9.3f [us]\n", t_vel / ntrial);
+  std::printf("computation time linear acceleration twists for all links  = %9.3f [us]\n", t_linacc / ntrial);
+  std::printf("computation time non linear acc. twists for all links  = %9.3f [us]\n", t_nonlinacc / ntrial);
   std::printf("computation time acceleration twists for all links     = %9.3f [us]\n", t_acc / ntrial);
+  std::printf("computation time jerk twists for all links             = %9.3f [us]\n", t_jerk / ntrial);
   std::printf("computation time joint torque                          = %9.3f [us]\n", t_torque / ntrial);
   std::printf("computation time joint inertia                         = %9.3f [us]\n", t_inertia / ntrial);
   std::printf("computation time regressor                             = %9.3f [us]\n", t_reg / ntrial);

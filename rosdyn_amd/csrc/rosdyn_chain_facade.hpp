@@ -276,6 +276,13 @@ public:
     run(rdyn_twist_parts(m_h, &m_b, d_dddq, nullptr, nullptr, out(0)), 6 * m_links_number);
     return fill6(m_DDtwists);
   }
+  // tool-link shortcuts (primitives.h:459-488), used by the reference's harness (rosdyn_speed_test.cpp:187-191)
+  const Vector6d& getDTwistLinearPartTool(const VectorXd& q, const VectorXd& DDq) { return getDTwistLinearPart(q, DDq).back(); }
+  const Vector6d& getDTwistNonLinearPartTool(const VectorXd& q, const VectorXd& Dq) { return getDTwistNonLinearPart(q, Dq).back(); }
+  const Vector6d& getDDTwistTool(const VectorXd& q, const VectorXd& Dq, const VectorXd& DDq, const VectorXd& DDDq)
+  {
+    return getDDTwist(q, Dq, DDq, DDDq).back();
+  }
   // getJointTorque with external wrenches applied TO the links, in link frames (primitives.h:539)
   const VectorXd& getJointTorque(const VectorXd& q, const VectorXd& Dq, const VectorXd& DDq, const VectorOfVector6d& ext_wrenches_in_link_frame)
   {
