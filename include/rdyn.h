@@ -186,6 +186,14 @@ int rdyn_twist(const rdyn_chain* chain, const rdyn_batch* batch, double* twists,
  * :488 -> links_number x 6 per sample each; any output may be NULL; dddq (layout of q) only for ddtwists. */
 int rdyn_twist_parts(const rdyn_chain* chain, const rdyn_batch* batch, const double* dddq, double* dtwists_linear,
                      double* dtwists_nonlinear, double* ddtwists);
+/* getDDTwistLinearPart (needs q, dddq) primitives.h:476 / primitives_impl.h:1126-1154 and getDDTwistNonLinearPart
+ * (q, dq, ddq) primitives.h:480 / primitives_impl.h:1156-1183 -> links_number x 6 per sample each; either may be NULL. */
+int rdyn_jerk_parts(const rdyn_chain* chain, const rdyn_batch* batch, const double* dddq, double* ddtwists_linear,
+                    double* ddtwists_nonlinear);
+/* getWrench(q, Dq, DDq, ext_wrenches_in_link_frame) primitives.h:530 / primitives_impl.h:1225-1262 -> links_number x 6 per
+ * sample: the wrench transmitted through every link ([force; torque], base-frame coordinates, referred to the link's
+ * origin); getWrenchTool is the last record.  ext_wrenches as in rdyn_joint_torque_ext, NULL = none. */
+int rdyn_wrench(const rdyn_chain* chain, const rdyn_batch* batch, const double* ext_wrenches, double* wrenches);
 /* getJointTorque(q, Dq, DDq) primitives.h:540 -> n per sample */
 int rdyn_joint_torque(const rdyn_chain* chain, const rdyn_batch* batch, double* tau);
 /* getJointTorque(q, Dq, DDq, ext_wrenches_in_link_frame) primitives.h:539: ext_wrenches = links_number x 6 per sample

@@ -44,7 +44,7 @@ def lib():
         l.orc_chain_create.restype = C.c_void_p
         l.orc_chain_create.argtypes = [C.c_int, C.POINTER(_UJoint), C.POINTER(_ULink), dp, C.c_int, C.POINTER(C.c_int)]
         l.orc_chain_destroy.argtypes = [C.c_void_p]
-        for name, nargs in (("orc_fk", 2), ("orc_jacobian", 2), ("orc_jacobian_link", 3),("orc_twist", 3), ("orc_dtwist", 6), ("orc_ddtwist", 5),
+        for name, nargs in (("orc_fk", 2), ("orc_jacobian", 2), ("orc_jacobian_link", 3),("orc_twist", 3), ("orc_dtwist", 6), ("orc_ddtwist", 5), ("orc_ddtwist_parts", 6),
                             ("orc_joint_torque", 6), ("orc_regressor", 4), ("orc_joint_inertia", 2),
                             ("orc_nominal_parameters", 1)):
             f = getattr(l, name)
@@ -189,6 +189,14 @@ class OracleChain(object):
         for s in range(len(q)):
             lib().orc_ddtwist(self._h, _p(q[s]), _p(dq[s]), _p(ddq[s]), _p(dddq[s]), _p(j[s]))
         return j
+
+    def ddtwist_parts(self, q, dq, ddq, dddq):
+        """(getDDTwistLinearPart, getDDTwistNonLinearPart), each (N, L, 6)."""
+        q, dq, ddq, dddq = self._in(q, dq, ddq, dddq)
+        jl, jn = np.empty((len(q), self.L, 6)), np.empty((len(q), self.L, 6))
+        for s in range(len(q)):
+            lib().orc_ddtwist_parts(self._h, _p(q[s]), _p(dq[s]), _p(ddq[s]), _p(dddq[s]), _p(jl[s]), _p(jn[s]))
+        return jl, jn
 
     def joint_torque(self, q, dq, ddq, ext=None, wrenches=False):
         q, dq, ddq = self._in(q, dq, ddq)

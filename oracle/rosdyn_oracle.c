@@ -565,6 +565,37 @@ void orc_ddtwist(const orc_chain* c, const double* q, const double* Dq, const do
   getDDTwist(c, &s, DDDq);
   for (int l = 0; l < c->links_number; l++) for (int i = 0; i < 6; i++) ddtw[l * 6 + i] = s.DDtwists[l].v[i];
 }
+/* getDDTwistLinearPart impl.h:1126-1154 (jl) and getDDTwistNonLinearPart impl.h:1156-1183 (jn); either may be NULL */
+void orc_ddtwist_parts(const orc_chain* c, const double* q, const double* Dq, const double* DDq, const double* DDDq, double* jl, double* jn)
+{
+  orc_state s;
+  computeFrames(c, &s, q);
+  computeScrews(c, &s);
+  getTwist(c, &s, Dq);
+  getDTwist(c, &s, DDq);
+  sort_in(c, DDDq, s.sorted_DDDq);
+  v6 lin_part[ORC_MAX_LINKS], nonlin_part[ORC_MAX_LINKS];
+  lin_part[0] = v6_zero();
+  nonlin_part[0] = v6_zero();
+  for (int nl = 1; nl < c->links_number; nl++)
+  {
+    int nj = nl - 1;
+    v3 d = v3_sub(T_p(&s.T_bl[nl]), T_p(&s.T_bl[nl - 1]));
+    lin_part[nl] = v6_add(spatialTranslation(lin_part[nl - 1], d), v6_scale(s.screws[nl], s.sorted_DDDq[nj]));      /* :1148-1149 */
+    v6 v_cross_s = spatialCrossProduct(s.twists[nl], s.screws[nl]);                                                   /* :1174 */
+    v6 r = spatialTranslation(nonlin_part[nl - 1], d);                                                                /* :1175 */
+    r = v6_add(r, v6_scale(v_cross_s, s.sorted_DDq[nj]));                                                             /* :1176 */
+    r = v6_add(r, v6_scale(v6_add(spatialCrossProduct(s.Dtwists[nl], s.screws[nl]), spatialCrossProduct(s.twists[nl], v_cross_s)),
+                           s.sorted_Dq[nj]));                                                                         /* :1177-1178 */
+    nonlin_part[nl] = r;
+  }
+  for (int l = 0; l < c->links_number; l++)
+    for (int i = 0; i < 6; i++)
+    {
+      if (jl) jl[l * 6 + i] = lin_part[l].v[i];
+      if (jn) jn[l * 6 + i] = nonlin_part[l].v[i];
+    }
+}
 /* getJointTorque impl.h:1264-1283 : tau = n_active ; wrenches (optional) = L x 6 */
 void orc_joint_torque(const orc_chain* c, const double* q, const double* Dq, const double* DDq, const double* ext, double* tau, double* wrenches)
 {

@@ -78,6 +78,8 @@ SYMBOLS = {
     "rdyn_jacobian_link": (_I, [_VP, _BP, _I, _VP]),
     "rdyn_twist": (_I, [_VP, _BP, _VP, _VP]),
     "rdyn_twist_parts": (_I, [_VP, _BP, _VP, _VP, _VP, _VP]),
+    "rdyn_jerk_parts": (_I, [_VP, _BP, _VP, _VP, _VP]),
+    "rdyn_wrench": (_I, [_VP, _BP, _VP, _VP]),
     "rdyn_joint_torque_ext": (_I, [_VP, _BP, _VP, _VP]),
     "rdyn_joint_torque": (_I, [_VP, _BP, _VP]),
     "rdyn_joint_torque_nonlinear": (_I, [_VP, _BP, _VP]),

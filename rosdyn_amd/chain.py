@@ -273,6 +273,30 @@ class Chain(object):
     def getDDTwist(self, q, Dq, DDq, DDDq, layout="sample"):           # primitives.h:488
         return self._parts(q, Dq, DDq, DDDq, layout, 2)
 
+    def getDDTwistLinearPart(self, q, DDDq, layout="sample"):          # primitives.h:476
+        b, N, lay = self._batch(layout, q)
+        out = self._out(q, N, lay, (self.getLinksNumber(), 6))
+        check(lib().rdyn_jerk_parts(self._h, C.byref(b), DDDq.data_ptr(), out.data_ptr(), None))
+        return out
+
+    def getDDTwistNonLinearPart(self, q, Dq, DDq, layout="sample"):    # primitives.h:480
+        b, N, lay = self._batch(layout, q, Dq, DDq)
+        out = self._out(q, N, lay, (self.getLinksNumber(), 6))
+        check(lib().rdyn_jerk_parts(self._h, C.byref(b), None, None, out.data_ptr()))
+        return out
+
+    def getWrench(self, q, Dq, DDq, ext_wrenches_in_link_frame=None, layout="sample", out=None):      # primitives.h:530
+        """Link wrenches (N, L, 6) / (L, 6, N), base-frame coordinates at the link origins; [:, -1] is getWrenchTool."""
+        b, N, lay = self._batch(layout, q, Dq, DDq)
+        w = self._out(q, N, lay, (self.getLinksNumber(), 6), out)
+        ext = ext_wrenches_in_link_frame.data_ptr() if ext_wrenches_in_link_frame is not None else None
+        check(lib().rdyn_wrench(self._h, C.byref(b), ext, w.data_ptr()))
+        return w
+
+    def jointIndex(self, name):                                         # primitives.h:447: -1 when not an input joint
+        names = self.getActiveJointsName()
+        return names.index(name) if name in names else -1
+
     def getJointTorqueExt(self, q, Dq, DDq, ext_wrenches_in_link_frame, layout="sample", out=None):   # primitives.h:539
         """ext: (N, L, 6) for layout="sample", (L, 6, N) for "element"."""
         b, N, lay = self._batch(layout, q, Dq, DDq)

@@ -352,6 +352,67 @@ int rdyn_twist_parts(const rdyn_chain* c, const rdyn_batch* b, const double* ddd
   return RDYN_OK;
 }
 
+int rdyn_jerk_parts(const rdyn_chain* c, const rdyn_batch* b, const double* dddq, double* ddtw_lin, double* ddtw_nonlin)
+{
+  int st = check_batch(c, b, ddtw_nonlin != nullptr, ddtw_nonlin != nullptr, "rdyn_jerk_parts");
+  if (st != RDYN_OK) return st;
+  if ((!ddtw_lin && !ddtw_nonlin) || (ddtw_lin && !dddq && b->n_samples > 0))
+  {
+    rdyn_set_error("rdyn_jerk_parts: no output, or the linear part without dddq");
+    return RDYN_ERR_INVALID_ARGUMENT;
+  }
+  if (b->n_samples == 0) return RDYN_OK;
+  DeviceGuard g;
+  st = g.enter(b->device);
+  if (st != RDYN_OK) return st;
+  RdynKinExtArgs a;
+  memset(&a, 0, sizeof a);
+  st = device_const(c, &a.chain);
+  if (st != RDYN_OK) return st;
+  a.q = b->q;
+  a.dq = ddtw_nonlin ? b->dq : nullptr;
+  a.ddq = ddtw_nonlin ? b->ddq : nullptr;
+  a.dddq = ddtw_lin ? dddq : nullptr;
+  a.n_samples = b->n_samples;
+  rec_strides(b, c->n_active(), &a.in_ss, &a.in_sj);
+  rec_strides(b, 6 * (int64_t)(c->n_joints() + 1), &a.out_ss, &a.out_se);
+  a.ddtw_lin = ddtw_lin;
+  a.ddtw_nonlin = ddtw_nonlin;
+  RDYN_HIP_TRY(rdyn_launch_base_ext(c->n_joints(), a, (hipStream_t)b->stream));
+  return RDYN_OK;
+}
+
+int rdyn_wrench(const rdyn_chain* c, const rdyn_batch* b, const double* ext, double* wrenches)
+{
+  int st = check_batch(c, b, true, true, "rdyn_wrench");
+  if (st != RDYN_OK) return st;
+  if (!wrenches && b->n_samples > 0)
+  {
+    rdyn_set_error("rdyn_wrench: null output");
+    return RDYN_ERR_INVALID_ARGUMENT;
+  }
+  if (b->n_samples == 0) return RDYN_OK;
+  DeviceGuard g;
+  st = g.enter(b->device);
+  if (st != RDYN_OK) return st;
+  RdynKinExtArgs a;
+  memset(&a, 0, sizeof a);
+  st = device_const(c, &a.chain);
+  if (st != RDYN_OK) return st;
+  a.q = b->q;
+  a.dq = b->dq;
+  a.ddq = b->ddq;
+  a.n_samples = b->n_samples;
+  rec_strides(b, c->n_active(), &a.in_ss, &a.in_sj);
+  rec_strides(b, 6 * (int64_t)(c->n_joints() + 1), &a.out_ss, &a.out_se);
+  a.wrench = wrenches;
+  a.ext = ext;
+  a.ext_ss = a.out_ss;
+  a.ext_se = a.out_se;
+  RDYN_HIP_TRY(rdyn_launch_base_ext(c->n_joints(), a, (hipStream_t)b->stream));
+  return RDYN_OK;
+}
+
 int rdyn_joint_torque_ext(const rdyn_chain* c, const rdyn_batch* b, const double* ext, double* tau)
 {
   int st = check_batch(c, b, true, true, "rdyn_joint_torque_ext");

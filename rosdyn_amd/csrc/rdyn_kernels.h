@@ -37,6 +37,11 @@ struct RdynKinExtArgs
   double* dtw_lin;
   double* dtw_nonlin;
   double* ddtw;
+  double* ddtw_lin;     // getDDTwistLinearPart
+  double* ddtw_nonlin;  // getDDTwistNonLinearPart
+  double* wrench;       // getWrench: base-frame link wrenches
+  const double* ext;    // wrench only, may be null: external wrenches, links x 6, element e of sample s at ext[s * ext_ss + e * ext_se]
+  int64_t ext_ss, ext_se;
 };
 hipError_t rdyn_launch_base_ext(int n_joints, const RdynKinExtArgs& a, hipStream_t st);
 

@@ -3,7 +3,13 @@
 //   getDTwistLinearPart      :1029-1061   aL[l] = translate(aL[l-1], d) + S DDq
 //   getDTwistNonLinearPart   :1063-1080   aN[l] = translate(aN[l-1], d) + (v x S) Dq
 //   getDDTwist               :1185-1223   j[l]  = translate(j[l-1], d) + S DDDq + (v x S) DDq + (a x S + v x (v x S)) Dq
+//   getDDTwistLinearPart     :1126-1154   jL[l] = translate(jL[l-1], d) + S DDDq
+//   getDDTwistNonLinearPart  :1156-1183   jN[l] = translate(jN[l-1], d) + (v x S) DDq + (a x S + v x (v x S)) Dq
+//   getWrench                :1225-1262   w[l]  = T(-ext[l]) + inertial[l] + gravity[l] + dualTranslate(w[l+1], p_l - p_l+1)
 // One thread per sample; every output record is links x 6 doubles ([lin; ang] per link).
+// The wrench recursion runs tool -> base in the reference; here every link's own wrench is added, as soon as the forward
+// sweep reaches it, to the accumulators of all links up to it (dualTranslate is additive in the offset), so there is no
+// backward pass and no per-link frame storage: 6 (L) accumulators + the link origins in registers.
 #include <hip/hip_runtime.h>
 #include "rdyn_device.h"
 #include "rdyn_devmath.h"
@@ -37,7 +43,7 @@ __device__ __forceinline__ S6 axpy6(S6 a, S6 b, double s)
   return r;
 }
 
-template <int NJ>
+template <int NJ, bool WRENCH>
 __global__ __launch_bounds__(256) void k_base_ext(const RdynKinExtArgs a)
 {
   ChainPtr c = as_const(a.chain);
@@ -53,10 +59,32 @@ __global__ __launch_bounds__(256) void k_base_ext(const RdynKinExtArgs a)
   };
   const S6 zero = {mk(0, 0, 0), mk(0, 0, 0)};
   double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
-  S6 v = zero, acc = zero, aL = zero, aN = zero, jk = zero;
+  S6 v = zero, acc = zero, aL = zero, aN = zero, jk = zero, jL = zero, jN = zero;
   if (a.dtw_lin) put6(a.dtw_lin + s * a.out_ss, zero);
   if (a.dtw_nonlin) put6(a.dtw_nonlin + s * a.out_ss, zero);
   if (a.ddtw) put6(a.ddtw + s * a.out_ss, zero);
+  if (a.ddtw_lin) put6(a.ddtw_lin + s * a.out_ss, zero);
+  if (a.ddtw_nonlin) put6(a.ddtw_nonlin + s * a.out_ss, zero);
+  // wrench accumulators of links 0 .. NJ and their origins (WRENCH only)
+  S6 W[WRENCH ? NJ + 1 : 1];
+  V3 po[WRENCH ? NJ + 1 : 1];
+  V3 p = mk(0, 0, 0);
+  const V3 grav = mk(c->g[0], c->g[1], c->g[2]);
+  auto ext_of = [&](int link) -> S6 {  // -ext_wrenches_in_link_frame.at(link), :1255
+    S6 e = zero;
+    if (a.ext)
+    {
+      const double* __restrict__ ep = a.ext + s * a.ext_ss + (int64_t)(6 * link) * a.ext_se;
+      e.l = mk(-ep[0], -ep[a.ext_se], -ep[2 * a.ext_se]);
+      e.a = mk(-ep[3 * a.ext_se], -ep[4 * a.ext_se], -ep[5 * a.ext_se]);
+    }
+    return e;
+  };
+  if (WRENCH)
+  {
+    po[0] = p;
+    W[0] = ext_of(0);  // spatialTranformation(-ext, T_bl[0] = identity); no inertial / gravity term on the base link (:1233-1237)
+  }
 #pragma unroll
   for (int f = 0; f < NJ; ++f)
   {
@@ -104,24 +132,77 @@ __global__ __launch_bounds__(256) void k_base_ext(const RdynKinExtArgs a)
     v = axpy6(shift(v, d), S, dqf);
     const S6 vxs = xs(v, S);
     acc = axpy6(axpy6(shift(acc, d), vxs, dqf), S, ddqf);   // getDTwist, :1116-1117 (needed by the jerk)
-    aL = axpy6(shift(aL, d), S, ddqf);
-    aN = axpy6(shift(aN, d), vxs, dqf);
-    const S6 axs = xs(acc, S), vvxs = xs(v, vxs);
-    S6 cq;
-    cq.l = axs.l + vvxs.l;
-    cq.a = axs.a + vvxs.a;
-    jk = axpy6(axpy6(axpy6(shift(jk, d), S, dddqf), vxs, ddqf), cq, dqf);
-    const int64_t off = (int64_t)(6 * (f + 1)) * es;
-    if (a.dtw_lin) put6(a.dtw_lin + s * a.out_ss + off, aL);
-    if (a.dtw_nonlin) put6(a.dtw_nonlin + s * a.out_ss + off, aN);
-    if (a.ddtw) put6(a.ddtw + s * a.out_ss + off, jk);
+    if (!WRENCH)  // the wrench instantiation is launched on its own (rdyn_wrench): no split / jerk state in its registers
+    {
+      aL = axpy6(shift(aL, d), S, ddqf);
+      aN = axpy6(shift(aN, d), vxs, dqf);
+      const S6 axs = xs(acc, S), vvxs = xs(v, vxs);
+      S6 cq;
+      cq.l = axs.l + vvxs.l;
+      cq.a = axs.a + vvxs.a;
+      jk = axpy6(axpy6(axpy6(shift(jk, d), S, dddqf), vxs, ddqf), cq, dqf);
+      jL = axpy6(shift(jL, d), S, dddqf);
+      jN = axpy6(axpy6(shift(jN, d), vxs, ddqf), cq, dqf);
+      const int64_t off = (int64_t)(6 * (f + 1)) * es;
+      if (a.dtw_lin) put6(a.dtw_lin + s * a.out_ss + off, aL);
+      if (a.dtw_nonlin) put6(a.dtw_nonlin + s * a.out_ss + off, aN);
+      if (a.ddtw) put6(a.ddtw + s * a.out_ss + off, jk);
+      if (a.ddtw_lin) put6(a.ddtw_lin + s * a.out_ss + off, jL);
+      if (a.ddtw_nonlin) put6(a.ddtw_nonlin + s * a.out_ss + off, jN);
+    }
+    if (WRENCH)
+    {
+      p = p + d;
+      po[f + 1] = p;
+      // link f + 1: spatial inertia about its origin from the nominal parameters [m, m c, Io] (primitives_impl.h:399-417)
+      const double m = J.pi[0];
+      const V3 mc = mk(J.pi[1], J.pi[2], J.pi[3]);
+      auto Imul = [&](S6 x) -> S6 {  // [[m 1, m c^T],[m c^, Io]] x   (spacevect_algebra.h:232-239)
+        S6 r;
+        r.l = mk(m * x.l.x, m * x.l.y, m * x.l.z) - cross(mc, x.a);
+        r.a = cross(mc, x.l) + symv(J.pi + 4, x.a);
+        return r;
+      };
+      S6 al, vloc;
+      al.l = rotT(R, acc.l); al.a = rotT(R, acc.a);      // spatialRotation(m_Dtwists, R^T), :1242
+      vloc.l = rotT(R, v.l); vloc.a = rotT(R, v.a);      // :1245
+      const S6 Iv = Imul(vloc), Ia = Imul(al);
+      S6 wl;  // I a + v x* (I v), spatialDualCrossProduct spacevect_algebra.h:108-113
+      wl.l = Ia.l + cross(vloc.a, Iv.l);
+      wl.a = Ia.a + cross(vloc.a, Iv.a) + cross(vloc.l, Iv.l);
+      S6 own;
+      own.l = rot(R, wl.l);                              // :1248
+      own.a = rot(R, wl.a);
+      own.l = own.l - mk(m * grav.x, m * grav.y, m * grav.z);   // gravity wrench, :1249-1250
+      own.a = own.a - cross(rot(R, mc), grav);
+      const S6 e = ext_of(f + 1);                        // spatialTranformation(-ext, T_bl): twist form, :1255 / spacevect_algebra.h:193-197
+      const V3 Ra = rot(R, e.a);
+      own.l = own.l + rot(R, e.l) + cross(Ra, p);
+      own.a = own.a + Ra;
+      W[f + 1] = own;
+#pragma unroll
+      for (int l = 0; l <= f; ++l)  // spatialDualTranslation(w, p_l - p_{f+1}): ang += lin x d, :1255
+      {
+        W[l].l = W[l].l + own.l;
+        W[l].a = W[l].a + own.a + cross(own.l, po[l] - p);
+      }
+    }
+  }
+  if (WRENCH)
+  {
+#pragma unroll
+    for (int l = 0; l <= NJ; ++l) put6(a.wrench + s * a.out_ss + (int64_t)(6 * l) * es, W[l]);
   }
 }
 
 template <int NJ>
 hipError_t launch_ext_nj(const RdynKinExtArgs& a, hipStream_t st)
 {
-  hipLaunchKernelGGL((k_base_ext<NJ>), dim3((unsigned)((a.n_samples + 255) / 256)), dim3(256), 0, st, a);
+  const dim3 grid((unsigned)((a.n_samples + 255) / 256));
+  if (a.wrench)
+    hipLaunchKernelGGL((k_base_ext<NJ, true>), grid, dim3(256), 0, st, a);
+  else
+    hipLaunchKernelGGL((k_base_ext<NJ, false>), grid, dim3(256), 0, st, a);
   return hipGetLastError();
 }
 }  // namespace

@@ -97,6 +97,23 @@ int main(int argc, char** argv)
     std::printf("IK %d", found ? 1 : 0);
     for (unsigned i = 0; i < n_joints; ++i) std::printf(" %.17g", sol(i));
     std::printf("\n");
+    {
+      rosdyn::VectorXd DDDq(n_joints);
+      for (unsigned i = 0; i < n_joints; ++i) DDDq(i) = 0.7 - 0.1 * i;
+      rosdyn::VectorOfVector6d ext(chain->getLinksNumber());
+      for (unsigned l = 0; l < chain->getLinksNumber(); ++l)
+        for (int i = 0; i < 6; ++i) ext[l](i) = 0.5 * (l + 1) - 0.3 * i;
+      const rosdyn::Vector6d& wt = chain->getWrench(q, Dq, DDq, ext).front();  // wrench at the base link: the whole chain
+      std::printf("W");
+      for (int i = 0; i < 6; ++i) std::printf(" %.17g", wt(i));
+      const rosdyn::Vector6d& jl = chain->getDDTwistLinearPartTool(q, DDDq);
+      const rosdyn::Vector6d jlc = jl;
+      const rosdyn::Vector6d& jn = chain->getDDTwistNonLinearPartTool(q, Dq, DDq);
+      for (int i = 0; i < 6; ++i) std::printf(" %.17g", jlc(i) + jn(i));
+      const rosdyn::Vector6d& jt = chain->getDDTwistTool(q, Dq, DDq, DDDq);
+      for (int i = 0; i < 6; ++i) std::printf(" %.17g", jt(i));
+      std::printf("\n");
+    }
     const std::string mid = chain->getLinksName().at(chain->getLinksNumber() / 2);
     rosdyn::Matrix6Xd Jl = chain->getJacobianLink(q, mid);
     std::printf("L");

@@ -276,6 +276,58 @@ public:
     run(rdyn_twist_parts(m_h, &m_b, d_dddq, nullptr, nullptr, out(0)), 6 * m_links_number);
     return fill6(m_DDtwists);
   }
+  // jerk split, primitives.h:476-484
+  const VectorOfVector6d& getDDTwistLinearPart(const VectorXd& q, const VectorXd& DDDq)
+  {
+    stage(&q, nullptr, nullptr);
+    if ((size_t)DDDq.rows() != m_active_joints_number) throw std::invalid_argument("Input data dimensions mismatch");
+    double* d_dddq = out(6 * (size_t)m_links_number);
+    hip(hipMemcpyAsync(d_dddq, DDDq.data(), m_active_joints_number * sizeof(double), hipMemcpyHostToDevice, nullptr));
+    hip(hipStreamSynchronize(nullptr));  // DDDq may be pageable caller memory
+    run(rdyn_jerk_parts(m_h, &m_b, d_dddq, out(0), nullptr), 6 * m_links_number);
+    return fill6(m_DDtwists_linear_part);
+  }
+  const VectorOfVector6d& getDDTwistNonLinearPart(const VectorXd& q, const VectorXd& Dq, const VectorXd& DDq)
+  {
+    stage(&q, &Dq, &DDq);
+    run(rdyn_jerk_parts(m_h, &m_b, nullptr, nullptr, out(0)), 6 * m_links_number);
+    return fill6(m_DDtwists_nonlinear_part);
+  }
+  const Vector6d& getDDTwistLinearPartTool(const VectorXd& q, const VectorXd& DDDq) { return getDDTwistLinearPart(q, DDDq).back(); }
+  const Vector6d& getDDTwistNonLinearPartTool(const VectorXd& q, const VectorXd& Dq, const VectorXd& DDq)
+  {
+    return getDDTwistNonLinearPart(q, Dq, DDq).back();
+  }
+  // link wrenches, primitives.h:530-535 (base-frame coordinates, referred to each link's origin)
+  const VectorOfVector6d& getWrench(const VectorXd& q, const VectorXd& Dq, const VectorXd& DDq, const VectorOfVector6d& ext_wrenches_in_link_frame)
+  {
+    if (ext_wrenches_in_link_frame.size() != m_links_number) throw std::invalid_argument("Input data dimensions mismatch");
+    stage(&q, &Dq, &DDq);
+    std::vector<double> e(6 * (size_t)m_links_number);
+    for (unsigned l = 0; l < m_links_number; ++l)
+      for (int i = 0; i < 6; ++i) e[6 * l + i] = ext_wrenches_in_link_frame[l](i);
+    double* d_ext = out(6 * (size_t)m_links_number);
+    hip(hipMemcpyAsync(d_ext, e.data(), e.size() * sizeof(double), hipMemcpyHostToDevice, nullptr));
+    hip(hipStreamSynchronize(nullptr));  // `e` is pageable stack-owned memory
+    run(rdyn_wrench(m_h, &m_b, d_ext, out(0)), 6 * m_links_number);
+    return fill6(m_wrenches);
+  }
+  const Vector6d& getWrenchTool(const VectorXd& q, const VectorXd& Dq, const VectorXd& DDq, const VectorOfVector6d& ext_wrenches_in_link_frame)
+  {
+    return getWrench(q, Dq, DDq, ext_wrenches_in_link_frame).back();
+  }
+  // per-axis limit getters and the input-joint lookup, primitives.h:434-447
+  double getQMax(int iAx) const { return m_q_max(iAx); }
+  double getQMin(int iAx) const { return m_q_min(iAx); }
+  double getDQMax(int iAx) const { return m_Dq_max(iAx); }
+  double getDDQMax(int iAx) const { return m_DDq_max(iAx); }
+  double getTauMax(int iAx) const { return m_tau_max(iAx); }
+  int jointIndex(const std::string& name) const
+  {
+    for (unsigned i = 0; i < m_active_joints_number; ++i)
+      if (m_active_joints_name[i] == name) return (int)i;
+    return -1;
+  }
   // tool-link shortcuts (primitives.h:459-488), used by the reference's harness (rosdyn_speed_test.cpp:187-191)
   const Vector6d& getDTwistLinearPartTool(const VectorXd& q, const VectorXd& DDq) { return getDTwistLinearPart(q, DDq).back(); }
   const Vector6d& getDTwistNonLinearPartTool(const VectorXd& q, const VectorXd& Dq) { return getDTwistNonLinearPart(q, Dq).back(); }
@@ -370,7 +422,8 @@ private:
   Affine3d m_T_bt;
   VectorOfAffine3d m_T_bl;
   Matrix6Xd m_jacobian;
-  VectorOfVector6d m_twists, m_Dtwists, m_Dtwists_linear_part, m_Dtwists_nonlinear_part, m_DDtwists;
+  VectorOfVector6d m_twists, m_Dtwists, m_Dtwists_linear_part, m_Dtwists_nonlinear_part, m_DDtwists, m_DDtwists_linear_part,
+      m_DDtwists_nonlinear_part, m_wrenches;
   MatrixXd m_joint_inertia;
   // staging: pinned host + device buffers for ONE sample
   double* m_dev = nullptr;

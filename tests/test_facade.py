@@ -45,7 +45,7 @@ def test_facade_single_sample_values_match_oracle():
     urdf = os.path.join(FIXTURES, "ur10_like.urdf")
     r = subprocess.run([BIN, urdf, "base_link", "tool0", "1", "dump"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr
-    vals = {l.split()[0]: np.array([float(x) for x in l.split()[1:]]) for l in r.stdout.splitlines() if l and l[0] in "tYMTJIL"}
+    vals = {l.split()[0]: np.array([float(x) for x in l.split()[1:]]) for l in r.stdout.splitlines() if l and l[0] in "tYMTJILW"}
     ref = OracleChain(urdf, "base_link", "tool0", (0.0, 0.0, -9.806))
     n = ref.n
     q = np.array([[0.1 * (i + 1) for i in range(n)]])
@@ -60,6 +60,14 @@ def test_facade_single_sample_values_match_oracle():
     close(vals["T"], ref.fk(q)[0, -1].T.reshape(-1))                       # column-major 3 x 4
     close(vals["J"], ref.jacobian(q)[0].T.reshape(-1))                     # column-major 6 x n
     close(vals["L"], ref.jacobian_link(q, ref.L // 2)[0].T.reshape(-1))    # getJacobianLink of the middle link
+    # getWrench with external loads (base-link record), jerk parts summing to the jerk (tool link)
+    dddq = np.array([[0.7 - 0.1 * i for i in range(n)]])
+    ext = np.array([[[0.5 * (l + 1) - 0.3 * i for i in range(6)] for l in range(ref.L)]])
+    _, w = ref.joint_torque(q, dq, ddq, ext=ext, wrenches=True)
+    close(vals["W"][:6], w[0, 0])
+    jerk = ref.ddtwist(q, dq, ddq, dddq)[0, -1]
+    close(vals["W"][6:12], jerk)
+    close(vals["W"][12:18], jerk)
     # computeLocalIk as in rosdyn_core/README.md:78-84: back to q from a displaced seed
     seed = q + np.array([[0.2 if i % 2 == 0 else -0.15 for i in range(n)]])
     rsol, rst, _ = ref.local_ik(ref.fk(q)[:, -1], seed, toll=1e-8, max_iter=50)

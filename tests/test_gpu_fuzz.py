@@ -107,6 +107,11 @@ def test_fuzzed_chain_all_entry_points(seed):
     close(host(chain.getDTwistLinearPart(tq, tddq, layout=layout)), al, "dtwist linear")
     close(host(chain.getDTwistNonLinearPart(tq, tdq, layout=layout)), an, "dtwist non-linear")
     close(host(chain.getDDTwist(tq, tdq, tddq, tdddq, layout=layout)), ref.ddtwist(q, dq, ddq, dddq), "jerk")
+    jl, jn = ref.ddtwist_parts(q, dq, ddq, dddq)
+    close(host(chain.getDDTwistLinearPart(tq, tdddq, layout=layout)), jl, "jerk linear")
+    close(host(chain.getDDTwistNonLinearPart(tq, tdq, tddq, layout=layout)), jn, "jerk non-linear")
+    _, wr = ref.joint_torque(q, dq, ddq, ext=ext, wrenches=True)
+    close(host(chain.getWrench(tq, tdq, tddq, text, layout=layout)), wr, "wrenches")
     tau = ref.joint_torque(q, dq, ddq)
     close(host(chain.getJointTorque(tq, tdq, tddq, layout=layout)), tau, "tau")
     close(host(chain.getJointTorqueNonLinearPart(tq, tdq, layout=layout)), ref.joint_torque(q, dq, 0 * ddq), "tau nl")
