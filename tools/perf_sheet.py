@@ -1,0 +1,54 @@
+#!/usr/bin/env python3
+"""One MI355X, one table: every batched entry point at N = 1e6 (UR10-like base_link -> wrist_3_link, n = 6, P = 60,
+element-major unless stated), time per call, calls/s per sample and the algorithmic HBM bytes each one moves."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from rosdyn_amd import Chain                 # noqa: E402
+from rosdyn_amd.components import ComponentSet  # noqa: E402
+from tools.probe import timeit               # noqa: E402
+
+N, n, L, P = 1000000, 6, 7, 60
+chain = Chain(os.path.join(ROOT, "tests/fixtures/ur10_like.urdf"), "base_link", "wrist_3_link", (0, 0, -9.806))
+q, dq, ddq, dddq = (torch.rand((n, N), dtype=torch.float64, device="cuda") * 2 - 1 for _ in range(4))
+qs, dqs, ddqs = (t.T.contiguous() for t in (q, dq, ddq))
+ext = torch.rand((L, 6, N), dtype=torch.float64, device="cuda")
+tau = chain.getJointTorque(q, dq, ddq, layout="element")
+rows = []
+
+
+def row(name, fn, bytes_per_eval, reps=10):
+    t = timeit(fn, reps=reps, warm=2)
+    rows.append((name, t * 1e6, N / t, bytes_per_eval, bytes_per_eval * N / t / 1e9))
+
+
+E = "element"
+row("getRegressor + tau (element-major Y)", lambda: chain.getRegressor(q, dq, ddq, layout=E, with_torque=True), 3072)
+row("getRegressor + tau (stacked column-major Y)", lambda: chain.getRegressor(qs, dqs, ddqs, y_layout="stacked", with_torque=True), 3072)
+row("getRegressor + tau (per-sample Eigen image)", lambda: chain.getRegressor(qs, dqs, ddqs, with_torque=True), 3072)
+row("getJointTorque", lambda: chain.getJointTorque(q, dq, ddq, layout=E), 192)
+row("getJointTorque with external wrenches", lambda: chain.getJointTorqueExt(q, dq, ddq, ext, layout=E), 192 + 48 * L)
+row("getJointTorqueNonLinearPart", lambda: chain.getJointTorqueNonLinearPart(q, dq, layout=E), 144)
+row("getJointInertia", lambda: chain.getJointInertia(q, layout=E), 48 + 288)
+row("getWrench (all links, external wrenches)", lambda: chain.getWrench(q, dq, ddq, ext, layout=E), 144 + 96 * L)
+row("getTransformation (tool)", lambda: chain.getTransformation(q, layout=E), 48 + 96)
+row("getTransformations (all links)", lambda: chain.getTransformations(q, layout=E), 48 + 96 * L)
+row("getJacobian", lambda: chain.getJacobian(q, layout=E), 48 + 288)
+row("getTwist (all links)", lambda: chain.getTwist(q, dq, layout=E), 96 + 48 * L)
+row("getDTwist (all links)", lambda: chain.getDTwist(q, dq, ddq, layout=E), 144 + 48 * L)
+row("getDDTwist (all links)", lambda: chain.getDDTwist(q, dq, ddq, dddq, layout=E), 192 + 48 * L)
+row("regressor -> Gram [A|tau]'[A|tau] fused", lambda: chain.getRegressorGram(q, dq, ddq, tau, layout=E), 192)
+comps = ComponentSet([dict(type=0, joint=j, min_velocity=1e-3, max_velocity=10.0, parameters=[0.1, 0.2]) for j in range(n)], n)
+row("friction components (6 x first order, dense n x K)", lambda: comps.getRegressor(q, dq, layout=E), 96 + 8 * n * comps.columns)
+T = chain.getTransformation(q, layout=E)
+seeds = q + 0.25 * (torch.rand_like(q) * 2 - 1)
+row("computeLocalIk, <= 8 updates, seeds within 0.25 rad", lambda: chain.computeLocalIk(T, seeds, toll=1e-6, max_iterations=8, layout=E), 96 + 48 + 48 + 8, reps=5)
+
+print("%-52s %10s %14s %10s %10s" % ("entry point (N = 1e6 per call)", "us / call", "evals/s", "B / eval", "GB/s"))
+for r in rows:
+    print("%-52s %10.1f %14.3e %10d %10.0f" % r)
