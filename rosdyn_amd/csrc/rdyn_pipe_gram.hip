@@ -21,8 +21,10 @@
 // VALU instructions per MFMA makes no difference (5, 10, 16: same time): the gain is stall filling, the floor is the SUM
 // of the two instruction streams (~18 k cycles per tile; the kernel runs at ~31 k, PMC in profiles/r1/pipe_gram_pmc.txt).
 // Same tile layout, arguments, accumulation order and epilogue as rdyn_lds_gram.hip: results are bit-identical to it.
-// Instantiated for up to 4 column blocks (chains of up to 6 joints): with 5 blocks (15 accumulator tiles) hipcc spills
-// (352 B of scratch at NJ = 7) and the kernel is slower than the two-phase one (6.33 vs 5.14 ms at n = 7, N = 4e6).
+// Chains of up to 6 joints: link loop unrolled.  7 joints (5 column blocks, 15 accumulator tiles): unrolled, hipcc spills
+// 352 B and the kernel is slower than the two-phase one (6.33 vs 5.14 ms at n = 7, N = 4e6); with the link loop ROLLED
+// and the body instantiated once per zero band it spills 44 B and wins (4.90 ms).  8+ joints: more spills, no gain
+// (2.97 vs 2.92 ms at 9 joints) -- those chains keep the two-phase kernel.
 #include <hip/hip_runtime.h>
 #include <atomic>
 #include <cstdint>
@@ -53,7 +55,7 @@ __device__ __forceinline__ void mfma_kstep(const d4* op, int t, int cbm, d4* acc
     }
 }
 __device__ __forceinline__ constexpr int tiles_from(int nb, int cbm) { return (nb - cbm) * (nb - cbm + 1) / 2; }
-template <int NJ>
+template <int NJ, bool ROLLED>
 __global__ __launch_bounds__(256) void k_regressor_gram_pipe(const RdynLdsGramArgs fa)
 {
   constexpr int NB = (10 * NJ + 1 + 15) / 16;
@@ -139,121 +141,66 @@ __global__ __launch_bounds__(256) void k_regressor_gram_pipe(const RdynLdsGramAr
     V3 lin = mk(-c->g[0], -c->g[1], -c->g[2]);
     V3 L0 = mk(0, 0, 0), A0 = mk(0, 0, 0), L1 = mk(0, 0, 0), A1 = mk(0, 0, 0);
 
-#pragma unroll
-    for (int f = 0; f < NJ; ++f)
+    if constexpr (!ROLLED)
     {
-      JointRef J = c->j[f];
-      const int type = J.type;
-      const int idx = J.in_idx;
-      const bool act = idx >= 0, rev = type == RDYN_REVOLUTE, pri = type == RDYN_PRISMATIC;
-      // input joint idx lives in lane (idx & 3) of my sample's quad, first or second slot (all wave-uniform choices)
-      const int sidx = act ? idx : 0;
-      const int src = (lane & ~3) | (sidx & 3);
-      const bool second = sidx >= 4;
-      const double qs = __shfl(second ? qb : qa, src), dqs = __shfl(second ? dqb : dqa, src), ddqs = __shfl(second ? ddqb : ddqa, src);
-      const double qf = act ? qs : 0.0, dqf = act ? dqs : 0.0, ddqf = act ? ddqs : 0.0;
-      // revolute: R = A + sin q B + (1 - cos q) C; every other kind takes the angle 0: sin = 0, 1 - cos = 0, R = A exactly
-      double sn, cs;
-      sincos(rev ? qf : 0.0, &sn, &cs);
-      const double oc = 1.0 - cs;
-      // ---------- from here to the end of the link: ONE basic block (selects, no branches)
-      double R[9];
 #pragma unroll
-      for (int i = 0; i < 9; ++i) R[i] = fma(sn, J.B[i], fma(oc, J.C[i], J.A[i]));
-      const V3 tt = axpy(ld3(J.t), ld3(J.up), pri ? qf : 0.0);
+      for (int f = 0; f < NJ; ++f)
       {
-        const V3 wn = rotT(R, w);
-        const V3 vn = rotT(R, vl + cross(w, tt));
-        const V3 aln = rotT(R, al);
-        const V3 an = rotT(R, lin + cross(al, tt));
-        w = wn; vl = vn; al = aln; lin = an;
-        const V3 nL0 = rotT(R, L0 + cross(A0, tt));
-        A0 = rotT(R, A0);
-        L0 = nL0;
-        const V3 nL1 = rotT(R, L1 + cross(A1, tt));
-        A1 = rotT(R, A1);
-        L1 = nL1;
+        const int CBM = (10 * f) >> 4;
+#include "rdyn_pipe_link_body.inc"
       }
-      const V3 u = ld3(J.u);
+    }
+    else
+    {
+      // longer chains: the unrolled form needs more registers than the file has (15+ accumulator tiles), so the link loop
+      // stays rolled and the body is instantiated once per zero band (CBM selects the MFMAs of row group f at compile time)
+#pragma nounroll
+      for (int f = 0; f < NJ; ++f)
       {
-        // revolute: lin += (vl x u) dq, al += (w x u) dq + u ddq, w += u dq;  prismatic: lin += (w x u) dq + u ddq, vl += u dq
-        const double dqr = rev ? dqf : 0.0, ddqr = rev ? ddqf : 0.0, dqp = pri ? dqf : 0.0, ddqp = pri ? ddqf : 0.0;
-        const V3 wxu = cross(w, u);
-        lin = axpy(axpy(axpy(lin, cross(vl, u), dqr), wxu, dqp), u, ddqp);
-        al = axpy(axpy(al, wxu, dqr), u, ddqr);
-        w = axpy(w, u, dqr);
-        vl = axpy(vl, u, dqp);
-      }
-      {
-        const V3 sl = mk(pri ? u.x : 0.0, pri ? u.y : 0.0, pri ? u.z : 0.0), sa = mk(rev ? u.x : 0.0, rev ? u.y : 0.0, rev ? u.z : 0.0);
-        const bool m0 = act && (idx == r0), m1 = act && (idx == r1);
-        L0 = mk(m0 ? sl.x : L0.x, m0 ? sl.y : L0.y, m0 ? sl.z : L0.z);
-        A0 = mk(m0 ? sa.x : A0.x, m0 ? sa.y : A0.y, m0 ? sa.z : A0.z);
-        L1 = mk(m1 ? sl.x : L1.x, m1 ? sl.y : L1.y, m1 ? sl.z : L1.z);
-        A1 = mk(m1 ? sa.x : A1.x, m1 ? sa.y : A1.y, m1 ? sa.z : A1.z);
-      }
-
-      // The PREVIOUS tile's row group f, read from LDS just in time: its rows only exist in the columns of links >= f,
-      // which this sweep has not rewritten yet (link f's own columns are written at the end of this block).  Its four
-      // k-steps are executed by the matrix pipe behind the VALU work of this block.
-      {
-        d4 op[NB];
-        lds_group(f, op);
-#pragma unroll
-        for (int t = 0; t < 4; ++t) mfma_kstep<NB>(op, t, (10 * f) >> 4, acc);
-      }
-
-      const V3 d = lin + cross(w, vl);
-      const double wxy = w.x * w.y, wxz = w.x * w.z, wyz = w.y * w.z;
-      const double wxx = w.x * w.x, wyy = w.y * w.y, wzz = w.z * w.z;
-      const double b00 = -(wyy + wzz), b01 = wxy - al.z, b02 = wxz + al.y;
-      const double b10 = wxy + al.z, b11 = -(wxx + wzz), b12 = wyz - al.x;
-      const double b20 = wxz - al.y, b21 = wyz + al.x, b22 = -(wxx + wyy);
-      double y0[10], y1[10];
-      {
-        const V3 dxA = cross(d, A0), x = cross(A0, w);
-        y0[0] = dot(L0, d);
-        y0[1] = fma(L0.x, b00, fma(L0.y, b10, fma(L0.z, b20, dxA.x)));
-        y0[2] = fma(L0.x, b01, fma(L0.y, b11, fma(L0.z, b21, dxA.y)));
-        y0[3] = fma(L0.x, b02, fma(L0.y, b12, fma(L0.z, b22, dxA.z)));
-        y0[4] = fma(A0.x, al.x, x.x * w.x);
-        y0[5] = fma(A0.x, al.y, fma(A0.y, al.x, fma(x.x, w.y, x.y * w.x)));
-        y0[6] = fma(A0.x, al.z, fma(A0.z, al.x, fma(x.x, w.z, x.z * w.x)));
-        y0[7] = fma(A0.y, al.y, x.y * w.y);
-        y0[8] = fma(A0.y, al.z, fma(A0.z, al.y, fma(x.y, w.z, x.z * w.y)));
-        y0[9] = fma(A0.z, al.z, x.z * w.z);
-      }
-      {
-        const V3 dxA = cross(d, A1), x = cross(A1, w);
-        y1[0] = dot(L1, d);
-        y1[1] = fma(L1.x, b00, fma(L1.y, b10, fma(L1.z, b20, dxA.x)));
-        y1[2] = fma(L1.x, b01, fma(L1.y, b11, fma(L1.z, b21, dxA.y)));
-        y1[3] = fma(L1.x, b02, fma(L1.y, b12, fma(L1.z, b22, dxA.z)));
-        y1[4] = fma(A1.x, al.x, x.x * w.x);
-        y1[5] = fma(A1.x, al.y, fma(A1.y, al.x, fma(x.x, w.y, x.y * w.x)));
-        y1[6] = fma(A1.x, al.z, fma(A1.z, al.x, fma(x.x, w.z, x.z * w.x)));
-        y1[7] = fma(A1.y, al.y, x.y * w.y);
-        y1[8] = fma(A1.y, al.z, fma(A1.z, al.y, fma(x.y, w.z, x.z * w.y)));
-        y1[9] = fma(A1.z, al.z, x.z * w.z);
-      }
-      // rows j < m_f are stored for the columns of link f (row = 16 j + sample); the others go to the dummy slot
-      const int mf = fa.lds_m[f], stride = fa.lds_stride[f];
-      char* const lf = tile + fa.lds_off[f] + s_loc * 8;
-      char* const p0 = r0 < mf ? lf + r0 * 128 : dummy;
-      char* const p1 = r1 < mf ? lf + r1 * 128 : dummy;
-      const int st0 = r0 < mf ? stride : 0, st1 = r1 < mf ? stride : 0;
-#pragma unroll
-      for (int p = 0; p < 10; ++p)
-      {
-        *(double*)(p0 + p * st0) = y0[p] * zmask;
-        *(double*)(p1 + p * st1) = y1[p] * zmask;
-      }
-      // scheduling pipeline for this block: one MFMA, then ten VALU instructions, for every MFMA of the link
-#pragma unroll
-      for (int i = 0; i < (RDYN_PIPE_VALU_PER_MFMA > 0 ? 4 * tiles_from(NB, (10 * f) >> 4) : 0); ++i)
-      {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x002, RDYN_PIPE_VALU_PER_MFMA, 0);
+        switch ((10 * f) >> 4)
+        {
+        case 0:
+        {
+          constexpr int CBM = 0;
+#include "rdyn_pipe_link_body.inc"
+        }
+        break;
+        case 1:
+          if constexpr (1 < NB)
+          {
+            constexpr int CBM = 1;
+#include "rdyn_pipe_link_body.inc"
+          }
+          break;
+        case 2:
+          if constexpr (2 < NB)
+          {
+            constexpr int CBM = 2;
+#include "rdyn_pipe_link_body.inc"
+          }
+          break;
+        case 3:
+          if constexpr (3 < NB)
+          {
+            constexpr int CBM = 3;
+#include "rdyn_pipe_link_body.inc"
+          }
+          break;
+        case 4:
+          if constexpr (4 < NB)
+          {
+            constexpr int CBM = 4;
+#include "rdyn_pipe_link_body.inc"
+          }
+          break;
+        default:
+          if constexpr (5 < NB)
+          {
+            constexpr int CBM = 5;
+#include "rdyn_pipe_link_body.inc"
+          }
+          break;
+        }
       }
     }
     // measured torque -> column P
@@ -276,7 +223,7 @@ __global__ __launch_bounds__(256) void k_regressor_gram_pipe(const RdynLdsGramAr
     d4 op[NB];
     lds_group(j, op);
 #pragma unroll
-    for (int t = 0; t < 4; ++t) mfma_kstep<NB>(op, t, (10 * j) >> 4, acc);
+    for (int t = 0; t < 4; ++t) mfma_kstep<NB>(op, t, (10 * j) >> 4, acc);  // operands left of the band are zero
   }
 
   // ================= epilogue: block reduction through LDS (the tiles are dead now), this block's Gram slab
@@ -312,16 +259,16 @@ hipError_t launch_pipe_nj(const RdynLdsGramArgs& a, int blocks, size_t lds_bytes
   const uint64_t bit = 1ull << (dev & 63);
   if (!(attr_set.load(std::memory_order_acquire) & bit))
   {
-    e = hipFuncSetAttribute((const void*)k_regressor_gram_pipe<NJ>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    e = hipFuncSetAttribute((const void*)k_regressor_gram_pipe<NJ, (NJ > 6)>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
     attr_set.fetch_or(bit, std::memory_order_release);
   }
-  hipLaunchKernelGGL((k_regressor_gram_pipe<NJ>), dim3(blocks), dim3(256), lds_bytes, st, a);
+  hipLaunchKernelGGL((k_regressor_gram_pipe<NJ, (NJ > 6)>), dim3(blocks), dim3(256), lds_bytes, st, a);
   return hipGetLastError();
 }
 }  // namespace
 
-bool rdyn_regressor_gram_pipe_supported(int n_cols) { return n_cols >= 20 && n_cols <= 60; }
+bool rdyn_regressor_gram_pipe_supported(int n_cols) { return n_cols >= 20 && n_cols <= 70; }
 
 hipError_t rdyn_launch_regressor_gram_pipe(int n_cols, const RdynLdsGramArgs& a, int blocks, size_t lds_bytes, hipStream_t st)
 {
@@ -332,6 +279,7 @@ hipError_t rdyn_launch_regressor_gram_pipe(int n_cols, const RdynLdsGramArgs& a,
   case 4: return launch_pipe_nj<4>(a, blocks, lds_bytes, st);
   case 5: return launch_pipe_nj<5>(a, blocks, lds_bytes, st);
   case 6: return launch_pipe_nj<6>(a, blocks, lds_bytes, st);
+  case 7: return launch_pipe_nj<7>(a, blocks, lds_bytes, st);
   default: return hipErrorInvalidValue;
   }
 }

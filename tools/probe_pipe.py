@@ -13,7 +13,8 @@ from tools.probe import timeit        # noqa: E402
 
 for name, urdf, base, tool, N in (("cfg2 n=6 P=60", "ur10_like.urdf", "base_link", "wrist_3_link", 1000000),
                                   ("n=6 P=70 (tool0)", "ur10_like.urdf", "base_link", "tool0", 1000000),
-                                  ("cfg3 n=7 P=70", "panda_like.urdf", "link0", "link7", 4000000)):
+                                  ("cfg3 n=7 P=70", "panda_like.urdf", "link0", "link7", 4000000),
+                                  ("n=7 P=90 (hand)", "panda_like.urdf", "link0", "hand", 1000000)):
     chain = Chain(os.path.join(ROOT, "tests/fixtures", urdf), base, tool, (0, 0, -9.806))
     n = chain.getActiveJointsNumber()
     q, dq, ddq, tm = (torch.rand((n, N), dtype=torch.float64, device="cuda") * 2 - 1 for _ in range(4))
