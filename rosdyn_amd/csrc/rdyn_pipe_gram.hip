@@ -33,6 +33,9 @@
 #include "rdyn_kernels.h"
 #include "rdyn_gram_common.h"
 
+#ifndef RDYN_PIPE_UNROLL_MAX
+#define RDYN_PIPE_UNROLL_MAX 6  // chains up to this many joints: unrolled link loop; longer: rolled (A/B: tools/probe_pipe.py)
+#endif
 #ifndef RDYN_PIPE_VALU_PER_MFMA
 #define RDYN_PIPE_VALU_PER_MFMA 10  // VALU instructions scheduled behind every MFMA (A/B: tools/probe_pipe.py)
 #endif
@@ -259,11 +262,11 @@ hipError_t launch_pipe_nj(const RdynLdsGramArgs& a, int blocks, size_t lds_bytes
   const uint64_t bit = 1ull << (dev & 63);
   if (!(attr_set.load(std::memory_order_acquire) & bit))
   {
-    e = hipFuncSetAttribute((const void*)k_regressor_gram_pipe<NJ, (NJ > 6)>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    e = hipFuncSetAttribute((const void*)k_regressor_gram_pipe<NJ, (NJ > RDYN_PIPE_UNROLL_MAX)>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
     attr_set.fetch_or(bit, std::memory_order_release);
   }
-  hipLaunchKernelGGL((k_regressor_gram_pipe<NJ, (NJ > 6)>), dim3(blocks), dim3(256), lds_bytes, st, a);
+  hipLaunchKernelGGL((k_regressor_gram_pipe<NJ, (NJ > RDYN_PIPE_UNROLL_MAX)>), dim3(blocks), dim3(256), lds_bytes, st, a);
   return hipGetLastError();
 }
 }  // namespace
