@@ -316,6 +316,17 @@ int rdyn_local_ik_damped(const rdyn_chain* c, const rdyn_batch* b, const double*
   a.max_iter = max_iterations;
   a.status = status;
   a.iterations = iterations;
+  // Two stages when the per-pose results are available to carry the state: most poses settle within a few updates, the
+  // rest would keep every wave alive for the whole cap.  Stage 1 runs everyone for kIkStage updates; stage 2 gathers the
+  // poses still running into dense waves and continues only those (same arithmetic per pose, rdyn_ik.hip).
+  const int kIkStage = 8;
+  if (max_iterations > kIkStage && status && iterations)
+  {
+    a.max_iter = kIkStage;
+    RDYN_HIP_TRY(rdyn_launch_local_ik(c->n_joints(), a, (hipStream_t)b->stream));
+    a.max_iter = max_iterations;
+    a.it_stage = kIkStage;
+  }
   RDYN_HIP_TRY(rdyn_launch_local_ik(c->n_joints(), a, (hipStream_t)b->stream));
   return RDYN_OK;
 }

@@ -134,12 +134,11 @@ __device__ __forceinline__ V3 rotation_vector(const double (&M)[9])
   return mk(qx * k, qy * k, qz * k);
 }
 
+// One pose: the iteration from update number it0 on, starting at `start` (the seeds, or the iterate a previous launch
+// left in a.sol); writes sol / status / iterations of pose s.
 template <int NJ>
-__global__ __launch_bounds__(64) void k_local_ik(const RdynIkArgs a)
+__device__ __forceinline__ void ik_pose(const RdynIkArgs& a, ChainPtr c, const int64_t s, const double* __restrict__ start, const int it0)
 {
-  ChainPtr c = as_const(a.chain);
-  const int64_t s = (int64_t)blockIdx.x * 64 + threadIdx.x;
-  if (s >= a.n_samples) return;
   constexpr int NH = NJ * (NJ + 1) / 2;
 
   // target frame, column-major 3x4 [R | p] (the record rdyn_transformation writes)
@@ -160,13 +159,13 @@ __global__ __launch_bounds__(64) void k_local_ik(const RdynIkArgs a)
   {
     const int idx = c->j[l].in_idx;
     const bool moves = idx >= 0 && c->j[l].type != RDYN_FIXED;
-    sol[l] = idx >= 0 ? a.seed[s * a.in_ss + idx * a.in_sj] : 0.0;  // :1403
+    sol[l] = idx >= 0 ? start[s * a.in_ss + idx * a.in_sj] : 0.0;  // :1403
     if (!moves) perm |= 1u << l;
     if (idx >= 0) ++n_active;
   }
   const double w0 = a.weight[0], w1 = a.weight[1], w2 = a.weight[2], w3 = a.weight[3], w4 = a.weight[4], w5 = a.weight[5];
 
-  int status = 0, it = 0;
+  int status = 0, it = it0;
   for (;; ++it)
   {
     // ---- frames and screws at sol (computeFrames / computeScrews, primitives_impl.h:863-882)
@@ -393,10 +392,55 @@ __global__ __launch_bounds__(64) void k_local_ik(const RdynIkArgs a)
 }
 
 template <int NJ>
+__global__ __launch_bounds__(64) void k_local_ik(const RdynIkArgs a)
+{
+  const int64_t s = (int64_t)blockIdx.x * 64 + threadIdx.x;
+  if (s >= a.n_samples) return;
+  ik_pose<NJ>(a, as_const(a.chain), s, a.seed, 0);
+}
+
+// Second stage: poses need very different numbers of updates (most converge within a few, some never do), and a wave
+// runs as long as its slowest lane.  After a first launch capped at a.it_stage updates, this kernel scans the statuses
+// in chunks of RDYN_IK_CHUNK poses, gathers the poses that are still running (status 0 with exactly it_stage updates)
+// into a dense list in LDS and continues ONLY those, 64 per pass, from the iterate the first stage left in a.sol.
+// Per pose the arithmetic is the same sequence of updates as in a single launch.
+#define RDYN_IK_CHUNK 4096
+template <int NJ>
+__global__ __launch_bounds__(64) void k_local_ik_resume(const RdynIkArgs a)
+{
+  __shared__ int list[RDYN_IK_CHUNK];
+  __shared__ int count;
+  ChainPtr c = as_const(a.chain);
+  const int64_t n_chunks = (a.n_samples + RDYN_IK_CHUNK - 1) / RDYN_IK_CHUNK;
+  for (int64_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x)
+  {
+    if (threadIdx.x == 0) count = 0;
+    __syncthreads();
+    const int64_t base = chunk * RDYN_IK_CHUNK;
+    for (int i = threadIdx.x; i < RDYN_IK_CHUNK; i += 64)
+    {
+      const int64_t s = base + i;
+      if (s < a.n_samples && a.status[s] == 0 && a.iterations[s] == a.it_stage) list[atomicAdd(&count, 1)] = i;
+    }
+    __syncthreads();
+    const int cnt = count;
+    for (int g0 = 0; g0 < cnt; g0 += 64)
+      if (g0 + (int)threadIdx.x < cnt) ik_pose<NJ>(a, c, base + list[g0 + threadIdx.x], a.sol, a.it_stage);
+    __syncthreads();
+  }
+}
+
+template <int NJ>
 hipError_t launch_ik_nj(const RdynIkArgs& a, hipStream_t st)
 {
   const unsigned grid = (unsigned)((a.n_samples + 63) / 64);
-  hipLaunchKernelGGL((k_local_ik<NJ>), dim3(grid), dim3(64), 0, st, a);
+  if (a.it_stage > 0)
+  {
+    const int64_t n_chunks = (a.n_samples + RDYN_IK_CHUNK - 1) / RDYN_IK_CHUNK;
+    hipLaunchKernelGGL((k_local_ik_resume<NJ>), dim3((unsigned)(n_chunks < 4096 ? n_chunks : 4096)), dim3(64), 0, st, a);
+  }
+  else
+    hipLaunchKernelGGL((k_local_ik<NJ>), dim3(grid), dim3(64), 0, st, a);
   return hipGetLastError();
 }
 

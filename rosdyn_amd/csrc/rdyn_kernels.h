@@ -60,6 +60,7 @@ struct RdynIkArgs
   double toll;
   double damping;                    // Levenberg term: damping^2 is added to the diagonal of J'WJ (0 = the reference's QP)
   int max_iter;
+  int it_stage;                      // > 0: resume launch -- continue the poses a first launch left unfinished after it_stage updates
   int* status;                       // per pose, may be null: 1 converged, 0 not within max_iter, < 0 QP failure
   int* iterations;                   // per pose, may be null: QP updates performed
 };
