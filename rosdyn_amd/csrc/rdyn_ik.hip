@@ -404,7 +404,7 @@ __global__ __launch_bounds__(64) void k_local_ik(const RdynIkArgs a)
 // in chunks of RDYN_IK_CHUNK poses, gathers the poses that are still running (status 0 with exactly it_stage updates)
 // into a dense list in LDS and continues ONLY those, 64 per pass, from the iterate the first stage left in a.sol.
 // Per pose the arithmetic is the same sequence of updates as in a single launch.
-#define RDYN_IK_CHUNK 4096
+#define RDYN_IK_CHUNK 1024
 template <int NJ>
 __global__ __launch_bounds__(64) void k_local_ik_resume(const RdynIkArgs a)
 {
@@ -437,7 +437,7 @@ hipError_t launch_ik_nj(const RdynIkArgs& a, hipStream_t st)
   if (a.it_stage > 0)
   {
     const int64_t n_chunks = (a.n_samples + RDYN_IK_CHUNK - 1) / RDYN_IK_CHUNK;
-    hipLaunchKernelGGL((k_local_ik_resume<NJ>), dim3((unsigned)(n_chunks < 4096 ? n_chunks : 4096)), dim3(64), 0, st, a);
+    hipLaunchKernelGGL((k_local_ik_resume<NJ>), dim3((unsigned)(n_chunks < 65536 ? n_chunks : 65536)), dim3(64), 0, st, a);
   }
   else
     hipLaunchKernelGGL((k_local_ik<NJ>), dim3(grid), dim3(64), 0, st, a);
