@@ -39,3 +39,40 @@ def test_regressor_and_gram_replay_from_a_graph():
     G2, c2, bb2 = chain.getRegressorGram(q, dq, ddq, tau2, layout="element", chunk_samples=8192)
     assert torch.equal(Y, Y2) and torch.equal(tau, tau2)
     assert torch.equal(out[0], G2) and torch.equal(out[1], c2) and torch.equal(out[2], bb2)
+
+
+def test_pipelined_gram_ik_and_wrench_replay_from_a_graph():
+    """The fused (LDS / pipelined) Gram path, the staged IK launches and the wrench sweep are capturable too."""
+    torch = pytest.importorskip("torch")
+    from rosdyn_amd import Chain
+    from rosdyn_amd._lib import lib
+    chain = Chain(os.path.join(FIXTURES, "ur10_like.urdf"), "base_link", "wrist_3_link", (0, 0, -9.806))
+    n, L, P, N = 6, 7, 60, 30000
+    q, dq, ddq = (torch.rand((n, N), dtype=torch.float64, device="cuda") * 2 - 1 for _ in range(3))
+    tau = chain.getJointTorque(q, dq, ddq, layout="element")           # first use: uploads the chain constants
+    out = (torch.empty((P, P), dtype=torch.float64, device="cuda"), torch.empty((P,), dtype=torch.float64, device="cuda"),
+           torch.empty((1,), dtype=torch.float64, device="cuda"))
+    ws = torch.empty((lib().rdyn_regressor_gram_workspace_bytes(chain._h, 0),), dtype=torch.uint8, device="cuda")
+    chain.getRegressorGram(q, dq, ddq, tau, layout="element", out=out, workspace=ws)   # sets the LDS opt-in attribute once
+    T = chain.getTransformation(q, layout="element")
+    seeds = q + 0.2 * (torch.rand_like(q) * 2 - 1)
+    sol = torch.empty_like(q)
+    w = torch.empty((L, 6, N), dtype=torch.float64, device="cuda")
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    s = torch.cuda.Stream()
+    holder = {}
+    with torch.cuda.stream(s):
+        with torch.cuda.graph(g, stream=s):
+            chain.getRegressorGram(q, dq, ddq, tau, layout="element", out=out, workspace=ws)
+            holder["ik"] = chain.computeLocalIk(T, seeds, toll=1e-8, max_iterations=25, layout="element", out=sol)
+            chain.getWrench(q, dq, ddq, layout="element", out=w)
+    dq.uniform_(-1, 1)
+    seeds.copy_(q + 0.1 * (torch.rand_like(q) * 2 - 1))
+    g.replay()
+    torch.cuda.synchronize()
+    G2, c2, bb2 = chain.getRegressorGram(q, dq, ddq, tau, layout="element")
+    assert torch.equal(out[0], G2) and torch.equal(out[1], c2) and torch.equal(out[2], bb2)
+    sol2, st2, it2 = chain.computeLocalIk(T, seeds, toll=1e-8, max_iterations=25, layout="element")
+    assert torch.equal(sol, sol2) and torch.equal(holder["ik"][1], st2) and torch.equal(holder["ik"][2], it2)
+    assert torch.equal(w, chain.getWrench(q, dq, ddq, layout="element"))
