@@ -158,3 +158,36 @@ def test_config3_full_size_properties(torch_cuda):
     Ys = ref.regressor(qs, dqs, ddqs)
     pred, truth = Ys @ x, ref.joint_torque(qs, dqs, ddqs)
     assert np.abs(pred - truth).max() <= 20 * sigma / np.sqrt(N / 1000.0) + 1e-9 * np.abs(truth).max()
+
+
+def test_identification_with_friction_columns_end_to_end(torch_cuda):
+    """The identification step the reference's component regressors exist for (SURVEY 8f ranks 1 + 2): stack the rigid-body
+    regressor and the friction columns [Y | C] in ONE element-major buffer, one MFMA Gram with the measured torque as b,
+    host solve -- the friction coefficients come back, the rigid-body part predicts the torques."""
+    from rosdyn_amd import Chain
+    from rosdyn_amd.components import FRICTION1, ComponentSet
+    from rosdyn_amd.gram import gram, solve_base_parameters
+    torch = torch_cuda
+    chain = Chain(os.path.join(FIXTURES, "ur10_like.urdf"), "base_link", "wrist_3_link", GRAV)
+    n, P, N = 6, 60, 200000
+    gen = torch.Generator(device="cuda").manual_seed(1234)
+    q, dq, ddq = (torch.rand((n, N), dtype=torch.float64, device="cuda", generator=gen) * 2 - 1 for _ in range(3))
+    coulomb = [1.5, 2.0, 1.0, 0.4, 0.3, 0.2]
+    viscous = [3.0, 2.5, 1.5, 0.5, 0.4, 0.1]
+    comps = ComponentSet([dict(type=FRICTION1, joint=j, min_velocity=1e-4, max_velocity=10.0, parameters=[coulomb[j], viscous[j]])
+                          for j in range(n)], n)
+    K = comps.columns
+    A = torch.empty((P + K, n, N), dtype=torch.float64, device="cuda")            # [Y | C], column-major (n N) x (P + K)
+    tau = torch.empty((n, N), dtype=torch.float64, device="cuda")
+    chain.getRegressor(q, dq, ddq, layout="element", out=A[:P], tau_out=tau)      # tau = Y pi
+    comps.getRegressor(q, dq, layout="element", out=A[P:], tau_add=tau)           # tau += C phi
+    sigma = 1e-2
+    tau_meas = tau + sigma * torch.randn((n, N), dtype=torch.float64, device="cuda", generator=gen)
+    G, c, bb = gram(A.reshape(P + K, n * N), tau_meas.reshape(n * N))
+    x, rank = solve_base_parameters(G, c)
+    assert P + K > rank >= K + 30                                                 # rigid-body part rank deficient, friction identifiable
+    phi = x[P:]                                                                   # [coulomb_0, viscous_0, coulomb_1, ...]
+    assert np.abs(phi[0::2] - np.array(coulomb)).max() < 20 * sigma / np.sqrt(N / 100.0)
+    assert np.abs(phi[1::2] - np.array(viscous)).max() < 20 * sigma / np.sqrt(N / 100.0)
+    pred = (A.reshape(P + K, n * N).T @ torch.from_numpy(x).cuda()).reshape(n, N)
+    assert float((pred - tau).abs().max()) < 0.05                                 # noise-free torques reproduced
