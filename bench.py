@@ -6,6 +6,9 @@ launch) over one batch of synthetic (q, Dq, DDq) samples that are already reside
 
 Workload (BASELINE.json configs[1]): 6-DOF chain (tests/fixtures/ur10_like.urdf cut at wrist_3_link:
 n = 6 active joints, 6 chain joints, P = 60 parameters), 1e6 samples per GPU, fp64, dense Y.
+Default layouts = SURVEY section 8(d) config 2 as written: inputs AoS [N][6] (sample-major), tau [N][6], Y = the stacked
+column-major (6 N) x 60 regressor A (k_rowpair_sweep<6>); --y-layout element selects the SoA form (k_local_sweep<6, REGRESSOR>,
+~2 % slower on the same box).
 Multi-GPU: the batch shards trivially (i.i.d. samples) -> every rank evaluates its own 1e6 samples, no
 data-path collective ("weak" scaling); the only exchange is the max-over-ranks of the elapsed time.
 
@@ -147,7 +150,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--samples", type=int, default=1000000, help="samples per GPU")
-    ap.add_argument("--y-layout", default="element", choices=["element", "stacked", "per_sample"])
+    ap.add_argument("--y-layout", default="stacked", choices=["element", "stacked", "per_sample"])
     ap.add_argument("--cpu-seconds", type=float, default=8.0, help="wall time of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-extras", action="store_true", help="skip the informational Gram/all-reduce leg after the timed region")
     args = ap.parse_args()

@@ -51,13 +51,13 @@ for tag, store in (("fetch", fetch), ("write", write)):
     acc = defaultdict(list)
     for r in rows("pmc_%s/**/*counter_collection.csv" % tag):
         name = r.get("Kernel_Name", "")
-        if "k_local_sweep" in name or "k_gram" in name:
+        if "k_local_sweep" in name or "k_gram" in name or "k_rowpair" in name:
             acc[name].append(float(r.get("Counter_Value", 0)))
     for k, v in acc.items():
         store[k] = sum(v) / len(v)
 if len(sys.argv) > 2:
     key = sys.argv[2]
-    names = [k for k in fetch if "k_local_sweep" in k and k in write]
+    names = [k for k in fetch if ("k_local_sweep" in k or "k_rowpair" in k) and k in write]
     if names:
         k = names[0]
         # FETCH_SIZE / WRITE_SIZE are in KB (1024 B).  gfx950: FETCH_SIZE reports 1/2 of the bytes of a coalesced
