@@ -161,6 +161,14 @@ def test_full_size_properties(torch_cuda):
     qn, dqn, ddqn = (x[:, :k].T.contiguous().cpu().numpy() for x in (q, dq, ddq))
     _close(Y[:, :, :k].cpu().numpy().transpose(2, 1, 0), ref.regressor(qn, dqn, ddqn), what="Y prefix")
     _close(tau[:, :k].T.cpu().numpy(), ref.joint_torque(qn, dqn, ddqn), what="tau prefix")
+    # the bench's default layouts (config 2 as written: AoS inputs, stacked column-major A = (6 N) x 60) at full size:
+    # the row-pair kernel must give the numbers of the element-major kernel (same arithmetic per entry up to rounding)
+    qs, dqs, ddqs = (x.T.contiguous() for x in (q, dq, ddq))
+    Ys, taus = chain.getRegressor(qs, dqs, ddqs, y_layout="stacked", with_torque=True)    # (P, N * n), (N, n)
+    d = (Ys.reshape(P, N, n).permute(0, 2, 1) - Y).abs().max()
+    assert float(d) <= 1e-11 * max(1.0, float(Y.abs().max()))
+    assert float((taus.T - tau).abs().max()) <= 1e-11 * scale
+    assert float((torch.einsum("pr,p->r", Ys, pi).reshape(N, n) - taus).abs().max()) <= 1e-11 * scale
 
 
 def test_empty_batch_and_errors(torch_cuda):
