@@ -206,3 +206,32 @@ def test_mixed_plan_with_fuzzed_chains_and_ragged_items():
         assert np.abs(Y.cpu().numpy().transpose(2, 1, 0) - Yr).max() <= TOL * max(1.0, np.abs(Yr).max())
         tr = ref.joint_torque(*b)
         assert np.abs(tau.cpu().numpy().T - tr).max() <= TOL * max(1.0, np.abs(tr).max())
+
+
+@pytest.mark.parametrize("scale_q,scale_dq,scale_ddq", [(1e3, 1.0, 1.0), (3.0, 50.0, 500.0), (1e-9, 1e-9, 1e-9), (1e5, 20.0, 100.0)])
+def test_extreme_input_ranges(scale_q, scale_dq, scale_ddq):
+    """Large joint angles (argument reduction of sincos up to 1e5 rad), fast motions and vanishing inputs: same relative
+    tolerance as everywhere else, |delta| <= 1e-11 max(1, |ref|_inf)."""
+    torch = pytest.importorskip("torch")
+    import os
+    from conftest import FIXTURES
+    from oracle.oracle import OracleChain
+    from rosdyn_amd import Chain
+    from rosdyn_amd.samples import trajectory_batch
+    path = os.path.join(FIXTURES, "mixed_joints.urdf")
+    grav = (0.1, -0.2, -9.806)
+    chain, ref = Chain(path, "world", "tip", grav), OracleChain(path, "world", "tip", grav)
+    N, n = 513, ref.n
+    q, dq, ddq = trajectory_batch(17, N, n)
+    q, dq, ddq = q * scale_q, dq * scale_dq, ddq * scale_ddq
+    tq, tdq, tddq = (torch.from_numpy(x).cuda() for x in (q, dq, ddq))
+
+    def close(a, b, what):
+        assert np.abs(a - b).max() <= TOL * max(1.0, np.abs(b).max()), "%s: %.3e vs scale %.3e" % (what, np.abs(a - b).max(), np.abs(b).max())
+    Y, tau = chain.getRegressor(tq, tdq, tddq, with_torque=True)
+    close(Y.cpu().numpy().transpose(0, 2, 1), ref.regressor(q, dq, ddq), "Y")
+    close(tau.cpu().numpy(), ref.joint_torque(q, dq, ddq), "tau fused")
+    close(chain.getJointTorque(tq, tdq, tddq).cpu().numpy(), ref.joint_torque(q, dq, ddq), "tau")
+    close(chain.getJointInertia(tq).cpu().numpy().transpose(0, 2, 1), ref.joint_inertia(q), "M")
+    close(chain.getTransformations(tq).cpu().numpy().transpose(0, 1, 3, 2), ref.fk(q), "T")
+    close(chain.getDTwist(tq, tdq, tddq).cpu().numpy(), ref.dtwist(q, dq, ddq), "dtwist")
