@@ -157,13 +157,16 @@ class NpChain(object):
         f = self._forward(q, dq, ddq)
         return np.stack([np.concatenate([f["al"][l], f["aa"][l]], 1) for l in range(self.L)], 1)
 
-    def joint_torque(self, q, dq, ddq):
-        """Textbook Newton-Euler about each centre of mass, base frame."""
+    def joint_torque(self, q, dq, ddq, wrenches=False):
+        """Textbook Newton-Euler about each centre of mass, base frame.  wrenches=True also returns the force / moment
+        transmitted through every link ((N, L, 6): [force; moment about the link origin], base-frame coordinates) -- what
+        Chain::getWrench (primitives_impl.h:1225-1262) returns without external loads; the base link carries the total."""
         f = self._forward(q, dq, ddq)
         N = f["N"]
         F = np.zeros((N, 3))   # force transmitted through joint l (on link l from its parent), base frame
         Mo = np.zeros((N, 3))  # moment about origin of link l
         tau_chain = np.zeros((N, self.nJ))
+        W = np.zeros((N, self.L, 6))
         pn = None
         for l in range(self.L - 1, 0, -1):
             Rl = f["R"][l]
@@ -181,11 +184,16 @@ class NpChain(object):
             F = F + f_net
             Mo = Mo + n_net + np.cross(rc, f_net)
             pn = f["p"][l]
+            W[:, l, :3], W[:, l, 3:] = F, Mo
             j = l - 1
             if self.jtype[j] == "R":
                 tau_chain[:, j] = np.einsum("ni,ni->n", Mo, f["z"][l])
             elif self.jtype[j] == "P":
                 tau_chain[:, j] = np.einsum("ni,ni->n", F, f["z"][l])
+        if wrenches:
+            W[:, 0, :3] = F                                           # base link: the same force, moment about ITS origin
+            W[:, 0, 3:] = Mo + (np.cross(pn - f["p"][0], F) if pn is not None else 0.0)
+            return tau_chain[:, self.spec.input_chain_index], W
         return tau_chain[:, self.spec.input_chain_index]
 
     def regressor(self, q, dq, ddq):
