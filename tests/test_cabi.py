@@ -131,3 +131,30 @@ def test_chain_from_desc_equals_chain_from_urdf():
     assert np.array_equal(a.getNominalParameters(), b.getNominalParameters())
     assert np.array_equal(a.getQMax(), b.getQMax()) and np.array_equal(a.getTauMax(), b.getTauMax())
     assert np.array_equal(a.getGravity(), b.getGravity())
+
+
+def _build_c_example(tmp_path):
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "regressor_batch")
+    cmd = ["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-I" + os.path.join(root, "include"),
+           os.path.join(root, "examples", "regressor_batch.c"), "-L" + os.path.join(root, "rosdyn_amd"), "-lrdyn_hip", "-L/opt/rocm/lib",
+           "-lamdhip64", "-Wl,-rpath," + os.path.join(root, "rosdyn_amd"), "-Wl,-rpath,/opt/rocm/lib", "-o", exe]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    return exe
+
+
+def test_header_is_plain_c_and_the_c_example_links(tmp_path):
+    """include/rdyn.h compiles as C99 (no C++-isms cross the ABI) and examples/regressor_batch.c links against the library."""
+    _build_c_example(tmp_path)
+
+
+@pytest.mark.gpu
+def test_c_example_runs(tmp_path):
+    import subprocess
+    exe = _build_c_example(tmp_path)
+    r = subprocess.run([exe, os.path.join(FIXTURES, "ur10_like.urdf"), "base_link", "wrist_3_link", "50000"], capture_output=True, text=True,
+                       timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "n = 6, P = 60" in r.stdout
