@@ -256,7 +256,9 @@ int rdyn_components_regressor(const rdyn_component* comps, int n_comps, int n_ac
  * One launch per group of chains with equal joint count evaluates rdyn_regressor for MANY (chain, batch) items:
  * grid = (ceil(max samples / 256), items); every workgroup reads its item's descriptor and its chain's constants
  * through scalar loads.  A plan freezes the items (device pointers, layouts) so that running it allocates and
- * copies nothing (graph-capturable).  All items must live on the same device (items[0].batch.device). */
+ * copies nothing (graph-capturable).  All items must live on the same device (items[0].batch.device).  A plan holds the
+ * device copies of its chains' constants: the chains must outlive the plan and must not be re-configured
+ * (rdyn_chain_set_input_joints) while it exists. */
 typedef struct rdyn_multi_item
 {
   const rdyn_chain* chain;
