@@ -15,6 +15,16 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_sessionstart(session):
+    """A fresh checkout has no librdyn_hip.so (build artefacts are git-ignored): build it once (hipcc cross-compiles for
+    gfx950 without a GPU, ~2 min) so that the C-ABI / ingest tests of the CPU suite do not depend on a previous build()."""
+    import subprocess
+    lib = os.path.join(ROOT, "rosdyn_amd", "librdyn_hip.so")
+    if not os.path.exists(lib) and os.path.exists("/opt/rocm/bin/hipcc"):
+        subprocess.call(["make", "-C", os.path.join(ROOT, "rosdyn_amd", "csrc"), "-j", str(min(8, os.cpu_count() or 1))],
+                        stdout=subprocess.DEVNULL)
+
+
 def golden_cases():
     return sorted(f[:-4] for f in os.listdir(GOLDEN) if f.endswith(".npz"))
 
