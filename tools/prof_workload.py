@@ -18,7 +18,9 @@ if which == "gram":
     n, N = 7, 4000000
     q, dq, ddq, tm = (torch.rand((n, N), dtype=torch.float64, device=dev) * 2 - 1 for _ in range(4))
     for _ in range(4):
-        chain.getRegressorGram(q, dq, ddq, tm, layout="element", chunk_samples=N)
+        chain.getRegressorGram(q, dq, ddq, tm, layout="element")                     # default: fused (pipelined LDS tile)
+    for _ in range(4):
+        chain.getRegressorGram(q, dq, ddq, tm, layout="element", chunk_samples=N)    # two kernels, image through HBM
 elif which == "multi":
     from rosdyn_amd.multi import MultiChainRegressor
     from rosdyn_amd.urdf_gen import mixed_chain_set
@@ -47,4 +49,9 @@ elif which == "torque":
         chain.getTransformations(q, layout="element")
         chain.getJacobian(q, layout="element")
         chain.getDTwist(q, dq, ddq, layout="element")
+        chain.getWrench(q, dq, ddq, layout="element")
+    T = chain.getTransformation(q, layout="element")
+    seeds = q + 0.25 * (torch.rand_like(q) * 2 - 1)
+    for _ in range(3):
+        chain.computeLocalIk(T, seeds, toll=1e-6, max_iterations=30, layout="element")
 torch.cuda.synchronize()

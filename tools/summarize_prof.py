@@ -26,7 +26,7 @@ dur = defaultdict(list)
 meta = {}
 for r in rows("trace/**/*kernel_trace.csv"):
     name = r.get("Kernel_Name", "")
-    if any(k in name for k in ("k_local_sweep", "k_base_sweep", "k_gram", "k_rowpair")):
+    if any(k in name for k in ("k_local_sweep", "k_base_sweep", "k_base_ext", "k_gram", "k_rowpair", "k_regressor_gram", "k_local_ik", "k_components")):
         dur[name].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
         meta[name] = (r.get("VGPR_Count"), r.get("Accum_VGPR_Count"), r.get("SGPR_Count"), r.get("LDS_Block_Size"), r.get("Scratch_Size"), r.get("Grid_Size"), r.get("Workgroup_Size"))
 for k, v in dur.items():
