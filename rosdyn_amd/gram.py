@@ -87,6 +87,16 @@ def r_factor(G, rtol=1e-10):
     return R[:rank], perm, rank
 
 
+def residual_sum_of_squares(G, c, bb, x):
+    """|A x - b|^2 from the normal-equation accumulators alone: bb - 2 c'x + x'G x (no second pass over the batch).
+    Cancellation limits it to ~1e-12 |b|^2; that is far below any measurement noise the identification works with."""
+    Gh = np.asarray(G.detach().cpu().numpy() if hasattr(G, "detach") else G, dtype=np.float64)
+    ch = np.asarray(c.detach().cpu().numpy() if hasattr(c, "detach") else c, dtype=np.float64)
+    b2 = float(bb.reshape(-1)[0].item() if hasattr(bb, "detach") else np.asarray(bb).reshape(-1)[0])
+    x = np.asarray(x, dtype=np.float64)
+    return b2 - 2.0 * float(ch @ x) + float(x @ (Gh @ x))
+
+
 def solve_base_parameters(G, c, rtol=1e-10):
     """Minimum-norm least-squares solution of G x = c on the host (P <= 100): the stacked regressor is structurally
     rank deficient (unobservable base-link parameters, fixed tail links), so the symmetric eigen-decomposition is

@@ -6,7 +6,7 @@ import numpy as np
 
 from conftest import FIXTURES
 from oracle.oracle import OracleChain
-from rosdyn_amd.gram import r_factor, solve_base_parameters
+from rosdyn_amd.gram import r_factor, residual_sum_of_squares, solve_base_parameters
 from rosdyn_amd.samples import trajectory_batch
 
 
@@ -43,3 +43,15 @@ def test_base_parameter_solve_reproduces_the_torques():
     assert rank < A.shape[1]
     assert np.abs(A @ x - tau).max() <= 1e-8 * np.abs(tau).max()   # same torques from the minimum-norm parameters
     assert np.linalg.norm(x) <= np.linalg.norm(pi) * (1 + 1e-9)
+
+
+def test_residual_sum_of_squares_from_the_accumulators():
+    A, pi = _stacked_regressor()
+    rng = np.random.default_rng(5)
+    b = A @ pi + 1e-2 * rng.normal(size=A.shape[0])
+    G, c, bb = A.T @ A, A.T @ b, np.array([b @ b])
+    x, _ = solve_base_parameters(G, c)
+    rss = residual_sum_of_squares(G, c, bb, x)
+    direct = float(np.sum((A @ x - b) ** 2))
+    assert abs(rss - direct) <= 1e-9 * float(b @ b)
+    assert 0.5e-4 * A.shape[0] < rss < 1.5e-4 * A.shape[0]        # ~ sigma^2 per row
