@@ -1,0 +1,71 @@
+#!/bin/bash
+# Host-side sanitizer run (CPU only; GPU sanitizers are not available on the pool): the URDF reader and chain ingest
+# (rdyn_urdf.cpp, rdyn_chain.cpp) under ASan + UBSan over 300 fuzzed chains (tests/test_gpu_fuzz.py generator) and 400
+# malformed variants of a fixture (truncations, byte flips, deleted / duplicated chunks).  Expected: no report.
+set -e
+ROOT=$(cd "$(dirname "$0")/.." && pwd)
+W=$(mktemp -d)
+cd "$W"
+python3 - "$ROOT" <<'PY'
+import os, random, sys
+root = sys.argv[1]
+sys.path.insert(0, os.path.join(root, "tests")); sys.path.insert(0, root)
+from test_gpu_fuzz import random_chain_xml
+os.makedirs("in", exist_ok=True)
+for s in range(300):
+    xml, b, t, _ = random_chain_xml(5000 + s)
+    open("in/f%03d.txt" % s, "w").write(b + "\n" + t + "\n" + xml)
+rnd = random.Random(1)
+base_xml = open(os.path.join(root, "tests/fixtures/mixed_joints.urdf")).read()
+for s in range(400):
+    x, mode = base_xml, s % 4
+    i = rnd.randrange(len(x))
+    if mode == 0: x = x[:i]
+    elif mode == 1: x = x[:i] + rnd.choice("<>/\"'= \n&") + x[i + 1:]
+    elif mode == 2: x = x[:i] + x[min(len(x), i + rnd.randrange(1, 200)):]
+    else: x = x[:i] + x[i:i + rnd.randrange(1, 300)] * 2 + x[i:]
+    open("in/m%03d.txt" % s, "w").write("world\ntip\n" + x)
+PY
+cat > harness.cpp <<'CPP'
+#include <cstdio>
+#include <fstream>
+#include <sstream>
+#include <string>
+#include "rdyn.h"
+int main(int argc, char** argv)
+{
+  int ok = 0, bad = 0;
+  for (int i = 1; i < argc; ++i)
+  {
+    std::ifstream f(argv[i]);
+    std::string base, tool;
+    std::getline(f, base);
+    std::getline(f, tool);
+    std::stringstream ss;
+    ss << f.rdbuf();
+    const double g[3] = {0, 0, -9.8};
+    rdyn_chain* c = nullptr;
+    if (rdyn_chain_from_urdf(ss.str().c_str(), base.c_str(), tool.c_str(), g, &c) == RDYN_OK)
+    {
+      ++ok;
+      double pi[128], lim[5][16];
+      rdyn_nominal_parameters(c, pi);
+      rdyn_chain_limits(c, lim[0], lim[1], lim[2], lim[3], lim[4]);
+      for (int k = 0; k < rdyn_chain_links_number(c); ++k) (void)rdyn_chain_link_name(c, k);
+      rdyn_chain* d = nullptr;
+      rdyn_chain_clone(c, &d);
+      rdyn_chain_destroy(d);
+      rdyn_chain_destroy(c);
+    }
+    else
+      ++bad;
+  }
+  std::printf("parsed %d, rejected %d\n", ok, bad);
+  return 0;
+}
+CPP
+g++ -std=c++17 -g -O1 -fsanitize=address,undefined -fno-omit-frame-pointer -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -I"$ROOT/include" \
+  -I"$ROOT/rosdyn_amd/csrc" harness.cpp "$ROOT/rosdyn_amd/csrc/rdyn_urdf.cpp" "$ROOT/rosdyn_amd/csrc/rdyn_chain.cpp" \
+  -L/opt/rocm/lib -lamdhip64 -Wl,-rpath,/opt/rocm/lib -o harness
+ASAN_OPTIONS=detect_leaks=0 ./harness in/*.txt
+rm -rf "$W"
