@@ -223,6 +223,21 @@ int rdyn_joint_inertia(const rdyn_chain* chain, const rdyn_batch* batch, double*
  * sol holds the last iterate. */
 int rdyn_local_ik(const rdyn_chain* chain, const rdyn_batch* batch, const double* T_target, const double* weight, double toll,
                   int max_iterations, double* sol, int32_t* status, int32_t* iterations);
+/* The pose-error functions of frame_distance.h on n_pairs pairs of frames (12 doubles each: the column-major 3x4 [R|p]
+ * record of rdyn_transformation; `layout` as in rdyn_batch) -> 6 per pair [translation; rotation], expressed in frame w:
+ *   RDYN_FRAME_DISTANCE_AXIS_ANGLE  getFrameDistance        frame_distance.h:44-49    [p_a - p_b; -R_wa (angle axis)(R_wa' R_wb)]
+ *   RDYN_FRAME_DISTANCE_QUAT        getFrameDistanceQuat    frame_distance.h:73-86    [p_a - p_b; -2 R_wa imag(q_ab)], q_ab.w >= 0
+ *   RDYN_FRAME_DISTANCE_QUAT_JAC    getFrameDistanceQuatJac frame_distance.h:112-126  [p_b - p_a; -2 R_wa imag(q_ab)] (the
+ *       translation is measured the other way round there) and, if jacobian != NULL, the 6 x 6 column-major
+ *       [I 0; 0 R_wa (w I - skew(imag q_ab)) R_wa'] per pair. */
+typedef enum rdyn_frame_distance_kind
+{
+  RDYN_FRAME_DISTANCE_AXIS_ANGLE = 0,
+  RDYN_FRAME_DISTANCE_QUAT = 1,
+  RDYN_FRAME_DISTANCE_QUAT_JAC = 2
+} rdyn_frame_distance_kind;
+int rdyn_frame_distance(int64_t n_pairs, const double* T_wa, const double* T_wb, int layout, int kind, double* distance,
+                        double* jacobian, int device, void* stream);
 /* The same iteration with a Levenberg term: damping^2 is added to the diagonal of J'WJ before the QP (damping = 0 is
  * rdyn_local_ik).  No counterpart in the reference; it is what makes the loop usable where the reference's QP is singular
  * (7-DOF arms: J'J is 7 x 7 of rank 6) and near singular poses. */

@@ -96,6 +96,69 @@ void orc_frame_distance(const double* T_wa, const double* T_wb, double* distance
   }
 }
 
+/* getFrameDistanceQuat (jacobian == NULL and jac_variant == 0, frame_distance.h:73-86) and getFrameDistanceQuatJac
+ * (jac_variant != 0, frame_distance.h:112-126: the translation part is T_wb - T_wa there; jacobian = 6 x 6 row-major, may
+ * be NULL).  T = row-major 3x4 [R|p]. */
+void orc_frame_distance_quat(const double* T_wa, const double* T_wb, const double* jac_variant, double* distance, double* jacobian)
+{
+  double Rab[3][3], q[4];
+  const int jv = jac_variant && jac_variant[0] != 0.0;
+  for (int i = 0; i < 3; i++) distance[i] = jv ? T_wb[i * 4 + 3] - T_wa[i * 4 + 3] : T_wa[i * 4 + 3] - T_wb[i * 4 + 3];
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++)
+    {
+      double acc = 0;
+      for (int k = 0; k < 3; k++) acc += T_wa[k * 4 + i] * T_wb[k * 4 + j];
+      Rab[i][j] = acc;
+    }
+  { /* Eigen::Quaterniond(Matrix3d), as in angle_axis_vector */
+    double t = Rab[0][0] + Rab[1][1] + Rab[2][2];
+    if (t > 0.0)
+    {
+      t = sqrt(t + 1.0);
+      q[3] = 0.5 * t;
+      t = 0.5 / t;
+      q[0] = (Rab[2][1] - Rab[1][2]) * t;
+      q[1] = (Rab[0][2] - Rab[2][0]) * t;
+      q[2] = (Rab[1][0] - Rab[0][1]) * t;
+    }
+    else
+    {
+      int i = 0;
+      if (Rab[1][1] > Rab[0][0]) i = 1;
+      if (Rab[2][2] > Rab[i][i]) i = 2;
+      int j = (i + 1) % 3, k = (j + 1) % 3;
+      t = sqrt(Rab[i][i] - Rab[j][j] - Rab[k][k] + 1.0);
+      q[i] = 0.5 * t;
+      t = 0.5 / t;
+      q[3] = (Rab[k][j] - Rab[j][k]) * t;
+      q[j] = (Rab[j][i] + Rab[i][j]) * t;
+      q[k] = (Rab[k][i] + Rab[i][k]) * t;
+    }
+  }
+  if (q[3] < 0) for (int i = 0; i < 4; i++) q[i] = -q[i];                /* :77-83 */
+  for (int i = 0; i < 3; i++)
+  {
+    double acc = 0;
+    for (int k = 0; k < 3; k++) acc += T_wa[i * 4 + k] * q[k];
+    distance[3 + i] = -2.0 * acc;                                        /* :84 */
+  }
+  if (jacobian)
+  {
+    const double K[3][3] = {{q[3], q[2], -q[1]}, {-q[2], q[3], q[0]}, {q[1], -q[0], q[3]}}; /* w I - skew(vec) */
+    for (int i = 0; i < 36; i++) jacobian[i] = 0.0;
+    for (int i = 0; i < 6; i++) jacobian[i * 6 + i] = 1.0;               /* setIdentity, :114 */
+    for (int i = 0; i < 3; i++)
+      for (int j = 0; j < 3; j++)
+      {
+        double acc = 0;                                                  /* R_wa K R_wa^-1, :125 */
+        for (int a = 0; a < 3; a++)
+          for (int b = 0; b < 3; b++) acc += T_wa[i * 4 + a] * K[a][b] * T_wa[j * 4 + b];
+        jacobian[(3 + i) * 6 + 3 + j] = acc;
+      }
+  }
+}
+
 /* ---------------------------------------------------------------- small dense helpers (row-major, leading dim IK_MAX_N) */
 static int cholesky(int n, const double A[IK_MAX_N][IK_MAX_N], double L[IK_MAX_N][IK_MAX_N], double floor)
 {

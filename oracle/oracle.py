@@ -55,6 +55,8 @@ def lib():
         l.orc_has_openmp.restype = C.c_int
         l.orc_frame_distance.restype = None
         l.orc_frame_distance.argtypes = [dp, dp, dp]
+        l.orc_frame_distance_quat.restype = None
+        l.orc_frame_distance_quat.argtypes = [dp, dp, dp, dp, dp]
         l.orc_solve_quadprog.restype = C.c_int
         l.orc_solve_quadprog.argtypes = [C.c_int, C.c_int, dp, dp, dp, dp, dp]
         l.orc_local_ik.restype = C.c_int
@@ -69,6 +71,14 @@ def frame_distance(T_wa, T_wb):
     a, b, d = _c(T_wa).reshape(12), _c(T_wb).reshape(12), np.empty(6)
     lib().orc_frame_distance(_p(a), _p(b), _p(d))
     return d
+
+
+def frame_distance_quat(T_wa, T_wb, jac=False):
+    """getFrameDistanceQuat (jac=False) / getFrameDistanceQuatJac (jac=True: returns (distance, 6x6 jacobian))."""
+    a, b, d = _c(T_wa).reshape(12), _c(T_wb).reshape(12), np.empty(6)
+    J = np.empty((6, 6)) if jac else None
+    lib().orc_frame_distance_quat(_p(a), _p(b), _p(np.array([1.0 if jac else 0.0])), _p(d), _p(J))
+    return (d, J) if jac else d
 
 
 def solve_quadprog(G, g0, CI, ci0):

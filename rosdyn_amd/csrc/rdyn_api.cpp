@@ -342,6 +342,38 @@ int rdyn_local_ik_damped(const rdyn_chain* c, const rdyn_batch* b, const double*
   return RDYN_OK;
 }
 
+int rdyn_frame_distance(int64_t n_pairs, const double* T_wa, const double* T_wb, int layout, int kind, double* distance, double* jacobian,
+                        int device, void* stream)
+{
+  if (n_pairs < 0 || (layout != RDYN_LAYOUT_SAMPLE_MAJOR && layout != RDYN_LAYOUT_ELEMENT_MAJOR) || kind < 0 || kind > 2 ||
+      (n_pairs > 0 && (!T_wa || !T_wb || !distance)) || (jacobian && kind != RDYN_FRAME_DISTANCE_QUAT_JAC))
+  {
+    rdyn_set_error("rdyn_frame_distance: invalid argument");
+    return RDYN_ERR_INVALID_ARGUMENT;
+  }
+  if (n_pairs == 0) return RDYN_OK;
+  DeviceGuard g;
+  int st = g.enter(device);
+  if (st != RDYN_OK) return st;
+  RdynFrameDistanceArgs a;
+  memset(&a, 0, sizeof a);
+  rdyn_batch b;
+  memset(&b, 0, sizeof b);
+  b.n_samples = n_pairs;
+  b.layout = layout;
+  a.T_wa = T_wa;
+  a.T_wb = T_wb;
+  a.n = n_pairs;
+  a.kind = kind;
+  a.distance = distance;
+  a.jacobian = jacobian;
+  rec_strides(&b, 12, &a.t_ss, &a.t_se);
+  rec_strides(&b, 6, &a.d_ss, &a.d_se);
+  rec_strides(&b, 36, &a.j_ss, &a.j_se);
+  RDYN_HIP_TRY(rdyn_launch_frame_distance(a, (hipStream_t)stream));
+  return RDYN_OK;
+}
+
 // ---- split / jerk sweeps, external wrenches ---------------------------------------------------------------
 int rdyn_twist_parts(const rdyn_chain* c, const rdyn_batch* b, const double* dddq, double* dtw_lin, double* dtw_nonlin, double* ddtw)
 {

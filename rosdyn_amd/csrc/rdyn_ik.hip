@@ -87,10 +87,9 @@ __device__ __forceinline__ bool masked_solve(const double (&H)[NJ * (NJ + 1) / 2
   return ok;
 }
 
-// Eigen::AngleAxisd(R).angle() * .axis()  (Eigen 3.3/3.4: matrix -> quaternion -> angle in [0, pi], axis = sign(w) vec / |vec|)
-__device__ __forceinline__ V3 rotation_vector(const double (&M)[9])
+// Eigen::Quaterniond(R) (Eigen 3.3/3.4: trace / largest-diagonal branches), R row-major
+__device__ __forceinline__ void quaternion_of(const double (&M)[9], double& qx, double& qy, double& qz, double& qw)
 {
-  double qx, qy, qz, qw;
   double t = M[0] + M[4] + M[8];
   if (t > 0.0)
   {
@@ -128,6 +127,13 @@ __device__ __forceinline__ V3 rotation_vector(const double (&M)[9])
     qx = (M[2] + M[6]) * t;
     qy = (M[5] + M[7]) * t;
   }
+}
+
+// Eigen::AngleAxisd(R).angle() * .axis()  (Eigen 3.3/3.4: quaternion -> angle in [0, pi], axis = sign(w) vec / |vec|)
+__device__ __forceinline__ V3 rotation_vector(const double (&M)[9])
+{
+  double qx, qy, qz, qw;
+  quaternion_of(M, qx, qy, qz, qw);
   const double n = sqrt(fma(qx, qx, fma(qy, qy, qz * qz)));
   if (n == 0.0) return mk(0, 0, 0);
   const double k = 2.0 * atan2(n, fabs(qw)) / (qw < 0.0 ? -n : n);
@@ -430,6 +436,76 @@ __global__ __launch_bounds__(64) void k_local_ik_resume(const RdynIkArgs a)
   }
 }
 
+// getFrameDistance (kind 0), getFrameDistanceQuat (1), getFrameDistanceQuatJac (2): frame_distance.h:44-49, 73-86, 112-126.
+// One thread per pair of frames (column-major 3x4 [R | p] records); the Jacobian is 6 x 6 column-major.
+__global__ __launch_bounds__(256) void k_frame_distance(const RdynFrameDistanceArgs a)
+{
+  const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (s >= a.n) return;
+  double Ra[9], Rb[9];
+  const double* __restrict__ ta = a.T_wa + s * a.t_ss;
+  const double* __restrict__ tb = a.T_wb + s * a.t_ss;
+#pragma unroll
+  for (int cc = 0; cc < 3; ++cc)
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+    {
+      Ra[r * 3 + cc] = ta[(int64_t)(cc * 3 + r) * a.t_se];
+      Rb[r * 3 + cc] = tb[(int64_t)(cc * 3 + r) * a.t_se];
+    }
+  const V3 pa = mk(ta[9 * a.t_se], ta[10 * a.t_se], ta[11 * a.t_se]), pb = mk(tb[9 * a.t_se], tb[10 * a.t_se], tb[11 * a.t_se]);
+  double Rab[9];  // R_wa^-1 R_wb
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int cc = 0; cc < 3; ++cc) Rab[r * 3 + cc] = fma(Ra[0 + r], Rb[0 + cc], fma(Ra[3 + r], Rb[3 + cc], Ra[6 + r] * Rb[6 + cc]));
+  V3 lin = pa - pb, ang;
+  double qx = 0.0, qy = 0.0, qz = 0.0, qw = 1.0;
+  if (a.kind == 0)
+  {
+    const V3 rv = rot(Ra, rotation_vector(Rab));  // -R_wa (angle * axis), :48
+    ang = mk(-rv.x, -rv.y, -rv.z);
+  }
+  else
+  {
+    quaternion_of(Rab, qx, qy, qz, qw);
+    if (qw < 0.0)  // :77-83, :118-122
+    {
+      qx = -qx; qy = -qy; qz = -qz; qw = -qw;
+    }
+    const V3 rv = rot(Ra, mk(qx, qy, qz));        // -2 R_wa imag(q_ab), :84 / :124
+    ang = mk(-2.0 * rv.x, -2.0 * rv.y, -2.0 * rv.z);
+    if (a.kind == 2) lin = pb - pa;               // the Jacobian variant measures the translation the other way round (:115)
+  }
+  double* __restrict__ o = a.distance + s * a.d_ss;
+  o[0] = lin.x; o[a.d_se] = lin.y; o[2 * a.d_se] = lin.z;
+  o[3 * a.d_se] = ang.x; o[4 * a.d_se] = ang.y; o[5 * a.d_se] = ang.z;
+  if (a.kind == 2 && a.jacobian)
+  {
+    // J = [I 0; 0 R_wa (w I - skew(vec)) R_wa^T], :125
+    const double K[9] = {qw, qz, -qy, -qz, qw, qx, qy, -qx, qw};  // w I - skew(v), row-major
+    double RK[9], B[9];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int cc = 0; cc < 3; ++cc) RK[r * 3 + cc] = fma(Ra[r * 3], K[cc], fma(Ra[r * 3 + 1], K[3 + cc], Ra[r * 3 + 2] * K[6 + cc]));
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int cc = 0; cc < 3; ++cc) B[r * 3 + cc] = fma(RK[r * 3], Ra[cc * 3], fma(RK[r * 3 + 1], Ra[cc * 3 + 1], RK[r * 3 + 2] * Ra[cc * 3 + 2]));
+    double* __restrict__ jo = a.jacobian + s * a.j_ss;
+#pragma unroll
+    for (int cc = 0; cc < 6; ++cc)
+#pragma unroll
+      for (int r = 0; r < 6; ++r)
+      {
+        double v = (r == cc) ? 1.0 : 0.0;
+        if (r >= 3 && cc >= 3) v = B[(r - 3) * 3 + (cc - 3)];
+        jo[(int64_t)(cc * 6 + r) * a.j_se] = v;
+      }
+  }
+}
+
 template <int NJ>
 hipError_t launch_ik_nj(const RdynIkArgs& a, hipStream_t st)
 {
@@ -445,6 +521,13 @@ hipError_t launch_ik_nj(const RdynIkArgs& a, hipStream_t st)
 }
 
 }  // namespace
+
+hipError_t rdyn_launch_frame_distance(const RdynFrameDistanceArgs& a, hipStream_t st)
+{
+  if (a.n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_frame_distance, dim3((unsigned)((a.n + 255) / 256)), dim3(256), 0, st, a);
+  return hipGetLastError();
+}
 
 hipError_t rdyn_launch_local_ik(int n_joints, const RdynIkArgs& a, hipStream_t st)
 {

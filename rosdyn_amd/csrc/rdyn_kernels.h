@@ -66,6 +66,19 @@ struct RdynIkArgs
 };
 hipError_t rdyn_launch_local_ik(int n_joints, const RdynIkArgs& a, hipStream_t st);
 
+// getFrameDistance family (frame_distance.h) on pairs of frames; element e of record s at base[s * X_ss + e * X_se]
+struct RdynFrameDistanceArgs
+{
+  const double *T_wa, *T_wb;   // 12 per frame, column-major 3x4 [R | p]
+  int64_t n, t_ss, t_se;
+  int kind;                    // 0 getFrameDistance, 1 getFrameDistanceQuat, 2 getFrameDistanceQuatJac
+  double* distance;            // 6 per pair
+  int64_t d_ss, d_se;
+  double* jacobian;            // kind 2 only, may be null: 36 per pair, column-major 6 x 6
+  int64_t j_ss, j_se;
+};
+hipError_t rdyn_launch_frame_distance(const RdynFrameDistanceArgs& a, hipStream_t st);
+
 // Base-frame kinematics outputs; record element e of sample s at out[s * X_ss + e * out_se].
 struct RdynKinArgs
 {

@@ -135,3 +135,45 @@ def test_damped_ik_makes_the_seven_dof_arm_solvable():
     assert max(np.linalg.norm(frame_distance(a, b)) for a, b in zip(T[st == 1][:200], Ts)) < 1e-6
     lo, hi = np.array(ref.spec.q_min), np.array(ref.spec.q_max)
     assert (sol[st >= 0] >= lo - 1e-12).all() and (sol[st >= 0] <= hi + 1e-12).all()
+
+
+@pytest.mark.parametrize("layout", ["sample", "element"])
+def test_frame_distance_family_matches_oracle(layout):
+    """rdyn_frame_distance: getFrameDistance / getFrameDistanceQuat / getFrameDistanceQuatJac (frame_distance.h) on random
+    frame pairs, including tiny relative rotations and rotations close to half a turn (trace < 0 branches)."""
+    torch = pytest.importorskip("torch")
+    from scipy.spatial.transform import Rotation
+    from oracle.oracle import frame_distance, frame_distance_quat
+    from rosdyn_amd.frames import getFrameDistance, getFrameDistanceQuat, getFrameDistanceQuatJac
+    rng = np.random.default_rng(11)
+    N = 600
+    Ra = Rotation.random(N, random_state=1)
+    rel = Rotation.random(N, random_state=2).as_rotvec()
+    rel[0:100] *= 1e-9 / np.linalg.norm(rel[0:100], axis=1, keepdims=True)                       # tiny angles
+    rel[100:250] *= (np.pi - rng.uniform(1e-9, 1e-3, 150))[:, None] / np.linalg.norm(rel[100:250], axis=1, keepdims=True)
+    Rb = Ra * Rotation.from_rotvec(rel)
+    Ta = np.concatenate([Ra.as_matrix(), rng.normal(size=(N, 3, 1))], axis=2)                    # (N, 3, 4)
+    Tb = np.concatenate([Rb.as_matrix(), rng.normal(size=(N, 3, 1))], axis=2)
+
+    def dev(T):
+        rec = np.ascontiguousarray(T.transpose(0, 2, 1))                                         # (N, 4, 3): columns of [R | p]
+        return torch.from_numpy(np.ascontiguousarray(np.moveaxis(rec, 0, -1)) if layout == "element" else rec).cuda()
+
+    def host(t):
+        return np.moveaxis(t.cpu().numpy(), -1, 0) if layout == "element" else t.cpu().numpy()
+    ta, tb = dev(Ta), dev(Tb)
+    d0 = host(getFrameDistance(ta, tb, layout=layout))
+    d1 = host(getFrameDistanceQuat(ta, tb, layout=layout))
+    d2, J2 = getFrameDistanceQuatJac(ta, tb, layout=layout)
+    d2, J2 = host(d2), host(J2)
+    r0 = np.array([frame_distance(a, b) for a, b in zip(Ta, Tb)])
+    r1 = np.array([frame_distance_quat(a, b) for a, b in zip(Ta, Tb)])
+    r2 = [frame_distance_quat(a, b, jac=True) for a, b in zip(Ta, Tb)]
+    # near half a turn the angle-axis vector is ill conditioned in the matrix (d angle / d R ~ 1 / sin): 1e-9 there, 1e-12 elsewhere
+    easy = np.ones(N, dtype=bool)
+    easy[100:250] = False
+    assert np.abs(d0[easy] - r0[easy]).max() < 1e-12 and np.abs(d0 - r0).max() < 1e-8
+    assert np.abs(d1 - r1).max() < 1e-12
+    assert np.abs(d2 - np.array([x[0] for x in r2])).max() < 1e-12
+    assert np.abs(J2.transpose(0, 2, 1) - np.array([x[1] for x in r2])).max() < 1e-12             # column-major 6 x 6 per pair
+    assert np.array_equal(d2[:, :3], -d1[:, :3]) and np.array_equal(d2[:, 3:], d1[:, 3:])       # :115 vs :75

@@ -102,3 +102,30 @@ def test_local_ik_reaches_reachable_targets(urdf, base, tool):
     # weighted variant with unit weights == unweighted (primitives_impl.h:1446-1452)
     solw, stw, itw = ref.local_ik(T, seeds, weight=np.ones(6), toll=1e-8, max_iter=40)
     assert np.array_equal(stw, st) and np.array_equal(solw, sol)
+
+
+def test_frame_distance_quat_and_its_jacobian():
+    """getFrameDistanceQuat / getFrameDistanceQuatJac (frame_distance.h:73-126) against scipy's quaternion of R_a' R_b."""
+    from scipy.spatial.transform import Rotation
+    rng = np.random.default_rng(8)
+    for k in range(100):
+        Ra, Rb = Rotation.random(random_state=2 * k), Rotation.random(random_state=2 * k + 1)
+        pa, pb = rng.normal(size=3), rng.normal(size=3)
+        Ta, Tb = np.hstack([Ra.as_matrix(), pa[:, None]]), np.hstack([Rb.as_matrix(), pb[:, None]])
+        q = (Ra.inv() * Rb).as_quat()                               # x, y, z, w
+        if q[3] < 0:
+            q = -q
+        d = O.frame_distance_quat(Ta, Tb)
+        assert np.abs(d[:3] - (pa - pb)).max() == 0.0
+        assert np.abs(d[3:] - (-2.0 * Ra.as_matrix() @ q[:3])).max() < 1e-13
+        dj, J = O.frame_distance_quat(Ta, Tb, jac=True)
+        assert np.abs(dj[:3] - (pb - pa)).max() == 0.0 and np.array_equal(dj[3:], d[3:])
+        v = q[:3]
+        K = q[3] * np.eye(3) - np.array([[0, -v[2], v[1]], [v[2], 0, -v[0]], [-v[1], v[0], 0]])
+        expect = np.eye(6)
+        expect[3:, 3:] = Ra.as_matrix() @ K @ Ra.as_matrix().T
+        assert np.abs(J - expect).max() < 1e-13
+        # for small relative rotations the quaternion form tends to the angle-axis form
+    Rb = Ra * Rotation.from_rotvec([1e-5, -2e-5, 3e-5])
+    Tb = np.hstack([Rb.as_matrix(), pb[:, None]])
+    assert np.abs(O.frame_distance_quat(Ta, Tb) - O.frame_distance(Ta, Tb)).max() < 1e-13
