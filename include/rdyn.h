@@ -309,6 +309,15 @@ int rdyn_gram(const double* A, int64_t rows, int64_t lda, int n_cols, const doub
  * for every chunk, sized to stay resident in the 256 MiB Infinity Cache) is produced by the regressor kernel
  * and consumed by the Gram kernel.  Multi-GPU: every rank calls this on its shard and all-reduces
  * [G | c | bb] (P*P + P + 1 doubles) once -- rosdyn_amd/gram.py. */
+/* The identification step in one call: normal equations of the stacked [Y | C] with the measured torque,
+ *   G = [Y C]'[Y C]  ((P + K) x (P + K)),  c = [Y C]' tau_meas,  bb = tau_meas' tau_meas,
+ * Y = getRegressor of the chain (P = 10 joints_number columns), C = the component columns of rdyn_components_regressor
+ * (K = rdyn_components_columns; n_comps = 0: none).  Neither Y nor C is handed to the caller: they are produced chunk by
+ * chunk into the workspace and reduced by the MFMA Gram kernel.  P + K <= 111.  Outputs / accumulate as rdyn_regressor_gram. */
+size_t rdyn_identification_gram_workspace_bytes(const rdyn_chain* chain, const rdyn_component* comps, int n_comps);
+int rdyn_identification_gram(const rdyn_chain* chain, const rdyn_component* comps, int n_comps, const rdyn_batch* batch,
+                             const double* tau_meas, double* G, double* c, double* bb, int accumulate, void* workspace,
+                             size_t workspace_bytes);
 size_t rdyn_regressor_gram_workspace_bytes(const rdyn_chain* chain, int64_t chunk_samples);
 int rdyn_regressor_gram(const rdyn_chain* chain, const rdyn_batch* batch, const double* tau_meas, double* G, double* c,
                         double* bb, int accumulate, int64_t chunk_samples, void* workspace, size_t workspace_bytes);

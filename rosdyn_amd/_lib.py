@@ -95,6 +95,8 @@ SYMBOLS = {
     "rdyn_multi_plan_destroy": (None, [_VP]),
     "rdyn_gram_workspace_bytes": (C.c_size_t, [_I]),
     "rdyn_gram": (_I, [_VP, C.c_int64, C.c_int64, _I, _VP, _VP, _VP, _VP, _I, _VP, C.c_size_t, _I, _VP]),
+    "rdyn_identification_gram_workspace_bytes": (C.c_size_t, [_VP, _VP, _I]),
+    "rdyn_identification_gram": (_I, [_VP, _VP, _I, _BP, _VP, _VP, _VP, _VP, _I, _VP, C.c_size_t]),
     "rdyn_regressor_gram_workspace_bytes": (C.c_size_t, [_VP, C.c_int64]),
     "rdyn_regressor_gram": (_I, [_VP, _BP, _VP, _VP, _VP, _VP, _I, C.c_int64, _VP, C.c_size_t]),
 }

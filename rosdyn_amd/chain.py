@@ -378,6 +378,31 @@ class Chain(object):
                                         workspace.data_ptr(), workspace.numel()))
         return G, c, bb
 
+    def getIdentificationGram(self, components, q, Dq, DDq, tau_meas, layout="sample", out=None, accumulate=False, workspace=None):
+        """The identification step in one call (include/rdyn.h: rdyn_identification_gram): normal equations of [Y | C] with
+        the measured torque; `components` is a rosdyn_amd.components.ComponentSet or None.  Returns (G (P+K, P+K), c (P+K,),
+        bb (1,)); the unknowns are [the 10-per-link inertial parameters ; the components' parameters]."""
+        torch = _torch()
+        b, N, lay = self._batch(layout, q, Dq, DDq)
+        if tau_meas.shape != q.shape or tau_meas.dtype != torch.float64 or not tau_meas.is_contiguous():
+            raise ValueError("Input data dimensions mismatch")
+        arr, n_comps = (C.cast(components._arr, C.c_void_p), components.n_comps) if components is not None else (None, 0)
+        cols = 10 * self.getJointsNumber() + (components.columns if components is not None else 0)
+        if out is None:
+            out = (torch.empty((cols, cols), dtype=torch.float64, device=q.device), torch.empty((cols,), dtype=torch.float64, device=q.device),
+                   torch.empty((1,), dtype=torch.float64, device=q.device))
+            if accumulate:
+                raise ValueError("accumulate needs out=")
+        G, c, bb = out
+        nbytes = lib().rdyn_identification_gram_workspace_bytes(self._h, arr, n_comps)
+        if nbytes == 0:
+            raise ValueError("at most 111 columns (regressor + components) are supported")
+        if workspace is None:
+            workspace = torch.empty((nbytes,), dtype=torch.uint8, device=q.device)
+        check(lib().rdyn_identification_gram(self._h, arr, n_comps, C.byref(b), tau_meas.data_ptr(), G.data_ptr(), c.data_ptr(),
+                                             bb.data_ptr(), 1 if accumulate else 0, workspace.data_ptr(), workspace.numel()))
+        return G, c, bb
+
 
 def createChain(urdf_xml, base_frame, tool_frame, gravity=(0.0, 0.0, 0.0)):
     return Chain(urdf_xml, base_frame, tool_frame, gravity)

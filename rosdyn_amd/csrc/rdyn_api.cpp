@@ -507,6 +507,26 @@ int rdyn_components_columns(const rdyn_component* comps, int n_comps)
   return k;
 }
 
+// validates the components and copies them with the constructor rules of the reference applied
+static int fill_components(const rdyn_component* comps, int n_comps, int n_active, RdynComponentArgs* a)
+{
+  for (int i = 0; i < n_comps; ++i)
+  {
+    const rdyn_component& c = comps[i];
+    if (c.type < RDYN_COMP_FRICTION1 || c.type > RDYN_COMP_SPRING || c.joint < 0 || c.joint >= n_active)
+    {
+      rdyn_set_error("component %d has an invalid type or joint", i);
+      return RDYN_ERR_INVALID_ARGUMENT;
+    }
+    a->comps[i].type = c.type;
+    a->comps[i].joint = c.joint;
+    a->comps[i].min_velocity = c.min_velocity < 1e-6 ? 1e-6 : c.min_velocity;  // friction_polynomial1.h:73-78
+    a->comps[i].max_velocity = c.max_velocity <= 0 ? 1.0e6 : c.max_velocity;   // friction_polynomial1.h:81-86
+    for (int k = 0; k < 3; ++k) a->comps[i].parameters[k] = c.parameters[k];
+  }
+  return RDYN_OK;
+}
+
 int rdyn_components_regressor(const rdyn_component* comps, int n_comps, int n_active, const rdyn_batch* b, double* C,
                               const rdyn_regressor_layout* cl, double* tau_add)
 {
@@ -523,20 +543,8 @@ int rdyn_components_regressor(const rdyn_component* comps, int n_comps, int n_ac
   }
   RdynComponentArgs a;
   memset(&a, 0, sizeof a);
-  for (int i = 0; i < n_comps; ++i)
-  {
-    const rdyn_component& c = comps[i];
-    if (c.type < RDYN_COMP_FRICTION1 || c.type > RDYN_COMP_SPRING || c.joint < 0 || c.joint >= n_active)
-    {
-      rdyn_set_error("rdyn_components_regressor: component %d has an invalid type or joint", i);
-      return RDYN_ERR_INVALID_ARGUMENT;
-    }
-    a.comps[i].type = c.type;
-    a.comps[i].joint = c.joint;
-    a.comps[i].min_velocity = c.min_velocity < 1e-6 ? 1e-6 : c.min_velocity;  // friction_polynomial1.h:73-78
-    a.comps[i].max_velocity = c.max_velocity <= 0 ? 1.0e6 : c.max_velocity;   // friction_polynomial1.h:81-86
-    for (int k = 0; k < 3; ++k) a.comps[i].parameters[k] = c.parameters[k];
-  }
+  int cst = fill_components(comps, n_comps, n_active, &a);
+  if (cst != RDYN_OK) return cst;
   if (b->n_samples == 0) return RDYN_OK;
   DeviceGuard g;
   int st = g.enter(b->device);
@@ -910,6 +918,117 @@ int rdyn_regressor_gram(const rdyn_chain* c, const rdyn_batch* b, const double* 
     RDYN_HIP_TRY(rdyn_launch_local_sweep(c->n_joints(), RDYN_MODE_REGRESSOR_GRAM, a, stream));
     const bool last = (s0 + cnt >= N);
     st = gram_launch(scratch, (int64_t)n * cnt, (int64_t)n * cnt, P, tau_meas ? scratch + (int64_t)P * n * cnt : nullptr, G, cvec, bb,
+                     s0 > 0 ? 1 : 0, last, accumulate ? 1 : 0, slabs, stream, cnt, first_col, n);
+    if (st != RDYN_OK) return st;
+  }
+  return RDYN_OK;
+}
+
+// ---- identification step: normal equations of [Y | C | tau_meas] (rigid-body regressor + component columns) -------------
+static const int64_t kIdentChunk = 131072;  // samples per image chunk (the image of one chunk stays L2 / Infinity-Cache sized)
+
+size_t rdyn_identification_gram_workspace_bytes(const rdyn_chain* c, const rdyn_component* comps, int n_comps)
+{
+  if (!c) return 0;
+  const int K = n_comps > 0 ? rdyn_components_columns(comps, n_comps) : 0;
+  const int cols = 10 * c->n_joints() + (K > 0 ? K : 0);
+  if (K < 0 || rdyn_gram_blocks_for(cols) > 7) return 0;
+  return gram_slab_bytes(cols) + (size_t)kIdentChunk * c->n_active() * (cols + 1) * sizeof(double);
+}
+
+int rdyn_identification_gram(const rdyn_chain* c, const rdyn_component* comps, int n_comps, const rdyn_batch* b, const double* tau_meas,
+                             double* G, double* cvec, double* bb, int accumulate, void* workspace, size_t workspace_bytes)
+{
+  int st = check_batch(c, b, true, true, "rdyn_identification_gram");
+  if (st != RDYN_OK) return st;
+  if (!G || !workspace || n_comps < 0 || n_comps > RDYN_MAX_COMPONENTS || (n_comps > 0 && !comps))
+  {
+    rdyn_set_error("rdyn_identification_gram: null output / workspace, or more than %d components", RDYN_MAX_COMPONENTS);
+    return RDYN_ERR_INVALID_ARGUMENT;
+  }
+  const int n = c->n_active(), P = 10 * c->n_joints();
+  const int K = n_comps > 0 ? rdyn_components_columns(comps, n_comps) : 0;
+  const int cols = P + K;
+  if (rdyn_gram_blocks_for(cols) > 7)
+  {
+    rdyn_set_error("rdyn_identification_gram: at most 111 columns (regressor + components) are supported");
+    return RDYN_ERR_UNSUPPORTED;
+  }
+  if (workspace_bytes < rdyn_identification_gram_workspace_bytes(c, comps, n_comps))
+  {
+    rdyn_set_error("rdyn_identification_gram: workspace too small");
+    return RDYN_ERR_INVALID_ARGUMENT;
+  }
+  RdynComponentArgs ca;
+  memset(&ca, 0, sizeof ca);
+  st = fill_components(comps, n_comps, n, &ca);
+  if (st != RDYN_OK) return st;
+  DeviceGuard g;
+  st = g.enter(b->device);
+  if (st != RDYN_OK) return st;
+  const RdynChainConst* dc = nullptr;
+  st = device_const(c, &dc);
+  if (st != RDYN_OK) return st;
+  hipStream_t stream = (hipStream_t)b->stream;
+  double* slabs = (double*)workspace;
+  double* scratch = (double*)((char*)workspace + gram_slab_bytes(cols));
+  const int64_t N = b->n_samples;
+  if (N == 0)
+  {
+    if (!accumulate)
+    {
+      RDYN_HIP_TRY(hipMemsetAsync(G, 0, sizeof(double) * cols * cols, stream));
+      if (cvec) RDYN_HIP_TRY(hipMemsetAsync(cvec, 0, sizeof(double) * cols, stream));
+      if (bb) RDYN_HIP_TRY(hipMemsetAsync(bb, 0, sizeof(double), stream));
+    }
+    return RDYN_OK;
+  }
+  const int64_t in_step = (b->layout == RDYN_LAYOUT_SAMPLE_MAJOR) ? n : 1;
+  int first_col[RDYN_MAX_JOINTS];
+  for (int j = 0; j < n; ++j) first_col[j] = 10 * c->active[j];  // the component columns lie to the right: always loaded
+  int64_t prev_cnt = -1;
+  for (int64_t s0 = 0; s0 < N; s0 += kIdentChunk)
+  {
+    const int64_t cnt = (N - s0 < kIdentChunk) ? (N - s0) : kIdentChunk;
+    if (cnt != prev_cnt)
+    {
+      RDYN_HIP_TRY(hipMemsetAsync(scratch, 0, sizeof(double) * (size_t)cnt * n * (cols + 1), stream));  // see rdyn_regressor_gram
+      prev_cnt = cnt;
+    }
+    // element-major image of the chunk: rows j * cnt + s, lda = n * cnt; columns [Y (P) | C (K) | tau_meas]
+    RdynSweepArgs a;
+    memset(&a, 0, sizeof a);
+    a.chain = dc;
+    a.q = b->q + s0 * in_step;
+    a.dq = b->dq + s0 * in_step;
+    a.ddq = b->ddq + s0 * in_step;
+    a.bcol = tau_meas ? tau_meas + s0 * in_step : nullptr;
+    a.bcol_col = cols;
+    a.n_samples = cnt;
+    rec_strides(b, n, &a.in_ss, &a.in_sj);
+    a.Y = scratch;
+    a.y_ss = 1;
+    a.y_sr = cnt;
+    a.y_sc = (int64_t)n * cnt;
+    RDYN_HIP_TRY(rdyn_launch_local_sweep(c->n_joints(), RDYN_MODE_REGRESSOR_GRAM, a, stream));
+    if (K > 0)
+    {
+      ca.q = a.q;
+      ca.dq = a.dq;
+      ca.n_samples = cnt;
+      ca.in_ss = a.in_ss;
+      ca.in_sj = a.in_sj;
+      ca.n_active = n;
+      ca.n_comps = n_comps;
+      ca.C = scratch + (int64_t)P * n * cnt;
+      ca.c_ss = 1;
+      ca.c_sr = cnt;
+      ca.c_sc = (int64_t)n * cnt;
+      ca.tau = nullptr;
+      RDYN_HIP_TRY(rdyn_launch_components(ca, stream));
+    }
+    const bool last = (s0 + cnt >= N);
+    st = gram_launch(scratch, (int64_t)n * cnt, (int64_t)n * cnt, cols, tau_meas ? scratch + (int64_t)cols * n * cnt : nullptr, G, cvec, bb,
                      s0 > 0 ? 1 : 0, last, accumulate ? 1 : 0, slabs, stream, cnt, first_col, n);
     if (st != RDYN_OK) return st;
   }

@@ -21,6 +21,7 @@ struct RdynSweepArgs
   // regressor mode only: optional measured torque, copied into regressor column P (the "b" column of the
   // normal equations) with the Y addressing; same layout as q.
   const double* bcol;
+  int bcol_col;                 // column that receives bcol; 0 = column P (right after the regressor)
   // torque mode only: optional external wrenches, links x 6 per sample ([force; torque] in the link's own frame,
   // applied TO the link; getWrench, primitives_impl.h:1225); element e of sample s at ext[s * ext_ss + e * ext_se]
   const double* ext;

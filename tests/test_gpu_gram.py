@@ -191,3 +191,20 @@ def test_identification_with_friction_columns_end_to_end(torch_cuda):
     assert np.abs(phi[1::2] - np.array(viscous)).max() < 20 * sigma / np.sqrt(N / 100.0)
     pred = (A.reshape(P + K, n * N).T @ torch.from_numpy(x).cuda()).reshape(n, N)
     assert float((pred - tau).abs().max()) < 0.05                                 # noise-free torques reproduced
+    # the same normal equations in ONE call, nothing materialised for the caller (rdyn_identification_gram); N is not a
+    # multiple of the internal chunk, inputs in both layouts, and accumulated over two halves
+    G1, c1, bb1 = chain.getIdentificationGram(comps, q, dq, ddq, tau_meas, layout="element")
+    assert _fro(G1.cpu().numpy(), G.cpu().numpy()) <= 1e-12 and _fro(c1.cpu().numpy(), c.cpu().numpy()) <= 1e-12
+    assert abs(bb1.item() - bb.item()) <= 1e-12 * bb.item()
+    qs, dqs, ddqs, tms = (t.T.contiguous() for t in (q, dq, ddq, tau_meas))
+    G2, c2, _ = chain.getIdentificationGram(comps, qs, dqs, ddqs, tms)
+    assert _fro(G2.cpu().numpy(), G.cpu().numpy()) <= 1e-12 and _fro(c2.cpu().numpy(), c.cpu().numpy()) <= 1e-12
+    h = 77777
+    out = chain.getIdentificationGram(comps, qs[:h].contiguous(), dqs[:h].contiguous(), ddqs[:h].contiguous(), tms[:h].contiguous())
+    G3, c3, bb3 = chain.getIdentificationGram(comps, qs[h:].contiguous(), dqs[h:].contiguous(), ddqs[h:].contiguous(), tms[h:].contiguous(),
+                                              out=out, accumulate=True)
+    assert _fro(G3.cpu().numpy(), G.cpu().numpy()) <= 1e-12 and abs(bb3.item() - bb.item()) <= 1e-12 * bb.item()
+    # without components it is the regressor Gram
+    G4, c4, _ = chain.getIdentificationGram(None, q, dq, ddq, tau_meas, layout="element")
+    G5, c5, _ = chain.getRegressorGram(q, dq, ddq, tau_meas, layout="element")
+    assert _fro(G4.cpu().numpy(), G5.cpu().numpy()) <= 1e-12 and _fro(c4.cpu().numpy(), c5.cpu().numpy()) <= 1e-12
