@@ -20,6 +20,7 @@ qs, dqs, ddqs = (t.T.contiguous() for t in (q, dq, ddq))
 ext = torch.rand((L, 6, N), dtype=torch.float64, device="cuda")
 tau = chain.getJointTorque(q, dq, ddq, layout="element")
 rows = []
+comps = ComponentSet([dict(type=0, joint=j, min_velocity=1e-3, max_velocity=10.0, parameters=[0.1, 0.2]) for j in range(n)], n)
 
 
 def row(name, fn, bytes_per_eval, reps=10):
@@ -43,7 +44,7 @@ row("getTwist (all links)", lambda: chain.getTwist(q, dq, layout=E), 96 + 48 * L
 row("getDTwist (all links)", lambda: chain.getDTwist(q, dq, ddq, layout=E), 144 + 48 * L)
 row("getDDTwist (all links)", lambda: chain.getDDTwist(q, dq, ddq, dddq, layout=E), 192 + 48 * L)
 row("regressor -> Gram [A|tau]'[A|tau] fused", lambda: chain.getRegressorGram(q, dq, ddq, tau, layout=E), 192)
-comps = ComponentSet([dict(type=0, joint=j, min_velocity=1e-3, max_velocity=10.0, parameters=[0.1, 0.2]) for j in range(n)], n)
+row("identification Gram [Y | 6 friction comps | tau] one call", lambda: chain.getIdentificationGram(comps, q, dq, ddq, tau, layout=E), 192)
 row("friction components (6 x first order, dense n x K)", lambda: comps.getRegressor(q, dq, layout=E), 96 + 8 * n * comps.columns)
 T = chain.getTransformation(q, layout=E)
 seeds = q + 0.25 * (torch.rand_like(q) * 2 - 1)
