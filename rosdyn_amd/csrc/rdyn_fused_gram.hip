@@ -163,23 +163,7 @@ __global__ __launch_bounds__(256) void k_regressor_gram_fused(const RdynFusedGra
 
   // ---------------- epilogue: block reduction in LDS, this block's Gram slab
   __shared__ double red[NT * 256];
-  for (int w = 0; w < 4; ++w)
-  {
-    if (wave == w)
-    {
-#pragma unroll
-      for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-        {
-          const int idx = t * 256 + ((g + 4 * r) * 16 + cl);
-          red[idx] = (w == 0) ? acc[t][r] : red[idx] + acc[t][r];
-        }
-    }
-    __syncthreads();
-  }
-  double* slab = fa.slabs + (int64_t)blockIdx.x * (NT * 256);
-  for (int i = threadIdx.x; i < NT * 256; i += 256) slab[i] = red[i];
+  gram_block_reduce_to_slab<NT>(acc, red, wave, cl, g, fa.slabs + (int64_t)blockIdx.x * (NT * 256), false);
 }
 
 template <int NJ>

@@ -130,24 +130,7 @@ __global__ __launch_bounds__(256) void k_gram(const RdynGramArgs a)
 
   // ---- block reduction in LDS, then add into this block's slab
   __shared__ double red[NT * 256];
-  for (int w = 0; w < 4; ++w)
-  {
-    if (wave == w)
-    {
-#pragma unroll
-      for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-        {
-          // C/D layout of v_mfma_f64_16x16x4_f64: row = (lane >> 4) + 4 * reg, col = lane & 15
-          const int idx = t * 256 + ((g + 4 * r) * 16 + c);
-          red[idx] = (w == 0) ? acc[t][r] : red[idx] + acc[t][r];
-        }
-    }
-    __syncthreads();
-  }
-  double* slab = a.slabs + (int64_t)blockIdx.x * (NT * 256);
-  for (int i = threadIdx.x; i < NT * 256; i += 256) slab[i] = a.accumulate ? slab[i] + red[i] : red[i];
+  gram_block_reduce_to_slab<NT>(acc, red, wave, c, g, a.slabs + (int64_t)blockIdx.x * (NT * 256), a.accumulate != 0);
 }
 
 // sums the per-block slabs (fixed order) and scatters the tiles into G (P x P, both triangles), c = A^T b, bb.

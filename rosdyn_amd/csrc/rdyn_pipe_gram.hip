@@ -232,23 +232,7 @@ __global__ __launch_bounds__(256) void k_regressor_gram_pipe(const RdynLdsGramAr
   // ================= epilogue: block reduction through LDS (the tiles are dead now), this block's Gram slab
   __syncthreads();
   double* red = (double*)lds_raw;
-  for (int wv = 0; wv < 4; ++wv)
-  {
-    if (wave == wv)
-    {
-#pragma unroll
-      for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-        {
-          const int idx = t * 256 + ((g + 4 * r) * 16 + cl);
-          red[idx] = (wv == 0) ? acc[t][r] : red[idx] + acc[t][r];
-        }
-    }
-    __syncthreads();
-  }
-  double* slab = fa.slabs + (int64_t)blockIdx.x * (NT * 256);
-  for (int i = threadIdx.x; i < NT * 256; i += 256) slab[i] = red[i];
+  gram_block_reduce_to_slab<NT>(acc, red, wave, cl, g, fa.slabs + (int64_t)blockIdx.x * (NT * 256), false);
 }
 
 template <int NJ>
