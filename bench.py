@@ -4,22 +4,36 @@
 A "step" is one pass of the hot path (rdyn_regressor: fused getJointTorque + getRegressor, one HIP kernel
 launch) over one batch of synthetic (q, Dq, DDq) samples that are already resident in HBM.
 
-Workload (BASELINE.json configs[1]): 6-DOF chain (tests/fixtures/ur10_like.urdf cut at wrist_3_link:
+Workload of `value` (BASELINE.json configs[1]): 6-DOF chain (tests/fixtures/ur10_like.urdf cut at wrist_3_link:
 n = 6 active joints, 6 chain joints, P = 60 parameters), 1e6 samples per GPU, fp64, dense Y.
 Default layouts = SURVEY section 8(d) config 2 as written: inputs AoS [N][6] (sample-major), tau [N][6], Y = the stacked
-column-major (6 N) x 60 regressor A (k_rowpair_sweep<6>); --y-layout element selects the SoA form (k_local_sweep<6, REGRESSOR>,
-~2 % slower on the same box).
+column-major (6 N) x 60 regressor A (k_rowpair_sweep<6>); --y-layout element selects the SoA form (k_local_sweep<6, REGRESSOR>),
+--y-layout per_sample the drop-in Eigen image (k_persample_sweep<6>).
 Multi-GPU: the batch shards trivially (i.i.d. samples) -> every rank evaluates its own 1e6 samples, no
 data-path collective ("weak" scaling); the only exchange is the max-over-ranks of the elapsed time.
 
+Beside `value` the line carries
+  * "config4": BASELINE.json configs[3] -- every rank's regressor -> fp64 Gram of its shard (the regressor never reaches
+    HBM) followed by ONE all-reduce of [G | c | bb | count] (P*P + P + 2 doubles, RCCL over xGMI), timed as its own
+    barrier-bracketed region (max over ranks), with the all-reduce latency separately;
+  * "extras" (rank 0's GPU, outside every timed region of the headline): configs[2] (7-DOF, N = 4e6, Gram) and configs[4]
+    (256 distinct chains x 4 096 samples) once each with their own roofline blocks;
+  * "cpu_baseline": the C oracle on rank 0's host cores (every line, also for N > 1).
+
   python bench.py [--gpus N] [--steps K] [--warmup W] [--samples S] [--y-layout element|stacked|per_sample]
-  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+      --gpus N > 1 without a torch.distributed environment: this process starts
+      `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py ...` as a CHILD
+      (before anything touches the GPU), relays rank 0's JSON line and exits with the child's return code.
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...      (what the driver runs)
+  python bench.py --gpus 2 --backend gloo --dry     launcher / process-group / all-reduce plumbing only, no GPU (CPU tests)
 
 Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -27,8 +41,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 TB/s achievable)
-GRAVITY = (0.0, 0.0, -9.806)   # rosdyn_speed_test.cpp:61-62
+HBM_PEAK_GBPS = 8000.0       # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 TB/s achievable)
+FP64_MATRIX_PEAK_TFLOPS = 78.6   # MI355X fp64 matrix (= vector) datasheet peak
+GRAVITY = (0.0, 0.0, -9.806)     # rosdyn_speed_test.cpp:61-62
 
 
 def shard_sizes(total, world):
@@ -46,6 +61,15 @@ def max_over_ranks(value, dist, device):
     return float(t.item())
 
 
+def ranks_seen(dist, device):
+    """SUM all-reduce of a one per rank: how many ranks really took part in the collective."""
+    import torch
+    t = torch.ones(1, dtype=torch.float64, device=device)
+    if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return int(round(float(t.item())))
+
+
 def usable_cores():
     """Host cores this process may actually use: min(CPU affinity, cgroup CPU quota).  The GPU boxes expose 256
     logical CPUs but cap the container at 16 (cpu.max = 1600000 100000): 256 OpenMP threads there only thrash."""
@@ -60,10 +84,11 @@ def usable_cores():
     return max(1, n)
 
 
-def measured_traffic(kernel_tag):
-    """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/pmc_latest.json, written by
-    tools/summarize_prof.py from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this same command;
-    FETCH_SIZE doubled per the gfx950 correction of MI355X_MICROARCH.md section HBM).  None if no profile matches."""
+def committed_traffic(kernel_tag):
+    """HBM bytes per launch of the dominant kernel from the COMMITTED PMC passes (profiles/pmc_latest.json, written by
+    tools/summarize_prof.py from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this same command on the
+    builder's box; FETCH_SIZE doubled per the gfx950 correction of MI355X_MICROARCH.md section HBM).  Not measured in
+    this run (PMC needs rocprofv3 around the process): the line says so in roofline.traffic_source.  None if no profile matches."""
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_latest.json")) as f:
             d = json.load(f)
@@ -76,6 +101,11 @@ def measured_traffic(kernel_tag):
 def algorithmic_bytes_per_eval(n, P):
     """3 n doubles read (q, Dq, DDq) + n written (tau) + n P written (dense Y)  -- SURVEY section 8(d)."""
     return 3 * n * 8 + n * 8 + n * P * 8
+
+
+def gram_flop_per_eval(n, P):
+    """Dense-syrk convention of SURVEY section 8(d): n P (P + 1) for A'A + 2 n P for A'tau."""
+    return n * P * (P + 1) + 2 * n * P
 
 
 def cpu_baseline(urdf, base, tool, n, seconds, chunk=262144):
@@ -111,37 +141,194 @@ def cpu_baseline(urdf, base, tool, n, seconds, chunk=262144):
                       "single-thread rate %.3e evals/s" % (passes, chunk, dt, used, m / dt1)}
 
 
-def gram_extras(chain, q, dq, ddq, tau, in_layout, N, n, P, world, dist, dev):
-    """Outside the timed region, informational only (BASELINE.json configs[3]: normal equations of every rank's shard
-    on the fp64 matrix cores + ONE all-reduce of [G | c | bb | count] = P*P + P + 2 doubles).  Never fails the bench."""
+def time_region(fn, steps, warmup, world, dist, dev):
+    """`warmup` untimed calls, then exactly `steps` calls bracketed by barrier + synchronize on both sides.
+    Returns (wall seconds, device milliseconds), each the MAX over ranks."""
     import torch
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()          # same stream the kernels are launched on (torch's current stream is passed to the C-ABI)
+    for _ in range(steps):
+        fn()
+    ev1.record()
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    d = dist if world > 1 else None
+    return max_over_ranks(wall, d, dev), max_over_ranks(ev0.elapsed_time(ev1), d, dev)
+
+
+def config4_block(chain, q, dq, ddq, tau, in_layout, N, n, P, world, dist, dev, steps, warmup):
+    """BASELINE.json configs[3]: the 6-DOF batch sharded over the ranks (weak: N per rank), every rank's normal equations
+    on the fp64 matrix cores without the regressor leaving the chip, then ONE all-reduce of P*P + P + 2 doubles."""
+    import torch
+    from rosdyn_amd._lib import lib
+    from rosdyn_amd.gram import allreduce_normal_equations
+    d = dist if world > 1 else None
+    ws = torch.empty((lib().rdyn_regressor_gram_workspace_bytes(chain._h, 0),), dtype=torch.uint8, device=dev)
+    acc = chain.getRegressorGram(q, dq, ddq, tau, layout=in_layout, workspace=ws)
+    result = {}
+
+    def step():
+        chain.getRegressorGram(q, dq, ddq, tau, layout=in_layout, out=acc, workspace=ws)
+        result["sum"] = allreduce_normal_equations(acc[0], acc[1], acc[2], N, d)
+
+    def gram_only():
+        chain.getRegressorGram(q, dq, ddq, tau, layout=in_layout, out=acc, workspace=ws)
+
+    def allreduce_only():
+        allreduce_normal_equations(acc[0], acc[1], acc[2], N, d)
+
+    wall, _ = time_region(step, steps, warmup, world, dist, dev)
+    _, gram_ms = time_region(gram_only, steps, 1, world, dist, dev)
+    ar_wall, _ = time_region(allreduce_only, 20, 3, world, dist, dev)
+    count = result["sum"][3]
+    f_eval = gram_flop_per_eval(n, P)
+    kernel_ms = gram_ms / steps
+    tf = f_eval * N / (kernel_ms * 1e-3) / 1e12
+    return {"workload": "configs[3]: 6-DOF chain, %d samples per GPU x %d GPUs, getRegressor -> Gram [A'A | A'tau | tau'tau] per rank "
+                        "(regressor stays on chip) + one all-reduce of %d doubles" % (N, world, P * P + P + 2),
+            "value": N * world * steps / wall, "unit": "evals/s", "ms_per_step": wall / steps * 1e3,
+            "regressor_gram_ms_per_rank": kernel_ms, "allreduce_us": ar_wall / 20 * 1e6, "allreduce_doubles": P * P + P + 2,
+            "samples_reduced": count, "backend": "nccl(RCCL)" if world > 1 else "none (1 rank)",
+            "roofline": {"bound": "fp64-matrix", "achieved": tf, "peak": FP64_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": tf / FP64_MATRIX_PEAK_TFLOPS, "flop_per_eval_dense_syrk": f_eval, "kernel_ms": kernel_ms}}
+
+
+def extras_config3(dev, steps=5):
+    """BASELINE.json configs[2]: Panda-like 7-DOF chain (panda_link0 -> panda_link7: n = 7, 7 chain joints, P = 70),
+    N = 4e6, regressor -> Gram on the fp64 matrix cores.  Once, outside the headline's timed region."""
+    import torch
+    from rosdyn_amd import Chain
+    from rosdyn_amd._lib import lib
+    chain = Chain(os.path.join(ROOT, "tests", "fixtures", "panda_like.urdf"), "panda_link0", "panda_link7", GRAVITY)
+    n, P, N = chain.getActiveJointsNumber(), 10 * chain.getJointsNumber(), 4000000
+    gen = torch.Generator(device=dev).manual_seed(0x5EED0003)
+    q, dq, ddq, tau = (torch.rand((N, n), dtype=torch.float64, device=dev, generator=gen) * 2 - 1 for _ in range(4))
+    ws = torch.empty((lib().rdyn_regressor_gram_workspace_bytes(chain._h, 0),), dtype=torch.uint8, device=dev)
+    acc = chain.getRegressorGram(q, dq, ddq, tau, workspace=ws)
+    torch.cuda.synchronize()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0.record()
+    for _ in range(steps):
+        chain.getRegressorGram(q, dq, ddq, tau, out=acc, workspace=ws)
+    ev1.record()
+    torch.cuda.synchronize()
+    ms = ev0.elapsed_time(ev1) / steps
+    f_eval = gram_flop_per_eval(n, P)
+    tf = f_eval * N / (ms * 1e-3) / 1e12
+    return {"workload": "configs[2]: 7-DOF panda_like panda_link0->panda_link7 (n=7, P=70), N=%d, getRegressor -> Gram" % N,
+            "value": N / (ms * 1e-3), "unit": "evals/s", "ms_per_step": ms,
+            "roofline": {"bound": "fp64-matrix", "achieved": tf, "peak": FP64_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": tf / FP64_MATRIX_PEAK_TFLOPS, "flop_per_eval_dense_syrk": f_eval, "kernel_ms": ms}}
+
+
+def extras_config5(dev, steps=5, n_chains=256, S=4096):
+    """BASELINE.json configs[4]: 256 distinct perturbed 6-/7-DOF chains x 4 096 samples, one launch per joint-count group."""
+    import torch
+    from rosdyn_amd import Chain
+    from rosdyn_amd.multi import MultiChainRegressor
+    from rosdyn_amd.urdf_gen import mixed_chain_set
+    items, nbytes = [], 0
+    gen = torch.Generator(device=dev).manual_seed(0x5EED0005)
+    for xml, base, tool in mixed_chain_set(os.path.join(ROOT, "tests", "fixtures"), n_chains):
+        c = Chain(xml, base, tool, GRAVITY)
+        n, P = c.getActiveJointsNumber(), 10 * c.getJointsNumber()
+        q, dq, ddq = (torch.rand((n, S), dtype=torch.float64, device=dev, generator=gen) * 2 - 1 for _ in range(3))
+        items.append((c, q, dq, ddq))
+        nbytes += S * algorithmic_bytes_per_eval(n, P)
+    plan = MultiChainRegressor(items)
+    plan.run()
+    torch.cuda.synchronize()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0.record()
+    for _ in range(steps):
+        plan.run()
+    ev1.record()
+    torch.cuda.synchronize()
+    ms = ev0.elapsed_time(ev1) / steps
+    gbps = nbytes / (ms * 1e-3) / 1e9
+    return {"workload": "configs[4]: %d distinct 6-/7-DOF chains x %d samples, getJointTorque + dense getRegressor, "
+                        "element-major, one launch per joint-count group" % (n_chains, S),
+            "value": n_chains * S / (ms * 1e-3), "unit": "evals/s", "ms_per_step": ms,
+            "roofline": {"bound": "hbm", "achieved": gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": gbps / HBM_PEAK_GBPS,
+                         "algorithmic_bytes_per_step": nbytes, "kernel_ms": ms, "traffic": None}}
+
+
+def guarded(fn, *a, **k):
+    """Informational legs never fail the run: they report their error instead."""
     try:
-        from rosdyn_amd._lib import lib
-        from rosdyn_amd.gram import allreduce_normal_equations
-        ws = torch.empty((lib().rdyn_regressor_gram_workspace_bytes(chain._h, 0),), dtype=torch.uint8, device=dev)
-        acc = chain.getRegressorGram(q, dq, ddq, tau, layout=in_layout, workspace=ws)
-        torch.cuda.synchronize()
-        reps = 5
-        t0 = time.perf_counter()
-        for _ in range(reps):
-            chain.getRegressorGram(q, dq, ddq, tau, layout=in_layout, out=acc, workspace=ws)
-        torch.cuda.synchronize()
-        t_gram = (time.perf_counter() - t0) / reps
-        ex = {"regressor_gram_ms_per_rank": t_gram * 1e3, "regressor_gram_evals_per_s": N * world / max_over_ranks(t_gram, dist, dev),
-              "gram_flop_per_eval_dense_syrk": n * P * (P + 1) + 2 * n * P,
-              "allreduce_doubles": P * P + P + 2, "allreduce_us": None}
-        if dist is not None:
-            for _ in range(3):
-                allreduce_normal_equations(acc[0], acc[1], acc[2], N, dist)
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(20):
-                allreduce_normal_equations(acc[0], acc[1], acc[2], N, dist)
-            torch.cuda.synchronize()
-            ex["allreduce_us"] = max_over_ranks((time.perf_counter() - t0) / 20, dist, dev) * 1e6
-        return ex
-    except Exception as e:   # informational leg: report, do not fail the run
+        return fn(*a, **k)
+    except Exception as e:   # noqa: BLE001
         return {"error": repr(e)}
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def self_launch(args, argv):
+    """--gpus N > 1 without a torch.distributed environment: run the ranks as CHILD processes of this one (never exec:
+    a process that has touched the GPU must not be replaced, and this one has not touched it yet), relay rank 0's JSON
+    line, return the child's exit code."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + argv
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    p = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=None, env=env, text=True)
+    line = None
+    for out in p.stdout:
+        s = out.strip()
+        if s.startswith("{") and '"metric"' in s:
+            line = s
+        else:
+            sys.stderr.write(out)
+    rc = p.wait()
+    if line is not None:
+        print(line)
+        sys.stdout.flush()
+    elif rc == 0:
+        rc = 1
+    return rc
+
+
+def dry_run(args, world, rank):
+    """No GPU: the launcher, the process group (gloo) and the ONE collective of the path (all-reduce of the packed normal
+    equations) on small CPU tensors.  Used by tests/test_bench_launch.py; `value` is null."""
+    import torch
+    import torch.distributed as dist
+    from rosdyn_amd.gram import allreduce_normal_equations
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group(backend=args.backend)
+    dev = torch.device("cpu")
+    P, N = 60, shard_sizes(args.samples * world, world)[rank]
+    g = torch.Generator().manual_seed(1234 + rank)
+    A = torch.rand((64, P), dtype=torch.float64, generator=g)
+    b = torch.rand((64,), dtype=torch.float64, generator=g)
+    G, c, bb, count = allreduce_normal_equations(A.T @ A, A.T @ b, (b @ b).reshape(1), N, dist if world > 1 else None)
+    seen = ranks_seen(dist if world > 1 else None, dev)
+    out = {"metric": "RNEA+regressor evals/s (6-DOF, batch 1e6)", "value": None, "unit": "evals/s", "n_gpus": world, "dry": True,
+           "backend": args.backend, "n_ranks_seen": seen, "samples_reduced": count, "gram_trace": float(torch.trace(G).item()),
+           "steps": args.steps, "warmup": args.warmup}
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+    return 0
 
 
 def main():
@@ -152,22 +339,37 @@ def main():
     ap.add_argument("--samples", type=int, default=1000000, help="samples per GPU")
     ap.add_argument("--y-layout", default="stacked", choices=["element", "stacked", "per_sample"])
     ap.add_argument("--cpu-seconds", type=float, default=8.0, help="wall time of the CPU-baseline sample (0 = skip)")
-    ap.add_argument("--no-extras", action="store_true", help="skip the informational Gram/all-reduce leg after the timed region")
+    ap.add_argument("--no-extras", action="store_true", help="skip the configs[2] / configs[4] legs after the timed region")
+    ap.add_argument("--no-config4", action="store_true", help="skip the regressor -> Gram -> all-reduce block (configs[3])")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="process-group backend (gloo: --dry only)")
+    ap.add_argument("--dry", action="store_true", help="no GPU work: launcher + process group + all-reduce plumbing (CPU tests)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args, sys.argv[1:]))   # before anything touches the GPU
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        sys.stderr.write("bench.py: WORLD_SIZE=%d but --gpus %d\n" % (world, args.gpus))
+        sys.exit(2)
+    if args.dry:
+        sys.exit(dry_run(args, world, rank))
+    if args.backend != "nccl":
+        sys.stderr.write("bench.py: --backend gloo is for --dry only\n")
+        sys.exit(2)
 
     import torch
     import torch.distributed as dist
     from rosdyn_amd import Chain
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    seen = ranks_seen(dist if world > 1 else None, dev)   # one RCCL all-reduce of ones: who is really here
 
     urdf = os.path.join(ROOT, "tests", "fixtures", "ur10_like.urdf")
     base, tool = "base_link", "wrist_3_link"
@@ -187,50 +389,41 @@ def main():
     def step():
         chain.getRegressor(q, dq, ddq, layout=in_layout, y_layout=args.y_layout, out=Y, tau_out=tau)
 
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    ev0.record()          # same stream the kernels are launched on (torch's current stream is passed to the C-ABI)
-    for _ in range(args.steps):
-        step()
-    ev1.record()
-    torch.cuda.synchronize()
-    wall = time.perf_counter() - t0
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dev_ms = ev0.elapsed_time(ev1)
-    wall = max_over_ranks(wall, dist if world > 1 else None, dev)
-    dev_ms = max_over_ranks(dev_ms, dist if world > 1 else None, dev)
+    wall, dev_ms = time_region(step, args.steps, args.warmup, world, dist, dev)
 
     total_evals = N * world * args.steps
     value = total_evals / wall
     b_eval = algorithmic_bytes_per_eval(n, P)
     kernel_ms = dev_ms / args.steps                       # one launch per step, back to back on one stream
     achieved = b_eval * N / (kernel_ms * 1e-3) / 1e9      # GB/s, algorithmic bytes per launch / launch duration
+    kernel = {"element": "k_local_sweep<6, REGRESSOR>", "stacked": "k_rowpair_sweep<6>", "per_sample": "k_persample_sweep<6>"}[args.y_layout]
+    traffic = committed_traffic("regressor_%s_n%d_P%d_N%d" % (args.y_layout, n, P, N))
 
     out = {
         "metric": "RNEA+regressor evals/s (6-DOF, batch 1e6)", "value": value, "unit": "evals/s",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall / args.steps * 1e3,
+        "n_gpus": world, "n_ranks_seen": seen, "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall / args.steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": "configs[1]: 6-DOF chain (ur10_like base_link->wrist_3_link, n=6, P=60), "
                                "batch %d samples per GPU, fp64 getJointTorque + dense getRegressor, "
                                "inputs %s-major, Y layout %s" % (N, in_layout, args.y_layout),
                    "samples_per_gpu": N, "n_active": n, "n_params": P, "parallelism": "sample-sharded x%d" % world},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBPS, "traffic": measured_traffic("regressor_%s_n%d_P%d_N%d" % (args.y_layout, n, P, N)),
-                     "kernel": "k_local_sweep<6, REGRESSOR>" if elem else "k_rowpair_sweep<6>", "kernel_ms": kernel_ms,
-                     "algorithmic_bytes_per_launch": b_eval * N},
+                     "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                     "traffic_source": "committed profile (profiles/pmc_latest.json, builder's box), not measured in this run" if traffic else None,
+                     "kernel": kernel, "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": b_eval * N},
     }
-    if not args.no_extras:
-        out["extras"] = gram_extras(chain, q, dq, ddq, tau, in_layout, N, n, P, world, dist if world > 1 else None, dev)
-    if rank == 0 and world == 1 and args.cpu_seconds > 0:
-        out["cpu_baseline"] = cpu_baseline(urdf, base, tool, n, args.cpu_seconds)
+    if not args.no_config4:
+        # measured torques of this rank's shard: tau of the evaluation just timed (noise-free: exact normal equations)
+        out["config4"] = guarded(config4_block, chain, q, dq, ddq, tau, in_layout, N, n, P, world, dist, dev,
+                                 max(1, min(args.steps, 10)), 2)
+    del Y
+    if rank == 0 and not args.no_extras:
+        torch.cuda.empty_cache()
+        out["extras"] = {"config3": guarded(extras_config3, dev), "config5": guarded(extras_config5, dev)}
+    if rank == 0 and args.cpu_seconds > 0:
+        out["cpu_baseline"] = guarded(cpu_baseline, urdf, base, tool, n, args.cpu_seconds)
+    if world > 1:
+        dist.barrier()   # the other ranks wait for rank 0's informational legs before the group is torn down
     if rank == 0:
         print(json.dumps(out))
     if world > 1:

@@ -1,0 +1,43 @@
+"""bench.py launches itself for --gpus N > 1: the parent starts torch.distributed.run as a CHILD process
+before touching any GPU, relays rank 0's JSON line and exits with the child's code.  Exercised here on the CPU box through
+--dry (gloo, no GPU work): launcher, process group, the all-reduce of the packed normal equations."""
+import json
+import os
+import subprocess
+import sys
+
+from conftest import ROOT
+
+
+def _run(*extra):
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    env.pop("LOCAL_RANK", None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--backend", "gloo", "--dry"] + list(extra),
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, timeout=300)
+    return p
+
+
+def test_self_launch_two_ranks_gloo_dry():
+    p = _run("--gpus", "2", "--samples", "1000")
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, p.stdout          # ONE JSON line, from rank 0
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["n_ranks_seen"] == 2 and d["dry"] is True
+    assert d["samples_reduced"] == 2000.0     # the count travels inside the one all-reduce payload
+
+
+def test_single_rank_dry_needs_no_launcher():
+    p = _run("--gpus", "1", "--samples", "10")
+    assert p.returncode == 0, p.stderr[-2000:]
+    d = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][0])
+    assert d["n_gpus"] == 1 and d["n_ranks_seen"] == 1
+
+
+def test_world_size_mismatch_is_an_error_not_an_assert():
+    env = dict(os.environ, WORLD_SIZE="3", RANK="0", LOCAL_RANK="0")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry", "--backend", "gloo"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, timeout=120)
+    assert p.returncode == 2 and "WORLD_SIZE=3" in p.stderr
