@@ -204,12 +204,12 @@ def config4_block(chain, q, dq, ddq, tau, in_layout, N, n, P, world, dist, dev, 
 
 
 def extras_config3(dev, steps=5):
-    """BASELINE.json configs[2]: Panda-like 7-DOF chain (panda_link0 -> panda_link7: n = 7, 7 chain joints, P = 70),
+    """BASELINE.json configs[2]: Panda-like 7-DOF chain (link0 -> link7: n = 7, 7 chain joints, P = 70),
     N = 4e6, regressor -> Gram on the fp64 matrix cores.  Once, outside the headline's timed region."""
     import torch
     from rosdyn_amd import Chain
     from rosdyn_amd._lib import lib
-    chain = Chain(os.path.join(ROOT, "tests", "fixtures", "panda_like.urdf"), "panda_link0", "panda_link7", GRAVITY)
+    chain = Chain(os.path.join(ROOT, "tests", "fixtures", "panda_like.urdf"), "link0", "link7", GRAVITY)
     n, P, N = chain.getActiveJointsNumber(), 10 * chain.getJointsNumber(), 4000000
     gen = torch.Generator(device=dev).manual_seed(0x5EED0003)
     q, dq, ddq, tau = (torch.rand((N, n), dtype=torch.float64, device=dev, generator=gen) * 2 - 1 for _ in range(4))
@@ -225,7 +225,7 @@ def extras_config3(dev, steps=5):
     ms = ev0.elapsed_time(ev1) / steps
     f_eval = gram_flop_per_eval(n, P)
     tf = f_eval * N / (ms * 1e-3) / 1e12
-    return {"workload": "configs[2]: 7-DOF panda_like panda_link0->panda_link7 (n=7, P=70), N=%d, getRegressor -> Gram" % N,
+    return {"workload": "configs[2]: 7-DOF panda_like link0->link7 (n=7, P=70), N=%d, getRegressor -> Gram" % N,
             "value": N / (ms * 1e-3), "unit": "evals/s", "ms_per_step": ms,
             "roofline": {"bound": "fp64-matrix", "achieved": tf, "peak": FP64_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": tf / FP64_MATRIX_PEAK_TFLOPS, "flop_per_eval_dense_syrk": f_eval, "kernel_ms": ms}}

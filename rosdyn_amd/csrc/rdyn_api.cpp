@@ -2,11 +2,13 @@
 // chain-constant residency per device, kernel launches.  No host<->device copies of batch data, no
 // allocation and no synchronisation after a chain's first use on a device.
 //
-// Diagnostic environment switches (A/B measurements only -- tools/probe_*.py; never needed for correct results, re-read
-// on every call so that a probe can flip them inside one process):
+// Diagnostic environment switches exist ONLY in builds compiled with -DRDYN_ENABLE_PROBES (tools/build_variant.sh; A/B
+// measurements, tools/probe_*.py and tools/kbench).  The shipped library never reads the environment: a variable left over
+// from a profiling shell cannot change results.
 //   RDYN_NO_ROWPAIR=1       regressor in row-contiguous layouts through the one-thread-per-sample kernel
-//   RDYN_GRAM_PATH=lds0|image|two   regressor->Gram kernel: two-phase LDS tile / global image / two kernels
-//                           (default: software-pipelined LDS tile where eligible, then LDS tile, then global image)
+//   RDYN_GRAM_PATH=pipe|lds0|image|two   regressor->Gram kernel: single-wave pipelined LDS tile / two-phase LDS tile /
+//                           global image / two kernels (default: wave-pair kernel where eligible, then the single-wave LDS
+//                           kernels, then the global image)
 //   RDYN_GRAM_UNFUSED=1     same as RDYN_GRAM_PATH=two
 //   RDYN_FUSED_BLOCKS=n     persistent workgroups of the fused Gram kernels (default 256 = one per CU)
 //   RDYN_FUSED_DEBUG=bits   phase ablation of the fused Gram kernels (timing only: results are then wrong)
@@ -22,6 +24,12 @@
 
 namespace
 {
+
+#ifdef RDYN_ENABLE_PROBES
+const char* probe_env(const char* name) { return getenv(name); }
+#else
+const char* probe_env(const char*) { return nullptr; }
+#endif
 
 #define RDYN_HIP_TRY(expr)                                                     \
   do                                                                           \
@@ -159,7 +167,7 @@ int run_local(const rdyn_chain* c, const rdyn_batch* b, int mode, double* tau, d
   // ceil(n/2) lanes per sample, 16-byte row-pair stores (k_rowpair_sweep) instead of 8-byte strided stores.
   const bool rowpair = mode == RDYN_MODE_REGRESSOR && yl && yl->stride_row == 1 && n >= 2 && n <= 10 &&
                        b->layout == RDYN_LAYOUT_SAMPLE_MAJOR && b->n_samples * ((n + 1) / 2) < (int64_t)0xFFFFFF00ll &&
-                       !getenv("RDYN_NO_ROWPAIR");
+                       !probe_env("RDYN_NO_ROWPAIR");
   if (rowpair)
   {
     // the kernel addresses Y with a 32-bit per-lane byte offset: split so that every launch spans < 4 GB of Y
@@ -728,7 +736,7 @@ int rdyn_gram(const double* A, int64_t rows, int64_t lda, int n_cols, const doub
 static int64_t default_chunk(int64_t chunk) { return chunk > 0 ? chunk : 32768; }
 // Fused regressor->Gram kernel: persistent workgroups, each with its own 256-sample tile image (rewritten per tile, so
 // it stays in L2 / Infinity Cache): 256 workgroups x 256 samples x n x (P + 1) doubles = 192 MB at n = 6, P = 60.
-static int fused_blocks_env() { const char* e = getenv("RDYN_FUSED_BLOCKS"); return e ? atoi(e) : 256; }
+static int fused_blocks_env() { const char* e = probe_env("RDYN_FUSED_BLOCKS"); return e ? atoi(e) : 256; }
 static const int kFusedBlocks = 256;  // upper bound used for the workspace size; the launch uses fused_blocks_env()
 
 size_t rdyn_regressor_gram_workspace_bytes(const rdyn_chain* c, int64_t chunk_samples)
@@ -788,9 +796,9 @@ int rdyn_regressor_gram(const rdyn_chain* c, const rdyn_batch* b, const double* 
   // structural zero band of every row block (input joint j): columns < 10 * chain index of joint j
   int first_col[RDYN_MAX_JOINTS];
   for (int j = 0; j < n; ++j) first_col[j] = 10 * c->active[j];
-  const char* path_env = getenv("RDYN_GRAM_PATH");  // A/B only: "lds" (default when eligible), "image", "two"
-  const bool want_lds = !path_env || !strcmp(path_env, "lds") || !strcmp(path_env, "lds0");
-  if (chunk_samples <= 0 && !getenv("RDYN_GRAM_UNFUSED") && want_lds && n >= 2 && n <= 8)
+  const char* path_env = probe_env("RDYN_GRAM_PATH");  // A/B only: "lds" (default when eligible), "image", "two"
+  const bool want_lds = !path_env || !strcmp(path_env, "lds") || !strcmp(path_env, "lds0") || !strcmp(path_env, "pipe") || !strcmp(path_env, "duo");
+  if (chunk_samples <= 0 && !probe_env("RDYN_GRAM_UNFUSED") && want_lds && n >= 2 && n <= 8)
   {
     // LDS-resident path (rdyn_lds_gram.hip): needs input joints in chain order (rows of a link's columns are a prefix)
     // and four tiles inside 160 KB of LDS.
@@ -813,7 +821,9 @@ int rdyn_regressor_gram(const rdyn_chain* c, const rdyn_batch* b, const double* 
     off += (16 * n + 4) * 8;
     // software-pipelined variant (rdyn_pipe_gram.hip) where its register budget allows; RDYN_GRAM_PATH=lds0 keeps the
     // two-phase kernel (A/B)
-    const bool pipe = rdyn_regressor_gram_pipe_supported(P) && !(path_env && !strcmp(path_env, "lds0"));
+    // wave-pair kernel (rdyn_duo_gram.hip) by default; RDYN_GRAM_PATH=pipe / lds0 keep the single-wave kernels (A/B)
+    const bool duo = rdyn_regressor_gram_duo_supported(P) && !(path_env && (!strcmp(path_env, "lds0") || !strcmp(path_env, "pipe")));
+    const bool pipe = !duo && rdyn_regressor_gram_pipe_supported(P) && !(path_env && !strcmp(path_env, "lds0"));
     la.lds_dummy_off = off;
     if (pipe) off += 64 * 8;
     la.tile_bytes = (off + 255) & ~255;
@@ -833,12 +843,14 @@ int rdyn_regressor_gram(const rdyn_chain* c, const rdyn_batch* b, const double* 
       la.n_active = n;
       for (int j = 0; j < n; ++j) la.first_col[j] = first_col[j];
       la.slabs = slabs;
-      if (const char* dbg = getenv("RDYN_FUSED_DEBUG")) la.debug = atoi(dbg);
+      if (const char* dbg = probe_env("RDYN_FUSED_DEBUG")) la.debug = atoi(dbg);
       const int64_t tiles = (N + 15) / 16;
       int want = fused_blocks_env();
       if (want < 1 || want > kFusedBlocks) want = kFusedBlocks;
       const int blocks = (int)((tiles + 3) / 4 < want ? (tiles + 3) / 4 : want);
-      if (pipe)
+      if (duo)
+        RDYN_HIP_TRY(rdyn_launch_regressor_gram_duo(P, la, blocks, lds_bytes, stream));
+      else if (pipe)
         RDYN_HIP_TRY(rdyn_launch_regressor_gram_pipe(P, la, blocks, lds_bytes, stream));
       else
         RDYN_HIP_TRY(rdyn_launch_regressor_gram_lds(P, la, blocks, lds_bytes, stream));
@@ -854,7 +866,7 @@ int rdyn_regressor_gram(const rdyn_chain* c, const rdyn_batch* b, const double* 
       return RDYN_OK;
     }
   }
-  if (chunk_samples <= 0 && !getenv("RDYN_GRAM_UNFUSED") && (!path_env || strcmp(path_env, "two")))
+  if (chunk_samples <= 0 && !probe_env("RDYN_GRAM_UNFUSED") && (!path_env || strcmp(path_env, "two")))
   {
     // default: ONE persistent kernel, the regressor image never goes through HBM (rdyn_fused_gram.hip).
     // chunk_samples > 0 selects the two-kernel chunked path below (kept for A/B and as the reference ordering).
@@ -871,7 +883,7 @@ int rdyn_regressor_gram(const rdyn_chain* c, const rdyn_batch* b, const double* 
     for (int j = 0; j < n; ++j) fa.first_col[j] = first_col[j];
     fa.images = scratch;
     fa.slabs = slabs;
-    if (const char* dbg = getenv("RDYN_FUSED_DEBUG")) fa.debug = atoi(dbg);
+    if (const char* dbg = probe_env("RDYN_FUSED_DEBUG")) fa.debug = atoi(dbg);
     const int64_t tiles = (N + 255) / 256;
     int want = fused_blocks_env();
     if (want < 1 || want > kFusedBlocks) want = kFusedBlocks;

@@ -1,0 +1,324 @@
+// rdyn_duo_gram.hip -- regressor rows -> fp64-MFMA Gram with the two instruction streams on TWO co-resident waves.
+//
+// rdyn_pipe_gram.hip interleaves the fp64 VALU sweep and the fp64 MFMA k-steps inside ONE wave.  Measured on gfx950
+// (tools/fp64_issue.hip, profiles/r2/fp64_issue.txt): a lone wave pays ~5 cycles per fp64 VALU instruction, 83 per
+// v_mfma_f64_16x16x4_f64 and ~80 more every time its stream switches between the two, and every scalar / LDS / 32-bit
+// instruction of the sweep (40 % of its stream) takes an issue slot of its own: 31 k cycles per 16-sample tile.
+// Here a 512-thread workgroup holds four PAIRS of waves (wave p and wave p + 4 land on the same SIMD: a workgroup's waves are
+// dealt to the SIMDs cyclically):
+//   * the SWEEPER (waves 0-3) runs the row-pair forward sweep of a 16-sample tile (4 lanes per sample, 2 regressor rows per
+//     lane, ~140 registers, no accumulators) and drops each finished link's 10-vectors into the pair's LDS tile;
+//   * the CONSUMER (waves 4-7) holds the Gram accumulators (80-120 registers) and runs the MFMA k-steps of the PREVIOUS tile
+//     out of the same LDS buffer: row group j (the 16 samples of input joint j) is read while the sweeper computes link j of
+//     the next tile, and only then -- after a workgroup barrier -- does the sweeper overwrite the columns of link j, which
+//     no later group reads (group j' > j only touches columns of links >= j').
+// One s_barrier per link plus one per tile keeps the two in step; the hardware interleaves the two streams cycle by cycle,
+// each role has its own register budget (the kernel fits 256 registers = two waves per SIMD), and scalar / LDS / address
+// instructions of one wave issue under the other's fp64 work.  Same tile layout, operand order and epilogue arithmetic as
+// rdyn_lds_gram.hip / rdyn_pipe_gram.hip: results are bit-identical to them.
+// Requirements (else rdyn_regressor_gram uses the single-wave kernels): 2 <= chain joints <= 7, input joints in chain order,
+// four tiles inside 160 KB of LDS.
+#include <hip/hip_runtime.h>
+#include <atomic>
+#include <cstdint>
+#include "rdyn_device.h"
+#include "rdyn_devmath.h"
+#include "rdyn_kernels.h"
+#include "rdyn_gram_common.h"
+
+#ifndef RDYN_DUO_SWEEP_UNROLL
+#define RDYN_DUO_SWEEP_UNROLL 1  // link loop of the sweeper: 1 = rolled (unrolled measured no better: more moves and SGPR spills)
+#endif
+
+namespace
+{
+
+// all 8 waves; LDS traffic of this wave retired first.  Plain s_barrier (not __syncthreads): no vmcnt(0), so the sweeper's
+// global prefetch of the next tile's inputs stays in flight across the barriers.
+#ifdef RDYN_DUO_STAMPS  // diagnostic build only (tools/kbench KB_STAMPS=1): cycles every wave spends inside the barriers
+#define DUO_STAMP_DECL unsigned long long st_wait = 0, st_t0 = __builtin_amdgcn_s_memtime(), st_tmp
+#define DUO_BARRIER_LDS() do { st_tmp = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); st_wait += __builtin_amdgcn_s_memtime() - st_tmp; } while (0)
+#define DUO_BARRIER() do { st_tmp = __builtin_amdgcn_s_memtime(); asm volatile("s_barrier" ::: "memory"); st_wait += __builtin_amdgcn_s_memtime() - st_tmp; } while (0)
+#define DUO_STAMP_OUT(NT_) do { if (lane == 0) { double* o = fa.slabs + ((int64_t)(256 + blockIdx.x) * (NT_ * 256)) + wave * 2; o[0] = (double)(__builtin_amdgcn_s_memtime() - st_t0); o[1] = (double)st_wait; } } while (0)
+#else
+#define DUO_STAMP_DECL
+#define DUO_BARRIER_LDS() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#define DUO_BARRIER() asm volatile("s_barrier" ::: "memory")
+#define DUO_STAMP_OUT(NT_)
+#endif
+
+// value of lane K of my quad (K a constant after unrolling): two v_mov_b32 with a quad_perm DPP control
+template <int K>
+__device__ __forceinline__ double quad_bcast_k(double x)
+{
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), K * 0x55, 0xF, 0xF, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), K * 0x55, 0xF, 0xF, false);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double quad_bcast(double x, int k)
+{
+  switch (k)
+  {
+  case 0: return quad_bcast_k<0>(x);
+  case 1: return quad_bcast_k<1>(x);
+  case 2: return quad_bcast_k<2>(x);
+  default: return quad_bcast_k<3>(x);
+  }
+}
+// LDS byte offset of link f's first column when every chain joint is an input joint (rows j <= f stored: stride (16 (f + 1) + 4) * 8)
+__device__ __forceinline__ constexpr int duo_direct_off(int f)
+{
+  int off = 0;
+  for (int g = 0; g < f; ++g) off += 10 * (16 * (g + 1) + 4) * 8;
+  return off;
+}
+
+template <int NJ, bool DIRECT>
+__global__ __launch_bounds__(512) void k_regressor_gram_duo(const RdynLdsGramArgs fa)
+{
+  constexpr int NB = (10 * NJ + 1 + 15) / 16;
+  constexpr int NT = NB * (NB + 1) / 2;
+  constexpr int P = 10 * NJ;
+  extern __shared__ __attribute__((aligned(32))) char lds_raw[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int pair = wave & 3;
+  const bool sweeper = wave < 4;
+  char* const tile = lds_raw + (size_t)pair * fa.tile_bytes;  // shared by the pair
+  const int n = fa.n_active;
+  const int64_t n_tiles = (fa.n_samples + 15) / 16;
+  const int64_t t_step = (int64_t)gridDim.x * 4;
+  const int64_t t_first = (int64_t)blockIdx.x * 4 + pair;
+  // same trip count for every wave of the workgroup (the barriers are workgroup-wide): pairs without a tile sweep masked samples
+  const int64_t trips_raw = (n_tiles - (int64_t)blockIdx.x * 4 + t_step - 1) / t_step;
+  const int64_t trips = trips_raw > 0 ? trips_raw : 0;
+  DUO_STAMP_DECL;
+
+  if (sweeper)
+  {
+    // ================================================================ sweeper: 16 samples x 4 lanes, rows 2k, 2k + 1
+    ChainPtr c = as_const(fa.chain);
+#ifdef RDYN_DUO_SWEEP_PRIO
+    __builtin_amdgcn_s_setprio(RDYN_DUO_SWEEP_PRIO);
+#endif
+    const int s_loc = lane >> 2, k = lane & 3;
+    // lane k of a sample's quad owns regressor rows k (slot 0) and k + 4 (slot 1) -- the same split as the inputs it fetches.
+    // Rows >= 4 belong to joints that sit at chain index >= fB: before link fB slot 1 is identically zero and is skipped
+    // (wave-uniform), which removes a third of the row work of a 6-joint chain.
+    const int r0 = k, r1 = k + 4;
+    int fB = DIRECT ? 4 : NJ;
+    if (!DIRECT)
+      for (int f = NJ - 1; f >= 0; --f)
+        if (fa.lds_m[f] >= 5) fB = f;
+    double nqa = 0.0, ndqa = 0.0, nddqa = 0.0, nqb = 0.0, ndqb = 0.0, nddqb = 0.0, nb0 = 0.0, nb1 = 0.0;
+    auto fetch = [&](int64_t tile_index) {
+      int64_t sx = tile_index * 16 + s_loc;
+      if (sx >= fa.n_samples) sx = fa.n_samples - 1;
+      const int64_t o = sx * fa.in_ss;
+      if (fa.bcol)
+      {
+        if (r0 < n) nb0 = fa.bcol[o + r0 * fa.in_sj];
+        if (r1 < n) nb1 = fa.bcol[o + r1 * fa.in_sj];
+      }
+      if (k < n)
+      {
+        nqa = fa.q[o + k * fa.in_sj];
+        ndqa = fa.dq[o + k * fa.in_sj];
+        nddqa = fa.ddq[o + k * fa.in_sj];
+      }
+      if (k + 4 < n)
+      {
+        nqb = fa.q[o + (k + 4) * fa.in_sj];
+        ndqb = fa.dq[o + (k + 4) * fa.in_sj];
+        nddqb = fa.ddq[o + (k + 4) * fa.in_sj];
+      }
+    };
+    if (t_first < n_tiles) fetch(t_first);
+    for (int64_t it = 0; it < trips; ++it)
+    {
+      const int64_t tl = t_first + it * t_step;
+      const bool valid = tl < n_tiles && tl * 16 + s_loc < fa.n_samples;
+      // a masked sample keeps zero joint twists for both rows (its rows never "start"), so every regressor entry is 0
+      const int m0idx = valid ? r0 : -2, m1idx = valid ? r1 : -2;
+      const double qa = nqa, dqa = ndqa, ddqa = nddqa, qb = nqb, dqb = ndqb, ddqb = nddqb;
+      const double tb0 = valid ? nb0 : 0.0, tb1 = valid ? nb1 : 0.0;
+      if (tl + t_step < n_tiles) fetch(tl + t_step);  // in flight during this tile's sweep
+      // sin / 1 - cos of MY two input joints, once per tile (the two evaluations interleave); the link loop gets its joint's
+      // pair by a quad shuffle instead of every lane of the quad repeating the same sincos per link
+      double sna, csa, snb, csb;
+      sincos(qa, &sna, &csa);
+      sincos(qb, &snb, &csb);
+      const double oca = 1.0 - csa, ocb = 1.0 - csb;
+
+      V3 w = mk(0, 0, 0), vl = mk(0, 0, 0), al = mk(0, 0, 0);
+      V3 lin = mk(-c->g[0], -c->g[1], -c->g[2]);
+      V3 L0 = mk(0, 0, 0), A0 = mk(0, 0, 0), L1 = mk(0, 0, 0), A1 = mk(0, 0, 0);
+      if constexpr (DIRECT)
+      {
+#pragma unroll
+        for (int f = 0; f < NJ; ++f)
+        {
+#include "rdyn_duo_link_body.inc"
+        }
+      }
+      else
+      {
+#pragma unroll 1
+        for (int f = 0; f < NJ; ++f)
+        {
+#include "rdyn_duo_link_body.inc"
+        }
+      }
+      {
+        char* const lb = tile + fa.lds_off_b + s_loc * 8;
+        if (r0 < n) *(double*)(lb + r0 * 128) = tb0;
+        if (r1 < n) *(double*)(lb + r1 * 128) = tb1;
+      }
+      DUO_BARRIER_LDS();  // the tile is complete
+    }
+  }
+  else
+  {
+    // ================================================================ consumer: MFMA k-steps of the previous tile
+#ifdef RDYN_DUO_MFMA_PRIO
+    __builtin_amdgcn_s_setprio(RDYN_DUO_MFMA_PRIO);
+#endif
+    const int cl = lane & 15, g = lane >> 4;
+    int colbase[NB], colm[NB];
+#pragma unroll
+    for (int cb = 0; cb < NB; ++cb)
+    {
+      const int p = 16 * cb + cl;
+      const int f = p < P ? p / 10 : 0;
+      colbase[cb] = (p < P ? fa.lds_off[f] + (p - 10 * f) * fa.lds_stride[f] : (p == P ? fa.lds_off_b : 0)) + g * 32;
+      colm[cb] = p < P ? fa.lds_m[f] : (p == P ? n : 0);
+    }
+    d4 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = (d4){0.0, 0.0, 0.0, 0.0};
+    // operands of row group j: column blocks >= (10 j) >> 4 (input joints in chain order: joint j sits at chain index >= j)
+    auto lds_group = [&](int j, int cbm, d4* op) {
+#pragma unroll
+      for (int cb = 0; cb < NB; ++cb)
+      {
+        d4 x = (d4){0.0, 0.0, 0.0, 0.0};
+        if (cb >= cbm && j < colm[cb]) x = *(const d4*)(tile + colbase[cb] + j * 128);
+        op[cb] = x;
+      }
+    };
+    auto mfma_band = [&](const d4* op, int cbm) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+      {
+        int ti = 0;
+#pragma unroll
+        for (int cb = 0; cb < NB; ++cb)
+#pragma unroll
+          for (int rb = 0; rb <= cb; ++rb)
+          {
+            if (rb >= cbm) acc[ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(op[rb][t], op[cb][t], acc[ti], 0, 0, 0);
+            ++ti;
+          }
+      }
+    };
+    d4 opa[NB], opb[NB];
+    for (int64_t it = 0; it <= trips; ++it)
+    {
+      // it > 0: the tile in LDS is complete (nothing to consume while the first tile is being swept): group 0
+      const bool have = it > 0;
+      if (have) lds_group(0, 0, opa);
+#pragma unroll
+      for (int f = 0; f < NJ; ++f)
+      {
+        d4* const cur = (f & 1) ? opb : opa;
+        d4* const nxt = (f & 1) ? opa : opb;
+        if (it < trips) DUO_BARRIER_LDS();  // my reads of group f have returned -> the sweeper may overwrite link f's columns
+        else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (have)
+        {
+          if (f + 1 < NJ) lds_group(f + 1, (10 * (f + 1)) >> 4, nxt);
+          mfma_band(cur, (10 * f) >> 4);
+        }
+      }
+      if (it < trips) DUO_BARRIER_LDS();  // end of the sweeper's tile
+    }
+
+    DUO_STAMP_OUT(NT);
+    // ---- block reduction of the four consumers (fixed order), this block's Gram slab.  The reduction area overlays the
+    // tiles: every consumer must be done with its own first.
+    DUO_BARRIER_LDS();
+    double* red = (double*)lds_raw;
+    const int cw = wave - 4;
+    for (int w = 0; w < 4; ++w)
+    {
+      if (cw == w)
+      {
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+          {
+            const int idx = t * 256 + ((g + 4 * r) * 16 + cl);
+            red[idx] = (w == 0) ? acc[t][r] : red[idx] + acc[t][r];
+          }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
+  }
+  if (sweeper)
+  {
+    DUO_STAMP_OUT(NT);
+    // the sweepers take part in the five barriers of the reduction above
+    for (int w = 0; w < 5; ++w) __builtin_amdgcn_s_barrier();
+  }
+  asm volatile("" ::: "memory");
+  {
+    const double* red = (const double*)lds_raw;
+    double* slab = fa.slabs + (int64_t)blockIdx.x * (NT * 256);
+    for (int i = threadIdx.x; i < NT * 256; i += 512) slab[i] = red[i];
+  }
+}
+
+template <int NJ, bool DIRECT>
+hipError_t launch_duo_nj2(const RdynLdsGramArgs& a, int blocks, size_t lds_bytes, hipStream_t st)
+{
+  static std::atomic<uint64_t> attr_set{0};
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  const uint64_t bit = 1ull << (dev & 63);
+  if (!(attr_set.load(std::memory_order_acquire) & bit))
+  {
+    e = hipFuncSetAttribute((const void*)k_regressor_gram_duo<NJ, DIRECT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
+    attr_set.fetch_or(bit, std::memory_order_release);
+  }
+  hipLaunchKernelGGL((k_regressor_gram_duo<NJ, DIRECT>), dim3(blocks), dim3(512), lds_bytes, st, a);
+  return hipGetLastError();
+}
+template <int NJ>
+hipError_t launch_duo_nj(const RdynLdsGramArgs& a, int blocks, size_t lds_bytes, hipStream_t st)
+{
+  // direct = every chain joint is an input joint, in chain order (the tile layout tables then follow from NJ alone)
+  bool direct = a.n_active == NJ;
+  for (int f = 0; direct && f < NJ; ++f) direct = a.lds_m[f] == f + 1 && a.first_col[f] == 10 * f;
+  return direct ? launch_duo_nj2<NJ, true>(a, blocks, lds_bytes, st) : launch_duo_nj2<NJ, false>(a, blocks, lds_bytes, st);
+}
+}  // namespace
+
+bool rdyn_regressor_gram_duo_supported(int n_cols) { return n_cols >= 20 && n_cols <= 70; }
+
+hipError_t rdyn_launch_regressor_gram_duo(int n_cols, const RdynLdsGramArgs& a, int blocks, size_t lds_bytes, hipStream_t st)
+{
+  switch (n_cols / 10)  // chain joints
+  {
+  case 2: return launch_duo_nj<2>(a, blocks, lds_bytes, st);
+  case 3: return launch_duo_nj<3>(a, blocks, lds_bytes, st);
+  case 4: return launch_duo_nj<4>(a, blocks, lds_bytes, st);
+  case 5: return launch_duo_nj<5>(a, blocks, lds_bytes, st);
+  case 6: return launch_duo_nj<6>(a, blocks, lds_bytes, st);
+  case 7: return launch_duo_nj<7>(a, blocks, lds_bytes, st);
+  default: return hipErrorInvalidValue;
+  }
+}

@@ -148,6 +148,9 @@ hipError_t rdyn_launch_regressor_gram_lds(int n_cols, const RdynLdsGramArgs& a, 
 // the same kernel software-pipelined inside the wave (rdyn_pipe_gram.hip): chains of 2..6 joints
 bool rdyn_regressor_gram_pipe_supported(int n_cols);
 hipError_t rdyn_launch_regressor_gram_pipe(int n_cols, const RdynLdsGramArgs& a, int blocks, size_t lds_bytes, hipStream_t st);
+// the two streams on two co-resident waves (rdyn_duo_gram.hip): chains of 2..7 joints, 512-thread workgroups
+bool rdyn_regressor_gram_duo_supported(int n_cols);
+hipError_t rdyn_launch_regressor_gram_duo(int n_cols, const RdynLdsGramArgs& a, int blocks, size_t lds_bytes, hipStream_t st);
 int rdyn_gram_blocks_for(int P);
 hipError_t rdyn_launch_gram(const RdynGramArgs& a, int blocks, hipStream_t st);
 hipError_t rdyn_launch_gram_finish(const RdynGramArgs& a, int blocks, hipStream_t st);

@@ -36,6 +36,9 @@
 #ifndef RDYN_PIPE_UNROLL_MAX
 #define RDYN_PIPE_UNROLL_MAX 6  // chains up to this many joints: unrolled link loop; longer: rolled (A/B: tools/probe_pipe.py)
 #endif
+#ifndef RDYN_PIPE_MFMA_BURST
+#define RDYN_PIPE_MFMA_BURST 1  // MFMAs issued back to back before the VALU group (an MFMA <-> fp64 VALU switch costs ~80 cycles: tools/fp64_issue.hip)
+#endif
 #ifndef RDYN_PIPE_VALU_PER_MFMA
 #define RDYN_PIPE_VALU_PER_MFMA 10  // VALU instructions scheduled behind every MFMA (A/B: tools/probe_pipe.py)
 #endif

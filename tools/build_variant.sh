@@ -1,0 +1,17 @@
+#!/bin/bash
+# tools/build_variant.sh <name> <file.hip> [-D... flags]: rebuilds ONE device translation unit with extra flags and links it with
+# the stock objects into rosdyn_amd/variants/librdyn_<name>.so (git-ignored, travels to the GPU box) for tools/kbench A/B runs.
+set -e
+NAME=$1; SRC=$2; shift 2
+cd /root/repo/rosdyn_amd/csrc
+mkdir -p ../variants _obj/var
+STEM=$(basename $(basename $SRC .hip) .cpp)
+OBJ=_obj/var/${NAME}_${STEM}.o
+if [[ $SRC == *.cpp ]]; then
+  g++ -O3 -std=c++17 -fPIC -Wall -Wextra -Wno-unused-parameter -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include "$@" -c $SRC -o $OBJ
+else
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wextra -Wno-unused-parameter -Wno-cuda-compat "$@" -c $SRC -o $OBJ
+fi
+OTHERS=$(ls _obj/*.o | grep -v "_obj/${STEM}.o")
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -o ../variants/librdyn_${NAME}.so $OBJ $OTHERS
+echo built ../variants/librdyn_${NAME}.so
