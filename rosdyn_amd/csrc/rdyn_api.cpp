@@ -168,7 +168,14 @@ int run_local(const rdyn_chain* c, const rdyn_batch* b, int mode, double* tau, d
   const bool rowpair = mode == RDYN_MODE_REGRESSOR && yl && yl->stride_row == 1 && n >= 2 && n <= 10 &&
                        b->layout == RDYN_LAYOUT_SAMPLE_MAJOR && b->n_samples * ((n + 1) / 2) < (int64_t)0xFFFFFF00ll &&
                        !probe_env("RDYN_NO_ROWPAIR");
-  if (rowpair)
+  // the drop-in per-sample image (either input layout): one thread per sample, link blocks staged through LDS (rdyn_image.hip)
+  bool image = mode == RDYN_MODE_REGRESSOR && yl && yl->stride_row == 1 && yl->stride_col == n &&
+               yl->stride_sample >= (int64_t)n * 10 * c->n_joints() && rdyn_image_supported(c->n_joints(), n, yl->stride_sample) &&
+               !probe_env("RDYN_NO_IMAGE");
+  for (int j = 0; image && j < n; ++j) image = c->active[j] == j;  // input joints = the first n chain joints, in order
+  if (image)
+    RDYN_HIP_TRY(rdyn_launch_image_sweep(c->n_joints(), n, a, (hipStream_t)b->stream));
+  else if (rowpair)
   {
     // the kernel addresses Y with a 32-bit per-lane byte offset: split so that every launch spans < 4 GB of Y
     const int64_t span = (a.y_ss > 0 ? a.y_ss : 1) * 8;

@@ -1,0 +1,314 @@
+// rdyn_image.hip -- getRegressor in the DROP-IN layout: every sample's regressor is the contiguous column-major n x P image
+// that rosdyn::Chain::getRegressor returns (primitives_impl.h:1350-1354), Y(s, j, p) at s * stride + p * n + j.
+//
+// k_image_sweep<NJ, NA>: ONE THREAD PER SAMPLE, the forward local-frame sweep of k_local_sweep (rdyn_kernels.hip: every link
+// unrolled, ~46 fp64 instructions per sample and link -- a third of what the row-pair kernels spend).  The ten columns x n rows
+// a link contributes to the sample's image (RUN = 80 n contiguous bytes) are NOT stored from the lane that computed them (64
+// scattered 8-byte stores per instruction); they go into a per-wave LDS staging area, one ring of RUN + 128 bytes per sample
+// addressed by image offset, and after every link the wave writes out, 16 bytes per lane with lanes running along a sample's
+// bytes, exactly the WHOLE 128-BYTE LINES of each image that are complete by now; the < 128 bytes behind the last line boundary
+// stay in the ring until the next link completes their line.
+// Why whole lines: RUN is 3.75 lines at n = 6, so a link-by-link copy-out leaves a partly written line at both ends of every
+// run; the two parts arrive a link apart, the L2 has usually evicted the first by then and HBM sees two masked writes
+// (read-modify-write under ECC).  Measured on MI355X, N = 1e6, n = 6 / P = 60 (profiles/r2/image_ab.txt): run-by-run copy-out
+// 0.86-0.95 ms (slower than the 48-byte row-pair stores it was meant to replace), line-aligned copy-out: see DESIGN.md.
+// Only the first / last line of an image can be partial (images are 22.5 lines long): 1 line in 22.
+// The ring pitch is RUN + 144 bytes: consecutive lanes' 8-byte staging writes fall into different LDS banks and the 16-byte
+// reads stay aligned.  Only wave-local ordering is needed (64-thread workgroups, no barrier).  The image stride may be padded
+// (stride_sample >= n P); wave bases are 64-bit, per-lane offsets 32-bit inside the wave's 64 images.
+//
+// Instantiated for the input-joint patterns the tile arithmetic can fold at compile time: the first NA chain joints are the
+// input joints 0 .. NA - 1 in order and the remaining NJ - NA joints are fixed (NA = NJ, or NA = NJ - 1: a fixed tool frame).
+// Other patterns keep the row-pair kernel (rdyn_rowpair.hip).
+#include <hip/hip_runtime.h>
+#include "rdyn_device.h"
+#include "rdyn_devmath.h"
+#include "rdyn_kernels.h"
+
+namespace
+{
+typedef double d2u __attribute__((ext_vector_type(2), aligned(8)));
+typedef double d2a __attribute__((ext_vector_type(2), aligned(16)));
+
+__device__ __forceinline__ void wave_lds_fence()
+{
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <int NJ, int NA, bool NT>
+__global__ __launch_bounds__(64) void k_image_sweep(const RdynSweepArgs a)
+{
+  constexpr int RUN = 80 * NA;                       // bytes one link adds to one sample's image
+  constexpr int IMG = NJ * RUN;                      // bytes of one image
+  constexpr int W = RUN + 128;                       // ring: the link's run + the < 128 bytes that wait for their line
+  constexpr int PITCH = W + 16;                      // staging slot of one sample
+  constexpr int MAXC = ((RUN + 127) / 128) * 8;      // most 16-byte chunks one sample flushes per link (whole lines)
+  constexpr int SPI = 64 / MAXC;                     // samples one copy-out instruction covers
+  constexpr int NIT = (64 + SPI - 1) / SPI;
+  extern __shared__ __attribute__((aligned(16))) char stage[];
+  ChainPtr c = as_const(a.chain);
+  const int lane = threadIdx.x;
+  const int64_t s_wave = (int64_t)blockIdx.x * 64;
+  const int64_t left = a.n_samples - s_wave;
+  const int valid = left < 64 ? (int)left : 64;
+  const bool mine = lane < valid;
+  const int64_t s = s_wave + (mine ? lane : 0);   // lanes past the batch idle along on the wave's first sample
+
+  const double* __restrict__ qp = a.q + s * a.in_ss;
+  const double* __restrict__ dqp = a.dq + s * a.in_ss;
+  const double* __restrict__ ddqp = a.ddq + s * a.in_ss;
+  char* const stg = stage + lane * PITCH;
+  // copy-out role of this lane: chunk cj of sample (it * SPI + sub) in iteration it
+  const int sub = lane / MAXC, cj = lane - sub * MAXC;
+  const bool cp_lane = lane < SPI * MAXC;
+  const uint32_t img = (uint32_t)(a.y_ss * 8);
+  char* const ywave = (char*)(a.Y + s_wave * a.y_ss);
+  // misalignment (bytes past a 128-byte line) of the image of sample (it * SPI + sub): m0 + it * dm  (mod 128)
+  const uint32_t m0 = ((uint32_t)(uintptr_t)ywave + (uint32_t)sub * img) & 127u;
+  const uint32_t dm = ((uint32_t)SPI * img) & 127u;
+  const bool m_const = dm == 0;                      // natural strides at n = 6: every lane keeps one alignment class
+
+  V3 w = mk(0, 0, 0), vl = mk(0, 0, 0), al = mk(0, 0, 0);
+  V3 acc = mk(-c->g[0], -c->g[1], -c->g[2]);  // base "acceleration" -g: gravity enters every link's d for free
+  V3 jl[NA], ja[NA];
+  double tau[NA];
+#pragma unroll
+  for (int l = 0; l < NA; ++l)
+  {
+    tau[l] = 0.0;
+    jl[l] = mk(0, 0, 0);
+    ja[l] = mk(0, 0, 0);
+  }
+
+#pragma unroll
+  for (int f = 0; f < NJ; ++f)
+  {
+    JointRef J = c->j[f];
+    const int type = J.type;
+    double qf = 0.0, dqf = 0.0, ddqf = 0.0;
+    if (f < NA)  // input joint f (pattern checked by the launcher); the rest are fixed
+    {
+      const int64_t o = f * a.in_sj;
+      qf = qp[o];
+      dqf = dqp[o];
+      ddqf = ddqp[o];
+    }
+    // ---- parent -> child transform (Joint::computedTpc, primitives_impl.h:38-47)
+    double R[9];
+    V3 t = ld3(J.t);
+    if (type == RDYN_REVOLUTE)
+    {
+      double sn, cs;
+      sincos(qf, &sn, &cs);
+      const double oc = 1.0 - cs;
+#pragma unroll
+      for (int i = 0; i < 9; ++i) R[i] = fma(sn, J.B[i], fma(oc, J.C[i], J.A[i]));
+    }
+    else
+    {
+#pragma unroll
+      for (int i = 0; i < 9; ++i) R[i] = J.A[i];
+      if (type == RDYN_PRISMATIC) t = axpy(t, ld3(J.up), qf);
+    }
+    {
+      const V3 wn = rotT(R, w);
+      const V3 vn = rotT(R, vl + cross(w, t));
+      const V3 aln = rotT(R, al);
+      const V3 an = rotT(R, acc + cross(al, t));
+      w = wn; vl = vn; al = aln; acc = an;
+    }
+#pragma unroll
+    for (int l = 0; l < (f < NA ? f : NA); ++l)
+    {
+      const V3 nl = rotT(R, jl[l] + cross(ja[l], t));
+      ja[l] = rotT(R, ja[l]);
+      jl[l] = nl;
+    }
+    const V3 u = ld3(J.u);
+    if (type == RDYN_REVOLUTE)
+    {
+      acc = axpy(acc, cross(vl, u), dqf);
+      al = axpy(axpy(al, cross(w, u), dqf), u, ddqf);
+      w = axpy(w, u, dqf);
+      if (f < NA)
+      {
+        jl[f < NA ? f : 0] = mk(0, 0, 0);
+        ja[f < NA ? f : 0] = u;
+      }
+    }
+    else if (type == RDYN_PRISMATIC)
+    {
+      acc = axpy(axpy(acc, cross(w, u), dqf), u, ddqf);
+      vl = axpy(vl, u, dqf);
+      if (f < NA)
+      {
+        jl[f < NA ? f : 0] = u;
+        ja[f < NA ? f : 0] = mk(0, 0, 0);
+      }
+    }
+    // ---- closed-form wrench regressor of link f + 1 in its own frame, rows of the input joints l <= f
+    const V3 d = acc + cross(w, vl);
+    const double wxy = w.x * w.y, wxz = w.x * w.z, wyz = w.y * w.z;
+    const double wxx = w.x * w.x, wyy = w.y * w.y, wzz = w.z * w.z;
+    const double b00 = -(wyy + wzz), b01 = wxy - al.z, b02 = wxz + al.y;
+    const double b10 = wxy + al.z, b11 = -(wxx + wzz), b12 = wyz - al.x;
+    const double b20 = wxz - al.y, b21 = wyz + al.x, b22 = -(wxx + wyy);
+    const RDYN_CONST_AS double* pi = J.pi;
+#pragma unroll
+    for (int l = 0; l < NA; ++l)
+    {
+      if (l <= f)
+      {
+        const V3 L = jl[l], A = ja[l];
+        const V3 dxA = cross(d, A);
+        const V3 x = cross(A, w);
+        double y[10];
+        y[0] = dot(L, d);
+        y[1] = fma(L.x, b00, fma(L.y, b10, fma(L.z, b20, dxA.x)));
+        y[2] = fma(L.x, b01, fma(L.y, b11, fma(L.z, b21, dxA.y)));
+        y[3] = fma(L.x, b02, fma(L.y, b12, fma(L.z, b22, dxA.z)));
+        y[4] = fma(A.x, al.x, x.x * w.x);
+        y[5] = fma(A.x, al.y, fma(A.y, al.x, fma(x.x, w.y, x.y * w.x)));
+        y[6] = fma(A.x, al.z, fma(A.z, al.x, fma(x.x, w.z, x.z * w.x)));
+        y[7] = fma(A.y, al.y, x.y * w.y);
+        y[8] = fma(A.y, al.z, fma(A.z, al.y, fma(x.y, w.z, x.z * w.y)));
+        y[9] = fma(A.z, al.z, x.z * w.z);
+        double tl = tau[l];
+#pragma unroll
+        for (int p = 0; p < 10; ++p)
+        {
+          tl = fma(y[p], pi[p], tl);
+          *(double*)(stg + (f * RUN + (p * NA + l) * 8) % W) = y[p];
+        }
+        tau[l] = tl;
+      }
+      else
+      {
+        // structural zero block (row of a joint downstream of this link): the image is dense
+#pragma unroll
+        for (int p = 0; p < 10; ++p) *(double*)(stg + (f * RUN + (p * NA + l) * 8) % W) = 0.0;
+      }
+    }
+    // ---- copy out the lines completed by this link: image bytes [Fp, Fc), Fx = E - ((m + E) mod 128) (everything at the last link)
+    wave_lds_fence();
+    {
+      const int Ep = f * RUN, Ec = (f + 1) * RUN;  // constants after unrolling
+      const bool last = f == NJ - 1;
+      // one sample's piece: x = first byte this lane moves (image offset), active if x < Fc
+      auto piece = [&](uint32_t m, uint32_t j, uint32_t& x, uint32_t& pos, bool& on) {
+        const uint32_t Fp = f == 0 ? 0u : (uint32_t)Ep - ((m + (uint32_t)Ep) & 127u);
+        const uint32_t Fc = last ? (uint32_t)IMG : (uint32_t)Ec - ((m + (uint32_t)Ec) & 127u);
+        x = Fp + 16u * j;
+        on = x < Fc;
+        // ring position of image byte x in [Ep - 127, Ec): the run starts at Ep mod W
+        int pr = (int)x - Ep + (Ep % W);
+        if (pr < 0) pr += W;
+        if (pr >= W) pr -= W;
+        pos = (uint32_t)pr;
+      };
+      if (cp_lane)
+      {
+        char* yl = ywave;  // wave-uniform, advanced by SPI images per iteration
+        if (valid == 64 && m_const && 64 % SPI == 0)
+        {
+          uint32_t x, pos;
+          bool on;
+          piece(m0, (uint32_t)cj, x, pos, on);
+          const uint32_t g_off = (uint32_t)sub * img + x;
+          const char* const lsrc = stage + sub * PITCH + pos;
+          if (on)
+          {
+#pragma unroll
+            for (int it = 0; it < NIT; ++it)
+            {
+              const d2a v = *(const d2a*)(lsrc + it * (SPI * PITCH));
+              if (NT) __builtin_nontemporal_store((d2u)v, (d2u*)(yl + g_off));
+              else *(d2u*)(yl + g_off) = (d2u)v;
+              yl += (int64_t)SPI * img;
+            }
+          }
+        }
+        else
+        {
+#pragma unroll
+          for (int it = 0; it < NIT; ++it)
+          {
+            uint32_t x, pos;
+            bool on;
+            piece((m0 + (uint32_t)it * dm) & 127u, (uint32_t)cj, x, pos, on);
+            if (on && it * SPI + sub < valid)
+            {
+              const d2a v = *(const d2a*)(stage + (it * SPI + sub) * PITCH + pos);
+              if (NT) __builtin_nontemporal_store((d2u)v, (d2u*)(yl + (uint32_t)sub * img + x));
+              else *(d2u*)(yl + (uint32_t)sub * img + x) = (d2u)v;
+            }
+            yl += (int64_t)SPI * img;
+          }
+        }
+      }
+      if (last)
+      {
+        // the image's last link can leave more than MAXC chunks (its final partial line): 8 lanes per sample pick up the rest
+        const int tsub = lane >> 3, tj = MAXC + (lane & 7);
+        char* yl = ywave;
+#pragma unroll
+        for (int it = 0; it < 8; ++it)
+        {
+          const int smp = it * 8 + tsub;
+          const uint32_t m = ((uint32_t)(uintptr_t)ywave + (uint32_t)smp * img) & 127u;
+          uint32_t x, pos;
+          bool on;
+          piece(m, (uint32_t)tj, x, pos, on);
+          if (on && smp < valid)
+          {
+            const d2a v = *(const d2a*)(stage + smp * PITCH + pos);
+            *(d2u*)(yl + (uint32_t)tsub * img + x) = (d2u)v;
+          }
+          yl += (int64_t)8 * img;
+        }
+      }
+    }
+    wave_lds_fence();  // the ring is written again by the next link
+  }
+  if (a.tau && mine)
+  {
+    double* __restrict__ tp = a.tau + s * a.tau_ss;
+#pragma unroll
+    for (int l = 0; l < NA; ++l) tp[l * a.tau_sj] = tau[l];
+  }
+}
+
+template <int NJ, int NA>
+hipError_t launch_image(const RdynSweepArgs& a, hipStream_t st)
+{
+  const dim3 grid((unsigned)((a.n_samples + 63) / 64));
+  const size_t lds = (size_t)64 * (80 * NA + 128 + 16);
+  // nontemporal copy-out: the lines are written whole, once, and never re-read (A/B, same box: 0.55 ms vs 0.72 ms per 1e6)
+#ifdef RDYN_IMAGE_PLAIN_STORES
+  hipLaunchKernelGGL((k_image_sweep<NJ, NA, false>), grid, dim3(64), lds, st, a);
+#else
+  hipLaunchKernelGGL((k_image_sweep<NJ, NA, true>), grid, dim3(64), lds, st, a);
+#endif
+  return hipGetLastError();
+}
+}  // namespace
+
+// n_fixed_tail = NJ - NA in {0, 1}; the caller has checked the input-joint pattern and the layout (y_sr == 1, y_sc == NA)
+bool rdyn_image_supported(int n_joints, int n_active, int64_t y_ss)
+{
+  return n_active >= 2 && n_active <= RDYN_MAX_JOINTS && (n_joints == n_active || n_joints == n_active + 1) && y_ss > 0 &&
+         (y_ss * 8) % 16 == 0 && 64 * y_ss * 8 < (int64_t)0xFFFFFFFFll;
+}
+
+hipError_t rdyn_launch_image_sweep(int n_joints, int n_active, const RdynSweepArgs& a, hipStream_t st)
+{
+  if (a.n_samples <= 0) return hipSuccess;
+#define IMG(NJ_, NA_) \
+  if (n_joints == NJ_ && n_active == NA_) return launch_image<NJ_, NA_>(a, st);
+  IMG(2, 2) IMG(3, 2) IMG(3, 3) IMG(4, 3) IMG(4, 4) IMG(5, 4) IMG(5, 5) IMG(6, 5) IMG(6, 6) IMG(7, 6) IMG(7, 7) IMG(8, 7) IMG(8, 8)
+  IMG(9, 8) IMG(9, 9) IMG(10, 9) IMG(10, 10)
+#undef IMG
+  return hipErrorInvalidValue;
+}

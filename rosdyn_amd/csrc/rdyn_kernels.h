@@ -180,6 +180,10 @@ enum { RDYN_MODE_REGRESSOR = 0, RDYN_MODE_TORQUE = 1, RDYN_MODE_INERTIA = 2, RDY
 hipError_t rdyn_launch_local_sweep(int n_joints, int mode, const RdynSweepArgs& a, hipStream_t st);
 hipError_t rdyn_launch_base_sweep(int n_joints, const RdynKinArgs& a, hipStream_t st);
 hipError_t rdyn_launch_rowpair_sweep(int n_joints, int n_active, const RdynSweepArgs& a, hipStream_t st);
+// per-sample Eigen image (y_sr == 1, y_sc == n_active): one thread per sample, link blocks staged through LDS and written in
+// whole 80 n-byte runs (rdyn_image.hip); input joints = the first n_active chain joints in order, at most one fixed tail joint
+bool rdyn_image_supported(int n_joints, int n_active, int64_t y_ss);
+hipError_t rdyn_launch_image_sweep(int n_joints, int n_active, const RdynSweepArgs& a, hipStream_t st);
 hipError_t rdyn_launch_local_sweep_multi(int n_joints, int mode, const RdynSweepArgs* table, int n_items, int64_t max_samples, hipStream_t st);
 
 #endif
