@@ -169,8 +169,11 @@ int run_local(const rdyn_chain* c, const rdyn_batch* b, int mode, double* tau, d
                        b->layout == RDYN_LAYOUT_SAMPLE_MAJOR && b->n_samples * ((n + 1) / 2) < (int64_t)0xFFFFFF00ll &&
                        !probe_env("RDYN_NO_ROWPAIR");
   // the drop-in per-sample image (either input layout): one thread per sample, link blocks staged through LDS (rdyn_image.hip)
-  bool image = mode == RDYN_MODE_REGRESSOR && yl && yl->stride_row == 1 && yl->stride_col == n &&
-               yl->stride_sample >= (int64_t)n * 10 * c->n_joints() && rdyn_image_supported(c->n_joints(), n, yl->stride_sample) &&
+  // and the stacked column-major (N n) x P matrix (stride_sample == n): same kernel, column-major staging tile per link
+  const bool lay_image = yl && yl->stride_row == 1 && yl->stride_col == n && yl->stride_sample >= (int64_t)n * 10 * c->n_joints();
+  const bool lay_stacked = yl && yl->stride_row == 1 && yl->stride_sample == n && yl->stride_col >= b->n_samples * n &&
+                           !probe_env("RDYN_NO_STACKED_LDS");
+  bool image = mode == RDYN_MODE_REGRESSOR && (lay_image || lay_stacked) && rdyn_image_supported(c->n_joints(), n, yl->stride_sample) &&
                !probe_env("RDYN_NO_IMAGE");
   for (int j = 0; image && j < n; ++j) image = c->active[j] == j;  // input joints = the first n chain joints, in order
   if (image)

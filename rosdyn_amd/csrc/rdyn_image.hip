@@ -37,7 +37,7 @@ __device__ __forceinline__ void wave_lds_fence()
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-template <int NJ, int NA, bool NT>
+template <int NJ, int NA, bool NT, bool STACKED>
 __global__ __launch_bounds__(64) void k_image_sweep(const RdynSweepArgs a)
 {
   constexpr int RUN = 80 * NA;                       // bytes one link adds to one sample's image
@@ -59,7 +59,10 @@ __global__ __launch_bounds__(64) void k_image_sweep(const RdynSweepArgs a)
   const double* __restrict__ qp = a.q + s * a.in_ss;
   const double* __restrict__ dqp = a.dq + s * a.in_ss;
   const double* __restrict__ ddqp = a.ddq + s * a.in_ss;
-  char* const stg = stage + lane * PITCH;
+  // staging position of element (row l, column p of link f): image kernel -> the sample's ring, stacked -> column-major tile
+  // [p][sample][row] of the link (64 NA doubles per column: exactly the bytes the wave owns in column 10 f + p of the matrix)
+  char* const stg = stage + (STACKED ? lane * (NA * 8) : lane * PITCH);
+  auto spos = [](int f, int pp, int l) { return STACKED ? pp * (64 * NA * 8) + l * 8 : (f * RUN + (pp * NA + l) * 8) % W; };
   // copy-out role of this lane: chunk cj of sample (it * SPI + sub) in iteration it
   const int sub = lane / MAXC, cj = lane - sub * MAXC;
   const bool cp_lane = lane < SPI * MAXC;
@@ -180,7 +183,7 @@ __global__ __launch_bounds__(64) void k_image_sweep(const RdynSweepArgs a)
         for (int p = 0; p < 10; ++p)
         {
           tl = fma(y[p], pi[p], tl);
-          *(double*)(stg + (f * RUN + (p * NA + l) * 8) % W) = y[p];
+          *(double*)(stg + spos(f, p, l)) = y[p];
         }
         tau[l] = tl;
       }
@@ -188,11 +191,38 @@ __global__ __launch_bounds__(64) void k_image_sweep(const RdynSweepArgs a)
       {
         // structural zero block (row of a joint downstream of this link): the image is dense
 #pragma unroll
-        for (int p = 0; p < 10; ++p) *(double*)(stg + (f * RUN + (p * NA + l) * 8) % W) = 0.0;
+        for (int p = 0; p < 10; ++p) *(double*)(stg + spos(f, p, l)) = 0.0;
       }
     }
     // ---- copy out the lines completed by this link: image bytes [Fp, Fc), Fx = E - ((m + E) mod 128) (everything at the last link)
     wave_lds_fence();
+    if constexpr (STACKED)
+    {
+      // the wave owns 64 NA consecutive doubles of every column: 512 NA bytes = 4 NA whole lines when the column is line aligned
+      const uint32_t lim = (uint32_t)valid * (NA * 8);
+#pragma unroll
+      for (int pp = 0; pp < 10; ++pp)
+      {
+        char* const ycol = (char*)(a.Y + (int64_t)(10 * f + pp) * a.y_sc + s_wave * NA);  // wave-uniform
+#pragma unroll
+        for (int it = 0; it < (32 * NA + 63) / 64; ++it)
+        {
+          const uint32_t off = (uint32_t)(it * 64 + lane) * 16u;
+          if (off < lim)
+          {
+            const d2a v = *(const d2a*)(stage + pp * (64 * NA * 8) + off);
+            if (off + 16u <= lim)
+            {
+              if (NT) __builtin_nontemporal_store((d2u)v, (d2u*)(ycol + off));
+              else *(d2u*)(ycol + off) = (d2u)v;
+            }
+            else
+              *(double*)(ycol + off) = v.x;  // odd number of valid doubles: the last chunk is half full
+          }
+        }
+      }
+    }
+    else
     {
       const int Ep = f * RUN, Ec = (f + 1) * RUN;  // constants after unrolling
       const bool last = f == NJ - 1;
@@ -280,16 +310,16 @@ __global__ __launch_bounds__(64) void k_image_sweep(const RdynSweepArgs a)
   }
 }
 
-template <int NJ, int NA>
+template <int NJ, int NA, bool STACKED>
 hipError_t launch_image(const RdynSweepArgs& a, hipStream_t st)
 {
   const dim3 grid((unsigned)((a.n_samples + 63) / 64));
-  const size_t lds = (size_t)64 * (80 * NA + 128 + 16);
+  const size_t lds = STACKED ? (size_t)10 * 64 * NA * 8 : (size_t)64 * (80 * NA + 128 + 16);
   // nontemporal copy-out: the lines are written whole, once, and never re-read (A/B, same box: 0.55 ms vs 0.72 ms per 1e6)
 #ifdef RDYN_IMAGE_PLAIN_STORES
-  hipLaunchKernelGGL((k_image_sweep<NJ, NA, false>), grid, dim3(64), lds, st, a);
+  hipLaunchKernelGGL((k_image_sweep<NJ, NA, false, STACKED>), grid, dim3(64), lds, st, a);
 #else
-  hipLaunchKernelGGL((k_image_sweep<NJ, NA, true>), grid, dim3(64), lds, st, a);
+  hipLaunchKernelGGL((k_image_sweep<NJ, NA, true, STACKED>), grid, dim3(64), lds, st, a);
 #endif
   return hipGetLastError();
 }
@@ -298,6 +328,7 @@ hipError_t launch_image(const RdynSweepArgs& a, hipStream_t st)
 // n_fixed_tail = NJ - NA in {0, 1}; the caller has checked the input-joint pattern and the layout (y_sr == 1, y_sc == NA)
 bool rdyn_image_supported(int n_joints, int n_active, int64_t y_ss)
 {
+  if (y_ss == n_active) return n_active >= 2 && n_active <= RDYN_MAX_JOINTS && (n_joints == n_active || n_joints == n_active + 1);  // stacked
   return n_active >= 2 && n_active <= RDYN_MAX_JOINTS && (n_joints == n_active || n_joints == n_active + 1) && y_ss > 0 &&
          (y_ss * 8) % 16 == 0 && 64 * y_ss * 8 < (int64_t)0xFFFFFFFFll;
 }
@@ -305,8 +336,9 @@ bool rdyn_image_supported(int n_joints, int n_active, int64_t y_ss)
 hipError_t rdyn_launch_image_sweep(int n_joints, int n_active, const RdynSweepArgs& a, hipStream_t st)
 {
   if (a.n_samples <= 0) return hipSuccess;
+  const bool stacked = a.y_ss == n_active;  // row = s n + j (stacked matrix) instead of one image per sample
 #define IMG(NJ_, NA_) \
-  if (n_joints == NJ_ && n_active == NA_) return launch_image<NJ_, NA_>(a, st);
+  if (n_joints == NJ_ && n_active == NA_) return stacked ? launch_image<NJ_, NA_, true>(a, st) : launch_image<NJ_, NA_, false>(a, st);
   IMG(2, 2) IMG(3, 2) IMG(3, 3) IMG(4, 3) IMG(4, 4) IMG(5, 4) IMG(5, 5) IMG(6, 5) IMG(6, 6) IMG(7, 6) IMG(7, 7) IMG(8, 7) IMG(8, 8)
   IMG(9, 8) IMG(9, 9) IMG(10, 9) IMG(10, 10)
 #undef IMG
