@@ -1,0 +1,98 @@
+"""GPU tests of the LDS-staged one-thread-per-sample regressor kernel (rdyn_image.hip: per-sample drop-in images written as whole
+128-byte lines, stacked matrix written as whole columns): every alignment class, ragged batches around the 64-sample wave, padded
+image strides, a fixed tool frame behind the input joints (NA = NJ - 1), 7 input joints, both input layouts -- against the CPU
+oracle and bit for bit against the element-major kernel, with poisoned outputs so that an unwritten byte is seen."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from conftest import FIXTURES
+
+pytestmark = pytest.mark.gpu
+GRAV = (0.0, 0.0, -9.806)
+CASES = [("ur10_like.urdf", "base_link", "wrist_3_link"),   # NJ = NA = 6: 2 880-byte images, two alignment classes
+         ("ur10_like.urdf", "base_link", "tool0"),           # NJ = 7, NA = 6 (fixed tool frame): 3 360-byte images
+         ("panda_like.urdf", "link0", "link7"),              # NJ = NA = 7: 3 920-byte images, eight alignment classes
+         ("panda_like.urdf", "link0", "link8")]              # NJ = 8, NA = 7
+
+
+def _chain_and_ref(case):
+    from oracle.oracle import OracleChain
+    from rosdyn_amd import Chain
+    urdf, base, tool = case
+    path = os.path.join(FIXTURES, urdf)
+    return Chain(path, base, tool, GRAV), OracleChain(path, base, tool, GRAV)
+
+
+@pytest.mark.parametrize("case", CASES, ids=["6of6", "6of7", "7of7", "7of8"])
+@pytest.mark.parametrize("N", [1, 2, 63, 64, 65, 127, 129, 1000])
+def test_image_and_stacked_match_oracle_and_element_kernel(case, N):
+    torch = pytest.importorskip("torch")
+    from rosdyn_amd.samples import trajectory_batch
+    chain, ref = _chain_and_ref(case)
+    n, P = chain.getActiveJointsNumber(), 10 * chain.getJointsNumber()
+    q, dq, ddq = trajectory_batch(900 + N, N, n)
+    tq, tdq, tddq = (torch.from_numpy(x).cuda() for x in (q, dq, ddq))
+    Yr, tr = ref.regressor(q, dq, ddq), ref.joint_torque(q, dq, ddq)
+    nan = float("nan")
+    Yp = torch.full((N + 1, P, n), nan, dtype=torch.float64, device="cuda")     # one image of slack: writes past the batch are seen
+    Yp_v, tau_p = chain.getRegressor(tq, tdq, tddq, y_layout="per_sample", out=Yp[:N], with_torque=True)
+    Ys = torch.full((P, N * n), nan, dtype=torch.float64, device="cuda")
+    chain.getRegressor(tq, tdq, tddq, y_layout="stacked", out=Ys)
+    Ye, tau_e = chain.getRegressor(*(x.t().contiguous() for x in (tq, tdq, tddq)), layout="element", with_torque=True)
+    torch.cuda.synchronize()
+    assert torch.isnan(Yp[N]).all()                                                # nothing written behind the last image
+    a = Yp_v.cpu().numpy().transpose(0, 2, 1)
+    b = Ys.cpu().numpy().reshape(P, N, n).transpose(1, 2, 0)
+    c = Ye.cpu().numpy().transpose(2, 1, 0)
+    assert not np.isnan(a).any() and not np.isnan(b).any()
+    assert np.array_equal(a, c) and np.array_equal(b, c)                           # same arithmetic, three layouts
+    assert np.array_equal(tau_p.cpu().numpy(), tau_e.cpu().numpy().T)
+    assert np.abs(a - Yr).max() <= 1e-11 * max(1.0, np.abs(Yr).max())
+    assert np.abs(tau_p.cpu().numpy() - tr).max() <= 1e-11 * max(1.0, np.abs(tr).max())
+
+
+@pytest.mark.parametrize("pad", [2, 6, 16, 1], ids=["pad2", "pad6", "pad16", "pad1_rowpair_fallback"])
+def test_padded_image_stride(pad):
+    """stride_sample = n P + pad doubles: even pads keep 16-byte alignment (image kernel, all eight alignment classes), an odd pad
+    falls back to the row-pair kernel.  The padding doubles between images must stay untouched."""
+    torch = pytest.importorskip("torch")
+    from rosdyn_amd._lib import Batch, RegressorLayout, check, lib
+    from rosdyn_amd.samples import trajectory_batch
+    chain, ref = _chain_and_ref(CASES[0])
+    n, P, N = 6, 60, 333
+    q, dq, ddq = trajectory_batch(31, N, n)
+    tq, tdq, tddq = (torch.from_numpy(x).cuda() for x in (q, dq, ddq))
+    ss = n * P + pad
+    buf = torch.full((N * ss,), -7.0, dtype=torch.float64, device="cuda")
+    b = Batch()
+    b.n_samples, b.q, b.dq, b.ddq, b.layout, b.device = N, tq.data_ptr(), tdq.data_ptr(), tddq.data_ptr(), 0, 0
+    b.stream = torch.cuda.current_stream().cuda_stream
+    yl = RegressorLayout(ss, 1, n)
+    check(lib().rdyn_regressor(chain._h, C.byref(b), None, buf.data_ptr(), C.byref(yl)))
+    torch.cuda.synchronize()
+    h = buf.cpu().numpy().reshape(N, ss)
+    assert np.all(h[:, n * P:] == -7.0)                                            # padding untouched
+    Yg = h[:, :n * P].reshape(N, P, n).transpose(0, 2, 1)
+    Yr = ref.regressor(q, dq, ddq)
+    assert np.abs(Yg - Yr).max() <= 1e-11 * max(1.0, np.abs(Yr).max())
+
+
+def test_image_kernel_with_prismatic_and_fixed_joints():
+    """mixed_joints.urdf (revolute / prismatic / fixed, input joints need not be the first chain joints): whatever kernel the API
+    picks, the per-sample image equals the oracle."""
+    torch = pytest.importorskip("torch")
+    from rosdyn_amd.samples import trajectory_batch
+    from oracle.oracle import OracleChain
+    from rosdyn_amd import Chain
+    path = os.path.join(FIXTURES, "mixed_joints.urdf")
+    base, tool = "world", "tip"
+    chain, ref = Chain(path, base, tool, GRAV), OracleChain(path, base, tool, GRAV)
+    n, N = chain.getActiveJointsNumber(), 257
+    q, dq, ddq = trajectory_batch(5, N, n)
+    Y = chain.getRegressor(*(torch.from_numpy(x).cuda() for x in (q, dq, ddq)), y_layout="per_sample")
+    torch.cuda.synchronize()
+    Yr = ref.regressor(q, dq, ddq)
+    assert np.abs(Y.cpu().numpy().transpose(0, 2, 1) - Yr).max() <= 1e-11 * max(1.0, np.abs(Yr).max())
