@@ -7,8 +7,8 @@ launch) over one batch of synthetic (q, Dq, DDq) samples that are already reside
 Workload of `value` (BASELINE.json configs[1]): 6-DOF chain (tests/fixtures/ur10_like.urdf cut at wrist_3_link:
 n = 6 active joints, 6 chain joints, P = 60 parameters), 1e6 samples per GPU, fp64, dense Y.
 Default layouts = SURVEY section 8(d) config 2 as written: inputs AoS [N][6] (sample-major), tau [N][6], Y = the stacked
-column-major (6 N) x 60 regressor A (k_rowpair_sweep<6>); --y-layout element selects the SoA form (k_local_sweep<6, REGRESSOR>),
---y-layout per_sample the drop-in Eigen image (k_persample_sweep<6>).
+column-major (6 N) x 60 regressor A (k_image_sweep<6, 6>: one thread per sample, link blocks staged in LDS, whole-line nontemporal
+copy-out); --y-layout element selects the SoA form (k_local_sweep<6, REGRESSOR>), --y-layout per_sample the drop-in Eigen image.
 Multi-GPU: the batch shards trivially (i.i.d. samples) -> every rank evaluates its own 1e6 samples, no
 data-path collective ("weak" scaling); the only exchange is the max-over-ranks of the elapsed time.
 
@@ -396,7 +396,7 @@ def main():
     b_eval = algorithmic_bytes_per_eval(n, P)
     kernel_ms = dev_ms / args.steps                       # one launch per step, back to back on one stream
     achieved = b_eval * N / (kernel_ms * 1e-3) / 1e9      # GB/s, algorithmic bytes per launch / launch duration
-    kernel = {"element": "k_local_sweep<6, REGRESSOR>", "stacked": "k_rowpair_sweep<6>", "per_sample": "k_persample_sweep<6>"}[args.y_layout]
+    kernel = {"element": "k_local_sweep<6, REGRESSOR>", "stacked": "k_image_sweep<6, 6, nt, stacked>", "per_sample": "k_image_sweep<6, 6, nt, image>"}[args.y_layout]
     traffic = committed_traffic("regressor_%s_n%d_P%d_N%d" % (args.y_layout, n, P, N))
 
     out = {

@@ -322,6 +322,19 @@ size_t rdyn_regressor_gram_workspace_bytes(const rdyn_chain* chain, int64_t chun
 int rdyn_regressor_gram(const rdyn_chain* chain, const rdyn_batch* batch, const double* tau_meas, double* G, double* c,
                         double* bb, int accumulate, int64_t chunk_samples, void* workspace, size_t workspace_bytes);
 
+/* ---- the small dense solves of the identification step (HOST pointers, column-major; rdyn_solve.cpp).  No counterpart inside
+ * rosdyn_core (external rosdyn_identification, README.md:15).
+ * rdyn_solve_normal_equations: minimum-norm least-squares solution x (n) of G x = c for the symmetric positive SEMI-definite
+ *   n x n Gram G (the stacked regressor is structurally rank deficient: unobservable base-link parameters, fixed tail links):
+ *   Jacobi eigen-decomposition, eigenvalues <= rtol * lambda_max dropped; *rank (may be NULL) = eigenvalues kept.
+ * rdyn_gram_r_factor: rank-revealing R factor of A from its Gram: pivoted Cholesky, R'R = G[perm][:, perm]; R is n x n
+ *   (rows >= *rank are zero), perm[n].  Squares the condition number (CholeskyQR): fine for cond(A) << 1e8.
+ * rdyn_solve_r_factor: minimum-norm solution of min |R x - d| for a rows x n factor R (leading dimension ldr) as the TSQR path
+ *   returns it (rdyn_regressor_tsqr below: condition number NOT squared), singular values <= rtol * sigma_max dropped. */
+int rdyn_solve_normal_equations(const double* G, const double* c, int n, double rtol, double* x, int* rank);
+int rdyn_gram_r_factor(const double* G, int n, double rtol, double* R, int32_t* perm, int* rank);
+int rdyn_solve_r_factor(const double* R, int64_t ldr, int rows, int n, const double* d, double rtol, double* x, int* rank);
+
 #ifdef __cplusplus
 }
 #endif

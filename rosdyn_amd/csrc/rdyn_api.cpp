@@ -161,6 +161,16 @@ int run_local(const rdyn_chain* c, const rdyn_batch* b, int mode, double* tau, d
     a.y_sr = yl->stride_row;
     a.y_sc = yl->stride_col;
   }
+  if (yl && mode == RDYN_MODE_REGRESSOR)
+  {
+    // the one-thread-per-sample kernel addresses a workgroup's 256 samples with 32-bit lane offsets: free strides must be
+    // positive and keep 255 * stride_sample * 8 inside 32 bits (the presets of rdyn.h are far below that)
+    if (yl->stride_sample < 1 || yl->stride_row < 1 || yl->stride_col < 1 || yl->stride_sample > (int64_t)0xFFFFFFFFll / (8 * 255))
+    {
+      rdyn_set_error("rdyn_regressor: strides must be positive and stride_sample below %lld doubles", (long long)((int64_t)0xFFFFFFFFll / (8 * 255)));
+      return RDYN_ERR_INVALID_ARGUMENT;
+    }
+  }
   a.M = M;
   rec_strides(b, (int64_t)n * n, &a.m_ss, &a.m_se);
   // Row-contiguous regressor layouts (stacked column-major, per-sample Eigen image) with sample-major inputs:
@@ -628,6 +638,13 @@ int rdyn_multi_plan_create(const rdyn_multi_item* items, int n_items, rdyn_multi
     if (it.batch.n_samples > 0 && !it.Y)
     {
       rdyn_set_error("rdyn_multi_plan_create: item %d has a null regressor output", i);
+      return RDYN_ERR_INVALID_ARGUMENT;
+    }
+    if (it.y_layout.stride_sample < 1 || it.y_layout.stride_row < 1 || it.y_layout.stride_col < 1 ||
+        it.y_layout.stride_sample > (int64_t)0xFFFFFFFFll / (8 * 255))
+    {
+      rdyn_set_error("rdyn_multi_plan_create: item %d: strides must be positive and stride_sample below %lld doubles", i,
+                     (long long)((int64_t)0xFFFFFFFFll / (8 * 255)));
       return RDYN_ERR_INVALID_ARGUMENT;
     }
     RdynSweepArgs a;

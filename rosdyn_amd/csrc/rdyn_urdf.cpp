@@ -128,9 +128,22 @@ struct XmlParser
     return o;
   }
 
+  int depth = 0;  // nesting of parse_element: a robot_description never nests deeper than a few levels
+  struct DepthGuard
+  {
+    int& d;
+    explicit DepthGuard(int& x) : d(x) { ++d; }
+    ~DepthGuard() { --d; }
+  };
   std::unique_ptr<XmlNode> parse_element()
   {
     // at '<' of a start tag
+    DepthGuard guard(depth);
+    if (depth > 256)  // recursion bound: a hostile document must not overflow the host stack
+    {
+      err = "XML nested deeper than 256 elements";
+      return nullptr;
+    }
     ++p;
     std::unique_ptr<XmlNode> n(new XmlNode());
     const char* s = p;
@@ -345,6 +358,11 @@ int rdyn_urdf_extract_chain(const char* xml, const char* base, const char* tool,
         rdyn_set_error("URDF parse error: <link> without name");
         return RDYN_ERR_URDF;
       }
+      if (nm->size() > 63)  // the POD descriptor keeps 63 characters: a longer name could never be matched as base / tool
+      {
+        rdyn_set_error("URDF parse error: link name longer than 63 characters: '%.80s'", nm->c_str());
+        return RDYN_ERR_URDF;
+      }
       TreeLink L;
       memset(&L.d, 0, sizeof L.d);
       copy_name(L.d.name, *nm);
@@ -390,6 +408,11 @@ int rdyn_urdf_extract_chain(const char* xml, const char* base, const char* tool,
       if (!nm || !ty || !par || !chi || !par->attr("link") || !chi->attr("link"))
       {
         rdyn_set_error("URDF parse error: <joint> needs name, type, <parent link>, <child link>");
+        return RDYN_ERR_URDF;
+      }
+      if (nm->size() > 63)
+      {
+        rdyn_set_error("URDF parse error: joint name longer than 63 characters: '%.80s'", nm->c_str());
         return RDYN_ERR_URDF;
       }
       TreeJoint J;

@@ -446,6 +446,7 @@ private:
     if (m_dev) (void)hipFree(m_dev);
     if (m_pin) (void)hipHostFree(m_pin);
     m_dev = m_pin = nullptr;
+    m_dev_doubles = 0;  // refresh() must allocate again (copy-assignment: release, clone, refresh)
     if (m_h) rdyn_chain_destroy(m_h);
     m_h = nullptr;
   }

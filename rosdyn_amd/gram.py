@@ -87,6 +87,32 @@ def r_factor(G, rtol=1e-10):
     return R[:rank], perm, rank
 
 
+def solve_normal_equations_abi(G, c, rtol=1e-10):
+    """The same minimum-norm solve through the C-ABI (rdyn_solve_normal_equations: host C++, what a C++ caller uses).
+    Returns (x, rank)."""
+    Gh = np.ascontiguousarray(np.asarray(G.detach().cpu() if hasattr(G, "detach") else G, dtype=np.float64).T)   # column-major
+    ch = np.ascontiguousarray(np.asarray(c.detach().cpu() if hasattr(c, "detach") else c, dtype=np.float64))
+    n = ch.shape[0]
+    x = np.zeros(n)
+    rank = C.c_int(0)
+    dp = C.POINTER(C.c_double)
+    check(lib().rdyn_solve_normal_equations(Gh.ctypes.data_as(dp), ch.ctypes.data_as(dp), n, float(rtol), x.ctypes.data_as(dp), C.byref(rank)))
+    return x, rank.value
+
+
+def r_factor_abi(G, rtol=1e-10):
+    """rdyn_gram_r_factor through the C-ABI: (R (rank x P), perm, rank) like r_factor()."""
+    Gh = np.ascontiguousarray(np.asarray(G.detach().cpu() if hasattr(G, "detach") else G, dtype=np.float64).T)
+    n = Gh.shape[0]
+    R = np.zeros((n, n))          # column-major on the C side == the transpose here
+    perm = np.zeros(n, dtype=np.int32)
+    rank = C.c_int(0)
+    dp = C.POINTER(C.c_double)
+    check(lib().rdyn_gram_r_factor(Gh.ctypes.data_as(dp), n, float(rtol), R.ctypes.data_as(dp), perm.ctypes.data_as(C.POINTER(C.c_int32)),
+                                   C.byref(rank)))
+    return R.T[:rank.value].copy(), perm.astype(np.int64), rank.value
+
+
 def residual_sum_of_squares(G, c, bb, x):
     """|A x - b|^2 from the normal-equation accumulators alone: bb - 2 c'x + x'G x (no second pass over the batch).
     Cancellation limits it to ~1e-12 |b|^2; that is far below any measurement noise the identification works with."""
