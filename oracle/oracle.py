@@ -81,6 +81,31 @@ def frame_distance_quat(T_wa, T_wb, jac=False):
     return (d, J) if jac else d
 
 
+class _OracleComponent(C.Structure):
+    _fields_ = [("type", C.c_int), ("joint", C.c_int), ("min_velocity", C.c_double), ("max_velocity", C.c_double),
+                ("parameters", C.c_double * 3)]
+
+
+def components_regressor(specs, n, q, dq):
+    """Per-joint additive components (components_oracle.c: friction_polynomial1.h:45-52, friction_polynomial2.h:42-58,
+    ideal_spring.h:64-70).  specs = [(type, joint, min_velocity, max_velocity, (p0, p1, p2)), ...]; q, dq (N, n).
+    Returns (C (N, n, K), tau (N, n))."""
+    arr = (_OracleComponent * len(specs))()
+    for a, (ty, joint, vmin, vmax, par) in zip(arr, specs):
+        a.type, a.joint, a.min_velocity, a.max_velocity = ty, joint, vmin, vmax
+        a.parameters[:] = (list(par) + [0.0, 0.0, 0.0])[:3]
+    K = sum(3 if sp[0] == 1 else 2 for sp in specs)
+    q, dq = _c(q), _c(dq)
+    N = len(q)
+    Cm, tau = np.empty((N, n, K)), np.zeros((N, n))
+    f = lib().orc_components_batch
+    f.restype = None
+    dp = C.POINTER(C.c_double)
+    f.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_long, dp, dp, dp, dp]
+    f(C.cast(arr, C.c_void_p), len(specs), n, N, _p(q), _p(dq), _p(Cm), _p(tau))
+    return Cm, tau
+
+
 def solve_quadprog(G, g0, CI, ci0):
     """min 1/2 x'Gx + g0'x  s.t.  CI'x + ci0 >= 0  (Goldfarb-Idnani); returns (status, x)."""
     G, g0, CI, ci0 = _c(G), _c(g0), _c(CI), _c(ci0)

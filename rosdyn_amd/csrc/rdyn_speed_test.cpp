@@ -8,6 +8,8 @@
 // usage: rdyn_speed_test <urdf file> <base link> <tool link> [ntrial]
 #include <chrono>
 #include <cstdint>
+#include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <fstream>
@@ -120,6 +122,101 @@ int main(int argc, char** argv)
     for (int c = 0; c < (int)n_joints; ++c)
       for (int r = 0; r < 6; ++r) std::printf(" %.17g", Jl(r, c));
     std::printf("\n");
+    // copy-assignment keeps a usable staging buffer: the assigned chain evaluates the same torque
+    {
+      rosdyn::Chain other(*chain);
+      other = *chain;
+      const rosdyn::VectorXd& t2 = other.getJointTorque(q, Dq, DDq);
+      std::printf("A");
+      for (unsigned i = 0; i < n_joints; ++i) std::printf(" %.17g", t2(i));
+      std::printf("\n");
+    }
+    // getMultiplicity (primitives_impl.h:1470): number of configurations, then the first three
+    {
+      const std::vector<rosdyn::VectorXd> mt = chain->getMultiplicity(q);
+      std::printf("P %zu", mt.size());
+      for (size_t k = 0; k < mt.size() && k < 3; ++k)
+        for (unsigned i = 0; i < n_joints; ++i) std::printf(" %.17g", mt[k](i));
+      std::printf("\n");
+    }
+    // per-joint components on joint 1 (friction_polynomial1.h / friction_polynomial2.h / ideal_spring.h):
+    // regressor row of the joint, getTorque, getAdditiveTorque, getNonAdditiveTorque of a unit additive torque
+    {
+      const std::vector<std::string>& names = chain->getActiveJointsName();
+      rosdyn::FirstOrderPolynomialFriction f1(names.at(1), names, 0.4, 0.9, 1e-3, 0.08);
+      rosdyn::SecondOrderPolynomialFriction f2(names.at(1), names, 0.4, 0.9, 0.25, 1e-3, 0.0);
+      rosdyn::IdealSpring sp(names.at(1), names, 12.0, -0.7);
+      rosdyn::ComponentBase* comps[3] = {&f1, &f2, &sp};
+      rosdyn::VectorXd add((int)n_joints);
+      for (unsigned i = 0; i < n_joints; ++i) add(i) = 1.0;
+      std::printf("C");
+      for (rosdyn::ComponentBase* cb : comps)
+      {
+        const rosdyn::MatrixXd R = cb->getRegressor(q, Dq, DDq);
+        for (int k = 0; k < R.cols(); ++k) std::printf(" %.17g", R(1, k));
+        std::printf(" %.17g %.17g %.17g %u", cb->getTorque(q, Dq, DDq)(1), cb->getAdditiveTorque(q, Dq, DDq)(1),
+                    cb->getNonAdditiveTorque(q, Dq, DDq, add)(1), cb->getParametersNumber());
+      }
+      std::printf("\n");
+    }
+    // frame_distance.h: T(q) against T(seed)
+    {
+      const rosdyn::Affine3d Ta = chain->getTransformation(q);
+      const rosdyn::Affine3d Tb = chain->getTransformation(seed);
+      rosdyn::Vector6d d0, d1, d2;
+      rosdyn::Matrix66d jac;
+      rosdyn::getFrameDistance(Ta, Tb, d0);
+      rosdyn::getFrameDistanceQuat(Ta, Tb, d1);
+      rosdyn::getFrameDistanceQuatJac(Ta, Tb, d2, jac);
+      std::printf("F");
+      for (int i = 0; i < 6; ++i) std::printf(" %.17g", d0(i));
+      for (int i = 0; i < 6; ++i) std::printf(" %.17g", d1(i));
+      for (int i = 0; i < 6; ++i) std::printf(" %.17g", d2(i));
+      for (int c = 0; c < 6; ++c)
+        for (int r = 0; r < 6; ++r) std::printf(" %.17g", jac(r, c));
+      std::printf("\n");
+    }
+    // identification in C++: Gram of 4 096 seeded samples with the exact torques as measurements, host solve, residual of G x = c
+    {
+      const int N = 4096, n = (int)n_joints, P = 10 * (int)chain->getJointsNumber();
+      std::vector<double> h((size_t)3 * N * n);
+      g_state = 0x5EED0042ULL;
+      for (double& v : h) v = pm1();
+      double *d_in, *d_tau, *d_G;
+      void* d_ws;
+      const size_t ws = chain->getRegressorGramWorkspaceBytes();
+      if (hipMalloc((void**)&d_in, h.size() * sizeof(double)) != hipSuccess || hipMalloc((void**)&d_tau, sizeof(double) * N * n) != hipSuccess ||
+          hipMalloc((void**)&d_G, sizeof(double) * (P * P + P + 1)) != hipSuccess || hipMalloc(&d_ws, ws) != hipSuccess)
+        throw std::runtime_error("hipMalloc failed");
+      hipMemcpy(d_in, h.data(), h.size() * sizeof(double), hipMemcpyHostToDevice);
+      rdyn_batch b;
+      std::memset(&b, 0, sizeof b);
+      b.n_samples = N;
+      b.q = d_in;
+      b.dq = d_in + (size_t)N * n;
+      b.ddq = d_in + (size_t)2 * N * n;
+      b.layout = RDYN_LAYOUT_SAMPLE_MAJOR;
+      b.device = -1;
+      chain->getJointTorqueBatch(b, d_tau);
+      chain->getRegressorGramBatch(b, d_tau, d_G, d_G + P * P, d_G + P * P + P, false, d_ws, ws);
+      rosdyn::MatrixXd G(P, P);
+      rosdyn::VectorXd c(P), x;
+      hipMemcpy(G.data(), d_G, sizeof(double) * P * P, hipMemcpyDeviceToHost);
+      hipMemcpy(c.data(), d_G + P * P, sizeof(double) * P, hipMemcpyDeviceToHost);
+      const int rank = rosdyn::Chain::solveNormalEquations(G, c, x);
+      double res = 0.0, cmax = 0.0;
+      for (int i = 0; i < P; ++i)
+      {
+        double s = -c(i);
+        for (int j = 0; j < P; ++j) s += G(i, j) * x(j);
+        res = std::max(res, std::fabs(s));
+        cmax = std::max(cmax, std::fabs(c(i)));
+      }
+      std::printf("S %d %.17g", rank, res / cmax);
+      for (int i = 0; i < P; ++i) std::printf(" %.17g", x(i));
+      std::printf("\n");
+      hipFree(d_in); hipFree(d_tau); hipFree(d_G); hipFree(d_ws);
+    }
     return 0;
   }
   g_state = 0x5EED0001ULL;

@@ -18,7 +18,9 @@
 #ifndef ROSDYN_CHAIN_FACADE_HPP
 #define ROSDYN_CHAIN_FACADE_HPP
 
+#include <algorithm>
 #include <array>
+#include <cmath>
 #include <cstring>
 #include <memory>
 #include <stdexcept>
@@ -35,6 +37,10 @@
 #include <Eigen/Geometry>
 #define RDYN_FACADE_HAS_EIGEN 1
 #endif
+#if __has_include(<urdf_model/model.h>)
+#include <urdf_model/model.h>  // urdfdom_headers: the createChain(const urdf::ModelInterface&, ...) overload of primitives.h:566
+#define RDYN_FACADE_HAS_URDFDOM 1
+#endif
 #endif
 
 namespace rosdyn
@@ -45,6 +51,7 @@ using VectorXd = Eigen::VectorXd;
 using MatrixXd = Eigen::MatrixXd;
 using Matrix6Xd = Eigen::Matrix<double, 6, Eigen::Dynamic>;
 using Vector6d = Eigen::Matrix<double, 6, 1>;
+using Matrix66d = Eigen::Matrix<double, 6, 6>;
 using Vector3d = Eigen::Vector3d;
 using Affine3d = Eigen::Affine3d;
 using VectorOfAffine3d = std::vector<Eigen::Affine3d, Eigen::aligned_allocator<Eigen::Affine3d>>;
@@ -94,6 +101,13 @@ struct Vector6d
   double& operator()(int i) { return v[i]; }
   double operator()(int i) const { return v[i]; }
 };
+struct Matrix66d  // column-major 6 x 6
+{
+  double v[36];
+  double& operator()(int i, int j) { return v[j * 6 + i]; }
+  double operator()(int i, int j) const { return v[j * 6 + i]; }
+  double* data() { return v; }
+};
 struct Vector3d
 {
   double v[3];
@@ -126,6 +140,12 @@ public:
   {
     int st = rdyn_chain_from_urdf(robot_description_xml.c_str(), base_link_name.c_str(), ee_link_name.c_str(), gravity.data(), &m_h);
     if (st != RDYN_OK) throw std::runtime_error(rdyn_last_error());
+    refresh();
+  }
+  // from the flat POD description (what createChain(const urdf::ModelInterface&, ...) below fills from a parsed urdf::Model)
+  explicit Chain(const rdyn_chain_desc& desc)
+  {
+    if (rdyn_chain_from_desc(&desc, &m_h) != RDYN_OK) throw std::runtime_error(rdyn_last_error());
     refresh();
   }
   Chain(const Chain& cpy)  // the reference's copy re-inits from the shared tree; here: an independent clone
@@ -402,6 +422,69 @@ public:
     chk(rdyn_local_ik(m_h, &seeds, T_target, weight, toll, max_iterations, sol, status, iterations));
   }
 
+  // ---- getMultiplicity, primitives.h:552 / primitives_impl.h:1470-1516: every joint vector equal to q up to whole turns of the
+  // revolute input joints inside [q_min, q_max] (host only).  The reference enumerates up to its 1e10 default limits; a joint
+  // without finite limits is refused instead of exhausting memory.
+  std::vector<VectorXd> getMultiplicity(const VectorXd& q) const
+  {
+    const unsigned n = m_active_joints_number;
+    if ((unsigned)q.rows() != n) throw std::invalid_argument("Input data dimensions mismatch");
+    const double two_pi = 6.283185307179586476925286766559;
+    std::vector<std::vector<double>> multiturn_ax(n);
+    for (unsigned idx = 0; idx < n; ++idx)
+    {
+      multiturn_ax[idx].push_back(q((int)idx));
+      if (!m_active_is_revolute[idx]) continue;
+      if (m_q_max((int)idx) - m_q_min((int)idx) > two_pi * 1e4)
+        throw std::invalid_argument("getMultiplicity: joint " + m_active_joints_name[idx] + " has no finite position limits");
+      for (double tmp = q((int)idx) + two_pi; !(tmp > m_q_max((int)idx)); tmp += two_pi) multiturn_ax[idx].push_back(tmp);
+      for (double tmp = q((int)idx) - two_pi; !(tmp < m_q_min((int)idx)); tmp -= two_pi) multiturn_ax[idx].push_back(tmp);
+    }
+    std::vector<VectorXd> multiturn;
+    multiturn.push_back(q);
+    for (unsigned idx = 0; idx < n; ++idx)
+    {
+      const size_t size_multiturn = multiturn.size();
+      for (size_t is = 1; is < multiturn_ax[idx].size(); ++is)
+        for (size_t im = 0; im < size_multiturn; ++im)
+        {
+          VectorXd new_q = multiturn[im];
+          new_q((int)idx) = multiturn_ax[idx][is];
+          multiturn.push_back(new_q);
+        }
+    }
+    return multiturn;
+  }
+
+  // ---- normal equations of the stacked regressor on the fp64 matrix cores (no counterpart inside rosdyn_core: the consumer of
+  // getRegressor was the external rosdyn_identification, README.md:15); device pointers, see include/rdyn.h
+  size_t getRegressorGramWorkspaceBytes() const { return rdyn_regressor_gram_workspace_bytes(m_h, 0); }
+  void getRegressorGramBatch(const rdyn_batch& b, const double* tau_meas, double* G, double* c, double* bb, bool accumulate, void* workspace,
+                             size_t workspace_bytes) const
+  {
+    chk(rdyn_regressor_gram(m_h, &b, tau_meas, G, c, bb, accumulate ? 1 : 0, 0, workspace, workspace_bytes));
+  }
+  size_t getIdentificationGramWorkspaceBytes(const std::vector<rdyn_component>& comps) const
+  {
+    return rdyn_identification_gram_workspace_bytes(m_h, comps.data(), (int)comps.size());
+  }
+  // [Y | C] with the columns of the per-joint components (ComponentBase::descriptor() of each, below)
+  void getIdentificationGramBatch(const std::vector<rdyn_component>& comps, const rdyn_batch& b, const double* tau_meas, double* G, double* c,
+                                  double* bb, bool accumulate, void* workspace, size_t workspace_bytes) const
+  {
+    chk(rdyn_identification_gram(m_h, comps.data(), (int)comps.size(), &b, tau_meas, G, c, bb, accumulate ? 1 : 0, workspace, workspace_bytes));
+  }
+  // minimum-norm base-parameter solve of G x = c on the host (G, c already copied back); returns the numerical rank
+  static int solveNormalEquations(const MatrixXd& G, const VectorXd& c, VectorXd& x, double rtol = 1e-10)
+  {
+    const int n = (int)c.rows();
+    if (G.rows() != n || G.cols() != n) throw std::invalid_argument("Input data dimensions mismatch");
+    x.resize(n);
+    int rank = 0;
+    chk(rdyn_solve_normal_equations(G.data(), c.data(), n, rtol, x.data(), &rank));
+    return rank;
+  }
+
   // ---- batched evaluation on device pointers (what the kernels are for); see include/rdyn.h for layouts
   void getJointTorqueBatch(const rdyn_batch& b, double* tau) const { chk(rdyn_joint_torque(m_h, &b, tau)); }
   void getRegressorBatch(const rdyn_batch& b, double* tau, double* Y, const rdyn_regressor_layout& yl) const
@@ -418,6 +501,7 @@ private:
   unsigned int m_links_number = 0, m_joints_number = 0, m_active_joints_number = 0;
   bool m_is_chain_ok = true;
   std::vector<std::string> m_links_name, m_moveable_joints_name, m_active_joints_name;
+  std::vector<char> m_active_is_revolute;  // per input joint (getMultiplicity)
   VectorXd m_q_max, m_q_min, m_Dq_max, m_DDq_max, m_tau_max, m_active_joint_torques;
   Affine3d m_T_bt;
   VectorOfAffine3d m_T_bl;
@@ -428,7 +512,7 @@ private:
   // staging: pinned host + device buffers for ONE sample
   double* m_dev = nullptr;
   double* m_pin = nullptr;
-  size_t m_dev_doubles = 0;
+  size_t m_dev_doubles = 0, m_need_doubles = 0;
   std::vector<double> m_host;
   rdyn_batch m_b;
 
@@ -461,20 +545,16 @@ private:
     for (unsigned i = 0; i < m_links_number; ++i) m_links_name.push_back(rdyn_chain_link_name(m_h, (int)i));
     for (int i = 0; i < rdyn_chain_moveable_joints_number(m_h); ++i) m_moveable_joints_name.push_back(rdyn_chain_moveable_joint_name(m_h, i));
     for (unsigned i = 0; i < m_active_joints_number; ++i) m_active_joints_name.push_back(rdyn_chain_active_joint_name(m_h, (int)i));
+    m_active_is_revolute.assign(m_active_joints_number, 0);
+    for (unsigned i = 0; i < m_active_joints_number; ++i)
+      for (unsigned j = 0; j < m_joints_number; ++j)
+        if (m_active_joints_name[i] == rdyn_chain_joint_name(m_h, (int)j)) m_active_is_revolute[i] = rdyn_chain_joint_type(m_h, (int)j) == RDYN_REVOLUTE;
     const int n = (int)m_active_joints_number;
     m_q_max.resize(n); m_q_min.resize(n); m_Dq_max.resize(n); m_DDq_max.resize(n); m_tau_max.resize(n);
     rdyn_chain_limits(m_h, m_q_max.data(), m_q_min.data(), m_Dq_max.data(), m_DDq_max.data(), m_tau_max.data());
     // device staging: 3 n inputs + the largest single-sample output (regressor n * P, frames 12 L)
     const size_t outs = std::max<size_t>((size_t)n * 10 * m_joints_number, 12 * (size_t)m_links_number) + 16;
-    const size_t need = 3 * (size_t)n + outs;
-    if (need > m_dev_doubles)
-    {
-      if (m_dev) (void)hipFree(m_dev);
-      if (m_pin) (void)hipHostFree(m_pin);
-      hip(hipMalloc((void**)&m_dev, need * sizeof(double)));
-      hip(hipHostMalloc((void**)&m_pin, need * sizeof(double), hipHostMallocDefault));
-      m_dev_doubles = need;
-    }
+    m_need_doubles = 3 * (size_t)n + outs;  // allocated by the first single-sample call (construction and the host-only getters need no GPU)
     m_host.assign(outs, 0.0);
     std::memset(&m_b, 0, sizeof m_b);
     m_b.n_samples = 1;
@@ -483,8 +563,20 @@ private:
     m_b.stream = nullptr;
   }
   double* out(size_t off) { return m_dev + 3 * (size_t)m_active_joints_number + off; }
+  void ensure_stage()
+  {
+    if (m_need_doubles <= m_dev_doubles) return;
+    if (m_dev) (void)hipFree(m_dev);
+    if (m_pin) (void)hipHostFree(m_pin);
+    m_dev = m_pin = nullptr;
+    m_dev_doubles = 0;
+    hip(hipMalloc((void**)&m_dev, m_need_doubles * sizeof(double)));
+    hip(hipHostMalloc((void**)&m_pin, m_need_doubles * sizeof(double), hipHostMallocDefault));
+    m_dev_doubles = m_need_doubles;
+  }
   void stage(const VectorXd* q, const VectorXd* dq, const VectorXd* ddq)
   {
+    ensure_stage();
     const size_t n = m_active_joints_number;
     const VectorXd* src[3] = {q, dq, ddq};
     for (int k = 0; k < 3; ++k)
@@ -551,6 +643,382 @@ inline ChainPtr createChain(const std::string& robot_description_xml, const std:
   return ChainPtr(new Chain(robot_description_xml, base_frame, tool_frame, gravity));
 }
 inline ChainPtr createChain(const ChainPtr& cpy) { return cpy->clone(); }
+inline ChainPtr createChain(const Chain& cpy) { return cpy.clone(); }  // primitives.h:584
+
+#ifdef RDYN_FACADE_HAS_URDFDOM
+// rosdyn::createChain(const urdf::ModelInterface&, base_frame, tool_frame, gravity)   primitives.h:566 / primitives_impl.h:1518.
+// Walks tool -> base through the parsed model exactly as Chain::init does (primitives_impl.h:600-636) and hands the flat POD
+// description to the library: no XML is re-parsed.  Same exceptions and texts as the reference constructors.
+namespace detail
+{
+inline void copy_name(char dst[64], const std::string& s)
+{
+  if (s.size() > 63) throw std::runtime_error("name longer than 63 characters: " + s);
+  std::memset(dst, 0, 64);
+  std::memcpy(dst, s.c_str(), s.size());
+}
+inline ChainPtr chain_from_urdfdom(const urdf::ModelInterface& model, const std::string& base_frame, const std::string& tool_frame,
+                                   const double gravity[3])
+{
+  if (!model.getLink(base_frame)) throw std::runtime_error("Base link not found");  // primitives_impl.h:603
+  urdf::LinkConstSharedPtr link = model.getLink(tool_frame);
+  if (!link) throw std::runtime_error("Tool link not found");                        // primitives_impl.h:610
+  std::vector<rdyn_joint_desc> joints;
+  std::vector<rdyn_link_desc> links;
+  auto push_link = [&](const urdf::Link& l) {
+    rdyn_link_desc d;
+    std::memset(&d, 0, sizeof d);
+    copy_name(d.name, l.name);
+    d.com_quat[3] = 1.0;
+    if (l.inertial)
+    {
+      d.has_inertial = 1;
+      d.mass = l.inertial->mass;
+      d.com_xyz[0] = l.inertial->origin.position.x; d.com_xyz[1] = l.inertial->origin.position.y; d.com_xyz[2] = l.inertial->origin.position.z;
+      d.com_quat[0] = l.inertial->origin.rotation.x; d.com_quat[1] = l.inertial->origin.rotation.y;
+      d.com_quat[2] = l.inertial->origin.rotation.z; d.com_quat[3] = l.inertial->origin.rotation.w;
+      d.ixx = l.inertial->ixx; d.ixy = l.inertial->ixy; d.ixz = l.inertial->ixz;
+      d.iyy = l.inertial->iyy; d.iyz = l.inertial->iyz; d.izz = l.inertial->izz;
+    }
+    links.push_back(d);
+  };
+  // tool -> base, front-inserting (primitives_impl.h:615-626)
+  while (true)
+  {
+    push_link(*link);
+    if (link->name == base_frame) break;
+    const urdf::JointSharedPtr j = link->parent_joint;
+    const urdf::LinkConstSharedPtr parent = link->getParent();
+    if (!j || !parent) throw std::runtime_error("Tool link is not a descendant of the base link");
+    rdyn_joint_desc d;
+    std::memset(&d, 0, sizeof d);
+    copy_name(d.name, j->name);
+    d.urdf_type = (int32_t)j->type;  // urdf::Joint::{UNKNOWN, REVOLUTE, CONTINUOUS, PRISMATIC, FLOATING, PLANAR, FIXED} = 0..6 = rdyn_urdf_joint_type
+    d.origin_xyz[0] = j->parent_to_joint_origin_transform.position.x;
+    d.origin_xyz[1] = j->parent_to_joint_origin_transform.position.y;
+    d.origin_xyz[2] = j->parent_to_joint_origin_transform.position.z;
+    d.origin_quat[0] = j->parent_to_joint_origin_transform.rotation.x;
+    d.origin_quat[1] = j->parent_to_joint_origin_transform.rotation.y;
+    d.origin_quat[2] = j->parent_to_joint_origin_transform.rotation.z;
+    d.origin_quat[3] = j->parent_to_joint_origin_transform.rotation.w;
+    d.axis[0] = j->axis.x; d.axis[1] = j->axis.y; d.axis[2] = j->axis.z;
+    if (j->limits)
+    {
+      d.has_limits = 1;
+      d.lower = j->limits->lower; d.upper = j->limits->upper; d.velocity = j->limits->velocity; d.effort = j->limits->effort;
+    }
+    joints.push_back(d);
+    link = parent;
+  }
+  std::reverse(joints.begin(), joints.end());
+  std::reverse(links.begin(), links.end());
+  rdyn_chain_desc desc;
+  desc.n_joints = (int32_t)joints.size();
+  desc.joints = joints.data();
+  desc.links = links.data();
+  for (int i = 0; i < 3; ++i) desc.gravity[i] = gravity[i];
+  return ChainPtr(new Chain(desc));
+}
+}  // namespace detail
+inline ChainPtr createChain(const urdf::ModelInterface& urdf_model_interface, const std::string& base_frame, const std::string& tool_frame,
+                            const std::array<double, 3>& gravity)
+{
+  return detail::chain_from_urdfdom(urdf_model_interface, base_frame, tool_frame, gravity.data());
+}
+#ifdef RDYN_FACADE_HAS_EIGEN
+inline ChainPtr createChain(const urdf::ModelInterface& urdf_model_interface, const std::string& base_frame, const std::string& tool_frame,
+                            const Eigen::Vector3d& gravity)
+{
+  const double g[3] = {gravity(0), gravity(1), gravity(2)};
+  return detail::chain_from_urdfdom(urdf_model_interface, base_frame, tool_frame, g);
+}
+#endif
+#endif  // RDYN_FACADE_HAS_URDFDOM
+
+namespace detail
+{
+// one-sample staging for the small free-standing calls below (components, frame distance): pinned host + device buffer
+struct SmallStage
+{
+  double* dev = nullptr;
+  double* pin = nullptr;
+  size_t cap = 0;
+  ~SmallStage()
+  {
+    if (dev) (void)hipFree(dev);
+    if (pin) (void)hipHostFree(pin);
+  }
+  void reserve(size_t doubles)
+  {
+    if (doubles <= cap) return;
+    if (dev) (void)hipFree(dev);
+    if (pin) (void)hipHostFree(pin);
+    dev = pin = nullptr;
+    cap = 0;
+    if (hipMalloc((void**)&dev, doubles * sizeof(double)) != hipSuccess || hipHostMalloc((void**)&pin, doubles * sizeof(double), hipHostMallocDefault) != hipSuccess)
+      throw std::runtime_error("HIP: staging allocation failed");
+    cap = doubles;
+  }
+  void up(size_t n) { if (hipMemcpyAsync(dev, pin, n * sizeof(double), hipMemcpyHostToDevice, nullptr) != hipSuccess) throw std::runtime_error("HIP: copy failed"); }
+  void down(size_t off, size_t n)
+  {
+    if (hipMemcpyAsync(pin + off, dev + off, n * sizeof(double), hipMemcpyDeviceToHost, nullptr) != hipSuccess || hipStreamSynchronize(nullptr) != hipSuccess)
+      throw std::runtime_error("HIP: copy failed");
+  }
+};
+inline void status(int st)
+{
+  if (st == RDYN_ERR_INVALID_ARGUMENT) throw std::invalid_argument(rdyn_last_error());
+  if (st != RDYN_OK) throw std::runtime_error(rdyn_last_error());
+}
+}  // namespace detail
+
+// ---- per-joint additive components (base_component.h:59-189, friction_polynomial1.h:39-146, friction_polynomial2.h:36-154,
+// ideal_spring.h:37-85).  Same class and method names; the constructors take the joint list and the constants directly instead
+// of reading "<robot>/joint_names" and "<robot>/<joint>/<type>/{coefficients,constants}" from a ros::NodeHandle
+// (base_component.h:87-99).  The regressor row is evaluated by the HIP kernel (rdyn_components_regressor), the torque variants are
+// the reference's products of that row with the parameters.  descriptor() feeds the batched calls (Chain::getIdentificationGramBatch).
+class ComponentBase
+{
+protected:
+  std::string m_type, m_component_joint_name;
+  std::vector<std::string> m_joint_names;
+  unsigned int m_joints_number = 0, m_component_joint_number = 0;
+  VectorXd m_torques, m_nominal_parameters;
+  MatrixXd m_regressor;
+  rdyn_component m_desc;
+  detail::SmallStage m_stage;
+
+  void computeRegressor(const VectorXd& q, const VectorXd& Dq)
+  {
+    const unsigned n = m_joints_number;
+    if ((unsigned)q.rows() != n || (unsigned)Dq.rows() != n) throw std::invalid_argument("Input data dimensions mismatch");
+    const int K = rdyn_components_columns(&m_desc, 1);
+    m_stage.reserve(2 * n + (size_t)n * K);
+    std::memcpy(m_stage.pin, q.data(), n * sizeof(double));
+    std::memcpy(m_stage.pin + n, Dq.data(), n * sizeof(double));
+    m_stage.up(2 * n);
+    rdyn_batch b;
+    std::memset(&b, 0, sizeof b);
+    b.n_samples = 1;
+    b.q = m_stage.dev;
+    b.dq = m_stage.dev + n;
+    b.layout = RDYN_LAYOUT_SAMPLE_MAJOR;
+    b.device = -1;
+    const rdyn_regressor_layout cl = {(int64_t)n * K, 1, (int64_t)n};  // column-major n x K
+    for (int k = 0; k < 3; ++k) m_desc.parameters[k] = k < (int)m_nominal_parameters.rows() ? m_nominal_parameters(k) : 0.0;
+    detail::status(rdyn_components_regressor(&m_desc, 1, (int)n, &b, m_stage.dev + 2 * n, &cl, nullptr));
+    m_stage.down(2 * n, (size_t)n * K);
+    m_regressor.resize((int)n, K);
+    std::memcpy(m_regressor.data(), m_stage.pin + 2 * n, sizeof(double) * n * K);
+  }
+  double rowTimesParameters(int first_col) const
+  {
+    double t = 0.0;
+    for (int k = first_col; k < m_regressor.cols(); ++k) t += m_regressor((int)m_component_joint_number, k) * m_nominal_parameters(k);
+    return t;
+  }
+
+public:
+  ComponentBase(const std::string& joint_name, const std::vector<std::string>& joint_names, int type) : m_component_joint_name(joint_name), m_joint_names(joint_names)
+  {
+    m_joints_number = (unsigned)m_joint_names.size();
+    for (m_component_joint_number = 0; m_component_joint_number < m_joints_number; ++m_component_joint_number)
+      if (m_joint_names[m_component_joint_number] == m_component_joint_name) break;
+    if (m_component_joint_number == m_joints_number)  // base_component.h:121-122
+      throw std::invalid_argument("Component Joint name '" + m_component_joint_name + "' is not a elemente of the joint names");
+    m_torques.resize((int)m_joints_number);
+    std::memset(&m_desc, 0, sizeof m_desc);
+    m_desc.type = type;
+    m_desc.joint = (int32_t)m_component_joint_number;
+  }
+  virtual ~ComponentBase() {}
+  ComponentBase(const ComponentBase&) = delete;
+  ComponentBase& operator=(const ComponentBase&) = delete;
+  virtual VectorXd getTorque(const VectorXd& q, const VectorXd& Dq, const VectorXd& DDq) = 0;
+  virtual VectorXd getAdditiveTorque(const VectorXd& q, const VectorXd& Dq, const VectorXd& DDq) { return getTorque(q, Dq, DDq); }  // base_component.h:130
+  virtual VectorXd getNonAdditiveTorque(const VectorXd&, const VectorXd&, const VectorXd&, const VectorXd&)  // base_component.h:135-141
+  {
+    VectorXd t((int)m_joints_number);
+    for (unsigned i = 0; i < m_joints_number; ++i) t((int)i) = 0.0;
+    return t;
+  }
+  virtual MatrixXd getRegressor(const VectorXd& q, const VectorXd& Dq, const VectorXd& DDq) = 0;
+  unsigned int getParametersNumber() { return (unsigned)m_nominal_parameters.rows(); }
+  VectorXd getNominalParameters() { return m_nominal_parameters; }
+  const std::string& getJointName() const { return m_component_joint_name; }
+  virtual bool setParameters(const VectorXd& parameters)
+  {
+    if (parameters.rows() != m_nominal_parameters.rows()) return false;  // ideal_spring.h:74-78
+    m_nominal_parameters = parameters;
+    return true;
+  }
+  // the C-ABI descriptor of this component with its current parameters (rdyn_components_regressor, rdyn_identification_gram)
+  rdyn_component descriptor() const
+  {
+    rdyn_component d = m_desc;
+    for (int k = 0; k < 3; ++k) d.parameters[k] = k < (int)m_nominal_parameters.rows() ? m_nominal_parameters(k) : 0.0;
+    return d;
+  }
+};
+
+// friction_polynomial1.h:39-146: regressor row [sign, omega], parameters {coloumb, viscous}
+class FirstOrderPolynomialFriction : public ComponentBase
+{
+protected:
+  double m_Dq_threshold, m_Dq_max;
+  VectorXd frictionNonAdditive(const VectorXd& Dq, const VectorXd& additive_torque)
+  {
+    VectorXd tau = additive_torque;
+    const int j = (int)m_component_joint_number;
+    const double c0 = m_nominal_parameters(0);
+    if (std::fabs(Dq(j)) < m_Dq_threshold)  // static condition, friction_polynomial1.h:109-117
+    {
+      if (std::fabs(additive_torque(j)) <= c0) tau(j) = 0;
+      else if (additive_torque(j) > c0) tau(j) -= c0;
+      else if (additive_torque(j) < -c0) tau(j) += c0;
+    }
+    else
+      tau(j) += m_regressor(j, 0) * c0;
+    return tau;
+  }
+
+public:
+  FirstOrderPolynomialFriction(const std::string& joint_name, const std::vector<std::string>& joint_names, double coloumb, double viscous,
+                               double min_velocity, double max_velocity, int type = RDYN_COMP_FRICTION1)
+    : ComponentBase(joint_name, joint_names, type)
+  {
+    m_type = "friction";
+    m_Dq_threshold = min_velocity < 1e-6 ? 1e-6 : min_velocity;  // friction_polynomial1.h:72-78
+    m_Dq_max = max_velocity <= 0 ? 1.0e6 : max_velocity;         // friction_polynomial1.h:80-86
+    m_desc.min_velocity = m_Dq_threshold;
+    m_desc.max_velocity = m_Dq_max;
+    m_nominal_parameters.resize(type == RDYN_COMP_FRICTION2 ? 3 : 2);
+    m_nominal_parameters(0) = coloumb;
+    m_nominal_parameters(1) = viscous;
+    m_regressor.resize((int)m_joints_number, (int)m_nominal_parameters.rows());
+  }
+  VectorXd getTorque(const VectorXd& q, const VectorXd& Dq, const VectorXd&) override
+  {
+    computeRegressor(q, Dq);
+    m_torques((int)m_component_joint_number) = rowTimesParameters(0);
+    return m_torques;
+  }
+  VectorXd getAdditiveTorque(const VectorXd& q, const VectorXd& Dq, const VectorXd&) override  // viscous part only, :97-103
+  {
+    computeRegressor(q, Dq);
+    m_torques((int)m_component_joint_number) = rowTimesParameters(1);
+    return m_torques;
+  }
+  VectorXd getNonAdditiveTorque(const VectorXd&, const VectorXd& Dq, const VectorXd&, const VectorXd& additive_torque) override
+  {
+    return frictionNonAdditive(Dq, additive_torque);
+  }
+  MatrixXd getRegressor(const VectorXd& q, const VectorXd& Dq, const VectorXd&) override
+  {
+    computeRegressor(q, Dq);
+    return m_regressor;
+  }
+  bool setParameters(const VectorXd& parameters) override  // the reference accepts any size here (:133-145); sizes are checked
+  {
+    return ComponentBase::setParameters(parameters);
+  }
+};
+
+// friction_polynomial2.h:36-154: regressor row [sign, omega, omega^2 sign], parameters {coloumb, first_order_viscous, second_order_viscous}
+class SecondOrderPolynomialFriction : public FirstOrderPolynomialFriction
+{
+public:
+  SecondOrderPolynomialFriction(const std::string& joint_name, const std::vector<std::string>& joint_names, double coloumb,
+                                double first_order_viscous, double second_order_viscous, double min_velocity, double max_velocity)
+    : FirstOrderPolynomialFriction(joint_name, joint_names, coloumb, first_order_viscous, min_velocity, max_velocity, RDYN_COMP_FRICTION2)
+  {
+    m_nominal_parameters(2) = second_order_viscous;
+  }
+};
+
+// ideal_spring.h:37-85: regressor row [q, 1], parameters {elasticity, offset_effort}.  The reference's getTorque reads
+// q(m_joints_number) -- one past the end (ideal_spring.h:60); the component's own joint is used here.
+class IdealSpring : public ComponentBase
+{
+public:
+  IdealSpring(const std::string& joint_name, const std::vector<std::string>& joint_names, double elasticity, double offset_effort)
+    : ComponentBase(joint_name, joint_names, RDYN_COMP_SPRING)
+  {
+    m_type = "spring";
+    m_nominal_parameters.resize(2);
+    m_nominal_parameters(0) = elasticity;
+    m_nominal_parameters(1) = offset_effort;
+    m_regressor.resize((int)m_joints_number, 2);
+  }
+  VectorXd getTorque(const VectorXd& q, const VectorXd& Dq, const VectorXd&) override
+  {
+    computeRegressor(q, Dq);
+    m_torques((int)m_component_joint_number) = rowTimesParameters(0);
+    return m_torques;
+  }
+  MatrixXd getRegressor(const VectorXd& q, const VectorXd& Dq, const VectorXd&) override
+  {
+    computeRegressor(q, Dq);
+    return m_regressor;
+  }
+};
+
+// ---- frame_distance.h:44-149: pose error between two frames, evaluated by k_frame_distance (one pair per call here; the batched
+// form is rdyn_frame_distance on device records)
+namespace detail
+{
+inline void frame_distance(const Affine3d& T_wa, const Affine3d& T_wb, int kind, Vector6d& distance, Matrix66d* jacobian)
+{
+  static thread_local SmallStage st;
+  st.reserve(24 + 6 + 36);
+  const Affine3d* T[2] = {&T_wa, &T_wb};
+  for (int k = 0; k < 2; ++k)
+    for (int c = 0; c < 4; ++c)
+      for (int r = 0; r < 3; ++r)
+#ifdef RDYN_FACADE_HAS_EIGEN
+        st.pin[12 * k + c * 3 + r] = T[k]->matrix()(r, c);
+#else
+        st.pin[12 * k + c * 3 + r] = (*T[k])(r, c);
+#endif
+  st.up(24);
+  status(rdyn_frame_distance(1, st.dev, st.dev + 12, RDYN_LAYOUT_SAMPLE_MAJOR, kind, st.dev + 24, jacobian ? st.dev + 30 : nullptr, -1, nullptr));
+  st.down(24, jacobian ? 42 : 6);
+  for (int i = 0; i < 6; ++i) distance(i) = st.pin[24 + i];
+  if (jacobian)
+    for (int c = 0; c < 6; ++c)
+      for (int r = 0; r < 6; ++r) (*jacobian)(r, c) = st.pin[30 + c * 6 + r];
+}
+}  // namespace detail
+inline void getFrameDistance(const Affine3d& T_wa, const Affine3d& T_wb, Vector6d& distance)          // frame_distance.h:44
+{
+  detail::frame_distance(T_wa, T_wb, RDYN_FRAME_DISTANCE_AXIS_ANGLE, distance, nullptr);
+}
+inline void getFrameDistanceQuat(const Affine3d& T_wa, const Affine3d& T_wb, Vector6d& distance)      // frame_distance.h:74
+{
+  detail::frame_distance(T_wa, T_wb, RDYN_FRAME_DISTANCE_QUAT, distance, nullptr);
+}
+inline void getFrameDistanceQuatJac(const Affine3d& T_wa, const Affine3d& T_wb, Vector6d& distance, Matrix66d& jacobian)  // :114
+{
+  detail::frame_distance(T_wa, T_wb, RDYN_FRAME_DISTANCE_QUAT_JAC, distance, &jacobian);
+}
+
+// ---- mixed-chain batch (BASELINE.json configs[4]): many (chain, batch) items, one launch per joint-count group
+class MultiChainPlan
+{
+public:
+  explicit MultiChainPlan(const std::vector<rdyn_multi_item>& items)
+  {
+    detail::status(rdyn_multi_plan_create(items.data(), (int)items.size(), &m_plan));
+  }
+  ~MultiChainPlan() { rdyn_multi_plan_destroy(m_plan); }
+  MultiChainPlan(const MultiChainPlan&) = delete;
+  MultiChainPlan& operator=(const MultiChainPlan&) = delete;
+  void getRegressor(hipStream_t stream = nullptr) const { detail::status(rdyn_multi_plan_regressor(m_plan, stream)); }
+
+private:
+  rdyn_multi_plan* m_plan = nullptr;
+};
 
 }  // namespace rosdyn
 

@@ -1,0 +1,92 @@
+// Compiled by tests/test_facade.py with -Itests/mock_include: the Eigen-typed and urdfdom-typed branches of the facade
+// (RDYN_FACADE_HAS_EIGEN, RDYN_FACADE_HAS_URDFDOM).  Host-only checks (no GPU call): a chain built from an in-memory urdf model
+// through createChain(const urdf::ModelInterface&, ...) must equal the chain the library builds from the same robot as XML.
+#include <cmath>
+#include <cstdio>
+#include "rosdyn_chain_facade.hpp"
+
+#if !defined(RDYN_FACADE_HAS_EIGEN) || !defined(RDYN_FACADE_HAS_URDFDOM)
+#error "compile with -Itests/mock_include"
+#endif
+
+static urdf::LinkSharedPtr add_link(urdf::ModelInterface& m, const char* name, double mass, double cx, double ixx)
+{
+  auto l = std::make_shared<urdf::Link>();
+  l->name = name;
+  if (mass > 0)
+  {
+    l->inertial = std::make_shared<urdf::Inertial>();
+    l->inertial->mass = mass;
+    l->inertial->origin.position.x = cx;
+    l->inertial->ixx = ixx; l->inertial->iyy = 2 * ixx; l->inertial->izz = 3 * ixx;
+  }
+  m.links_[name] = l;
+  return l;
+}
+static void add_joint(urdf::ModelInterface& m, const char* name, int type, urdf::LinkSharedPtr p, urdf::LinkSharedPtr c, double x, double z, double ax, double az)
+{
+  auto j = std::make_shared<urdf::Joint>();
+  j->name = name;
+  j->type = type;
+  j->parent_link_name = p->name;
+  j->child_link_name = c->name;
+  j->parent_to_joint_origin_transform.position.x = x;
+  j->parent_to_joint_origin_transform.position.z = z;
+  j->axis.x = ax; j->axis.z = az;
+  if (type != urdf::Joint::FIXED)
+  {
+    j->limits = std::make_shared<urdf::JointLimits>();
+    j->limits->lower = -2; j->limits->upper = 2; j->limits->velocity = 1.5; j->limits->effort = 30;
+  }
+  c->parent_joint = j;
+  c->setParent(p);
+  p->child_joints.push_back(j);
+  p->child_links.push_back(c);
+  m.joints_[name] = j;
+}
+
+int main()
+{
+  urdf::ModelInterface m;
+  auto b = add_link(m, "base", 0, 0, 0), l1 = add_link(m, "l1", 2.0, 0.1, 0.01), l2 = add_link(m, "l2", 1.5, 0.2, 0.02),
+       l3 = add_link(m, "l3", 0.5, 0.05, 0.005), tool = add_link(m, "tool", 0, 0, 0);
+  m.root_link_ = b;
+  add_joint(m, "j1", urdf::Joint::REVOLUTE, b, l1, 0.0, 0.3, 0, 1);
+  add_joint(m, "j2", urdf::Joint::PRISMATIC, l1, l2, 0.4, 0.0, 1, 0);
+  add_joint(m, "j3", urdf::Joint::CONTINUOUS, l2, l3, 0.2, 0.1, 0, 2);   // axis not normalised
+  add_joint(m, "jt", urdf::Joint::FIXED, l3, tool, 0.1, 0.0, 0, 0);
+  const char* xml =
+      "<robot name='r'><link name='base'/>"
+      "<link name='l1'><inertial><origin xyz='0.1 0 0'/><mass value='2.0'/><inertia ixx='0.01' ixy='0' ixz='0' iyy='0.02' iyz='0' izz='0.03'/></inertial></link>"
+      "<link name='l2'><inertial><origin xyz='0.2 0 0'/><mass value='1.5'/><inertia ixx='0.02' ixy='0' ixz='0' iyy='0.04' iyz='0' izz='0.06'/></inertial></link>"
+      "<link name='l3'><inertial><origin xyz='0.05 0 0'/><mass value='0.5'/><inertia ixx='0.005' ixy='0' ixz='0' iyy='0.01' iyz='0' izz='0.015'/></inertial></link>"
+      "<link name='tool'/>"
+      "<joint name='j1' type='revolute'><parent link='base'/><child link='l1'/><origin xyz='0 0 0.3'/><axis xyz='0 0 1'/><limit lower='-2' upper='2' velocity='1.5' effort='30'/></joint>"
+      "<joint name='j2' type='prismatic'><parent link='l1'/><child link='l2'/><origin xyz='0.4 0 0'/><axis xyz='1 0 0'/><limit lower='-2' upper='2' velocity='1.5' effort='30'/></joint>"
+      "<joint name='j3' type='continuous'><parent link='l2'/><child link='l3'/><origin xyz='0.2 0 0.1'/><axis xyz='0 0 2'/><limit lower='-2' upper='2' velocity='1.5' effort='30'/></joint>"
+      "<joint name='jt' type='fixed'><parent link='l3'/><child link='tool'/><origin xyz='0.1 0 0'/></joint></robot>";
+  Eigen::Vector3d g;
+  g(0) = 0; g(1) = 0; g(2) = -9.806;
+  rosdyn::ChainPtr a = rosdyn::createChain(m, "base", "tool", g);                       // the reference's signature, primitives.h:566
+  rosdyn::ChainPtr c = rosdyn::createChain(std::string(xml), "base", "tool", {0.0, 0.0, -9.806});
+  int bad = 0;
+  bad += a->getLinksNumber() != c->getLinksNumber() || a->getJointsNumber() != 4 || a->getActiveJointsNumber() != 3;
+  bad += a->getActiveJointsName() != c->getActiveJointsName() || a->getLinksName() != c->getLinksName();
+  const rosdyn::VectorXd pa = a->getNominalParameters(), pc = c->getNominalParameters();
+  for (int i = 0; i < pa.rows(); ++i) bad += std::fabs(pa(i) - pc(i)) > 1e-15;
+  for (int i = 0; i < 3; ++i) bad += a->getQMax()(i) != c->getQMax()(i) || a->getDQMax()(i) != c->getDQMax()(i) || a->getTauMax()(i) != c->getTauMax()(i);
+  try { rosdyn::createChain(m, "nope", "tool", g); ++bad; } catch (const std::runtime_error& e) { bad += std::string(e.what()) != "Base link not found"; }
+  try { rosdyn::createChain(m, "base", "nope", g); ++bad; } catch (const std::runtime_error& e) { bad += std::string(e.what()) != "Tool link not found"; }
+  // getMultiplicity on Eigen types (host only): the continuous joint j3 has the reference's +-1e10 limits -> refused;
+  // without it (input joints j1, j2) q has no other turn inside [-2, 2]: exactly one vector
+  rosdyn::VectorXd q(3);
+  q(0) = 0.1; q(1) = 0.2; q(2) = 0.3;
+  try { a->getMultiplicity(q); ++bad; } catch (const std::invalid_argument&) {}
+  bad += !a->setInputJointsName({"j1", "j2"});
+  rosdyn::VectorXd q2(2);
+  q2(0) = 0.1; q2(1) = 0.2;
+  bad += a->getMultiplicity(q2).size() != 1;
+  std::printf("facade typed surface: %s (%u links, %u joints, %u active, %d parameters)\n", bad ? "MISMATCH" : "ok", a->getLinksNumber(),
+              a->getJointsNumber(), a->getActiveJointsNumber(), (int)pa.rows());
+  return bad ? 1 : 0;
+}

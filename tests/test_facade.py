@@ -17,6 +17,20 @@ def test_facade_header_compiles_standalone(tmp_path):
                            "-I" + os.path.join(ROOT, "rosdyn_amd", "csrc"), str(src)])
 
 
+def test_eigen_and_urdfdom_typed_branches_compile_and_run(tmp_path):
+    """The RDYN_FACADE_HAS_EIGEN / RDYN_FACADE_HAS_URDFDOM branches of the facade against test-only stand-ins of the few Eigen /
+    urdfdom names they touch (tests/mock_include: neither library is installed here).  createChain(const urdf::ModelInterface&, ...)
+    must build the same chain as the XML route; host-only, runs on the CPU box."""
+    exe = tmp_path / "typed"
+    subprocess.check_call(["g++", "-std=c++17", "-Wall", "-Wextra", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include",
+                           "-I" + os.path.join(ROOT, "tests", "mock_include"), "-I" + os.path.join(ROOT, "rosdyn_amd", "csrc"),
+                           os.path.join(ROOT, "tests", "cpp", "facade_typed_surface.cpp"), "-o", str(exe),
+                           "-L" + os.path.join(ROOT, "rosdyn_amd"), "-lrdyn_hip", "-L/opt/rocm/lib", "-lamdhip64",
+                           "-Wl,-rpath," + os.path.join(ROOT, "rosdyn_amd"), "-Wl,-rpath,/opt/rocm/lib"])
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
+
+
 def test_harness_binary_is_built_and_reports_usage():
     assert os.path.exists(BIN), "run __graft_entry__.build()"
     r = subprocess.run([BIN], capture_output=True, text=True)
@@ -45,7 +59,7 @@ def test_facade_single_sample_values_match_oracle():
     urdf = os.path.join(FIXTURES, "ur10_like.urdf")
     r = subprocess.run([BIN, urdf, "base_link", "tool0", "1", "dump"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr
-    vals = {l.split()[0]: np.array([float(x) for x in l.split()[1:]]) for l in r.stdout.splitlines() if l and l[0] in "tYMTJILW"}
+    vals = {l.split()[0]: np.array([float(x) for x in l.split()[1:]]) for l in r.stdout.splitlines() if l and l[0] in "tYMTJILWAPCFS"}
     ref = OracleChain(urdf, "base_link", "tool0", (0.0, 0.0, -9.806))
     n = ref.n
     q = np.array([[0.1 * (i + 1) for i in range(n)]])
@@ -73,3 +87,42 @@ def test_facade_single_sample_values_match_oracle():
     rsol, rst, _ = ref.local_ik(ref.fk(q)[:, -1], seed, toll=1e-8, max_iter=50)
     assert vals["IK"][0] == 1.0 and rst[0] == 1
     assert np.abs(vals["IK"][1:] - rsol[0]).max() < 1e-9
+    # ---- the rest of the reference's surface
+    close(vals["A"], ref.joint_torque(q, dq, ddq)[0])                      # copy-assigned chain evaluates
+    # getMultiplicity: ur10_like limits are +-2 pi on every joint -> q + 2 pi k stays inside for k in {-1, 0} (q > 0): 2^6 vectors
+    counts = [1 + int(np.floor((ref.spec.q_max[i] - q[0, i]) / (2 * np.pi))) + int(np.floor((q[0, i] - ref.spec.q_min[i]) / (2 * np.pi)))
+              for i in range(n)]
+    assert vals["P"][0] == np.prod(counts)
+    assert np.allclose(vals["P"][1:1 + n], q[0])                           # the first entry is q itself (primitives_impl.h:1500)
+    # components on joint 1: rows / torques against the oracle's restatement (oracle/components_oracle.c)
+    from oracle.oracle import components_regressor
+    specs = [(0, 1, 1e-3, 0.08, (0.4, 0.9, 0.0)), (1, 1, 1e-3, 0.0, (0.4, 0.9, 0.25)), (2, 1, 0.0, 0.0, (12.0, -0.7, 0.0))]
+    got, k = vals["C"], 0
+    for spec in specs:
+        Cr, tr = components_regressor([spec], n, q, dq)                    # (1, n, K), (1, n)
+        K = Cr.shape[2]
+        row = Cr[0, 1]
+        close(got[k:k + K], row)
+        par = np.array(spec[4][:K])
+        torque = float(row @ par)
+        additive = float(row[1:] @ par[1:]) if spec[0] < 2 else torque      # friction: viscous part only; spring: base class = getTorque
+        close(got[k + K:k + K + 2], np.array([torque, additive]))
+        if spec[0] < 2:    # getNonAdditiveTorque(additive_torque = 1): moving joint -> + sign * coloumb
+            close(got[k + K + 2:k + K + 3], np.array([1.0 + row[0] * par[0]]))
+        else:
+            assert got[k + K + 2] == 0.0
+        assert got[k + K + 3] == K
+        k += K + 4
+    # frame distances of T(q) vs T(seed)
+    from oracle.oracle import frame_distance, frame_distance_quat
+    Ta, Tb = ref.fk(q)[0, -1], ref.fk(seed)[0, -1]
+    close(vals["F"][0:6], frame_distance(Ta, Tb))
+    close(vals["F"][6:12], frame_distance_quat(Ta, Tb))
+    d2, jac = frame_distance_quat(Ta, Tb, jac=True)
+    close(vals["F"][12:18], d2)
+    close(vals["F"][18:54], jac.T.reshape(-1))
+    # identification in C++: rank-deficient normal equations solved on the host, G x = c to rounding, same torques as the nominal set
+    assert vals["S"][0] < 10 * ref.L - 10 and vals["S"][1] <= 1e-9
+    x = vals["S"][2:]
+    Yq = ref.regressor(q, dq, ddq)[0]
+    close(Yq @ x, ref.joint_torque(q, dq, ddq)[0])
