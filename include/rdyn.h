@@ -322,6 +322,23 @@ size_t rdyn_regressor_gram_workspace_bytes(const rdyn_chain* chain, int64_t chun
 int rdyn_regressor_gram(const rdyn_chain* chain, const rdyn_batch* batch, const double* tau_meas, double* G, double* c,
                         double* bb, int accumulate, int64_t chunk_samples, void* workspace, size_t workspace_bytes);
 
+/* ---- BASELINE.json configs[3] inside the library (rdyn_multi_gpu.cpp): one process, the trajectory batch
+ * sharded over the GPUs of a node, every GPU the fused regressor -> Gram of its shard, then ONE
+ * ncclAllReduce(P*P + P + 2 doubles, ncclDouble, ncclSum) over RCCL / xGMI.  rdyn_multi_gpu_create initialises one communicator
+ * (ncclCommInitAll) and one stream per device; RCCL is resolved at run time (librccl.so.1) -> RDYN_ERR_UNSUPPORTED if absent.
+ * rdyn_regressor_gram_multi: batches[i] (device pointers on devices[i]; batch.device = devices[i] or -1; the stream field is
+ * ignored: the context's stream of that device is used), tau_meas[i] (may be NULL as a whole or per shard), acc[i] = a device
+ * buffer of P*P + P + 2 doubles on devices[i].  On return (asynchronous: rdyn_multi_gpu_synchronize, or synchronise the devices)
+ * EVERY acc[i] holds the sums over all shards  [G = A'A (P*P, column-major) | c = A'tau_meas (P) | bb = tau_meas'tau_meas | count].
+ * No reference counterpart (rosdyn_core has no multi-device code). */
+typedef struct rdyn_multi_gpu rdyn_multi_gpu;
+int rdyn_multi_gpu_create(const int* devices, int n_devices, rdyn_multi_gpu** out);
+void rdyn_multi_gpu_destroy(rdyn_multi_gpu* ctx);
+int rdyn_multi_gpu_device_count(const rdyn_multi_gpu* ctx);
+int rdyn_multi_gpu_synchronize(rdyn_multi_gpu* ctx);
+int rdyn_regressor_gram_multi(rdyn_multi_gpu* ctx, const rdyn_chain* chain, const rdyn_batch* batches, const double* const* tau_meas,
+                              double* const* acc);
+
 /* ---- the small dense solves of the identification step (HOST pointers, column-major; rdyn_solve.cpp).  No counterpart inside
  * rosdyn_core (external rosdyn_identification, README.md:15).
  * rdyn_solve_normal_equations: minimum-norm least-squares solution x (n) of G x = c for the symmetric positive SEMI-definite

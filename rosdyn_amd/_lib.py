@@ -99,6 +99,11 @@ SYMBOLS = {
     "rdyn_identification_gram": (_I, [_VP, _VP, _I, _BP, _VP, _VP, _VP, _VP, _I, _VP, C.c_size_t]),
     "rdyn_regressor_gram_workspace_bytes": (C.c_size_t, [_VP, C.c_int64]),
     "rdyn_regressor_gram": (_I, [_VP, _BP, _VP, _VP, _VP, _VP, _I, C.c_int64, _VP, C.c_size_t]),
+    "rdyn_multi_gpu_create": (_I, [C.POINTER(C.c_int), _I, C.POINTER(_VP)]),
+    "rdyn_multi_gpu_destroy": (None, [_VP]),
+    "rdyn_multi_gpu_device_count": (_I, [_VP]),
+    "rdyn_multi_gpu_synchronize": (_I, [_VP]),
+    "rdyn_regressor_gram_multi": (_I, [_VP, _VP, _BP, C.POINTER(_VP), C.POINTER(_VP)]),
     "rdyn_solve_normal_equations": (_I, [_DP, _DP, _I, C.c_double, _DP, C.POINTER(C.c_int)]),
     "rdyn_gram_r_factor": (_I, [_DP, _I, C.c_double, _DP, C.POINTER(C.c_int32), C.POINTER(C.c_int)]),
     "rdyn_solve_r_factor": (_I, [_DP, C.c_int64, _I, _I, _DP, C.c_double, _DP, C.POINTER(C.c_int)]),

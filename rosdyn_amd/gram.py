@@ -134,3 +134,51 @@ def solve_base_parameters(G, c, rtol=1e-10):
     keep = w > rtol * w.max()
     x = V[:, keep] @ ((V[:, keep].T @ ch) / w[keep])
     return x, int(keep.sum())
+
+
+class MultiGpuGram(object):
+    """include/rdyn.h: rdyn_multi_gpu_* -- one process, the batch sharded over `devices`, every device the fused regressor -> Gram of
+    its shard, ONE ncclAllReduce of [G | c | bb | count] inside the library (RCCL resolved at run time)."""
+
+    def __init__(self, devices):
+        self.devices = [int(d) for d in devices]
+        arr = (C.c_int * len(self.devices))(*self.devices)
+        self._h = C.c_void_p()
+        check(lib().rdyn_multi_gpu_create(arr, len(self.devices), C.byref(self._h)))
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            lib().rdyn_multi_gpu_destroy(h)
+            self._h = None
+
+    def regressor_gram(self, chain, shards, layout="sample"):
+        """shards[i] = (q, Dq, DDq, tau_meas) float64 CUDA tensors on devices[i].  Returns the list of per-device accumulators
+        (P*P + P + 2,): after synchronisation every one holds the sums over all shards."""
+        import torch
+        from ._lib import Batch, LAYOUT_ELEMENT_MAJOR, LAYOUT_SAMPLE_MAJOR
+        assert len(shards) == len(self.devices)
+        P = 10 * chain.getJointsNumber()
+        n = chain.getActiveJointsNumber()
+        batches = (Batch * len(shards))()
+        taus = (C.c_void_p * len(shards))()
+        accs = (C.c_void_p * len(shards))()
+        out = []
+        for i, (q, dq, ddq, tau) in enumerate(shards):
+            for t in (q, dq, ddq, tau):
+                assert t.is_cuda and t.device.index == self.devices[i] and t.dtype == torch.float64 and t.is_contiguous()
+            b = batches[i]
+            b.n_samples = q.shape[1] if layout == "element" else q.shape[0]
+            assert (q.shape[0] if layout == "element" else q.shape[1]) == n
+            b.q, b.dq, b.ddq = q.data_ptr(), dq.data_ptr(), ddq.data_ptr()
+            b.layout = LAYOUT_ELEMENT_MAJOR if layout == "element" else LAYOUT_SAMPLE_MAJOR
+            b.device = self.devices[i]
+            taus[i] = tau.data_ptr()
+            a = torch.empty((P * P + P + 2,), dtype=torch.float64, device=q.device)
+            accs[i] = a.data_ptr()
+            out.append(a)
+        for d in self.devices:
+            torch.cuda.synchronize(d)      # the inputs were produced on torch's streams; the library uses its own
+        check(lib().rdyn_regressor_gram_multi(self._h, chain._h, batches, taus, accs))
+        check(lib().rdyn_multi_gpu_synchronize(self._h))
+        return out

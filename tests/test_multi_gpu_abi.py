@@ -1,0 +1,44 @@
+"""rdyn_multi_gpu_* (RCCL inside the library).  CPU box: the symbols exist and the argument checks answer
+before anything touches a device.  GPU box: the world-1 degenerate case (one device, the all-reduce of one rank) equals
+rdyn_regressor_gram and carries the sample count; an 8-GPU node is the driver's."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from conftest import FIXTURES
+
+
+def test_symbols_and_argument_checks_without_a_gpu():
+    from rosdyn_amd._lib import lib
+    l = lib()
+    h = C.c_void_p()
+    assert l.rdyn_multi_gpu_create(None, 0, C.byref(h)) == 1 and b"device ordinals" in l.rdyn_last_error()
+    two_same = (C.c_int * 2)(0, 0)
+    assert l.rdyn_multi_gpu_create(two_same, 2, C.byref(h)) == 1 and b"distinct" in l.rdyn_last_error()
+    assert l.rdyn_multi_gpu_device_count(None) == 0
+    assert l.rdyn_multi_gpu_synchronize(None) == 1
+    assert l.rdyn_regressor_gram_multi(None, None, None, None, None) == 1
+    l.rdyn_multi_gpu_destroy(None)      # harmless
+
+
+@pytest.mark.gpu
+def test_world_one_equals_single_device_gram():
+    torch = pytest.importorskip("torch")
+    from rosdyn_amd import Chain
+    from rosdyn_amd.gram import MultiGpuGram
+    chain = Chain(os.path.join(FIXTURES, "ur10_like.urdf"), "base_link", "wrist_3_link", (0.0, 0.0, -9.806))
+    n, P, N = 6, 60, 50000 + 3
+    gen = torch.Generator(device="cuda").manual_seed(8)
+    q, dq, ddq, tau = (torch.rand((N, n), dtype=torch.float64, device="cuda:0", generator=gen) * 2 - 1 for _ in range(4))
+    ctx = MultiGpuGram([0])
+    acc = ctx.regressor_gram(chain, [(q, dq, ddq, tau)])[0].cpu().numpy()
+    G, c, bb = chain.getRegressorGram(q, dq, ddq, tau)
+    torch.cuda.synchronize()
+    assert np.array_equal(acc[:P * P].reshape(P, P), G.cpu().numpy())
+    assert np.array_equal(acc[P * P:P * P + P], c.cpu().numpy())
+    assert acc[P * P + P] == float(bb.cpu()[0]) and acc[P * P + P + 1] == N
+    # a second call reuses communicator, stream and workspace
+    acc2 = ctx.regressor_gram(chain, [(q, dq, ddq, tau)])[0].cpu().numpy()
+    assert np.array_equal(acc, acc2)
