@@ -777,6 +777,36 @@ size_t rdyn_regressor_gram_workspace_bytes(const rdyn_chain* c, int64_t chunk_sa
   return gram_slab_bytes(P) + (chunked > fused ? chunked : fused);
 }
 
+// Tile layout of the LDS-resident regressor -> Gram kernels (rdyn_lds_gram.hip, rdyn_pipe_gram.hip, rdyn_duo_gram.hip): the columns
+// of link f keep the rows of the input joints at chain index <= f; K component columns (one 16-row group each) and the measured
+// torque follow.  Returns false when the input joints are not in chain order (the packed rows must be a prefix).
+static bool build_lds_tile(const rdyn_chain* c, int n_comp_cols, bool dummy_slot, RdynLdsGramArgs* la)
+{
+  const int n = c->n_active(), nJ = c->n_joints();
+  bool monotonic = true;
+  for (int j = 1; j < n; ++j) monotonic = monotonic && c->active[j] > c->active[j - 1];
+  int off = 0;
+  for (int f = 0; f < nJ; ++f)
+  {
+    int m = 0;
+    for (int j = 0; j < n; ++j) m += (c->active[j] <= f) ? 1 : 0;
+    la->lds_m[f] = m;
+    la->lds_stride[f] = (16 * m + 4) * 8;
+    la->lds_off[f] = off;
+    off += 10 * la->lds_stride[f];
+  }
+  la->lds_off_c = off;
+  off += n_comp_cols * 160;
+  la->lds_off_b = off;
+  off += (16 * n + 4) * 8;
+  la->lds_dummy_off = off;
+  if (dummy_slot) off += 64 * 8;
+  la->tile_bytes = (off + 255) & ~255;
+  la->n_active = n;
+  for (int j = 0; j < n; ++j) la->first_col[j] = 10 * c->active[j];
+  return monotonic;
+}
+
 int rdyn_regressor_gram(const rdyn_chain* c, const rdyn_batch* b, const double* tau_meas, double* G, double* cvec, double* bb,
                         int accumulate, int64_t chunk_samples, void* workspace, size_t workspace_bytes)
 {
@@ -829,31 +859,12 @@ int rdyn_regressor_gram(const rdyn_chain* c, const rdyn_batch* b, const double* 
   {
     // LDS-resident path (rdyn_lds_gram.hip): needs input joints in chain order (rows of a link's columns are a prefix)
     // and four tiles inside 160 KB of LDS.
-    bool monotonic = true;
-    for (int j = 1; j < n; ++j) monotonic = monotonic && c->active[j] > c->active[j - 1];
     RdynLdsGramArgs la;
     memset(&la, 0, sizeof la);
-    const int nJ = c->n_joints();
-    int off = 0;
-    for (int f = 0; f < nJ; ++f)
-    {
-      int m = 0;
-      for (int j = 0; j < n; ++j) m += (c->active[j] <= f) ? 1 : 0;
-      la.lds_m[f] = m;
-      la.lds_stride[f] = (16 * m + 4) * 8;
-      la.lds_off[f] = off;
-      off += 10 * la.lds_stride[f];
-    }
-    la.lds_off_b = off;
-    off += (16 * n + 4) * 8;
-    // software-pipelined variant (rdyn_pipe_gram.hip) where its register budget allows; RDYN_GRAM_PATH=lds0 keeps the
-    // two-phase kernel (A/B)
     // wave-pair kernel (rdyn_duo_gram.hip) by default; RDYN_GRAM_PATH=pipe / lds0 keep the single-wave kernels (A/B)
     const bool duo = rdyn_regressor_gram_duo_supported(P) && !(path_env && (!strcmp(path_env, "lds0") || !strcmp(path_env, "pipe")));
     const bool pipe = !duo && rdyn_regressor_gram_pipe_supported(P) && !(path_env && !strcmp(path_env, "lds0"));
-    la.lds_dummy_off = off;
-    if (pipe) off += 64 * 8;
-    la.tile_bytes = (off + 255) & ~255;
+    const bool monotonic = build_lds_tile(c, 0, pipe, &la);
     const int nb = rdyn_gram_blocks_for(P);
     size_t lds_bytes = 4 * (size_t)la.tile_bytes;
     const size_t red_bytes = (size_t)(nb * (nb + 1) / 2) * 256 * sizeof(double);
@@ -867,8 +878,6 @@ int rdyn_regressor_gram(const rdyn_chain* c, const rdyn_batch* b, const double* 
       la.bcol = tau_meas;
       la.n_samples = N;
       rec_strides(b, n, &la.in_ss, &la.in_sj);
-      la.n_active = n;
-      for (int j = 0; j < n; ++j) la.first_col[j] = first_col[j];
       la.slabs = slabs;
       if (const char* dbg = probe_env("RDYN_FUSED_DEBUG")) la.debug = atoi(dbg);
       const int64_t tiles = (N + 15) / 16;
@@ -1021,6 +1030,50 @@ int rdyn_identification_gram(const rdyn_chain* c, const rdyn_component* comps, i
       if (bb) RDYN_HIP_TRY(hipMemsetAsync(bb, 0, sizeof(double), stream));
     }
     return RDYN_OK;
+  }
+  // ---- fused: regressor rows AND component columns stay in LDS (rdyn_duo_gram.hip); else the chunk image below
+  if (n >= 2 && n <= 8 && rdyn_regressor_gram_duo_supports_components(P, K) && !probe_env("RDYN_IDENT_UNFUSED"))
+  {
+    RdynLdsGramArgs la;
+    memset(&la, 0, sizeof la);
+    const bool monotonic = build_lds_tile(c, K, false, &la);
+    const int nbt = rdyn_gram_blocks_for(cols);
+    size_t lds_bytes = 4 * (size_t)la.tile_bytes;
+    const size_t red_bytes = (size_t)(nbt * (nbt + 1) / 2) * 256 * sizeof(double);
+    if (lds_bytes < red_bytes) lds_bytes = red_bytes;
+    if (monotonic && lds_bytes <= 160 * 1024)
+    {
+      la.chain = dc;
+      la.q = b->q;
+      la.dq = b->dq;
+      la.ddq = b->ddq;
+      la.bcol = tau_meas;
+      la.n_samples = N;
+      rec_strides(b, n, &la.in_ss, &la.in_sj);
+      la.slabs = slabs;
+      la.n_comps = n_comps;
+      la.n_comp_cols = K;
+      int col = 0;
+      for (int i = 0; i < n_comps; ++i)
+      {
+        la.comps[i] = ca.comps[i];
+        const int w = ca.comps[i].type == RDYN_COMP_FRICTION2 ? 3 : 2;
+        for (int k = 0; k < w; ++k) la.comp_col_row[col++] = (signed char)ca.comps[i].joint;
+      }
+      const int64_t tiles = (N + 15) / 16;
+      const int blocks = (int)((tiles + 3) / 4 < kFusedBlocks ? (tiles + 3) / 4 : kFusedBlocks);
+      RDYN_HIP_TRY(rdyn_launch_regressor_gram_duo(P, la, blocks, lds_bytes, stream));
+      RdynGramArgs ga;
+      memset(&ga, 0, sizeof ga);
+      ga.P = cols;
+      ga.add_to_output = accumulate ? 1 : 0;
+      ga.slabs = slabs;
+      ga.G = G;
+      ga.c = cvec;
+      ga.bb = bb;
+      RDYN_HIP_TRY(rdyn_launch_gram_finish(ga, blocks, stream));
+      return RDYN_OK;
+    }
   }
   const int64_t in_step = (b->layout == RDYN_LAYOUT_SAMPLE_MAJOR) ? n : 1;
   int first_col[RDYN_MAX_JOINTS];

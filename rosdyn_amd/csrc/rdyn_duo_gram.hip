@@ -73,10 +73,11 @@ __device__ __forceinline__ constexpr int duo_direct_off(int f)
   return off;
 }
 
-template <int NJ, bool DIRECT>
+// XB: extra 16-column blocks for the component columns of rdyn_identification_gram (0: plain regressor Gram)
+template <int NJ, bool DIRECT, int XB>
 __global__ __launch_bounds__(512) void k_regressor_gram_duo(const RdynLdsGramArgs fa)
 {
-  constexpr int NB = (10 * NJ + 1 + 15) / 16;
+  constexpr int NB = (10 * NJ + 1 + 15) / 16 + XB;
   constexpr int NT = NB * (NB + 1) / 2;
   constexpr int P = 10 * NJ;
   extern __shared__ __attribute__((aligned(32))) char lds_raw[];
@@ -169,6 +170,44 @@ __global__ __launch_bounds__(512) void k_regressor_gram_duo(const RdynLdsGramArg
 #include "rdyn_duo_link_body.inc"
         }
       }
+      if (XB > 0 || fa.n_comps > 0)
+      {
+        // per-joint component columns (friction_polynomial1.h:45-52, friction_polynomial2.h:42-58, ideal_spring.h:64-70): a row of
+        // joint j only needs q_j / Dq_j, which this lane fetched if it owns the row.  The consumer has read every row group of the
+        // previous tile by now (the last link's barrier is behind us).
+        int col = 0;
+        for (int ci = 0; ci < fa.n_comps; ++ci)
+        {
+          const int type = fa.comps[ci].type, jc = fa.comps[ci].joint;
+          const int cols = type == RDYN_COMP_FRICTION2 ? 3 : 2;
+          const double qv = jc >= 4 ? qb : qa, dv = jc >= 4 ? dqb : dqa;
+          double row[3] = {0.0, 0.0, 0.0};
+          if (type == RDYN_COMP_SPRING)
+          {
+            row[0] = qv;
+            row[1] = 1.0;
+          }
+          else
+          {
+            const double vmax = fa.comps[ci].max_velocity, vmin = fa.comps[ci].min_velocity;
+            const double omega = fmin(fmax(dv, -vmax), vmax);
+            double sg;
+            if (type == RDYN_COMP_FRICTION1)
+              sg = fmin(fmax(omega / vmin, -1.0), 1.0);
+            else
+              sg = (omega == 0.0) ? 0.0 : (omega > vmin ? 1.0 : (omega < -vmin ? -1.0 : omega / vmin));
+            row[0] = sg;
+            row[1] = omega;
+            row[2] = omega * omega * sg;
+          }
+          if (k == (jc & 3))
+          {
+            char* const lc = tile + fa.lds_off_c + col * 160 + s_loc * 8;
+            for (int e = 0; e < cols; ++e) *(double*)(lc + e * 160) = valid ? row[e] : 0.0;
+          }
+          col += cols;
+        }
+      }
       {
         char* const lb = tile + fa.lds_off_b + s_loc * 8;
         if (r0 < n) *(double*)(lb + r0 * 128) = tb0;
@@ -184,14 +223,34 @@ __global__ __launch_bounds__(512) void k_regressor_gram_duo(const RdynLdsGramArg
     __builtin_amdgcn_s_setprio(RDYN_DUO_MFMA_PRIO);
 #endif
     const int cl = lane & 15, g = lane >> 4;
-    int colbase[NB], colm[NB];
+    // per column block: LDS offset of MY column (for row group 0) and the row groups [collo, colm) it stores
+    int colbase[NB], colm[NB], collo[NB];
+    const int K = XB > 0 || fa.n_comp_cols > 0 ? fa.n_comp_cols : 0;
 #pragma unroll
     for (int cb = 0; cb < NB; ++cb)
     {
       const int p = 16 * cb + cl;
-      const int f = p < P ? p / 10 : 0;
-      colbase[cb] = (p < P ? fa.lds_off[f] + (p - 10 * f) * fa.lds_stride[f] : (p == P ? fa.lds_off_b : 0)) + g * 32;
-      colm[cb] = p < P ? fa.lds_m[f] : (p == P ? n : 0);
+      int base = 0, hi = 0, lo = 0;
+      if (p < P)
+      {
+        const int f = p / 10;
+        base = fa.lds_off[f] + (p - 10 * f) * fa.lds_stride[f];
+        hi = fa.lds_m[f];
+      }
+      else if (p < P + K)
+      {
+        lo = fa.comp_col_row[p - P];          // one row group: the component's own joint
+        hi = lo + 1;
+        base = fa.lds_off_c + (p - P) * 160 - lo * 128;
+      }
+      else if (p == P + K)
+      {
+        base = fa.lds_off_b;
+        hi = n;
+      }
+      colbase[cb] = base + g * 32;
+      colm[cb] = hi;
+      collo[cb] = lo;
     }
     d4 acc[NT];
 #pragma unroll
@@ -202,7 +261,7 @@ __global__ __launch_bounds__(512) void k_regressor_gram_duo(const RdynLdsGramArg
       for (int cb = 0; cb < NB; ++cb)
       {
         d4 x = (d4){0.0, 0.0, 0.0, 0.0};
-        if (cb >= cbm && j < colm[cb]) x = *(const d4*)(tile + colbase[cb] + j * 128);
+        if (cb >= cbm && j < colm[cb] && j >= collo[cb]) x = *(const d4*)(tile + colbase[cb] + j * 128);
         op[cb] = x;
       }
     };
@@ -280,7 +339,7 @@ __global__ __launch_bounds__(512) void k_regressor_gram_duo(const RdynLdsGramArg
   }
 }
 
-template <int NJ, bool DIRECT>
+template <int NJ, bool DIRECT, int XB>
 hipError_t launch_duo_nj2(const RdynLdsGramArgs& a, int blocks, size_t lds_bytes, hipStream_t st)
 {
   static std::atomic<uint64_t> attr_set{0};
@@ -290,11 +349,11 @@ hipError_t launch_duo_nj2(const RdynLdsGramArgs& a, int blocks, size_t lds_bytes
   const uint64_t bit = 1ull << (dev & 63);
   if (!(attr_set.load(std::memory_order_acquire) & bit))
   {
-    e = hipFuncSetAttribute((const void*)k_regressor_gram_duo<NJ, DIRECT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    e = hipFuncSetAttribute((const void*)k_regressor_gram_duo<NJ, DIRECT, XB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
     attr_set.fetch_or(bit, std::memory_order_release);
   }
-  hipLaunchKernelGGL((k_regressor_gram_duo<NJ, DIRECT>), dim3(blocks), dim3(512), lds_bytes, st, a);
+  hipLaunchKernelGGL((k_regressor_gram_duo<NJ, DIRECT, XB>), dim3(blocks), dim3(512), lds_bytes, st, a);
   return hipGetLastError();
 }
 template <int NJ>
@@ -303,11 +362,23 @@ hipError_t launch_duo_nj(const RdynLdsGramArgs& a, int blocks, size_t lds_bytes,
   // direct = every chain joint is an input joint, in chain order (the tile layout tables then follow from NJ alone)
   bool direct = a.n_active == NJ;
   for (int f = 0; direct && f < NJ; ++f) direct = a.lds_m[f] == f + 1 && a.first_col[f] == 10 * f;
-  return direct ? launch_duo_nj2<NJ, true>(a, blocks, lds_bytes, st) : launch_duo_nj2<NJ, false>(a, blocks, lds_bytes, st);
+  const int xb = (10 * NJ + a.n_comp_cols + 1 + 15) / 16 - (10 * NJ + 1 + 15) / 16;
+  if (xb == 0) return direct ? launch_duo_nj2<NJ, true, 0>(a, blocks, lds_bytes, st) : launch_duo_nj2<NJ, false, 0>(a, blocks, lds_bytes, st);
+  if constexpr (NJ >= 5)  // identification with component columns: one extra column block, arms of 5-7 joints
+  {
+    if (xb == 1) return direct ? launch_duo_nj2<NJ, true, 1>(a, blocks, lds_bytes, st) : launch_duo_nj2<NJ, false, 1>(a, blocks, lds_bytes, st);
+  }
+  return hipErrorInvalidValue;
 }
 }  // namespace
 
 bool rdyn_regressor_gram_duo_supported(int n_cols) { return n_cols >= 20 && n_cols <= 70; }
+bool rdyn_regressor_gram_duo_supports_components(int n_cols, int n_comp_cols)
+{
+  if (!rdyn_regressor_gram_duo_supported(n_cols) || n_comp_cols < 0 || n_comp_cols > 96) return false;
+  const int xb = (n_cols + n_comp_cols + 1 + 15) / 16 - (n_cols + 1 + 15) / 16;
+  return xb == 0 || (xb == 1 && n_cols >= 50);
+}
 
 hipError_t rdyn_launch_regressor_gram_duo(int n_cols, const RdynLdsGramArgs& a, int blocks, size_t lds_bytes, hipStream_t st)
 {

@@ -127,6 +127,14 @@ struct RdynFusedGramArgs
 };
 hipError_t rdyn_launch_regressor_gram_fused(int n_joints, const RdynFusedGramArgs& a, int blocks, hipStream_t st);
 
+// per-joint additive components (rdyn_components.hip); constants already sanitised by the API
+#define RDYN_MAX_COMPONENTS 30
+struct RdynComponent
+{
+  int type, joint;
+  double min_velocity, max_velocity;
+  double parameters[3];
+};
 // LDS-resident regressor -> Gram kernel (rdyn_lds_gram.hip): 16 samples per wave, packed column-major tile in LDS
 struct RdynLdsGramArgs
 {
@@ -143,6 +151,13 @@ struct RdynLdsGramArgs
   int tile_bytes;                      // one wave's tile
   double* slabs;
   int debug;                           // timing experiments only (RDYN_FUSED_DEBUG): bit 0 sweep only the first tile, bit 1 no Gram phase
+  // wave-pair kernel only (rdyn_duo_gram.hip): the per-joint component columns [Y | C | tau_meas] of rdyn_identification_gram.
+  // Column P + k of the tile belongs to component comp_col_comp[k] and is non-zero only in the rows of that component's joint:
+  // it is stored as ONE 16-row group (stride 160 bytes) at lds_off_c + 160 k; the measured torque moves to column P + n_comp_cols.
+  int n_comps, n_comp_cols;
+  int lds_off_c;
+  signed char comp_col_row[96];        // per component column: the input joint (row group) it belongs to
+  RdynComponent comps[RDYN_MAX_COMPONENTS];
 };
 hipError_t rdyn_launch_regressor_gram_lds(int n_cols, const RdynLdsGramArgs& a, int blocks, size_t lds_bytes, hipStream_t st);
 // the same kernel software-pipelined inside the wave (rdyn_pipe_gram.hip): chains of 2..6 joints
@@ -150,19 +165,13 @@ bool rdyn_regressor_gram_pipe_supported(int n_cols);
 hipError_t rdyn_launch_regressor_gram_pipe(int n_cols, const RdynLdsGramArgs& a, int blocks, size_t lds_bytes, hipStream_t st);
 // the two streams on two co-resident waves (rdyn_duo_gram.hip): chains of 2..7 joints, 512-thread workgroups
 bool rdyn_regressor_gram_duo_supported(int n_cols);
+// n_cols = 10 * chain joints; a.n_comp_cols extra component columns may add at most one 16-column block
+bool rdyn_regressor_gram_duo_supports_components(int n_cols, int n_comp_cols);
 hipError_t rdyn_launch_regressor_gram_duo(int n_cols, const RdynLdsGramArgs& a, int blocks, size_t lds_bytes, hipStream_t st);
 int rdyn_gram_blocks_for(int P);
 hipError_t rdyn_launch_gram(const RdynGramArgs& a, int blocks, hipStream_t st);
 hipError_t rdyn_launch_gram_finish(const RdynGramArgs& a, int blocks, hipStream_t st);
 
-// per-joint additive components (rdyn_components.hip); constants already sanitised by the API
-#define RDYN_MAX_COMPONENTS 30
-struct RdynComponent
-{
-  int type, joint;
-  double min_velocity, max_velocity;
-  double parameters[3];
-};
 struct RdynComponentArgs
 {
   const double *q, *dq;
