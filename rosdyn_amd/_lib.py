@@ -104,6 +104,11 @@ SYMBOLS = {
     "rdyn_multi_gpu_device_count": (_I, [_VP]),
     "rdyn_multi_gpu_synchronize": (_I, [_VP]),
     "rdyn_regressor_gram_multi": (_I, [_VP, _VP, _BP, C.POINTER(_VP), C.POINTER(_VP)]),
+    "rdyn_tsqr_workspace_bytes": (C.c_size_t, [_I]),
+    "rdyn_tsqr": (_I, [_VP, C.c_int64, C.c_int64, _I, _VP, _VP, _I, _VP, C.c_size_t, _I, _VP]),
+    "rdyn_regressor_tsqr_workspace_bytes": (C.c_size_t, [_VP]),
+    "rdyn_regressor_tsqr": (_I, [_VP, _BP, _VP, _VP, _I, _VP, C.c_size_t]),
+    "rdyn_tsqr_combine_host": (_I, [_DP, _I, _I, _DP]),
     "rdyn_solve_normal_equations": (_I, [_DP, _DP, _I, C.c_double, _DP, C.POINTER(C.c_int)]),
     "rdyn_gram_r_factor": (_I, [_DP, _I, C.c_double, _DP, C.POINTER(C.c_int32), C.POINTER(C.c_int)]),
     "rdyn_solve_r_factor": (_I, [_DP, C.c_int64, _I, _I, _DP, C.c_double, _DP, C.POINTER(C.c_int)]),

@@ -378,6 +378,24 @@ class Chain(object):
                                         workspace.data_ptr(), workspace.numel()))
         return G, c, bb
 
+    def getRegressorTsqr(self, q, Dq, DDq, tau_meas=None, layout="sample", out=None, accumulate=False, workspace=None):
+        """R factor of the stacked [regressor | tau_meas] of this batch WITHOUT forming A'A (include/rdyn.h: rdyn_regressor_tsqr,
+        BASELINE.json configs[2]).  Returns R1 = [R d; 0 rho] as a (P + 1, P + 1) tensor in math layout (upper triangular)."""
+        torch = _torch()
+        b, N, lay = self._batch(layout, q, Dq, DDq)
+        P1 = 10 * self.getJointsNumber() + 1
+        if tau_meas is not None and (tau_meas.shape != q.shape or tau_meas.dtype != torch.float64 or not tau_meas.is_contiguous()):
+            raise ValueError("Input data dimensions mismatch")
+        buf = torch.zeros((P1, P1), dtype=torch.float64, device=q.device) if out is None else out.t().contiguous()
+        nbytes = lib().rdyn_regressor_tsqr_workspace_bytes(self._h)
+        if nbytes == 0:
+            raise ValueError("rdyn_regressor_tsqr: chains of 2..7 joints")
+        if workspace is None:
+            workspace = torch.empty((nbytes,), dtype=torch.uint8, device=q.device)
+        check(lib().rdyn_regressor_tsqr(self._h, C.byref(b), tau_meas.data_ptr() if tau_meas is not None else None, buf.data_ptr(),
+                                        1 if accumulate else 0, workspace.data_ptr(), workspace.numel()))
+        return buf.t()
+
     def getIdentificationGram(self, components, q, Dq, DDq, tau_meas, layout="sample", out=None, accumulate=False, workspace=None):
         """The identification step in one call (include/rdyn.h: rdyn_identification_gram): normal equations of [Y | C] with
         the measured torque; `components` is a rosdyn_amd.components.ComponentSet or None.  Returns (G (P+K, P+K), c (P+K,),

@@ -972,6 +972,104 @@ int rdyn_regressor_gram(const rdyn_chain* c, const rdyn_batch* b, const double* 
   return RDYN_OK;
 }
 
+// ---- tall-skinny QR: the R factor without forming A'A (rdyn_tsqr.hip) ---------------------------------------------------------
+static const int kTsqrBlocks = 256;  // persistent workgroups (one per CU), four waves = four running factors each
+
+size_t rdyn_tsqr_workspace_bytes(int n_cols_with_rhs)
+{
+  const int nc = rdyn_tsqr_padded_cols(n_cols_with_rhs);
+  return nc ? rdyn_tsqr_workspace_doubles(nc, kTsqrBlocks) * sizeof(double) : 0;
+}
+
+int rdyn_tsqr(const double* A, int64_t rows, int64_t lda, int n_cols, const double* bvec, double* R, int accumulate, void* workspace,
+              size_t workspace_bytes, int device, void* stream)
+{
+  if (!A || !R || rows < 0 || lda < rows || n_cols < 1 || !workspace)
+  {
+    rdyn_set_error("rdyn_tsqr: invalid argument");
+    return RDYN_ERR_INVALID_ARGUMENT;
+  }
+  const int n1 = n_cols + (bvec ? 1 : 0);
+  if (!rdyn_tsqr_padded_cols(n1))
+  {
+    rdyn_set_error("rdyn_tsqr: at most 64 columns (right-hand side included) are supported");
+    return RDYN_ERR_UNSUPPORTED;
+  }
+  if (workspace_bytes < rdyn_tsqr_workspace_bytes(n1))
+  {
+    rdyn_set_error("rdyn_tsqr: workspace too small");
+    return RDYN_ERR_INVALID_ARGUMENT;
+  }
+  DeviceGuard g;
+  int st = g.enter(device);
+  if (st != RDYN_OK) return st;
+  if (rows == 0)
+  {
+    if (!accumulate) RDYN_HIP_TRY(hipMemsetAsync(R, 0, sizeof(double) * n1 * n1, (hipStream_t)stream));
+    return RDYN_OK;
+  }
+  const int64_t blocks32 = (rows + 31) / 32;
+  const int blocks = (int)((blocks32 + 3) / 4 < kTsqrBlocks ? (blocks32 + 3) / 4 : kTsqrBlocks);
+  RDYN_HIP_TRY(rdyn_launch_tsqr_rows(A, bvec, rows, lda, n_cols, blocks, (double*)workspace, R, accumulate ? 1 : 0, (hipStream_t)stream));
+  return RDYN_OK;
+}
+
+size_t rdyn_regressor_tsqr_workspace_bytes(const rdyn_chain* c)
+{
+  if (!c || c->n_joints() < 2 || c->n_joints() > 7) return 0;
+  const int nc = 10 * c->n_joints() + 1;
+  return rdyn_tsqr_workspace_doubles(nc, kTsqrBlocks) * sizeof(double);
+}
+
+int rdyn_regressor_tsqr(const rdyn_chain* c, const rdyn_batch* b, const double* tau_meas, double* R, int accumulate, void* workspace,
+                        size_t workspace_bytes)
+{
+  int st = check_batch(c, b, true, true, "rdyn_regressor_tsqr");
+  if (st != RDYN_OK) return st;
+  if (!R || !workspace)
+  {
+    rdyn_set_error("rdyn_regressor_tsqr: null output or workspace");
+    return RDYN_ERR_INVALID_ARGUMENT;
+  }
+  const int n = c->n_active(), nJ = c->n_joints(), P1 = 10 * nJ + 1;
+  RdynLdsGramArgs la;
+  memset(&la, 0, sizeof la);
+  const bool monotonic = nJ >= 2 && nJ <= 7 && n >= 1 && n <= 8 && build_lds_tile(c, 0, false, &la);
+  if (!monotonic || 4 * (size_t)la.tile_bytes > 160 * 1024)
+  {
+    rdyn_set_error("rdyn_regressor_tsqr: chains of 2..7 joints with the input joints in chain order are supported");
+    return RDYN_ERR_UNSUPPORTED;
+  }
+  if (workspace_bytes < rdyn_regressor_tsqr_workspace_bytes(c))
+  {
+    rdyn_set_error("rdyn_regressor_tsqr: workspace too small");
+    return RDYN_ERR_INVALID_ARGUMENT;
+  }
+  DeviceGuard g;
+  st = g.enter(b->device);
+  if (st != RDYN_OK) return st;
+  const RdynChainConst* dc = nullptr;
+  st = device_const(c, &dc);
+  if (st != RDYN_OK) return st;
+  hipStream_t stream = (hipStream_t)b->stream;
+  if (b->n_samples == 0)
+  {
+    if (!accumulate) RDYN_HIP_TRY(hipMemsetAsync(R, 0, sizeof(double) * P1 * P1, stream));
+    return RDYN_OK;
+  }
+  la.chain = dc;
+  la.q = b->q;
+  la.dq = b->dq;
+  la.ddq = b->ddq;
+  la.bcol = tau_meas;
+  la.n_samples = b->n_samples;
+  rec_strides(b, n, &la.in_ss, &la.in_sj);
+  const int64_t tiles = (b->n_samples + 15) / 16;
+  const int blocks = (int)((tiles + 3) / 4 < kTsqrBlocks ? (tiles + 3) / 4 : kTsqrBlocks);
+  RDYN_HIP_TRY(rdyn_launch_regressor_tsqr(nJ, la, blocks, 4 * (size_t)la.tile_bytes, (double*)workspace, R, accumulate ? 1 : 0, stream));
+  return RDYN_OK;
+}
+
 // ---- identification step: normal equations of [Y | C | tau_meas] (rigid-body regressor + component columns) -------------
 static const int64_t kIdentChunk = 131072;  // samples per image chunk (the image of one chunk stays L2 / Infinity-Cache sized)
 

@@ -25,6 +25,7 @@
 #include "rdyn_devmath.h"
 #include "rdyn_kernels.h"
 #include "rdyn_gram_common.h"
+#include "rdyn_duo_common.h"
 
 #ifndef RDYN_DUO_SWEEP_UNROLL
 #define RDYN_DUO_SWEEP_UNROLL 1  // link loop of the sweeper: 1 = rolled (unrolled measured no better: more moves and SGPR spills)
@@ -46,32 +47,6 @@ namespace
 #define DUO_BARRIER() asm volatile("s_barrier" ::: "memory")
 #define DUO_STAMP_OUT(NT_)
 #endif
-
-// value of lane K of my quad (K a constant after unrolling): two v_mov_b32 with a quad_perm DPP control
-template <int K>
-__device__ __forceinline__ double quad_bcast_k(double x)
-{
-  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), K * 0x55, 0xF, 0xF, false);
-  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), K * 0x55, 0xF, 0xF, false);
-  return __hiloint2double(hi, lo);
-}
-__device__ __forceinline__ double quad_bcast(double x, int k)
-{
-  switch (k)
-  {
-  case 0: return quad_bcast_k<0>(x);
-  case 1: return quad_bcast_k<1>(x);
-  case 2: return quad_bcast_k<2>(x);
-  default: return quad_bcast_k<3>(x);
-  }
-}
-// LDS byte offset of link f's first column when every chain joint is an input joint (rows j <= f stored: stride (16 (f + 1) + 4) * 8)
-__device__ __forceinline__ constexpr int duo_direct_off(int f)
-{
-  int off = 0;
-  for (int g = 0; g < f; ++g) off += 10 * (16 * (g + 1) + 4) * 8;
-  return off;
-}
 
 // XB: extra 16-column blocks for the component columns of rdyn_identification_gram (0: plain regressor Gram)
 template <int NJ, bool DIRECT, int XB>

@@ -168,6 +168,13 @@ bool rdyn_regressor_gram_duo_supported(int n_cols);
 // n_cols = 10 * chain joints; a.n_comp_cols extra component columns may add at most one 16-column block
 bool rdyn_regressor_gram_duo_supports_components(int n_cols, int n_comp_cols);
 hipError_t rdyn_launch_regressor_gram_duo(int n_cols, const RdynLdsGramArgs& a, int blocks, size_t lds_bytes, hipStream_t st);
+// tall-skinny QR (rdyn_tsqr.hip): R factor of [A | b] without forming A'A
+int rdyn_tsqr_padded_cols(int n_cols_with_rhs);              // 16 / 32 / 48 / 64, 0 = unsupported
+size_t rdyn_tsqr_workspace_doubles(int nc, int blocks);
+hipError_t rdyn_launch_regressor_tsqr(int n_joints, const RdynLdsGramArgs& a, int blocks, size_t lds_bytes, double* workspace, double* R, int accumulate,
+                                      hipStream_t st);
+hipError_t rdyn_launch_tsqr_rows(const double* A, const double* b, int64_t rows, int64_t lda, int n_cols, int blocks, double* workspace, double* R,
+                                 int accumulate, hipStream_t st);
 int rdyn_gram_blocks_for(int P);
 hipError_t rdyn_launch_gram(const RdynGramArgs& a, int blocks, hipStream_t st);
 hipError_t rdyn_launch_gram_finish(const RdynGramArgs& a, int blocks, hipStream_t st);

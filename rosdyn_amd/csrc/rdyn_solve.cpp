@@ -225,4 +225,43 @@ int rdyn_solve_r_factor(const double* R, int64_t ldr, int rows, int n, const dou
   return RDYN_OK;
 }
 
+int rdyn_tsqr_combine_host(const double* R_stack, int n_factors, int n, double* R_out)
+{
+  if (!R_stack || !R_out || n_factors < 1 || n < 1)
+  {
+    rdyn_set_error("rdyn_tsqr_combine_host: invalid argument");
+    return RDYN_ERR_INVALID_ARGUMENT;
+  }
+  // Householder QR of the stacked factors (n_factors * n rows, n columns), exploiting nothing: the problem is tiny
+  const int m = n_factors * n;
+  std::vector<double> M((size_t)m * n);
+  for (int f = 0; f < n_factors; ++f)
+    for (int j = 0; j < n; ++j)
+      for (int i = 0; i < n; ++i) M[(size_t)j * m + f * n + i] = i <= j ? R_stack[(size_t)f * n * n + (size_t)j * n + i] : 0.0;
+  for (int k = 0; k < n; ++k)
+  {
+    double sigma = 0.0;
+    for (int i = k + 1; i < m; ++i) sigma += M[(size_t)k * m + i] * M[(size_t)k * m + i];
+    const double alpha = M[(size_t)k * m + k];
+    if (sigma == 0.0) continue;
+    const double norm = std::sqrt(alpha * alpha + sigma);
+    const double beta = alpha > 0 ? -norm : norm;
+    const double v0 = alpha - beta;
+    const double scale = 2.0 / (v0 * v0 + sigma);
+    for (int j = k + 1; j < n; ++j)
+    {
+      double w = v0 * M[(size_t)j * m + k];
+      for (int i = k + 1; i < m; ++i) w += M[(size_t)k * m + i] * M[(size_t)j * m + i];
+      const double f = scale * w;
+      M[(size_t)j * m + k] -= f * v0;
+      for (int i = k + 1; i < m; ++i) M[(size_t)j * m + i] -= f * M[(size_t)k * m + i];
+    }
+    M[(size_t)k * m + k] = beta;
+    for (int i = k + 1; i < m; ++i) M[(size_t)k * m + i] = 0.0;
+  }
+  for (int j = 0; j < n; ++j)
+    for (int i = 0; i < n; ++i) R_out[(size_t)j * n + i] = i <= j ? M[(size_t)j * m + i] : 0.0;
+  return RDYN_OK;
+}
+
 }  // extern "C"

@@ -136,6 +136,48 @@ def solve_base_parameters(G, c, rtol=1e-10):
     return x, int(keep.sum())
 
 
+def tsqr(A, b=None, out=None, accumulate=False, workspace=None):
+    """rdyn_tsqr: R factor of [A | b] without forming A'A.  A: (P, R) torch.float64 CUDA tensor = column-major R x P matrix (as
+    gram()); b: (R,) or None.  Returns R1 as a (n1, n1) tensor in MATH layout (R1[i, j], upper triangular), n1 = P + (b is not None)."""
+    import torch
+    assert A.is_cuda and A.dtype == torch.float64 and A.dim() == 2 and A.is_contiguous()
+    P, rows = A.shape
+    n1 = P + (1 if b is not None else 0)
+    buf = torch.zeros((n1, n1), dtype=torch.float64, device=A.device) if out is None else out.t().contiguous()
+    nbytes = lib().rdyn_tsqr_workspace_bytes(n1)
+    if nbytes == 0:
+        raise ValueError("rdyn_tsqr: at most 64 columns (right-hand side included)")
+    if workspace is None:
+        workspace = torch.empty((nbytes,), dtype=torch.uint8, device=A.device)
+    check(lib().rdyn_tsqr(A.data_ptr(), rows, rows, P, b.data_ptr() if b is not None else None, buf.data_ptr(), 1 if accumulate else 0,
+                          workspace.data_ptr(), workspace.numel(), A.device.index if A.device.index is not None else -1,
+                          torch.cuda.current_stream(A.device).cuda_stream))
+    return buf.t()          # the C side is column-major
+
+
+def tsqr_combine_host(factors):
+    """rdyn_tsqr_combine_host: folds upper-triangular factors (list of (n, n) numpy arrays in math layout) into one."""
+    n = factors[0].shape[0]
+    stack = np.ascontiguousarray(np.stack([np.asarray(f, dtype=np.float64).T for f in factors]))   # each column-major
+    out = np.zeros((n, n))
+    dp = C.POINTER(C.c_double)
+    check(lib().rdyn_tsqr_combine_host(stack.ctypes.data_as(dp), len(factors), n, out.ctypes.data_as(dp)))
+    return out.T.copy()
+
+
+def solve_r_factor(R1, n_cols, rtol=1e-10):
+    """Minimum-norm least-squares solution from R1 = [R d; 0 rho] (math layout, numpy or tensor): rdyn_solve_r_factor."""
+    Rh = np.asarray(R1.detach().cpu() if hasattr(R1, "detach") else R1, dtype=np.float64)
+    Rf = np.asfortranarray(Rh[:n_cols, :n_cols])
+    d = np.ascontiguousarray(Rh[:n_cols, n_cols])
+    x = np.zeros(n_cols)
+    rank = C.c_int(0)
+    dp = C.POINTER(C.c_double)
+    check(lib().rdyn_solve_r_factor(Rf.ctypes.data_as(dp), n_cols, n_cols, n_cols, d.ctypes.data_as(dp), float(rtol), x.ctypes.data_as(dp),
+                                    C.byref(rank)))
+    return x, rank.value
+
+
 class MultiGpuGram(object):
     """include/rdyn.h: rdyn_multi_gpu_* -- one process, the batch sharded over `devices`, every device the fused regressor -> Gram of
     its shard, ONE ncclAllReduce of [G | c | bb | count] inside the library (RCCL resolved at run time)."""

@@ -1,0 +1,113 @@
+"""GPU tests of the tall-skinny QR path (rdyn_tsqr.hip; BASELINE.json configs[2] "regressor + TSQR"): the R factor of [A | b]
+without forming A'A.  Oracle: numpy.linalg.qr of the same rows (|R| up to row signs where A has full column rank), the invariant
+R1'R1 = [A b]'[A b] everywhere, and the case the Gram route cannot do: cond(A) = 1e9."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import FIXTURES
+
+pytestmark = pytest.mark.gpu
+GRAV = (0.0, 0.0, -9.806)
+
+
+def _abs_rows_equal(R, Rq, tol):
+    s = np.sign(np.diag(R)) * np.sign(np.diag(Rq))
+    s[s == 0] = 1.0
+    assert np.abs(R - s[:, None] * Rq).max() <= tol * np.abs(Rq).max()
+
+
+@pytest.mark.parametrize("rows,n,with_b", [(1000, 12, True), (33, 5, False), (7, 15, True), (50001, 31, True), (4096, 63, True), (64, 16, False)])
+def test_generic_tsqr_matches_numpy_qr(rows, n, with_b):
+    torch = pytest.importorskip("torch")
+    from rosdyn_amd.gram import tsqr
+    rng = np.random.default_rng(rows + n)
+    A = rng.normal(size=(rows, n))
+    b = rng.normal(size=rows) if with_b else None
+    At = torch.from_numpy(np.ascontiguousarray(A.T)).cuda()
+    R1 = tsqr(At, torch.from_numpy(b).cuda() if with_b else None).cpu().numpy()
+    M = np.column_stack([A, b]) if with_b else A
+    assert np.allclose(np.tril(R1, -1), 0.0)
+    assert np.abs(R1.T @ R1 - M.T @ M).max() <= 1e-12 * np.abs(M.T @ M).max()
+    if rows >= M.shape[1]:
+        _abs_rows_equal(R1, np.linalg.qr(M, mode="r"), 1e-11)
+
+
+def test_tsqr_solves_what_the_normal_equations_cannot():
+    """cond(A) = 1e9 (cond(A'A) = 1e18 > 1 / eps): TSQR + rdyn_solve_r_factor recover x to ~cond * eps, the Gram route does not."""
+    torch = pytest.importorskip("torch")
+    from rosdyn_amd.gram import gram, solve_base_parameters, solve_r_factor, tsqr
+    rng = np.random.default_rng(3)
+    m, n = 20000, 24
+    U, _ = np.linalg.qr(rng.normal(size=(m, n)))
+    V, _ = np.linalg.qr(rng.normal(size=(n, n)))
+    A = U @ np.diag(np.logspace(0, -9, n)) @ V.T
+    x_true = V @ rng.normal(size=n)
+    b = A @ x_true
+    At, bt = torch.from_numpy(np.ascontiguousarray(A.T)).cuda(), torch.from_numpy(b).cuda()
+    R1 = tsqr(At, bt)
+    x_qr, rank = solve_r_factor(R1, n, rtol=1e-13)
+    assert rank == n
+    err_qr = np.abs(x_qr - x_true).max() / np.abs(x_true).max()
+    G, c, _ = gram(At, bt)
+    x_ne, _ = solve_base_parameters(G, c, rtol=1e-15)
+    err_ne = np.abs(x_ne - x_true).max() / np.abs(x_true).max()
+    assert err_qr <= 1e-5, err_qr                # ~ cond * eps
+    assert err_ne >= 1e-3 > 100 * err_qr, (err_ne, err_qr)
+
+
+@pytest.mark.parametrize("urdf,base,tool", [("ur10_like.urdf", "base_link", "wrist_3_link"), ("ur10_like.urdf", "base_link", "tool0"),
+                                            ("panda_like.urdf", "link0", "link7")], ids=["6of6", "6of7", "7of7_two_slots"])
+@pytest.mark.parametrize("N", [1, 17, 1000])
+def test_regressor_tsqr_against_the_oracle_rows(urdf, base, tool, N):
+    torch = pytest.importorskip("torch")
+    from oracle.oracle import OracleChain
+    from rosdyn_amd import Chain
+    from rosdyn_amd.gram import solve_r_factor
+    from rosdyn_amd.samples import trajectory_batch
+    path = os.path.join(FIXTURES, urdf)
+    chain, ref = Chain(path, base, tool, GRAV), OracleChain(path, base, tool, GRAV)
+    n, P = chain.getActiveJointsNumber(), 10 * chain.getJointsNumber()
+    q, dq, ddq = trajectory_batch(40 + N, N, n)
+    rng = np.random.default_rng(N)
+    Y = ref.regressor(q, dq, ddq)                                  # (N, n, P)
+    tau = ref.joint_torque(q, dq, ddq) + 1e-3 * rng.normal(size=(N, n))
+    M = np.column_stack([Y.reshape(-1, P), tau.reshape(-1)])       # rows (s, j)
+    R1 = chain.getRegressorTsqr(*(torch.from_numpy(x).cuda() for x in (q, dq, ddq, tau))).cpu().numpy()
+    assert R1.shape == (P + 1, P + 1) and np.allclose(np.tril(R1, -1), 0.0)
+    G = M.T @ M
+    assert np.abs(R1.T @ R1 - G).max() <= 1e-11 * np.abs(G).max()  # Q is orthogonal: the factor reproduces the normal equations
+    if N == 1000:
+        # least-squares solution straight from the factor == numpy lstsq on the oracle's rows (minimum norm: rank deficient)
+        x, rank = solve_r_factor(R1, P, rtol=1e-9)
+        x_ls = np.linalg.lstsq(M[:, :P], M[:, P], rcond=1e-9)[0]
+        assert rank == np.linalg.matrix_rank(M[:, :P], tol=1e-9 * np.linalg.norm(M[:, :P], 2))
+        assert np.abs(M[:, :P] @ (x - x_ls)).max() <= 1e-8 * np.abs(M[:, P]).max()
+        # the residual norm from the factor alone: rho^2 + |R x - d|^2 (the second term: the rank-deficient directions)
+        res = np.linalg.norm(M[:, :P] @ x_ls - M[:, P])
+        res_f = np.sqrt(R1[P, P] ** 2 + np.sum((R1[:P, :P] @ x - R1[:P, P]) ** 2))
+        assert abs(res_f - res) <= 1e-6 * res
+
+
+def test_accumulate_and_host_combine_equal_one_shot():
+    torch = pytest.importorskip("torch")
+    from rosdyn_amd import Chain
+    from rosdyn_amd.gram import tsqr_combine_host
+    from rosdyn_amd.samples import trajectory_batch
+    chain = Chain(os.path.join(FIXTURES, "ur10_like.urdf"), "base_link", "wrist_3_link", GRAV)
+    n, N = 6, 3000
+    q, dq, ddq = (torch.from_numpy(x).cuda() for x in trajectory_batch(9, N, n))
+    tau = chain.getJointTorque(q, dq, ddq)
+    full = chain.getRegressorTsqr(q, dq, ddq, tau).cpu().numpy()
+    h = 1234
+    first = chain.getRegressorTsqr(q[:h].contiguous(), dq[:h].contiguous(), ddq[:h].contiguous(), tau[:h].contiguous())
+    second = chain.getRegressorTsqr(q[h:].contiguous(), dq[h:].contiguous(), ddq[h:].contiguous(), tau[h:].contiguous())
+    acc = chain.getRegressorTsqr(q[h:].contiguous(), dq[h:].contiguous(), ddq[h:].contiguous(), tau[h:].contiguous(), out=first.clone(), accumulate=True)
+    ref = full.T @ full
+    for R in (acc.cpu().numpy(), tsqr_combine_host([first.cpu().numpy(), second.cpu().numpy()])):
+        assert np.allclose(np.tril(R, -1), 0.0)
+        assert np.abs(R.T @ R - ref).max() <= 1e-11 * np.abs(ref).max()
+    # reproducible: same launch, same bits
+    again = chain.getRegressorTsqr(q, dq, ddq, tau).cpu().numpy()
+    assert np.array_equal(full, again)
