@@ -43,8 +43,11 @@ __device__ __forceinline__ S6 axpy6(S6 a, S6 b, double s)
   return r;
 }
 
+#ifndef RDYN_KIN_EXT_WAVES
+#define RDYN_KIN_EXT_WAVES 4  // waves per SIMD the register allocation is held to (streaming kernel: occupancy hides the store latency)
+#endif
 template <int NJ, bool WRENCH>
-__global__ __launch_bounds__(256) void k_base_ext(const RdynKinExtArgs a)
+__global__ __launch_bounds__(256, RDYN_KIN_EXT_WAVES) void k_base_ext(const RdynKinExtArgs a)
 {
   ChainPtr c = as_const(a.chain);
   const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -54,36 +57,59 @@ __global__ __launch_bounds__(256) void k_base_ext(const RdynKinExtArgs a)
   const double* __restrict__ ddqp = a.ddq ? a.ddq + s * a.in_ss : nullptr;
   const double* __restrict__ dddqp = a.dddq ? a.dddq + s * a.in_ss : nullptr;
   const int64_t es = a.out_se;
-  auto put6 = [&](double* __restrict__ o, S6 x) {
-    o[0] = x.l.x; o[es] = x.l.y; o[2 * es] = x.l.z; o[3 * es] = x.a.x; o[4 * es] = x.a.y; o[5 * es] = x.a.z;
+  // output addressing = wave-uniform 64-bit base (SGPRs) + one 32-bit per-lane byte offset (the saddr store form): with a full
+  // 64-bit pointer per record element hipcc keeps dozens of address pairs alive in the unrolled link loop (204 VGPRs)
+  const int64_t blk_off = (int64_t)blockIdx.x * 256 * a.out_ss;
+  const uint32_t lane_off = threadIdx.x * (uint32_t)a.out_ss * 8u;
+  auto put6 = [&](double* base, int64_t first_elem, S6 x) {
+    char* const o = (char*)(base + blk_off + first_elem * es);  // uniform
+    const int64_t eb = es * 8;
+    *(double*)(o + lane_off) = x.l.x;
+    *(double*)(o + eb + lane_off) = x.l.y;
+    *(double*)(o + 2 * eb + lane_off) = x.l.z;
+    *(double*)(o + 3 * eb + lane_off) = x.a.x;
+    *(double*)(o + 4 * eb + lane_off) = x.a.y;
+    *(double*)(o + 5 * eb + lane_off) = x.a.z;
   };
   const S6 zero = {mk(0, 0, 0), mk(0, 0, 0)};
   double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
   S6 v = zero, acc = zero, aL = zero, aN = zero, jk = zero, jL = zero, jN = zero;
-  if (a.dtw_lin) put6(a.dtw_lin + s * a.out_ss, zero);
-  if (a.dtw_nonlin) put6(a.dtw_nonlin + s * a.out_ss, zero);
-  if (a.ddtw) put6(a.ddtw + s * a.out_ss, zero);
-  if (a.ddtw_lin) put6(a.ddtw_lin + s * a.out_ss, zero);
-  if (a.ddtw_nonlin) put6(a.ddtw_nonlin + s * a.out_ss, zero);
-  // wrench accumulators of links 0 .. NJ and their origins (WRENCH only)
-  S6 W[WRENCH ? NJ + 1 : 1];
+  if (a.dtw_lin) put6(a.dtw_lin, 0, zero);
+  if (a.dtw_nonlin) put6(a.dtw_nonlin, 0, zero);
+  if (a.ddtw) put6(a.ddtw, 0, zero);
+  if (a.ddtw_lin) put6(a.ddtw_lin, 0, zero);
+  if (a.ddtw_nonlin) put6(a.ddtw_nonlin, 0, zero);
+  // WRENCH: origins of links 0 .. NJ.  The per-link wrench accumulators do NOT live in registers (6 (NJ + 1) doubles pushed the
+  // kernel to 200 VGPRs = 2 waves per SIMD on a streaming kernel): every link's OWN wrench goes to its output record referred
+  // to the base origin (moment + p x force), and a short backward pass over the thread's own records (L2-hot, read once) forms
+  // the suffix sums and refers each one back to its link's origin.
   V3 po[WRENCH ? NJ + 1 : 1];
+  auto get6 = [&](const double* base, int64_t first_elem) -> S6 {
+    const char* const o = (const char*)(base + blk_off + first_elem * es);
+    const int64_t eb = es * 8;
+    S6 x;
+    x.l = mk(*(const double*)(o + lane_off), *(const double*)(o + eb + lane_off), *(const double*)(o + 2 * eb + lane_off));
+    x.a = mk(*(const double*)(o + 3 * eb + lane_off), *(const double*)(o + 4 * eb + lane_off), *(const double*)(o + 5 * eb + lane_off));
+    return x;
+  };
   V3 p = mk(0, 0, 0);
   const V3 grav = mk(c->g[0], c->g[1], c->g[2]);
   auto ext_of = [&](int link) -> S6 {  // -ext_wrenches_in_link_frame.at(link), :1255
     S6 e = zero;
     if (a.ext)
     {
-      const double* __restrict__ ep = a.ext + s * a.ext_ss + (int64_t)(6 * link) * a.ext_se;
-      e.l = mk(-ep[0], -ep[a.ext_se], -ep[2 * a.ext_se]);
-      e.a = mk(-ep[3 * a.ext_se], -ep[4 * a.ext_se], -ep[5 * a.ext_se]);
+      const char* const ep = (const char*)(a.ext + (int64_t)blockIdx.x * 256 * a.ext_ss + (int64_t)(6 * link) * a.ext_se);  // uniform
+      const uint32_t ev = threadIdx.x * (uint32_t)a.ext_ss * 8u;
+      const int64_t eb = a.ext_se * 8;
+      e.l = mk(-*(const double*)(ep + ev), -*(const double*)(ep + eb + ev), -*(const double*)(ep + 2 * eb + ev));
+      e.a = mk(-*(const double*)(ep + 3 * eb + ev), -*(const double*)(ep + 4 * eb + ev), -*(const double*)(ep + 5 * eb + ev));
     }
     return e;
   };
   if (WRENCH)
   {
     po[0] = p;
-    W[0] = ext_of(0);  // spatialTranformation(-ext, T_bl[0] = identity); no inertial / gravity term on the base link (:1233-1237)
+    put6(a.wrench, 0, ext_of(0));  // spatialTranformation(-ext, T_bl[0] = identity); no inertial / gravity term on the base link (:1233-1237)
   }
 #pragma unroll
   for (int f = 0; f < NJ; ++f)
@@ -143,12 +169,11 @@ __global__ __launch_bounds__(256) void k_base_ext(const RdynKinExtArgs a)
       jk = axpy6(axpy6(axpy6(shift(jk, d), S, dddqf), vxs, ddqf), cq, dqf);
       jL = axpy6(shift(jL, d), S, dddqf);
       jN = axpy6(axpy6(shift(jN, d), vxs, ddqf), cq, dqf);
-      const int64_t off = (int64_t)(6 * (f + 1)) * es;
-      if (a.dtw_lin) put6(a.dtw_lin + s * a.out_ss + off, aL);
-      if (a.dtw_nonlin) put6(a.dtw_nonlin + s * a.out_ss + off, aN);
-      if (a.ddtw) put6(a.ddtw + s * a.out_ss + off, jk);
-      if (a.ddtw_lin) put6(a.ddtw_lin + s * a.out_ss + off, jL);
-      if (a.ddtw_nonlin) put6(a.ddtw_nonlin + s * a.out_ss + off, jN);
+      if (a.dtw_lin) put6(a.dtw_lin, 6 * (f + 1), aL);
+      if (a.dtw_nonlin) put6(a.dtw_nonlin, 6 * (f + 1), aN);
+      if (a.ddtw) put6(a.ddtw, 6 * (f + 1), jk);
+      if (a.ddtw_lin) put6(a.ddtw_lin, 6 * (f + 1), jL);
+      if (a.ddtw_nonlin) put6(a.ddtw_nonlin, 6 * (f + 1), jN);
     }
     if (WRENCH)
     {
@@ -179,19 +204,25 @@ __global__ __launch_bounds__(256) void k_base_ext(const RdynKinExtArgs a)
       const V3 Ra = rot(R, e.a);
       own.l = own.l + rot(R, e.l) + cross(Ra, p);
       own.a = own.a + Ra;
-      W[f + 1] = own;
-#pragma unroll
-      for (int l = 0; l <= f; ++l)  // spatialDualTranslation(w, p_l - p_{f+1}): ang += lin x d, :1255
-      {
-        W[l].l = W[l].l + own.l;
-        W[l].a = W[l].a + own.a + cross(own.l, po[l] - p);
-      }
+      own.a = own.a + cross(p, own.l);  // referred to the base origin: suffix sums need no per-pair translation
+      put6(a.wrench, 6 * (f + 1), own);
     }
   }
   if (WRENCH)
   {
+    // w[l] = sum over links f >= l, referred to link l's origin: spatialDualTranslation(w, p_l - p_f), :1255 (ang += lin x d)
+    S6 run = zero;
 #pragma unroll
-    for (int l = 0; l <= NJ; ++l) put6(a.wrench + s * a.out_ss + (int64_t)(6 * l) * es, W[l]);
+    for (int l = NJ; l >= 0; --l)
+    {
+      const S6 own = get6(a.wrench, 6 * l);
+      run.l = run.l + own.l;
+      run.a = run.a + own.a;
+      S6 w;
+      w.l = run.l;
+      w.a = run.a - cross(po[l], run.l);
+      put6(a.wrench, 6 * l, w);
+    }
   }
 }
 

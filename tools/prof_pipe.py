@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""rocprofv3 workload: the default (software-pipelined) regressor->Gram kernel on config 2, a few launches."""
+"""rocprofv3 workload: the default regressor->Gram kernel (wave-pair kernel since round 2) on config 2 and config 3, a few launches."""
 import os
 import sys
 
@@ -14,4 +14,11 @@ n, N = 6, 1000000
 q, dq, ddq, tm = (torch.rand((n, N), dtype=torch.float64, device="cuda") * 2 - 1 for _ in range(4))
 for _ in range(4):
     chain.getRegressorGram(q, dq, ddq, tm, layout="element")
+torch.cuda.synchronize()
+
+chain3 = Chain(os.path.join(ROOT, "tests/fixtures/panda_like.urdf"), "link0", "link7", (0, 0, -9.806))
+N3 = 4000000
+q3, dq3, ddq3, tm3 = (torch.rand((N3, 7), dtype=torch.float64, device="cuda") * 2 - 1 for _ in range(4))
+for _ in range(3):
+    chain3.getRegressorGram(q3, dq3, ddq3, tm3)
 torch.cuda.synchronize()
