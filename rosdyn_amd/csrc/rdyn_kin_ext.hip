@@ -44,7 +44,7 @@ __device__ __forceinline__ S6 axpy6(S6 a, S6 b, double s)
 }
 
 #ifndef RDYN_KIN_EXT_WAVES
-#define RDYN_KIN_EXT_WAVES 4  // waves per SIMD the register allocation is held to (streaming kernel: occupancy hides the store latency)
+#define RDYN_KIN_EXT_WAVES 1  // minimum waves per SIMD asked of the register allocator.  3 and 4 were measured: hipcc then spills (196-404 B of scratch) and getWrench / getDDTwist slow down 1.2-5x (profiles/r2/perf_sheet.txt)
 #endif
 template <int NJ, bool WRENCH>
 __global__ __launch_bounds__(256, RDYN_KIN_EXT_WAVES) void k_base_ext(const RdynKinExtArgs a)
