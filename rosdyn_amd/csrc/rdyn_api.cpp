@@ -640,8 +640,9 @@ int rdyn_multi_plan_create(const rdyn_multi_item* items, int n_items, rdyn_multi
       rdyn_set_error("rdyn_multi_plan_create: item %d has a null regressor output", i);
       return RDYN_ERR_INVALID_ARGUMENT;
     }
-    if (it.y_layout.stride_sample < 1 || it.y_layout.stride_row < 1 || it.y_layout.stride_col < 1 ||
-        it.y_layout.stride_sample > (int64_t)0xFFFFFFFFll / (8 * 255))
+    if (it.batch.n_samples > 0 &&  // an empty item's strides are never used (its row stride is its sample count: 0)
+        (it.y_layout.stride_sample < 1 || it.y_layout.stride_row < 1 || it.y_layout.stride_col < 1 ||
+         it.y_layout.stride_sample > (int64_t)0xFFFFFFFFll / (8 * 255)))
     {
       rdyn_set_error("rdyn_multi_plan_create: item %d: strides must be positive and stride_sample below %lld doubles", i,
                      (long long)((int64_t)0xFFFFFFFFll / (8 * 255)));

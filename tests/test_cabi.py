@@ -158,3 +158,22 @@ def test_c_example_runs(tmp_path):
                        timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "n = 6, P = 60" in r.stdout
+
+
+def test_hostile_urdf_is_rejected_not_crashed():
+    """the XML reader recursed without a bound (2e5 nested elements overflowed the host stack) and names longer than the
+    63 characters the POD descriptor keeps could never be matched.  Both are RDYN_ERR_URDF now."""
+    import ctypes as C
+    from rosdyn_amd._lib import lib
+    l = lib()
+    g = (C.c_double * 3)(0, 0, 0)
+    h = C.c_void_p()
+    deep = "<robot name='r'>" + "<a>" * 200000 + "</a>" * 200000 + "<link name='b'/></robot>"
+    assert l.rdyn_chain_from_urdf(deep.encode(), b"b", b"b", g, C.byref(h)) == 4 and b"nested" in l.rdyn_last_error()
+    long_name = "L" * 64
+    xml = ("<robot name='r'><link name='b'/><link name='%s'/><joint name='j' type='revolute'><parent link='b'/><child link='%s'/>"
+           "<axis xyz='0 0 1'/><limit lower='-1' upper='1' effort='1' velocity='1'/></joint></robot>" % (long_name, long_name))
+    assert l.rdyn_chain_from_urdf(xml.encode(), b"b", long_name.encode(), g, C.byref(h)) == 4 and b"63 characters" in l.rdyn_last_error()
+    ok63 = xml.replace(long_name, "L" * 63)
+    assert l.rdyn_chain_from_urdf(ok63.encode(), b"b", ("L" * 63).encode(), g, C.byref(h)) == 0
+    l.rdyn_chain_destroy(h)

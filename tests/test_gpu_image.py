@@ -96,3 +96,24 @@ def test_image_kernel_with_prismatic_and_fixed_joints():
     torch.cuda.synchronize()
     Yr = ref.regressor(q, dq, ddq)
     assert np.abs(Y.cpu().numpy().transpose(0, 2, 1) - Yr).max() <= 1e-11 * max(1.0, np.abs(Yr).max())
+
+
+def test_regressor_strides_are_validated():
+    """rdyn_regressor took any stride triple; a zero / negative stride or a sample stride that overflows the kernels'
+    32-bit lane offsets wrote to wrong addresses.  They are RDYN_ERR_INVALID_ARGUMENT now (also per item of a multi-chain plan)."""
+    torch = pytest.importorskip("torch")
+    from rosdyn_amd._lib import Batch, MultiItem, RegressorLayout, lib
+    from rosdyn_amd import Chain
+    chain = Chain(os.path.join(FIXTURES, "ur10_like.urdf"), "base_link", "wrist_3_link", GRAV)
+    n, P, N = 6, 60, 8
+    q = torch.zeros((N, n), dtype=torch.float64, device="cuda")
+    Y = torch.zeros((N * n * P,), dtype=torch.float64, device="cuda")
+    b = Batch()
+    b.n_samples, b.q, b.dq, b.ddq, b.layout, b.device = N, q.data_ptr(), q.data_ptr(), q.data_ptr(), 0, 0
+    for bad in (RegressorLayout(0, 1, n), RegressorLayout(n * P, -1, n), RegressorLayout(n * P, 1, 0), RegressorLayout(3000000, 1, n)):
+        assert lib().rdyn_regressor(chain._h, C.byref(b), None, Y.data_ptr(), C.byref(bad)) == 1
+        assert b"strides must be positive" in lib().rdyn_last_error()
+    it = (MultiItem * 1)()
+    it[0].chain, it[0].batch, it[0].Y, it[0].y_layout = chain._h, b, Y.data_ptr(), RegressorLayout(-1, N, n * N)
+    h = C.c_void_p()
+    assert lib().rdyn_multi_plan_create(C.cast(it, C.c_void_p), 1, C.byref(h)) == 1
