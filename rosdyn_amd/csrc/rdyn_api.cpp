@@ -899,6 +899,7 @@ int rdyn_regressor_gram(const rdyn_chain* c, const rdyn_batch* b, const double* 
       ga.G = G;
       ga.c = cvec;
       ga.bb = bb;
+      ga.desc_nj = duo ? c->n_joints() : 0;  // the wave-pair kernel accumulates in descending link order
       RDYN_HIP_TRY(rdyn_launch_gram_finish(ga, blocks, stream));
       return RDYN_OK;
     }
@@ -1136,7 +1137,7 @@ int rdyn_identification_gram(const rdyn_chain* c, const rdyn_component* comps, i
     RdynLdsGramArgs la;
     memset(&la, 0, sizeof la);
     const bool monotonic = build_lds_tile(c, K, false, &la);
-    const int nbt = rdyn_gram_blocks_for(cols);
+    const int nbt = K > 0 ? rdyn_gram_blocks_for(P) + 1 : rdyn_gram_blocks_for(P);  // the kernel's slab layout (XB = 1 with components)
     size_t lds_bytes = 4 * (size_t)la.tile_bytes;
     const size_t red_bytes = (size_t)(nbt * (nbt + 1) / 2) * 256 * sizeof(double);
     if (lds_bytes < red_bytes) lds_bytes = red_bytes;
@@ -1164,6 +1165,8 @@ int rdyn_identification_gram(const rdyn_chain* c, const rdyn_component* comps, i
       RDYN_HIP_TRY(rdyn_launch_regressor_gram_duo(P, la, blocks, lds_bytes, stream));
       RdynGramArgs ga;
       memset(&ga, 0, sizeof ga);
+      ga.desc_nj = K == 0 ? c->n_joints() : 0;  // without component columns the kernel accumulates in descending link order
+      ga.slab_nb = nbt;
       ga.P = cols;
       ga.add_to_output = accumulate ? 1 : 0;
       ga.slabs = slabs;

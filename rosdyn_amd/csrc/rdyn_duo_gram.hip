@@ -199,12 +199,17 @@ __global__ __launch_bounds__(512) void k_regressor_gram_duo(const RdynLdsGramArg
 #endif
     const int cl = lane & 15, g = lane >> 4;
     // per column block: LDS offset of MY column (for row group 0) and the row groups [collo, colm) it stores
+    constexpr bool DESC = XB == 0;
     int colbase[NB], colm[NB], collo[NB];
     const int K = XB > 0 || fa.n_comp_cols > 0 ? fa.n_comp_cols : 0;
 #pragma unroll
     for (int cb = 0; cb < NB; ++cb)
     {
-      const int p = 16 * cb + cl;
+      // XB == 0: the Gram is accumulated in the column order [tau_meas | link NJ-1 | ... | link 0]: row group j is non-zero in
+      // the FIRST 10 (NJ - j) + 1 columns, so its zero band ends at a 16-column boundary more often than in natural order
+      // (48 instead of 62 tile k-steps per tile at 7 joints, 33 instead of 36 at 6); k_gram_finish undoes the permutation
+      const int pp = 16 * cb + cl;
+      const int p = !DESC ? pp : (pp == 0 ? P : (pp > P ? P + 1 : 10 * (NJ - 1 - (pp - 1) / 10) + (pp - 1) % 10));
       int base = 0, hi = 0, lo = 0;
       if (p < P)
       {
@@ -231,16 +236,17 @@ __global__ __launch_bounds__(512) void k_regressor_gram_duo(const RdynLdsGramArg
 #pragma unroll
     for (int t = 0; t < NT; ++t) acc[t] = (d4){0.0, 0.0, 0.0, 0.0};
     // operands of row group j: column blocks >= (10 j) >> 4 (input joints in chain order: joint j sits at chain index >= j)
-    auto lds_group = [&](int j, int cbm, d4* op) {
+    // band of row group j: natural order -> column blocks >= (10 j) >> 4; descending order -> column blocks <= (10 (NJ - j)) >> 4
+    auto lds_group = [&](int j, int band, d4* op) {
 #pragma unroll
       for (int cb = 0; cb < NB; ++cb)
       {
         d4 x = (d4){0.0, 0.0, 0.0, 0.0};
-        if (cb >= cbm && j < colm[cb] && j >= collo[cb]) x = *(const d4*)(tile + colbase[cb] + j * 128);
+        if ((DESC ? cb <= band : cb >= band) && j < colm[cb] && j >= collo[cb]) x = *(const d4*)(tile + colbase[cb] + j * 128);
         op[cb] = x;
       }
     };
-    auto mfma_band = [&](const d4* op, int cbm) {
+    auto mfma_band = [&](const d4* op, int band) {
 #pragma unroll
       for (int t = 0; t < 4; ++t)
       {
@@ -250,7 +256,7 @@ __global__ __launch_bounds__(512) void k_regressor_gram_duo(const RdynLdsGramArg
 #pragma unroll
           for (int rb = 0; rb <= cb; ++rb)
           {
-            if (rb >= cbm) acc[ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(op[rb][t], op[cb][t], acc[ti], 0, 0, 0);
+            if (DESC ? cb <= band : rb >= band) acc[ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(op[rb][t], op[cb][t], acc[ti], 0, 0, 0);
             ++ti;
           }
       }
@@ -260,7 +266,7 @@ __global__ __launch_bounds__(512) void k_regressor_gram_duo(const RdynLdsGramArg
     {
       // it > 0: the tile in LDS is complete (nothing to consume while the first tile is being swept): group 0
       const bool have = it > 0;
-      if (have) lds_group(0, 0, opa);
+      if (have) lds_group(0, DESC ? (10 * NJ) >> 4 : 0, opa);
 #pragma unroll
       for (int f = 0; f < NJ; ++f)
       {
@@ -270,8 +276,8 @@ __global__ __launch_bounds__(512) void k_regressor_gram_duo(const RdynLdsGramArg
         else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (have)
         {
-          if (f + 1 < NJ) lds_group(f + 1, (10 * (f + 1)) >> 4, nxt);
-          mfma_band(cur, (10 * f) >> 4);
+          if (f + 1 < NJ) lds_group(f + 1, DESC ? (10 * (NJ - f - 1)) >> 4 : (10 * (f + 1)) >> 4, nxt);
+          mfma_band(cur, DESC ? (10 * (NJ - f)) >> 4 : (10 * f) >> 4);
         }
       }
       if (it < trips) DUO_BARRIER_LDS();  // end of the sweeper's tile
@@ -337,7 +343,8 @@ hipError_t launch_duo_nj(const RdynLdsGramArgs& a, int blocks, size_t lds_bytes,
   // direct = every chain joint is an input joint, in chain order (the tile layout tables then follow from NJ alone)
   bool direct = a.n_active == NJ;
   for (int f = 0; direct && f < NJ; ++f) direct = a.lds_m[f] == f + 1 && a.first_col[f] == 10 * f;
-  const int xb = (10 * NJ + a.n_comp_cols + 1 + 15) / 16 - (10 * NJ + 1 + 15) / 16;
+  // component columns always take the XB = 1 instantiation (natural column order); without them XB = 0 (descending link order)
+  const int xb = a.n_comp_cols > 0 ? 1 : 0;
   if (xb == 0) return direct ? launch_duo_nj2<NJ, true, 0>(a, blocks, lds_bytes, st) : launch_duo_nj2<NJ, false, 0>(a, blocks, lds_bytes, st);
   if constexpr (NJ >= 5)  // identification with component columns: one extra column block, arms of 5-7 joints
   {
@@ -351,8 +358,9 @@ bool rdyn_regressor_gram_duo_supported(int n_cols) { return n_cols >= 20 && n_co
 bool rdyn_regressor_gram_duo_supports_components(int n_cols, int n_comp_cols)
 {
   if (!rdyn_regressor_gram_duo_supported(n_cols) || n_comp_cols < 0 || n_comp_cols > 96) return false;
-  const int xb = (n_cols + n_comp_cols + 1 + 15) / 16 - (n_cols + 1 + 15) / 16;
-  return xb == 0 || (xb == 1 && n_cols >= 50);
+  if (n_comp_cols == 0) return true;
+  const int nb1 = (n_cols + 1 + 15) / 16 + 1;  // one extra 16-column block
+  return n_cols >= 50 && n_cols + n_comp_cols + 1 <= 16 * nb1;
 }
 
 hipError_t rdyn_launch_regressor_gram_duo(int n_cols, const RdynLdsGramArgs& a, int blocks, size_t lds_bytes, hipStream_t st)

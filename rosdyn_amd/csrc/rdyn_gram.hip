@@ -154,20 +154,27 @@ __global__ __launch_bounds__(256) void k_gram_finish(const RdynGramArgs a, int n
   int cb = 0;
   while ((cb + 1) * (cb + 2) / 2 <= t) ++cb;
   const int rb = t - cb * (cb + 1) / 2;
-  const int p1 = 16 * rb + (e >> 4), p2 = 16 * cb + (e & 15);
+  const int pp1 = 16 * rb + (e >> 4), pp2 = 16 * cb + (e & 15);  // positions in the slabs' column order
   const int P = a.P;
+  // slab column -> regressor column (P = the measured-torque column, > P = padding)
+  auto col_of = [&](int pp) -> int {
+    if (a.desc_nj <= 0) return pp;
+    if (pp == 0) return P;
+    if (pp > P) return P + 1;
+    return 10 * (a.desc_nj - 1 - (pp - 1) / 10) + (pp - 1) % 10;
+  };
+  const int p1 = col_of(pp1), p2 = col_of(pp2);
   const double prev_scale = a.add_to_output ? 1.0 : 0.0;
+  if (rb == cb && pp1 > pp2) return;  // diagonal tiles hold both triangles: keep the upper one
   if (p1 < P && p2 < P)
   {
-    if (rb != cb || p1 <= p2)
-    {
-      a.G[(int64_t)p2 * P + p1] = prev_scale * a.G[(int64_t)p2 * P + p1] + s;
-      if (p1 != p2) a.G[(int64_t)p1 * P + p2] = prev_scale * a.G[(int64_t)p1 * P + p2] + s;
-    }
+    a.G[(int64_t)p2 * P + p1] = prev_scale * a.G[(int64_t)p2 * P + p1] + s;
+    if (p1 != p2) a.G[(int64_t)p1 * P + p2] = prev_scale * a.G[(int64_t)p1 * P + p2] + s;
   }
-  else if (p2 == P && p1 < P)
+  else if ((p2 == P && p1 < P) || (p1 == P && p2 < P))
   {
-    if (a.c) a.c[p1] = prev_scale * a.c[p1] + s;
+    const int pc = p1 < P ? p1 : p2;
+    if (a.c) a.c[pc] = prev_scale * a.c[pc] + s;
   }
   else if (p1 == P && p2 == P)
   {
@@ -204,7 +211,7 @@ hipError_t rdyn_launch_gram(const RdynGramArgs& a, int blocks, hipStream_t st)
 
 hipError_t rdyn_launch_gram_finish(const RdynGramArgs& a, int blocks, hipStream_t st)
 {
-  const int nb = rdyn_gram_blocks_for(a.P);
+  const int nb = a.slab_nb > 0 ? a.slab_nb : rdyn_gram_blocks_for(a.P);
   const int nt = nb * (nb + 1) / 2;
   hipLaunchKernelGGL(k_gram_finish, dim3((nt * 256 + 31) / 32), dim3(256), 0, st, a, nb, blocks);
   return hipGetLastError();

@@ -114,6 +114,10 @@ struct RdynGramArgs
   // row_block == 0: no structure assumed.  Column blocks (16 wide) left of first_col[j] are neither loaded nor multiplied.
   int64_t row_block;
   int first_col[RDYN_MAX_JOINTS];
+  // finish only: > 0 = the slabs hold the columns in the wave-pair kernel's order [tau_meas | link desc_nj - 1 | ... | link 0]
+  // (rdyn_duo_gram.hip: the zero band of every row group then ends at a 16-column boundary more often); 0 = natural order
+  int desc_nj;
+  int slab_nb;  // finish only: 16-column blocks of the slabs' tile layout if it is wider than P + 1 columns need (0 = derive from P)
 };
 // fused regressor -> Gram persistent kernel (rdyn_fused_gram.hip)
 struct RdynFusedGramArgs
