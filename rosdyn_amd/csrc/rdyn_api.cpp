@@ -781,8 +781,11 @@ size_t rdyn_regressor_gram_workspace_bytes(const rdyn_chain* c, int64_t chunk_sa
 // Tile layout of the LDS-resident regressor -> Gram kernels (rdyn_lds_gram.hip, rdyn_pipe_gram.hip, rdyn_duo_gram.hip): the columns
 // of link f keep the rows of the input joints at chain index <= f; K component columns (one 16-row group each) and the measured
 // torque follow.  Returns false when the input joints are not in chain order (the packed rows must be a prefix).
-static bool build_lds_tile(const rdyn_chain* c, int n_comp_cols, bool dummy_slot, RdynLdsGramArgs* la)
+static bool build_lds_tile(const rdyn_chain* c, int n_comp_cols, bool dummy_slot, RdynLdsGramArgs* la, bool compact = false)
 {
+  // column padding: 4 doubles keep the 16 lanes of an MFMA operand read on disjoint banks; the compact layout (2 doubles, 2-way
+  // conflicts on the consumer's reads, which has slack) is what lets four 7-joint tiles WITH component columns fit 160 KB
+  const int pad = compact ? 2 : 4;
   const int n = c->n_active(), nJ = c->n_joints();
   bool monotonic = true;
   for (int j = 1; j < n; ++j) monotonic = monotonic && c->active[j] > c->active[j - 1];
@@ -792,14 +795,15 @@ static bool build_lds_tile(const rdyn_chain* c, int n_comp_cols, bool dummy_slot
     int m = 0;
     for (int j = 0; j < n; ++j) m += (c->active[j] <= f) ? 1 : 0;
     la->lds_m[f] = m;
-    la->lds_stride[f] = (16 * m + 4) * 8;
+    la->lds_stride[f] = (16 * m + pad) * 8;
     la->lds_off[f] = off;
     off += 10 * la->lds_stride[f];
   }
   la->lds_off_c = off;
-  off += n_comp_cols * 160;
+  la->comp_stride = (16 + pad) * 8;
+  off += n_comp_cols * la->comp_stride;
   la->lds_off_b = off;
-  off += (16 * n + 4) * 8;
+  off += (16 * n + pad) * 8;
   la->lds_dummy_off = off;
   if (dummy_slot) off += 64 * 8;
   la->tile_bytes = (off + 255) & ~255;
@@ -1136,7 +1140,8 @@ int rdyn_identification_gram(const rdyn_chain* c, const rdyn_component* comps, i
   {
     RdynLdsGramArgs la;
     memset(&la, 0, sizeof la);
-    const bool monotonic = build_lds_tile(c, K, false, &la);
+    bool monotonic = build_lds_tile(c, K, false, &la);
+    if (4 * (size_t)la.tile_bytes > 160 * 1024) monotonic = build_lds_tile(c, K, false, &la, true);  // compact layout (7 joints + components)
     const int nbt = K > 0 ? rdyn_gram_blocks_for(P) + 1 : rdyn_gram_blocks_for(P);  // the kernel's slab layout (XB = 1 with components)
     size_t lds_bytes = 4 * (size_t)la.tile_bytes;
     const size_t red_bytes = (size_t)(nbt * (nbt + 1) / 2) * 256 * sizeof(double);

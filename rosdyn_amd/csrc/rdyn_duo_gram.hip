@@ -49,6 +49,8 @@ namespace
 #endif
 
 // XB: extra 16-column blocks for the component columns of rdyn_identification_gram (0: plain regressor Gram)
+typedef double d4h __attribute__((ext_vector_type(4), aligned(16)));  // operand quads: 16-byte aligned in the compact tile layout
+
 template <int NJ, bool DIRECT, int XB>
 __global__ __launch_bounds__(512) void k_regressor_gram_duo(const RdynLdsGramArgs fa)
 {
@@ -177,8 +179,8 @@ __global__ __launch_bounds__(512) void k_regressor_gram_duo(const RdynLdsGramArg
           }
           if (k == (jc & 3))
           {
-            char* const lc = tile + fa.lds_off_c + col * 160 + s_loc * 8;
-            for (int e = 0; e < cols; ++e) *(double*)(lc + e * 160) = valid ? row[e] : 0.0;
+            char* const lc = tile + fa.lds_off_c + col * fa.comp_stride + s_loc * 8;
+            for (int e = 0; e < cols; ++e) *(double*)(lc + e * fa.comp_stride) = valid ? row[e] : 0.0;
           }
           col += cols;
         }
@@ -221,7 +223,7 @@ __global__ __launch_bounds__(512) void k_regressor_gram_duo(const RdynLdsGramArg
       {
         lo = fa.comp_col_row[p - P];          // one row group: the component's own joint
         hi = lo + 1;
-        base = fa.lds_off_c + (p - P) * 160 - lo * 128;
+        base = fa.lds_off_c + (p - P) * fa.comp_stride - lo * 128;
       }
       else if (p == P + K)
       {
@@ -242,7 +244,7 @@ __global__ __launch_bounds__(512) void k_regressor_gram_duo(const RdynLdsGramArg
       for (int cb = 0; cb < NB; ++cb)
       {
         d4 x = (d4){0.0, 0.0, 0.0, 0.0};
-        if ((DESC ? cb <= band : cb >= band) && j < colm[cb] && j >= collo[cb]) x = *(const d4*)(tile + colbase[cb] + j * 128);
+        if ((DESC ? cb <= band : cb >= band) && j < colm[cb] && j >= collo[cb]) x = *(const d4h*)(tile + colbase[cb] + j * 128);
         op[cb] = x;
       }
     };
@@ -342,7 +344,7 @@ hipError_t launch_duo_nj(const RdynLdsGramArgs& a, int blocks, size_t lds_bytes,
 {
   // direct = every chain joint is an input joint, in chain order (the tile layout tables then follow from NJ alone)
   bool direct = a.n_active == NJ;
-  for (int f = 0; direct && f < NJ; ++f) direct = a.lds_m[f] == f + 1 && a.first_col[f] == 10 * f;
+  for (int f = 0; direct && f < NJ; ++f) direct = a.lds_m[f] == f + 1 && a.first_col[f] == 10 * f && a.lds_stride[f] == (16 * (f + 1) + 4) * 8;
   // component columns always take the XB = 1 instantiation (natural column order); without them XB = 0 (descending link order)
   const int xb = a.n_comp_cols > 0 ? 1 : 0;
   if (xb == 0) return direct ? launch_duo_nj2<NJ, true, 0>(a, blocks, lds_bytes, st) : launch_duo_nj2<NJ, false, 0>(a, blocks, lds_bytes, st);

@@ -159,7 +159,7 @@ struct RdynLdsGramArgs
   // Column P + k of the tile belongs to component comp_col_comp[k] and is non-zero only in the rows of that component's joint:
   // it is stored as ONE 16-row group (stride 160 bytes) at lds_off_c + 160 k; the measured torque moves to column P + n_comp_cols.
   int n_comps, n_comp_cols;
-  int lds_off_c;
+  int lds_off_c, comp_stride;          // component column k at lds_off_c + comp_stride * k (160, or 144 in the compact layout)
   signed char comp_col_row[96];        // per component column: the input joint (row group) it belongs to
   RdynComponent comps[RDYN_MAX_COMPONENTS];
 };
