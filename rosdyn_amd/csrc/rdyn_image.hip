@@ -13,8 +13,8 @@
 // (read-modify-write under ECC).  Measured on MI355X, N = 1e6, n = 6 / P = 60 (profiles/r2/image_ab.txt): run-by-run copy-out
 // 0.86-0.95 ms (slower than the 48-byte row-pair stores it was meant to replace), line-aligned copy-out: see DESIGN.md.
 // Only the first / last line of an image can be partial (images are 22.5 lines long): 1 line in 22.
-// The ring pitch is RUN + 144 bytes: consecutive lanes' 8-byte staging writes fall into different LDS banks and the 16-byte
-// reads stay aligned.  Only wave-local ordering is needed (64-thread workgroups, no barrier).  The image stride may be padded
+// The ring pitch is RUN + 144 (or 160) bytes, an odd number of 16-byte units: consecutive lanes' 8-byte staging writes fall into
+// different LDS banks and the 16-byte reads stay aligned.  Only wave-local ordering is needed (64-thread workgroups, no barrier).  The image stride may be padded
 // (stride_sample >= n P); wave bases are 64-bit, per-lane offsets 32-bit inside the wave's 64 images.
 //
 // Instantiated for the input-joint patterns the tile arithmetic can fold at compile time: the first NA chain joints are the
@@ -37,14 +37,35 @@ __device__ __forceinline__ void wave_lds_fence()
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// pieces a link's ten columns are flushed in (1, 2 or 5).  One piece when a copy-out instruction already covers >= 2 samples
+// (NA <= 6: 64 lanes / 8 * ceil(80 NA / 128) chunks); five pieces beyond, where the ring of a whole link leaves 3 waves per CU and
+// one sample per store instruction (measured, 1e6 samples, NA = 7: 1078 / 859 / 772 us with 1 / 2 / 5 pieces; NA = 6: 527 / 555 /
+// 540 us; NA = 8: 942 / 927 / 945 us -- profiles/r2/image_ab.txt).  -DRDYN_IMAGE_FLUSHES=k forces one value (A/B builds).
+constexpr int image_flushes(int na)
+{
+#ifdef RDYN_IMAGE_FLUSHES
+  (void)na;
+  return RDYN_IMAGE_FLUSHES;
+#else
+  return 64 / (((80 * na + 127) / 128) * 8) >= 2 ? 1 : 5;
+#endif
+}
+
 template <int NJ, int NA, bool NT, bool STACKED>
 __global__ __launch_bounds__(64) void k_image_sweep(const RdynSweepArgs a)
 {
   constexpr int RUN = 80 * NA;                       // bytes one link adds to one sample's image
   constexpr int IMG = NJ * RUN;                      // bytes of one image
-  constexpr int W = RUN + 128;                       // ring: the link's run + the < 128 bytes that wait for their line
-  constexpr int PITCH = W + 16;                      // staging slot of one sample
-  constexpr int MAXC = ((RUN + 127) / 128) * 8;      // most 16-byte chunks one sample flushes per link (whole lines)
+  // the image kernel flushes a link in NF pieces of CPF columns: half the ring, twice the waves per CU (the copy-out is bound
+  // by LDS / store latency, not by instruction count: 3-4 waves per CU left one SIMD idle)
+  constexpr int NF = STACKED ? 1 : image_flushes(NA);
+  constexpr int CPF = 10 / NF;                       // columns per flush
+  constexpr int RUNF = CPF * NA * 8;                 // bytes per flush and sample
+  constexpr int W = ((RUNF + 15) / 16) * 16 + 128;   // ring: one flush's run + the < 128 bytes that wait for their line
+  // staging slot of one sample: the pitch in 16-byte units is ODD, so that the 8-byte staging writes of 16 consecutive lanes fall
+  // on different LDS banks (2-way at worst)
+  constexpr int PITCH = W + ((W / 16) % 2 ? 32 : 16);
+  constexpr int MAXC = ((RUNF + 127) / 128) * 8;     // most 16-byte chunks one sample flushes at once (whole lines)
   constexpr int SPI = 64 / MAXC;                     // samples one copy-out instruction covers
   constexpr int NIT = (64 + SPI - 1) / SPI;
   extern __shared__ __attribute__((aligned(16))) char stage[];
@@ -72,6 +93,8 @@ __global__ __launch_bounds__(64) void k_image_sweep(const RdynSweepArgs a)
   const uint32_t m0 = ((uint32_t)(uintptr_t)ywave + (uint32_t)sub * img) & 127u;
   const uint32_t dm = ((uint32_t)SPI * img) & 127u;
   const bool m_const = dm == 0;                      // natural strides at n = 6: every lane keeps one alignment class
+  int n_phase = 1;                                   // period of the alignment class in the copy-out iteration index
+  while (((uint32_t)n_phase * dm) & 127u) ++n_phase;  // dm is a multiple of 16: at most 8
 
   V3 w = mk(0, 0, 0), vl = mk(0, 0, 0), al = mk(0, 0, 0);
   V3 acc = mk(-c->g[0], -c->g[1], -c->g[2]);  // base "acceleration" -g: gravity enters every link's d for free
@@ -160,6 +183,10 @@ __global__ __launch_bounds__(64) void k_image_sweep(const RdynSweepArgs a)
     const double b20 = wxz - al.y, b21 = wyz + al.x, b22 = -(wxx + wyy);
     const RDYN_CONST_AS double* pi = J.pi;
 #pragma unroll
+    for (int hf = 0; hf < NF; ++hf)
+    {
+    const int p_lo = hf * CPF, p_hi = p_lo + CPF;  // this flush's columns (the other columns' arithmetic is dead code here)
+#pragma unroll
     for (int l = 0; l < NA; ++l)
     {
       if (l <= f)
@@ -182,6 +209,7 @@ __global__ __launch_bounds__(64) void k_image_sweep(const RdynSweepArgs a)
 #pragma unroll
         for (int p = 0; p < 10; ++p)
         {
+          if (p < p_lo || p >= p_hi) continue;
           tl = fma(y[p], pi[p], tl);
           *(double*)(stg + spos(f, p, l)) = y[p];
         }
@@ -191,7 +219,8 @@ __global__ __launch_bounds__(64) void k_image_sweep(const RdynSweepArgs a)
       {
         // structural zero block (row of a joint downstream of this link): the image is dense
 #pragma unroll
-        for (int p = 0; p < 10; ++p) *(double*)(stg + spos(f, p, l)) = 0.0;
+        for (int p = 0; p < 10; ++p)
+          if (p >= p_lo && p < p_hi) *(double*)(stg + spos(f, p, l)) = 0.0;
       }
     }
     // ---- copy out the lines completed by this link: image bytes [Fp, Fc), Fx = E - ((m + E) mod 128) (everything at the last link)
@@ -224,11 +253,11 @@ __global__ __launch_bounds__(64) void k_image_sweep(const RdynSweepArgs a)
     }
     else
     {
-      const int Ep = f * RUN, Ec = (f + 1) * RUN;  // constants after unrolling
-      const bool last = f == NJ - 1;
+      const int Ep = f * RUN + hf * RUNF, Ec = Ep + RUNF;  // constants after unrolling
+      const bool last = f == NJ - 1 && hf == NF - 1;
       // one sample's piece: x = first byte this lane moves (image offset), active if x < Fc
       auto piece = [&](uint32_t m, uint32_t j, uint32_t& x, uint32_t& pos, bool& on) {
-        const uint32_t Fp = f == 0 ? 0u : (uint32_t)Ep - ((m + (uint32_t)Ep) & 127u);
+        const uint32_t Fp = Ep == 0 ? 0u : (uint32_t)Ep - ((m + (uint32_t)Ep) & 127u);
         const uint32_t Fc = last ? (uint32_t)IMG : (uint32_t)Ec - ((m + (uint32_t)Ec) & 127u);
         x = Fp + 16u * j;
         on = x < Fc;
@@ -250,7 +279,9 @@ __global__ __launch_bounds__(64) void k_image_sweep(const RdynSweepArgs a)
           const char* const lsrc = stage + sub * PITCH + pos;
           if (on)
           {
-#pragma unroll
+            // a few iterations per trip: fully unrolled (NIT up to 64 per link) the kernel body outgrows what hipcc will unroll
+            // over the links, and the per-link arrays of the sweep then live in scratch
+#pragma unroll 4
             for (int it = 0; it < NIT; ++it)
             {
               const d2a v = *(const d2a*)(lsrc + it * (SPI * PITCH));
@@ -262,19 +293,35 @@ __global__ __launch_bounds__(64) void k_image_sweep(const RdynSweepArgs a)
         }
         else
         {
-#pragma unroll
-          for (int it = 0; it < NIT; ++it)
+          // general strides / alignments: the misalignment of sample (it * SPI + sub) repeats with a short period in `it`
+          // (n_phase <= 8: 128 / gcd(SPI * stride mod 128, 128)).  Iterations are visited phase by phase, it = ph + n_phase * k:
+          // inside a phase every lane keeps ONE alignment class, so the piece arithmetic (a dozen VALU instructions) runs once
+          // per phase and an iteration costs one address add, one LDS read and one store -- evaluated per iteration it took
+          // 1.3 ms per 1e6 evaluations at 7 joints (3 920-byte images, eight classes) against 0.62 ms for the stacked layout.
+          for (int ph = 0; ph < n_phase; ++ph)
           {
             uint32_t x, pos;
             bool on;
-            piece((m0 + (uint32_t)it * dm) & 127u, (uint32_t)cj, x, pos, on);
-            if (on && it * SPI + sub < valid)
+            piece((m0 + (uint32_t)ph * dm) & 127u, (uint32_t)cj, x, pos, on);
+            const uint32_t g_off = (uint32_t)sub * img + x;
+            uint32_t l_addr = (uint32_t)((ph * SPI + sub) * PITCH) + pos;
+            char* yp = yl + (int64_t)ph * SPI * img;  // wave-uniform
+            const int64_t g_step = (int64_t)n_phase * SPI * img;
+            const uint32_t l_step = (uint32_t)(n_phase * SPI * PITCH);
+            // the LDS read is unconditional (a slot past the wave's 64 reads as zeros, nothing is stored from it), so that several
+            // reads of the unrolled trip are in flight: one read -> wait -> store per trip exposed the LDS latency 64 times per link
+#pragma unroll 4
+            for (int it = ph; it < NIT; it += n_phase)
             {
-              const d2a v = *(const d2a*)(stage + (it * SPI + sub) * PITCH + pos);
-              if (NT) __builtin_nontemporal_store((d2u)v, (d2u*)(yl + (uint32_t)sub * img + x));
-              else *(d2u*)(yl + (uint32_t)sub * img + x) = (d2u)v;
+              const d2a v = *(const d2a*)(stage + l_addr);
+              if (on && it * SPI + sub < valid)
+              {
+                if (NT) __builtin_nontemporal_store((d2u)v, (d2u*)(yp + g_off));
+                else *(d2u*)(yp + g_off) = (d2u)v;
+              }
+              l_addr += l_step;
+              yp += g_step;
             }
-            yl += (int64_t)SPI * img;
           }
         }
       }
@@ -300,7 +347,8 @@ __global__ __launch_bounds__(64) void k_image_sweep(const RdynSweepArgs a)
         }
       }
     }
-    wave_lds_fence();  // the ring is written again by the next link
+    wave_lds_fence();  // the ring is written again by the next flush
+    }
   }
   if (a.tau && mine)
   {
@@ -314,7 +362,8 @@ template <int NJ, int NA, bool STACKED>
 hipError_t launch_image(const RdynSweepArgs& a, hipStream_t st)
 {
   const dim3 grid((unsigned)((a.n_samples + 63) / 64));
-  const size_t lds = STACKED ? (size_t)10 * 64 * NA * 8 : (size_t)64 * (80 * NA + 128 + 16);
+  constexpr int runf = (10 / image_flushes(NA)) * NA * 8, w = ((runf + 15) / 16) * 16 + 128, pitch = w + ((w / 16) % 2 ? 32 : 16);
+  const size_t lds = STACKED ? (size_t)10 * 64 * NA * 8 : (size_t)64 * pitch;
   // nontemporal copy-out: the lines are written whole, once, and never re-read (A/B, same box: 0.55 ms vs 0.72 ms per 1e6)
 #ifdef RDYN_IMAGE_PLAIN_STORES
   hipLaunchKernelGGL((k_image_sweep<NJ, NA, false, STACKED>), grid, dim3(64), lds, st, a);

@@ -188,7 +188,7 @@ int main(int argc, char** argv)
       if (hipMalloc((void**)&d_in, h.size() * sizeof(double)) != hipSuccess || hipMalloc((void**)&d_tau, sizeof(double) * N * n) != hipSuccess ||
           hipMalloc((void**)&d_G, sizeof(double) * (P * P + P + 1)) != hipSuccess || hipMalloc(&d_ws, ws) != hipSuccess)
         throw std::runtime_error("hipMalloc failed");
-      hipMemcpy(d_in, h.data(), h.size() * sizeof(double), hipMemcpyHostToDevice);
+      if (hipMemcpy(d_in, h.data(), h.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) throw std::runtime_error("hipMemcpy failed");
       rdyn_batch b;
       std::memset(&b, 0, sizeof b);
       b.n_samples = N;
@@ -201,8 +201,9 @@ int main(int argc, char** argv)
       chain->getRegressorGramBatch(b, d_tau, d_G, d_G + P * P, d_G + P * P + P, false, d_ws, ws);
       rosdyn::MatrixXd G(P, P);
       rosdyn::VectorXd c(P), x;
-      hipMemcpy(G.data(), d_G, sizeof(double) * P * P, hipMemcpyDeviceToHost);
-      hipMemcpy(c.data(), d_G + P * P, sizeof(double) * P, hipMemcpyDeviceToHost);
+      if (hipMemcpy(G.data(), d_G, sizeof(double) * P * P, hipMemcpyDeviceToHost) != hipSuccess ||
+          hipMemcpy(c.data(), d_G + P * P, sizeof(double) * P, hipMemcpyDeviceToHost) != hipSuccess)
+        throw std::runtime_error("hipMemcpy failed");
       const int rank = rosdyn::Chain::solveNormalEquations(G, c, x);
       double res = 0.0, cmax = 0.0;
       for (int i = 0; i < P; ++i)
@@ -215,7 +216,7 @@ int main(int argc, char** argv)
       std::printf("S %d %.17g", rank, res / cmax);
       for (int i = 0; i < P; ++i) std::printf(" %.17g", x(i));
       std::printf("\n");
-      hipFree(d_in); hipFree(d_tau); hipFree(d_G); hipFree(d_ws);
+      (void)hipFree(d_in); (void)hipFree(d_tau); (void)hipFree(d_G); (void)hipFree(d_ws);
     }
     return 0;
   }

@@ -10,7 +10,7 @@ OBJ=_obj/var/${NAME}_${STEM}.o
 if [[ $SRC == *.cpp ]]; then
   g++ -O3 -std=c++17 -fPIC -Wall -Wextra -Wno-unused-parameter -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include "$@" -c $SRC -o $OBJ
 else
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wextra -Wno-unused-parameter -Wno-cuda-compat "$@" -c $SRC -o $OBJ
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wextra -Wno-unused-parameter -Wno-cuda-compat -ffp-contract=on "$@" -c $SRC -o $OBJ
 fi
 OTHERS=$(ls _obj/*.o | grep -v "_obj/${STEM}.o")
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -o ../variants/librdyn_${NAME}.so $OBJ $OTHERS

@@ -3,7 +3,7 @@
 # kernel's largest loop (absolute paths: safe from any working directory)
 F=$1; K=$2; shift 2
 cd /root/repo/rosdyn_amd/csrc
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -I. -S --cuda-device-only -Wno-cuda-compat "$@" $F -o /tmp/isa_$$.s 2>&1 | grep -E "error" -A4
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -I. -S --cuda-device-only -Wno-cuda-compat -ffp-contract=on "$@" $F -o /tmp/isa_$$.s 2>&1 | grep -E "error" -A4
 awk "/amdhsa_kernel .*$K/,/end_amdhsa_kernel/" /tmp/isa_$$.s | grep -E "next_free_vgpr|next_free_sgpr|private_segment_fixed" | tr '\n' ' '; echo
 python3 - /tmp/isa_$$.s "$K" <<'PY'
 import re,collections,sys
