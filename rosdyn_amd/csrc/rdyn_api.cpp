@@ -1014,8 +1014,8 @@ int rdyn_tsqr(const double* A, int64_t rows, int64_t lda, int n_cols, const doub
     if (!accumulate) RDYN_HIP_TRY(hipMemsetAsync(R, 0, sizeof(double) * n1 * n1, (hipStream_t)stream));
     return RDYN_OK;
   }
-  const int64_t blocks32 = (rows + 31) / 32;
-  const int blocks = (int)((blocks32 + 3) / 4 < kTsqrBlocks ? (blocks32 + 3) / 4 : kTsqrBlocks);
+  const int64_t blocks64 = (rows + 63) / 64;  // one wave folds 64 rows at a time
+  const int blocks = (int)((blocks64 + 3) / 4 < kTsqrBlocks ? (blocks64 + 3) / 4 : kTsqrBlocks);
   RDYN_HIP_TRY(rdyn_launch_tsqr_rows(A, bvec, rows, lda, n_cols, blocks, (double*)workspace, R, accumulate ? 1 : 0, (hipStream_t)stream));
   return RDYN_OK;
 }

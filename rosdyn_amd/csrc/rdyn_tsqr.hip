@@ -2,23 +2,26 @@
 // "regressor + TSQR Gram").  The Gram route (rdyn_duo_gram.hip -> pivoted Cholesky) squares the condition number: fine for
 // excitation trajectories, useless beyond cond(A) ~ 1e8.  Here the R factor itself is accumulated:
 //
-//   leaf     every wave keeps a running upper-triangular R (lane j holds column j in registers) and folds row blocks into it by
-//            Householder reflections: R <- qr([R ; block]).  A block is the LDS tile of 16 samples that the wave's own row-pair
-//            sweep has just produced (rdyn_regressor_tsqr; packed column-major tile of rdyn_lds_gram.hip: the columns of link f
-//            only hold the rows of the joints that can be non-zero there, so the reflections skip the structural zeros), or 32
-//            rows of a device matrix (rdyn_tsqr).  Per column k: one pass over the block's rows gives |y_k|^2 and y_k . y_j for
-//            every lane's column j, the reflection is applied in a second pass; y_k is read by all lanes from one LDS address
-//            (broadcast).  No cross-lane reduction, no barrier: a wave never touches another wave's data.
-//   tree     k_tsqr_combine folds four R factors into one per wave, level by level in a fixed order (bitwise reproducible),
-//            with the same update (an R factor is a block whose column k has k + 1 rows).
+//   leaf     every wave keeps a running upper-triangular R in registers and folds row blocks into it by Householder reflections:
+//            R <- qr([R ; block]).  A block is the LDS tile of 16 samples that the wave's own row-pair sweep has just produced
+//            (rdyn_regressor_tsqr; packed column-major tile of rdyn_lds_gram.hip: the columns of link f only hold the rows of the
+//            joints that can be non-zero there) or 64 rows of a device matrix (rdyn_tsqr).  Block and factor are spread over the
+//            wave in two dimensions (16 column slots x 4 row groups, tsqr_fold2d below); a column step exchanges one column
+//            through LDS and sums the row groups with v_permlane16/32_swap.  A wave never touches another wave's data in the loop.
+//   block    the four waves of a workgroup fold their factors 1 -> 0, 3 -> 2, 2 -> 0 through LDS before anything is written.
+//   tree     k_tsqr_combine folds two factors into one per wave, level by level in a fixed order (bitwise reproducible).
 //   ranks    the (P + 1)^2 factor of every rank is all-gathered and folded on the host (rdyn_tsqr_combine_host): same payload
 //            as the Gram all-reduce.
 // Result: R1 = [R d; 0 rho] with A = Q R, d = Q' tau_meas, rho = |residual| -- solve with rdyn_solve_r_factor.
-// Cost: ~4 (n = 6) to ~8 (n = 7: 71 columns on 64 lanes, two column slots) times the Gram kernel; it is the robust path, the
-// Gram stays the default.  fp64 VALU + LDS only (Householder updates are rank-1: nothing for the matrix cores at this width).
+// Cost (1e6 samples, n = 6): 3.2 ms = 5 x the Gram kernel, of which 0.4 ms are the block + tree levels (10 dependent folds).  A fold
+// is 61 dependent column steps of ~1 400 cycles: LDS round trip 40 %, the fmas 35 %, row-group sums, sqrt and divide the rest --
+// a latency chain at one wave per SIMD (300+ VGPRs), not a throughput bound.  The Gram stays the default; this is the robust path.
+// Round 2's first version (lane = column, block re-read from LDS twice per step) ran 8.7 ms at the LDS roofline.
+// fp64 VALU + LDS only (Householder updates are rank-1: nothing for the matrix cores at this width).
 #include <hip/hip_runtime.h>
 #include <atomic>
 #include <cstdint>
+#include <utility>
 #include "rdyn_device.h"
 #include "rdyn_devmath.h"
 #include "rdyn_kernels.h"
@@ -30,12 +33,6 @@ namespace
 {
 typedef double d2a __attribute__((ext_vector_type(2), aligned(16)));
 
-__device__ __forceinline__ double lane_value(double x, int src_lane)  // src_lane: compile-time constant after unrolling
-{
-  const int lo = __builtin_amdgcn_readlane(__double2loint(x), src_lane);
-  const int hi = __builtin_amdgcn_readlane(__double2hiint(x), src_lane);
-  return __hiloint2double(hi, lo);
-}
 __device__ __forceinline__ void wave_lds_fence()
 {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -43,110 +40,223 @@ __device__ __forceinline__ void wave_lds_fence()
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// R <- qr([R ; block]).  NC columns; lane j owns column j (Rc) and, if TWO, column 64 + j (Rc2).  colinfo(k, base, rows): LDS byte
-// offset of column k of the block and the (even) number of rows it stores; my_base / my_base2: the same for this lane's columns.
-// Columns to the right of k store at least as many rows as column k (prefix property of every block kind used here).
-// RQ: the rows of every column are a multiple of RQ (16 for the sweep tiles and the 32-row blocks, 2 for triangular factors): the
-// row loops move RQ rows per iteration with all their LDS reads issued up front -- a lone wave is bound by the LDS round trip,
-// not by the arithmetic (two rows per trip measured 14 ms at N = 1e6, n = 6).
-template <int NC, bool TWO, int RQ, class ColInfo>
-__device__ __forceinline__ void tsqr_update(double (&Rc)[NC], double (&Rc2)[TWO ? NC : 1], const char* blk, ColInfo colinfo, int my_base, int my_base2,
-                                            int lane)
+// ---------------------------------------------------------------- leaf update, 2-D register-resident (round 2b)
+// The lane = column update above moves every block element through LDS twice per column step (|y_k|^2 / y_k . y_j, then the
+// reflection): 1 350 LDS cycles per step and wave, and the LDS pipe is shared by the CU -- 8.7 ms at config 2 was the LDS roofline,
+// with the fp64 pipes a quarter busy.  The leaves therefore keep the block in REGISTERS, spread over the wave in two dimensions:
+//   lane = (cs = lane & 15, rg = lane >> 4):  column j lives in column slot (j >> 4) of the 16 lanes with cs == (j & 15); row slot r
+//   of the block is 16 rows, row group rg owns rows 4 rg .. 4 rg + 3 of every slot (sweep tiles: slot = joint row, rows = samples).
+//   R[k][j] lives in lane (cs = j & 15, rg = k & 3), register Rr[j >> 4][k >> 2].
+// Column step k: the four lanes that own y_k publish it (<= 1 KB) together with row k of R, every lane reads the slice of its row
+// group, forms the partial dots of its <= NCI columns, the four row groups are summed with two v_permlane*_swap exchanges (gfx950:
+// no LDS), and the reflection is applied in registers.  Work per step and lane: rows/4 * (columns right of k)/16 fmas instead of
+// `rows` fmas for the active lanes only -- and 2-3 LDS instructions per row slot instead of 6 per row pair.
+// The step loop is unrolled over (k >> 4, (k >> 2) & 3) so that every register index is static and rolled over k & 3.
+__device__ __forceinline__ double rowgroup_sum(double x)
 {
-  constexpr int H = RQ / 2;  // 16-byte pairs per iteration
-#pragma unroll
-  for (int k = 0; k < NC; ++k)
+  // v_permlane16_swap a, b: rows 1, 3 of a <-> rows 0, 2 of b (row = 16 lanes); with a = b = x: a' = [x0 x0 x2 x2], b' = [x1 x1 x3 x3]
+  const unsigned lo = (unsigned)__double2loint(x), hi = (unsigned)__double2hiint(x);
+  const auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+  const auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+  const double s = __hiloint2double((int)b[0], (int)a[0]) + __hiloint2double((int)b[1], (int)a[1]);
+  const unsigned lo2 = (unsigned)__double2loint(s), hi2 = (unsigned)__double2hiint(s);
+  const auto c = __builtin_amdgcn_permlane32_swap(lo2, lo2, false, false);  // upper half of a <-> lower half of b
+  const auto d = __builtin_amdgcn_permlane32_swap(hi2, hi2, false, false);
+  return __hiloint2double((int)d[0], (int)c[0]) + __hiloint2double((int)d[1], (int)c[1]);
+}
+
+// RMaxOf::of(c): static bound of the row slots the columns of column slot c can hold (non-decreasing in c); the slots a column does
+// not store are zeros in Y and stay zeros (a column never stores fewer slots than a column to its left), so the steps run over
+// RMaxOf::of(k >> 4) slots without run-time row counts: ~20 % more fmas than the exact counts of a sweep tile, no selects.
+// buf: >= (RM * 16 + NCI * 16) doubles of LDS, wave-private.
+template <int NC, int RM, class RMaxOf, int KCI, int KQ>
+__device__ __forceinline__ void tsqr_fold2d_steps(double (&Rr)[(NC + 15) / 16][(NC + 3) / 4], double (&Y)[(NC + 15) / 16][RM][4], char* buf, int lane)
+{
+  constexpr int NCI = (NC + 15) / 16;
+  constexpr int LEFT = NC - (16 * KCI + 4 * KQ), KR = LEFT < 4 ? LEFT : 4;  // steps 16 KCI + 4 KQ + (0 .. KR - 1)
+  if constexpr (KR > 0)
   {
-    int base_k, rows;
-    colinfo(k, base_k, rows);
-    if (rows <= 0) continue;  // wave-uniform
-    const char* const yk_p = blk + base_k;
-    double sigma = 0.0, d = 0.0, d2 = 0.0;
-    for (int r = 0; r < rows; r += RQ)
+    const int cs = lane & 15, rg = lane >> 4;
+    char* const pv = buf + rg * 32;       // my row group's slice of the published column: [r][16 rows]
+    char* const rrow = buf + RM * 128;    // row k of R: [NCI * 16]
+#pragma unroll 1
+  for (int kr = 0; kr < KR; ++kr)
+  {
+    const int kcs = 4 * KQ + kr, k = 16 * KCI + kcs;
+    // ---- publish y_k (its four owner lanes) and row k of R (the 16 lanes of row group k & 3)
+    if (cs == kcs)
     {
-      d2a yk[H], yj[H], yq[TWO ? H : 1];
 #pragma unroll
-      for (int h = 0; h < H; ++h)
+      for (int r = 0; r < RM; ++r)
+        if (r < RMaxOf::of(KCI))
+        {
+          d2a v0, v1;
+          v0.x = Y[KCI][r][0]; v0.y = Y[KCI][r][1]; v1.x = Y[KCI][r][2]; v1.y = Y[KCI][r][3];
+          *(d2a*)(pv + r * 128) = v0;
+          *(d2a*)(pv + r * 128 + 16) = v1;
+        }
+    }
+    if (rg == kr)
+    {
+#pragma unroll
+      for (int c = KCI; c < NCI; ++c) *(double*)(rrow + (16 * c + cs) * 8) = Rr[c][4 * KCI + KQ];
+    }
+    wave_lds_fence();
+    // ---- my row group's slice of y_k, my columns' entries of row k
+    double yk[RM][4], rk[NCI], dp[NCI];
+#pragma unroll
+    for (int r = 0; r < RM; ++r)
+      if (r < RMaxOf::of(KCI))
       {
-        yk[h] = *(const d2a*)(yk_p + (r + 2 * h) * 8);
-        yj[h] = *(const d2a*)(blk + my_base + (r + 2 * h) * 8);
-        if (TWO) yq[h] = *(const d2a*)(blk + my_base2 + (r + 2 * h) * 8);
+        const d2a v0 = *(const d2a*)(pv + r * 128), v1 = *(const d2a*)(pv + r * 128 + 16);
+        yk[r][0] = v0.x; yk[r][1] = v0.y; yk[r][2] = v1.x; yk[r][3] = v1.y;
       }
 #pragma unroll
-      for (int h = 0; h < H; ++h)
+    for (int c = KCI; c < NCI; ++c) rk[c] = *(const double*)(rrow + (16 * c + cs) * 8);
+    const double alpha = *(const double*)(rrow + k * 8);
+#pragma unroll
+    for (int c = KCI; c < NCI; ++c) dp[c] = 0.0;
+#pragma unroll
+    for (int r = 0; r < RM; ++r)
+      if (r < RMaxOf::of(KCI))
       {
-        sigma = fma(yk[h].x, yk[h].x, fma(yk[h].y, yk[h].y, sigma));
-        d = fma(yk[h].x, yj[h].x, fma(yk[h].y, yj[h].y, d));
-        if (TWO) d2 = fma(yk[h].x, yq[h].x, fma(yk[h].y, yq[h].y, d2));
+#pragma unroll
+        for (int c = KCI; c < NCI; ++c)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) dp[c] = fma(yk[r][i], Y[c][r][i], dp[c]);
+      }
+#pragma unroll
+    for (int c = KCI; c < NCI; ++c) dp[c] = rowgroup_sum(dp[c]);
+    // |y_k|^2 is the dot of column k with itself: lane kcs (row group 0) holds it in dp[KCI]
+    const double sigma = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(dp[KCI]), kcs), __builtin_amdgcn_readlane(__double2loint(dp[KCI]), kcs));
+    if (sigma != 0.0)  // wave-uniform
+    {
+      const double norm = sqrt(fma(alpha, alpha, sigma));
+      const double beta = alpha > 0.0 ? -norm : norm;
+      const double v0 = alpha - beta;
+      const double scale = 2.0 / fma(v0, v0, sigma);
+#pragma unroll
+      for (int c = KCI; c < NCI; ++c)
+      {
+        const int j = 16 * c + cs;
+        const double f = (j > k && j < NC) ? scale * fma(v0, rk[c], dp[c]) : 0.0;
+        if (rg == kr) Rr[c][4 * KCI + KQ] = j == k ? beta : fma(-f, v0, rk[c]);
+#pragma unroll
+        for (int r = 0; r < RM; ++r)
+          if (r < RMaxOf::of(KCI))
+          {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) Y[c][r][i] = fma(-f, yk[r][i], Y[c][r][i]);
+          }
       }
     }
-    if (sigma == 0.0) continue;  // every lane computed the same sigma: uniform
-    const double alpha = k < 64 ? lane_value(Rc[k < NC ? k : 0], k & 63) : lane_value(Rc2[TWO ? k : 0], k & 63);
-    const double norm = sqrt(fma(alpha, alpha, sigma));
-    const double beta = alpha > 0.0 ? -norm : norm;
-    const double v0 = alpha - beta;
-    const double scale = 2.0 / fma(v0, v0, sigma);
-    const bool on = lane > k && lane < NC;
-    const bool on2 = TWO && 64 + lane > k && 64 + lane < NC;
-    const double f = on ? scale * fma(v0, Rc[k], d) : 0.0;
-    const double f2 = on2 ? scale * fma(v0, Rc2[TWO ? k : 0], d2) : 0.0;
-    Rc[k] = fma(-f, v0, Rc[k]);
-    if (lane == k) Rc[k] = beta;
-    if (TWO)
-    {
-      Rc2[TWO ? k : 0] = fma(-f2, v0, Rc2[TWO ? k : 0]);
-      if (64 + lane == k) Rc2[TWO ? k : 0] = beta;
-    }
-    if (on || on2)
-      for (int r = 0; r < rows; r += RQ)
-      {
-        d2a yk[H], yj[H], yq[TWO ? H : 1];
-#pragma unroll
-        for (int h = 0; h < H; ++h)
-        {
-          yk[h] = *(const d2a*)(yk_p + (r + 2 * h) * 8);
-          yj[h] = *(const d2a*)(blk + my_base + (r + 2 * h) * 8);
-          if (TWO) yq[h] = *(const d2a*)(blk + my_base2 + (r + 2 * h) * 8);
-        }
-#pragma unroll
-        for (int h = 0; h < H; ++h)
-        {
-          if (on)
-          {
-            yj[h].x = fma(-f, yk[h].x, yj[h].x);
-            yj[h].y = fma(-f, yk[h].y, yj[h].y);
-            *(d2a*)(blk + my_base + (r + 2 * h) * 8) = yj[h];
-          }
-          if (TWO && on2)
-          {
-            yq[h].x = fma(-f2, yk[h].x, yq[h].x);
-            yq[h].y = fma(-f2, yk[h].y, yq[h].y);
-            *(d2a*)(blk + my_base2 + (r + 2 * h) * 8) = yq[h];
-          }
-        }
-      }
-    wave_lds_fence();  // the next column reads what this step wrote
+    wave_lds_fence();  // the next step publishes into the same buffer
+  }
   }
 }
 
-// lane's column(s) of an NC x NC upper-triangular factor, column-major with leading dimension ld
-template <int NC, bool TWO>
-__device__ __forceinline__ void store_factor(const double (&Rc)[NC], const double (&Rc2)[TWO ? NC : 1], double* out, int ld, int n_cols, int lane)
+template <int NC, int RM, class RMaxOf, int... I>
+__device__ __forceinline__ void tsqr_fold2d_seq(double (&Rr)[(NC + 15) / 16][(NC + 3) / 4], double (&Y)[(NC + 15) / 16][RM][4], char* buf, int lane,
+                                                std::integer_sequence<int, I...>)
 {
+  (tsqr_fold2d_steps<NC, RM, RMaxOf, I / 4, I % 4>(Rr, Y, buf, lane), ...);
+}
+
+template <int NC, int RM, class RMaxOf>
+__device__ __forceinline__ void tsqr_fold2d(double (&Rr)[(NC + 15) / 16][(NC + 3) / 4], double (&Y)[(NC + 15) / 16][RM][4], char* buf, int lane)
+{
+  tsqr_fold2d_seq<NC, RM, RMaxOf>(Rr, Y, buf, lane, std::make_integer_sequence<int, 4 * ((NC + 15) / 16)>{});
+}
+
+// R[k][j] of the 2-D distribution -> n_cols x n_cols factor, column-major with leading dimension ld (zeros below the diagonal)
+template <int NC, class Ptr>
+__device__ __forceinline__ void store_factor2d(const double (&Rr)[(NC + 15) / 16][(NC + 3) / 4], Ptr out, int ld, int n_cols, int lane)
+{
+  const int cs = lane & 15, rg = lane >> 4;
 #pragma unroll
-  for (int i = 0; i < NC; ++i)
+  for (int c = 0; c < (NC + 15) / 16; ++c)
+#pragma unroll
+    for (int kk = 0; kk < (NC + 3) / 4; ++kk)
+    {
+      const int j = 16 * c + cs, k = 4 * kk + rg;
+      if (j < n_cols && k < n_cols) out[j * ld + k] = k <= j ? Rr[c][kk] : 0.0;
+    }
+}
+
+// the running factor from memory (inverse of store_factor2d)
+template <int NC, class Ptr>
+__device__ __forceinline__ void load_factor2d(double (&Rr)[(NC + 15) / 16][(NC + 3) / 4], Ptr in, int ld, int n_cols, int lane)
+{
+  const int cs = lane & 15, rg = lane >> 4;
+#pragma unroll
+  for (int c = 0; c < (NC + 15) / 16; ++c)
+#pragma unroll
+    for (int kk = 0; kk < (NC + 3) / 4; ++kk)
+    {
+      const int j = 16 * c + cs, k = 4 * kk + rg;
+      Rr[c][kk] = (j < n_cols && k <= j) ? in[j * ld + k] : 0.0;
+    }
+}
+
+// an upper-triangular factor as the BLOCK of a fold: column 16 c + cs stores rows 0 .. 16 c + cs, i.e. at most c + 1 row slots
+struct TriRowSlots
+{
+  static constexpr int of(int c) { return c + 1; }
+};
+template <int NC, class Ptr>
+__device__ __forceinline__ void load_tri_block(double (&Y)[(NC + 15) / 16][(NC + 15) / 16][4], Ptr f, int ld, int n_cols, int lane)
+{
+  const int cs = lane & 15, rg = lane >> 4;
+#pragma unroll
+  for (int c = 0; c < (NC + 15) / 16; ++c)
+#pragma unroll
+    for (int r = 0; r <= c; ++r)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+      {
+        const int j = 16 * c + cs, row = 16 * r + 4 * rg + i;
+        Y[c][r][i] = (j < n_cols && row <= j) ? f[j * ld + row] : 0.0;
+      }
+}
+
+// leading dimension of a factor parked in LDS: even (16-byte aligned row slices) and not a multiple of 256 bytes (banks)
+constexpr int lds_factor_ld(int nc) { return ((nc + 1) & ~1) + ((((nc + 1) & ~1) * 8) % 256 == 0 ? 2 : 0); }
+
+// the four running factors of a workgroup -> one (wave 0's), through LDS: 1 -> 0 and 3 -> 2, then 2 -> 0, a fixed order.
+// region(w): LDS of wave w, at least NC * lds_factor_ld(NC) doubles from region(0) / region(2) on (two waves' regions are contiguous)
+template <int NC, class Region>
+__device__ __forceinline__ void block_combine(double (&Rr)[(NC + 15) / 16][(NC + 3) / 4], Region region, int wave, int lane)
+{
+  constexpr int NCI = (NC + 15) / 16, LD = lds_factor_ld(NC);
+#pragma unroll 1
+  for (int level = 0; level < 2; ++level)
   {
-    if (lane < n_cols && i < n_cols) out[(int64_t)lane * ld + i] = i <= lane ? Rc[i] : 0.0;
-    if (TWO && 64 + lane < n_cols && i < n_cols) out[(int64_t)(64 + lane) * ld + i] = i <= 64 + lane ? Rc2[TWO ? i : 0] : 0.0;
+    const int sender = level == 0 ? (wave & 1) : (wave == 2), receiver = level == 0 ? !(wave & 1) : (wave == 0);
+    __syncthreads();  // the regions are free (tile loop / previous level done)
+    if (sender) store_factor2d<NC>(Rr, (double*)region(level == 0 ? wave - 1 : 0), LD, NC, lane);
+    __syncthreads();
+    if (receiver)
+    {
+      char* const reg = region(wave);
+      double Y[NCI][NCI][4];
+      load_tri_block<NC>(Y, (const double*)reg, LD, NC, lane);
+      wave_lds_fence();
+      tsqr_fold2d<NC, NCI, TriRowSlots>(Rr, Y, reg, lane);
+    }
   }
 }
 
 // ---------------------------------------------------------------- leaf: regressor rows from the wave's own sweep
 template <int NJ>
+struct SweepRowSlots  // columns 16 c .. 16 c + 15 belong to links <= (16 c + 15) / 10, whose columns store <= link + 1 joint rows
+{
+  static constexpr int of(int c) { return (16 * c + 15) / 10 + 1 < NJ ? (16 * c + 15) / 10 + 1 : NJ; }
+};
+
+template <int NJ>
 __global__ __launch_bounds__(256) void k_regressor_tsqr(const RdynLdsGramArgs fa, double* __restrict__ factors)
 {
-  constexpr int P = 10 * NJ, NC = P + 1;
-  constexpr bool TWO = NC > 64;
+  constexpr int P = 10 * NJ, NC = P + 1, NCI = (NC + 15) / 16, NK = (NC + 3) / 4;
   constexpr bool DIRECT = false;
   extern __shared__ __attribute__((aligned(32))) char lds_raw[];
   ChainPtr c = as_const(fa.chain);
@@ -159,30 +269,36 @@ __global__ __launch_bounds__(256) void k_regressor_tsqr(const RdynLdsGramArgs fa
   int fB = NJ;
   for (int f = NJ - 1; f >= 0; --f)
     if (fa.lds_m[f] >= 5) fB = f;
-  // my column(s) of the tile
-  auto col_of = [&](int p, int& base, int& rows) {
+  // tile column p: byte offset and row slots (joint rows; 16 samples each)
+  auto col_of = [&](int p, int& base, int& slots) {
     if (p < P)
     {
       const int f = p / 10;
       base = fa.lds_off[f] + (p - 10 * f) * fa.lds_stride[f];
-      rows = 16 * fa.lds_m[f];
+      slots = fa.lds_m[f];
     }
     else
     {
       base = fa.lds_off_b;
-      rows = 16 * n;
+      slots = n;
     }
   };
-  int my_base = 0, my_rows = 0, my_base2 = 0, my_rows2 = 0;
-  col_of(lane < NC ? lane : NC - 1, my_base, my_rows);
-  if (TWO) col_of(64 + lane < NC ? 64 + lane : NC - 1, my_base2, my_rows2);
-  (void)my_rows;
-  (void)my_rows2;
-  double Rc[NC], Rc2[TWO ? NC : 1];
+  // my columns of the tile (2-D distribution of tsqr_fold2d): column 16 c + cs, rows 4 rg .. 4 rg + 3 of every slot
+  const int cs = lane & 15, rg = lane >> 4;
+  int yb[NCI], ys[NCI];
 #pragma unroll
-  for (int i = 0; i < NC; ++i) Rc[i] = 0.0;
+  for (int ci = 0; ci < NCI; ++ci)
+  {
+    const int j = 16 * ci + cs;
+    col_of(j < NC ? j : NC - 1, yb[ci], ys[ci]);
+    yb[ci] += rg * 32;
+    if (j >= NC) ys[ci] = 0;
+  }
+  double Rr[NCI][NK];
 #pragma unroll
-  for (int i = 0; i < (TWO ? NC : 1); ++i) Rc2[i] = 0.0;
+  for (int ci = 0; ci < NCI; ++ci)
+#pragma unroll
+    for (int i = 0; i < NK; ++i) Rr[ci][i] = 0.0;
 
   const int64_t n_tiles = (fa.n_samples + 15) / 16;
   const int64_t t_first = (int64_t)blockIdx.x * 4 + wave, t_step = (int64_t)gridDim.x * 4;
@@ -231,93 +347,114 @@ __global__ __launch_bounds__(256) void k_regressor_tsqr(const RdynLdsGramArgs fa
       if (r1 < n) *(double*)(lb + r1 * 128) = tb1;
     }
     wave_lds_fence();
-    // ---------------- fold the tile into the running factor
-    tsqr_update<NC, TWO, 16>(Rc, Rc2, tile, col_of, my_base, my_base2, lane);
+    // ---------------- the tile moves into registers and is folded into the running factor; its LDS is the fold's exchange buffer
+    double Y[NCI][NJ][4];
+#pragma unroll
+    for (int ci = 0; ci < NCI; ++ci)
+#pragma unroll
+      for (int r = 0; r < NJ; ++r)
+        if (r < SweepRowSlots<NJ>::of(ci))
+        {
+          d2a v0 = {0.0, 0.0}, v1 = {0.0, 0.0};
+          if (r < ys[ci])
+          {
+            v0 = *(const d2a*)(tile + yb[ci] + r * 128);
+            v1 = *(const d2a*)(tile + yb[ci] + r * 128 + 16);
+          }
+          Y[ci][r][0] = v0.x; Y[ci][r][1] = v0.y; Y[ci][r][2] = v1.x; Y[ci][r][3] = v1.y;
+        }
+    wave_lds_fence();
+    tsqr_fold2d<NC, NJ, SweepRowSlots<NJ>>(Rr, Y, tile, lane);
   }
-  store_factor<NC, TWO>(Rc, Rc2, factors + ((int64_t)blockIdx.x * 4 + wave) * (NC * NC), NC, NC, lane);
+  // ---------------- the workgroup's four factors -> one
+  block_combine<NC>(Rr, [&](int w) { return lds_raw + (size_t)w * fa.tile_bytes; }, wave, lane);
+  if (wave == 0) store_factor2d<NC>(Rr, factors + (int64_t)blockIdx.x * (NC * NC), NC, NC, lane);
 }
 
-// ---------------------------------------------------------------- leaf: 32-row blocks of a column-major device matrix
+// ---------------------------------------------------------------- leaf: 64-row blocks of a column-major device matrix
+template <int SLOTS>
+struct ConstRowSlots
+{
+  static constexpr int of(int) { return SLOTS; }
+};
+
 template <int NC>
 __global__ __launch_bounds__(256) void k_tsqr_rows(const double* __restrict__ A, const double* __restrict__ b, int64_t rows, int64_t lda, int n_cols,
                                                    double* __restrict__ factors)
 {
-  constexpr int TR = 32, SB = (TR + 2) * 8;  // block: NC columns of TR rows (+ pad), column-major
+  constexpr int TR = 64, SB = (TR + 2) * 8;  // block: NC columns of TR rows (+ pad), column-major
+  constexpr int NCI = (NC + 15) / 16, NK = (NC + 3) / 4, RM = TR / 16;
   extern __shared__ __attribute__((aligned(32))) char lds_raw[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   char* const blk = lds_raw + (size_t)wave * (NC * SB);
-  double Rc[NC], Rc2[1] = {0.0};
+  const int cs = lane & 15, rg = lane >> 4;
+  double Rr[NCI][NK];
 #pragma unroll
-  for (int i = 0; i < NC; ++i) Rc[i] = 0.0;
+  for (int ci = 0; ci < NCI; ++ci)
+#pragma unroll
+    for (int i = 0; i < NK; ++i) Rr[ci][i] = 0.0;
   const int nc1 = n_cols + (b ? 1 : 0);  // the right-hand side rides as one more column
-  auto col_of = [&](int kcol, int& base, int& nrows) {
-    base = kcol * SB;
-    nrows = kcol < nc1 ? TR : 0;
-  };
-  const int my_base = (lane < NC ? lane : NC - 1) * SB;
-  for (int i = lane * 8; i < NC * SB; i += 64 * 8) *(double*)(blk + i) = 0.0;  // columns >= nc1 are never loaded: keep them zero
-  wave_lds_fence();
   const int64_t n_blocks = (rows + TR - 1) / TR;
   const int64_t b_first = (int64_t)blockIdx.x * 4 + wave, b_step = (int64_t)gridDim.x * 4;
-  const int half = lane >> 5, rl = lane & 31;
   for (int64_t bi = b_first; bi < n_blocks; bi += b_step)
   {
-    const int64_t r = bi * TR + rl;
-    for (int cc = 0; cc < nc1; cc += 2)  // two columns per instruction: lanes 0-31 / 32-63
+    // coalesced along the rows (512 B per column), transposed into the 2-D distribution through LDS
+    const int64_t r = bi * TR + lane;
+    for (int col = 0; col < nc1; ++col)
     {
-      const int col = cc + half;
       double v = 0.0;
-      if (col < nc1 && r < rows) v = col < n_cols ? A[(int64_t)col * lda + r] : b[r];
-      if (col < NC) *(double*)(blk + col * SB + rl * 8) = v;
+      if (r < rows) v = col < n_cols ? A[(int64_t)col * lda + r] : b[r];
+      *(double*)(blk + col * SB + lane * 8) = v;
     }
     wave_lds_fence();
-    tsqr_update<NC, false, 16>(Rc, Rc2, blk, col_of, my_base, 0, lane);
+    double Y[NCI][RM][4];
+#pragma unroll
+    for (int ci = 0; ci < NCI; ++ci)
+#pragma unroll
+      for (int rs = 0; rs < RM; ++rs)
+      {
+        d2a v0 = {0.0, 0.0}, v1 = {0.0, 0.0};
+        const int j = 16 * ci + cs;
+        if (j < nc1)  // the padding columns (nc1 .. NC - 1) are never loaded
+        {
+          v0 = *(const d2a*)(blk + j * SB + (rs * 16 + rg * 4) * 8);
+          v1 = *(const d2a*)(blk + j * SB + (rs * 16 + rg * 4) * 8 + 16);
+        }
+        Y[ci][rs][0] = v0.x; Y[ci][rs][1] = v0.y; Y[ci][rs][2] = v1.x; Y[ci][rs][3] = v1.y;
+      }
+    wave_lds_fence();
+    tsqr_fold2d<NC, RM, ConstRowSlots<RM>>(Rr, Y, blk, lane);
   }
-  store_factor<NC, false>(Rc, Rc2, factors + ((int64_t)blockIdx.x * 4 + wave) * (NC * NC), NC, NC, lane);
+  block_combine<NC>(Rr, [&](int w) { return lds_raw + (size_t)w * (NC * SB); }, wave, lane);
+  if (wave == 0) store_factor2d<NC>(Rr, factors + (int64_t)blockIdx.x * (NC * NC), NC, NC, lane);
 }
 
-// ---------------------------------------------------------------- tree: every wave folds up to four factors into one
+// ---------------------------------------------------------------- tree: every wave folds two factors into one
+// (2 : 1 -- a fold is 61 .. 71 dependent column steps whatever the block holds, so the DEPTH of the tree is its cost: 4 : 1 levels
+// fold three blocks one after the other per level)
 template <int NC>
 __global__ __launch_bounds__(64) void k_tsqr_combine(const double* __restrict__ in, int count, double* __restrict__ out, int out_ld, int out_cols,
                                                      const double* __restrict__ extra /* one more factor (accumulate), or null */, int extra_ld)
 {
-  constexpr bool TWO = NC > 64;
-  constexpr int SB = ((NC + 3) & ~1) * 8;
-  extern __shared__ __attribute__((aligned(32))) char blk[];
+  constexpr int NCI = (NC + 15) / 16, NK = (NC + 3) / 4;
+  __shared__ __attribute__((aligned(32))) char buf[2 * NCI * 128];
   const int lane = threadIdx.x;
-  const int first = blockIdx.x * 4;
-  double Rc[NC], Rc2[TWO ? NC : 1];
-  // the first factor becomes the running one
-  {
-    const double* f0 = in + (int64_t)first * (NC * NC);
-#pragma unroll
-    for (int i = 0; i < NC; ++i)
-    {
-      Rc[i] = (lane < NC && i <= lane) ? f0[(int64_t)lane * NC + i] : 0.0;
-      if (TWO) Rc2[TWO ? i : 0] = (64 + lane < NC && i <= 64 + lane) ? f0[(int64_t)(64 + lane) * NC + i] : 0.0;
-    }
-    if (!TWO) Rc2[0] = 0.0;
-  }
-  auto col_of = [&](int kcol, int& base, int& nrows) {
-    base = kcol * SB;
-    nrows = (kcol + 2) & ~1;  // column k of an upper-triangular factor: rows 0 .. k (+ one zero row to make it even)
-  };
-  const int my_base = (lane < NC ? lane : NC - 1) * SB, my_base2 = (64 + lane < NC ? 64 + lane : NC - 1) * SB;
-  const int n_more = (count - first < 4 ? count - first : 4) - 1;
+  const int first = blockIdx.x * 2;
+  double Rr[NCI][NK];
+  load_factor2d<NC>(Rr, in + (int64_t)first * (NC * NC), NC, NC, lane);
+  const int n_more = first + 1 < count ? 1 : 0;
   for (int t = 1; t <= n_more + (extra && blockIdx.x == 0 ? 1 : 0); ++t)
   {
     const bool is_extra = t > n_more;
-    const double* ft = is_extra ? extra : in + (int64_t)(first + t) * (NC * NC);
-    const int ld = is_extra ? extra_ld : NC;
-    const int cols = is_extra ? out_cols : NC;
-    for (int col = 0; col < NC; ++col)
-      for (int i = lane; i < NC + 1; i += 64)
-        *(double*)(blk + col * SB + i * 8) = (col < cols && i <= col) ? ft[(int64_t)col * ld + i] : 0.0;
-    wave_lds_fence();
-    tsqr_update<NC, TWO, 2>(Rc, Rc2, blk, col_of, my_base, my_base2, lane);
+    double Y[NCI][NCI][4];
+    if (is_extra)
+      load_tri_block<NC>(Y, extra, extra_ld, out_cols, lane);
+    else
+      load_tri_block<NC>(Y, in + (int64_t)(first + 1) * (NC * NC), NC, NC, lane);
+    tsqr_fold2d<NC, NCI, TriRowSlots>(Rr, Y, buf, lane);
   }
-  store_factor<NC, TWO>(Rc, Rc2, out + (int64_t)blockIdx.x * (NC * NC), out_ld, out_cols, lane);  // the last level is one wave: offset 0
+  store_factor2d<NC>(Rr, out + (int64_t)blockIdx.x * (NC * NC), out_ld, out_cols, lane);  // the last level is one wave: offset 0
 }
 
 template <class K>
@@ -340,23 +477,19 @@ hipError_t opt_in_lds(K kernel, std::atomic<uint64_t>& done)
 template <int NC>
 hipError_t combine_tree(double* slab, int count, double* scratch, double* R, int n_out, const double* extra, hipStream_t st)
 {
-  static std::atomic<uint64_t> attr{0};
-  hipError_t e = opt_in_lds(k_tsqr_combine<NC>, attr);
-  if (e != hipSuccess) return e;
-  const size_t lds = (size_t)NC * (((NC + 3) & ~1) * 8);
   double* in = slab;
   double* out = scratch;
-  while (count > 4)
+  while (count > 2)
   {
-    const int nout = (count + 3) / 4;
-    hipLaunchKernelGGL((k_tsqr_combine<NC>), dim3(nout), dim3(64), lds, st, in, count, out, NC, NC, nullptr, 0);
+    const int nout = (count + 1) / 2;
+    hipLaunchKernelGGL((k_tsqr_combine<NC>), dim3(nout), dim3(64), 0, st, in, count, out, NC, NC, nullptr, 0);
     count = nout;
     double* t = in;
     in = out;
     out = t;
   }
   // last level: straight into the caller's buffer (compact n_out x n_out), folding the caller's previous factor if accumulating
-  hipLaunchKernelGGL((k_tsqr_combine<NC>), dim3(1), dim3(64), lds, st, in, count, R, n_out, n_out, extra, n_out);
+  hipLaunchKernelGGL((k_tsqr_combine<NC>), dim3(1), dim3(64), 0, st, in, count, R, n_out, n_out, extra, n_out);
   return hipGetLastError();
 }
 
@@ -370,7 +503,7 @@ hipError_t launch_regressor_tsqr(const RdynLdsGramArgs& a, int blocks, size_t ld
   hipLaunchKernelGGL((k_regressor_tsqr<NJ>), dim3(blocks), dim3(256), lds_bytes, st, a, slab);
   e = hipGetLastError();
   if (e != hipSuccess) return e;
-  return combine_tree<10 * NJ + 1>(slab, blocks * 4, scratch, R, 10 * NJ + 1, extra, st);
+  return combine_tree<10 * NJ + 1>(slab, blocks, scratch, R, 10 * NJ + 1, extra, st);
 }
 
 template <int NC>
@@ -380,23 +513,23 @@ hipError_t launch_tsqr_rows(const double* A, const double* b, int64_t rows, int6
   static std::atomic<uint64_t> attr{0};
   hipError_t e = opt_in_lds(k_tsqr_rows<NC>, attr);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL((k_tsqr_rows<NC>), dim3(blocks), dim3(256), (size_t)4 * NC * (34 * 8), st, A, b, rows, lda, n_cols, slab);
+  hipLaunchKernelGGL((k_tsqr_rows<NC>), dim3(blocks), dim3(256), (size_t)4 * NC * ((64 + 2) * 8), st, A, b, rows, lda, n_cols, slab);
   e = hipGetLastError();
   if (e != hipSuccess) return e;
-  return combine_tree<NC>(slab, blocks * 4, scratch, R, n_cols + (b ? 1 : 0), extra, st);
+  return combine_tree<NC>(slab, blocks, scratch, R, n_cols + (b ? 1 : 0), extra, st);
 }
 }  // namespace
 
 // factors per launch and doubles of workspace (two slab regions: leaves + tree levels)
 int rdyn_tsqr_padded_cols(int n_cols_with_rhs) { return n_cols_with_rhs <= 16 ? 16 : n_cols_with_rhs <= 32 ? 32 : n_cols_with_rhs <= 48 ? 48 : n_cols_with_rhs <= 64 ? 64 : 0; }
-size_t rdyn_tsqr_workspace_doubles(int nc, int blocks) { return (size_t)(blocks * 4 + blocks + 4) * nc * nc; }
+size_t rdyn_tsqr_workspace_doubles(int nc, int blocks) { return (size_t)(blocks + (blocks + 1) / 2 + 2) * nc * nc; }
 
 hipError_t rdyn_launch_regressor_tsqr(int n_joints, const RdynLdsGramArgs& a, int blocks, size_t lds_bytes, double* workspace, double* R, int accumulate,
                                       hipStream_t st)
 {
   const int nc = 10 * n_joints + 1;
   double* slab = workspace;
-  double* scratch = workspace + (size_t)blocks * 4 * nc * nc;
+  double* scratch = workspace + (size_t)blocks * nc * nc;
   const double* extra = accumulate ? R : nullptr;
   switch (n_joints)
   {
@@ -415,7 +548,7 @@ hipError_t rdyn_launch_tsqr_rows(const double* A, const double* b, int64_t rows,
 {
   const int nc = rdyn_tsqr_padded_cols(n_cols + (b ? 1 : 0));
   double* slab = workspace;
-  double* scratch = workspace + (size_t)blocks * 4 * nc * nc;
+  double* scratch = workspace + (size_t)blocks * nc * nc;
   const double* extra = accumulate ? R : nullptr;
   switch (nc)
   {
