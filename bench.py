@@ -223,10 +223,19 @@ def extras_config3(dev, steps=5):
     ev1.record()
     torch.cuda.synchronize()
     ms = ev0.elapsed_time(ev1) / steps
+    # the same batch through the tall-skinny QR (the R factor of [A | tau] without forming A'A): the robust route, not the default
+    chain.getRegressorTsqr(q, dq, ddq, tau)
+    torch.cuda.synchronize()
+    ev0.record()
+    for _ in range(2):
+        chain.getRegressorTsqr(q, dq, ddq, tau)
+    ev1.record()
+    torch.cuda.synchronize()
+    tsqr_ms = ev0.elapsed_time(ev1) / 2
     f_eval = gram_flop_per_eval(n, P)
     tf = f_eval * N / (ms * 1e-3) / 1e12
     return {"workload": "configs[2]: 7-DOF panda_like link0->link7 (n=7, P=70), N=%d, getRegressor -> Gram" % N,
-            "value": N / (ms * 1e-3), "unit": "evals/s", "ms_per_step": ms,
+            "value": N / (ms * 1e-3), "unit": "evals/s", "ms_per_step": ms, "tsqr_ms_per_step": tsqr_ms,
             "roofline": {"bound": "fp64-matrix", "achieved": tf, "peak": FP64_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": tf / FP64_MATRIX_PEAK_TFLOPS, "flop_per_eval_dense_syrk": f_eval, "kernel_ms": ms}}
 

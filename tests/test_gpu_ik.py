@@ -60,6 +60,30 @@ def test_local_ik_matches_oracle(urdf, base, tool, layout):
     assert worst < 1e-6
 
 
+@pytest.mark.parametrize("urdf,base,tool,damping", [("ur10_like.urdf", "base_link", "tool0", 0.0), ("panda_like.urdf", "link0", "link8", 1e-3)])
+def test_ik_resume_launches_are_bit_identical_to_one_launch(urdf, base, tool, damping):
+    """The staged path (8 updates for every pose, then the survivors re-packed into dense waves and resumed by
+    k_local_ik_resume) against ONE launch that runs every pose to the cap (the C-ABI takes that path when `iterations` is
+    NULL): the same arithmetic per pose, so solution AND status must agree bit for bit on every pose -- including the
+    slow, chaotic ones the oracle comparison above can only check statistically."""
+    torch = pytest.importorskip("torch")
+    import ctypes as C
+    from rosdyn_amd._lib import lib, check
+    chain, ref, q_goal, seeds, T = _setup(urdf, base, tool, 5000, 0.6, seed=21)   # wide seeds: many poses need > 8 updates
+    Tt = torch.from_numpy(np.ascontiguousarray(T.transpose(0, 2, 1))).cuda()
+    ts = torch.from_numpy(np.ascontiguousarray(seeds)).cuda()
+    sol_a, st_a, it_a = chain.computeLocalIk(Tt, ts, toll=1e-8, max_iterations=40, damping=damping)
+    b, N, lay = chain._batch("sample", ts)
+    sol_b = torch.empty_like(sol_a)
+    st_b = torch.empty(N, dtype=torch.int32, device="cuda")
+    check(lib().rdyn_local_ik_damped(chain._h, C.byref(b), Tt.data_ptr(), None, 1e-8, float(damping), 40, sol_b.data_ptr(), st_b.data_ptr(), None))
+    torch.cuda.synchronize()
+    it = it_a.cpu().numpy()
+    assert (it > 8).mean() > 0.05, (it > 8).mean()          # the resume launch really had work to do
+    assert torch.equal(st_a, st_b)
+    assert torch.equal(sol_a, sol_b)
+
+
 def test_weighted_ik_and_joint_limits():
     """Position-only weights (orientation free) and targets whose unconstrained solution leaves the joint range: the
     bound-constrained QP must keep every iterate inside [q_min, q_max] exactly as the oracle's Goldfarb-Idnani does."""
