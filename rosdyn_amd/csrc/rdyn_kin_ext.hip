@@ -7,9 +7,9 @@
 //   getDDTwistNonLinearPart  :1156-1183   jN[l] = translate(jN[l-1], d) + (v x S) DDq + (a x S + v x (v x S)) Dq
 //   getWrench                :1225-1262   w[l]  = T(-ext[l]) + inertial[l] + gravity[l] + dualTranslate(w[l+1], p_l - p_l+1)
 // One thread per sample; every output record is links x 6 doubles ([lin; ang] per link).
-// The wrench recursion runs tool -> base in the reference; here every link's own wrench is added, as soon as the forward
-// sweep reaches it, to the accumulators of all links up to it (dualTranslate is additive in the offset), so there is no
-// backward pass and no per-link frame storage: 6 (L) accumulators + the link origins in registers.
+// The wrench recursion runs tool -> base in the reference; here the forward sweep parks every link's OWN wrench, referred to the
+// base origin (dualTranslate is additive in the offset), in wave-private LDS, and a short backward pass over the thread's own
+// records forms the suffix sums: no per-link frame storage, no 6 (L) accumulators in registers.
 #include <hip/hip_runtime.h>
 #include "rdyn_device.h"
 #include "rdyn_devmath.h"
@@ -44,13 +44,16 @@ __device__ __forceinline__ S6 axpy6(S6 a, S6 b, double s)
 }
 
 #ifndef RDYN_KIN_EXT_WAVES
-#define RDYN_KIN_EXT_WAVES 1  // minimum waves per SIMD asked of the register allocator.  3 and 4 were measured: hipcc then spills (196-404 B of scratch) and getWrench / getDDTwist slow down 1.2-5x (profiles/r2/perf_sheet.txt)
+#define RDYN_KIN_EXT_WAVES 1  // minimum waves per SIMD asked of the register allocator.  3 and 4 were measured: hipcc then spills (60-404 B of scratch) and getWrench / getDDTwist slow down 1.15-5x (profiles/r2/perf_sheet.txt)
 #endif
+// WRENCH: 64-thread workgroups (the wave parks every link's own wrench in LDS, 48 (NJ + 1) bytes per thread; no barrier)
 template <int NJ, bool WRENCH>
-__global__ __launch_bounds__(256, RDYN_KIN_EXT_WAVES) void k_base_ext(const RdynKinExtArgs a)
+__global__ __launch_bounds__(WRENCH ? 64 : 256, RDYN_KIN_EXT_WAVES) void k_base_ext(const RdynKinExtArgs a)
 {
+  constexpr int BS = WRENCH ? 64 : 256;
+  extern __shared__ __attribute__((aligned(16))) double own_lds[];  // WRENCH: [6 (NJ + 1)][64]
   ChainPtr c = as_const(a.chain);
-  const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t s = (int64_t)blockIdx.x * BS + threadIdx.x;
   if (s >= a.n_samples) return;
   const double* __restrict__ qp = a.q + s * a.in_ss;
   const double* __restrict__ dqp = a.dq ? a.dq + s * a.in_ss : nullptr;
@@ -59,7 +62,7 @@ __global__ __launch_bounds__(256, RDYN_KIN_EXT_WAVES) void k_base_ext(const Rdyn
   const int64_t es = a.out_se;
   // output addressing = wave-uniform 64-bit base (SGPRs) + one 32-bit per-lane byte offset (the saddr store form): with a full
   // 64-bit pointer per record element hipcc keeps dozens of address pairs alive in the unrolled link loop (204 VGPRs)
-  const int64_t blk_off = (int64_t)blockIdx.x * 256 * a.out_ss;
+  const int64_t blk_off = (int64_t)blockIdx.x * BS * a.out_ss;
   const uint32_t lane_off = threadIdx.x * (uint32_t)a.out_ss * 8u;
   auto put6 = [&](double* base, int64_t first_elem, S6 x) {
     char* const o = (char*)(base + blk_off + first_elem * es);  // uniform
@@ -80,16 +83,20 @@ __global__ __launch_bounds__(256, RDYN_KIN_EXT_WAVES) void k_base_ext(const Rdyn
   if (a.ddtw_lin) put6(a.ddtw_lin, 0, zero);
   if (a.ddtw_nonlin) put6(a.ddtw_nonlin, 0, zero);
   // WRENCH: origins of links 0 .. NJ.  The per-link wrench accumulators do NOT live in registers (6 (NJ + 1) doubles pushed the
-  // kernel to 200 VGPRs = 2 waves per SIMD on a streaming kernel): every link's OWN wrench goes to its output record referred
-  // to the base origin (moment + p x force), and a short backward pass over the thread's own records (L2-hot, read once) forms
-  // the suffix sums and refers each one back to its link's origin.
+  // kernel to 200 VGPRs = 2 waves per SIMD on a streaming kernel): every link's OWN wrench is parked in LDS referred to the base
+  // origin (moment + p x force), and a short backward pass over the thread's own records forms the suffix sums and refers each
+  // one back to its link's origin.  (Round 2's first version parked them in the output records: the store -> load round trip
+  // through L2 / HBM, at two waves per SIMD, left the kernel waiting on memory for two thirds of its cycles.)
   V3 po[WRENCH ? NJ + 1 : 1];
-  auto get6 = [&](const double* base, int64_t first_elem) -> S6 {
-    const char* const o = (const char*)(base + blk_off + first_elem * es);
-    const int64_t eb = es * 8;
+  auto park6 = [&](int link, S6 x) {
+    double* const o = own_lds + (6 * link) * 64 + threadIdx.x;
+    o[0] = x.l.x; o[64] = x.l.y; o[128] = x.l.z; o[192] = x.a.x; o[256] = x.a.y; o[320] = x.a.z;
+  };
+  auto parked6 = [&](int link) -> S6 {
+    const double* const o = own_lds + (6 * link) * 64 + threadIdx.x;
     S6 x;
-    x.l = mk(*(const double*)(o + lane_off), *(const double*)(o + eb + lane_off), *(const double*)(o + 2 * eb + lane_off));
-    x.a = mk(*(const double*)(o + 3 * eb + lane_off), *(const double*)(o + 4 * eb + lane_off), *(const double*)(o + 5 * eb + lane_off));
+    x.l = mk(o[0], o[64], o[128]);
+    x.a = mk(o[192], o[256], o[320]);
     return x;
   };
   V3 p = mk(0, 0, 0);
@@ -98,7 +105,7 @@ __global__ __launch_bounds__(256, RDYN_KIN_EXT_WAVES) void k_base_ext(const Rdyn
     S6 e = zero;
     if (a.ext)
     {
-      const char* const ep = (const char*)(a.ext + (int64_t)blockIdx.x * 256 * a.ext_ss + (int64_t)(6 * link) * a.ext_se);  // uniform
+      const char* const ep = (const char*)(a.ext + (int64_t)blockIdx.x * BS * a.ext_ss + (int64_t)(6 * link) * a.ext_se);  // uniform
       const uint32_t ev = threadIdx.x * (uint32_t)a.ext_ss * 8u;
       const int64_t eb = a.ext_se * 8;
       e.l = mk(-*(const double*)(ep + ev), -*(const double*)(ep + eb + ev), -*(const double*)(ep + 2 * eb + ev));
@@ -109,7 +116,7 @@ __global__ __launch_bounds__(256, RDYN_KIN_EXT_WAVES) void k_base_ext(const Rdyn
   if (WRENCH)
   {
     po[0] = p;
-    put6(a.wrench, 0, ext_of(0));  // spatialTranformation(-ext, T_bl[0] = identity); no inertial / gravity term on the base link (:1233-1237)
+    park6(0, ext_of(0));  // spatialTranformation(-ext, T_bl[0] = identity); no inertial / gravity term on the base link (:1233-1237)
   }
 #pragma unroll
   for (int f = 0; f < NJ; ++f)
@@ -205,7 +212,7 @@ __global__ __launch_bounds__(256, RDYN_KIN_EXT_WAVES) void k_base_ext(const Rdyn
       own.l = own.l + rot(R, e.l) + cross(Ra, p);
       own.a = own.a + Ra;
       own.a = own.a + cross(p, own.l);  // referred to the base origin: suffix sums need no per-pair translation
-      put6(a.wrench, 6 * (f + 1), own);
+      park6(f + 1, own);
     }
   }
   if (WRENCH)
@@ -215,7 +222,7 @@ __global__ __launch_bounds__(256, RDYN_KIN_EXT_WAVES) void k_base_ext(const Rdyn
 #pragma unroll
     for (int l = NJ; l >= 0; --l)
     {
-      const S6 own = get6(a.wrench, 6 * l);
+      const S6 own = parked6(l);
       run.l = run.l + own.l;
       run.a = run.a + own.a;
       S6 w;
@@ -231,7 +238,7 @@ hipError_t launch_ext_nj(const RdynKinExtArgs& a, hipStream_t st)
 {
   const dim3 grid((unsigned)((a.n_samples + 255) / 256));
   if (a.wrench)
-    hipLaunchKernelGGL((k_base_ext<NJ, true>), grid, dim3(256), 0, st, a);
+    hipLaunchKernelGGL((k_base_ext<NJ, true>), dim3((unsigned)((a.n_samples + 63) / 64)), dim3(64), (size_t)6 * (NJ + 1) * 64 * sizeof(double), st, a);
   else
     hipLaunchKernelGGL((k_base_ext<NJ, false>), grid, dim3(256), 0, st, a);
   return hipGetLastError();
