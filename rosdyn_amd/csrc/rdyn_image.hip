@@ -52,7 +52,7 @@ constexpr int image_flushes(int na)
 }
 
 template <int NJ, int NA, bool NT, bool STACKED>
-__global__ __launch_bounds__(64) void k_image_sweep(const RdynSweepArgs a)
+__global__ __launch_bounds__(64, (!STACKED && NJ == NA && NJ <= 8) ? 2 : 1) void k_image_sweep(const RdynSweepArgs a)
 {
   constexpr int RUN = 80 * NA;                       // bytes one link adds to one sample's image
   constexpr int IMG = NJ * RUN;                      // bytes of one image
@@ -93,6 +93,13 @@ __global__ __launch_bounds__(64) void k_image_sweep(const RdynSweepArgs a)
   const uint32_t m0 = ((uint32_t)(uintptr_t)ywave + (uint32_t)sub * img) & 127u;
   const uint32_t dm = ((uint32_t)SPI * img) & 127u;
   const bool m_const = dm == 0;                      // natural strides at n = 6: every lane keeps one alignment class
+  // natural stride, line-aligned wave base, full wave: the 64 images are ONE contiguous run of whole lines.  The line an image's
+  // tail shares with the head of the next image is then written ONCE, whole, at the end (merge pass below) instead of as two partial
+  // lines a whole sweep apart (1 line in 22.5 at n = 6, 1.75 in 30.6 at n = 7: partial lines cost a read-modify-write in HBM)
+  const bool merge = !STACKED && img == (uint32_t)IMG && valid == 64 && (((uint32_t)(uintptr_t)ywave) & 127u) == 0;
+  double h0[10];                                     // row 0 of link 0: all that is non-zero in the first 112 bytes of an image
+#pragma unroll
+  for (int pp = 0; pp < 10; ++pp) h0[pp] = 0.0;
   int n_phase = 1;                                   // period of the alignment class in the copy-out iteration index
   while (((uint32_t)n_phase * dm) & 127u) ++n_phase;  // dm is a multiple of 16: at most 8
 
@@ -212,6 +219,7 @@ __global__ __launch_bounds__(64) void k_image_sweep(const RdynSweepArgs a)
           if (p < p_lo || p >= p_hi) continue;
           tl = fma(y[p], pi[p], tl);
           *(double*)(stg + spos(f, p, l)) = y[p];
+          if (!STACKED && f == 0 && l == 0) h0[p] = y[p];
         }
         tau[l] = tl;
       }
@@ -257,8 +265,8 @@ __global__ __launch_bounds__(64) void k_image_sweep(const RdynSweepArgs a)
       const bool last = f == NJ - 1 && hf == NF - 1;
       // one sample's piece: x = first byte this lane moves (image offset), active if x < Fc
       auto piece = [&](uint32_t m, uint32_t j, uint32_t& x, uint32_t& pos, bool& on) {
-        const uint32_t Fp = Ep == 0 ? 0u : (uint32_t)Ep - ((m + (uint32_t)Ep) & 127u);
-        const uint32_t Fc = last ? (uint32_t)IMG : (uint32_t)Ec - ((m + (uint32_t)Ec) & 127u);
+        const uint32_t Fp = Ep == 0 ? ((merge && m) ? 128u - m : 0u) : (uint32_t)Ep - ((m + (uint32_t)Ep) & 127u);
+        const uint32_t Fc = (last && !merge) ? (uint32_t)IMG : (uint32_t)Ec - ((m + (uint32_t)Ec) & 127u);
         x = Fp + 16u * j;
         on = x < Fc;
         // ring position of image byte x in [Ep - 127, Ec): the run starts at Ep mod W
@@ -348,6 +356,49 @@ __global__ __launch_bounds__(64) void k_image_sweep(const RdynSweepArgs a)
       }
     }
     wave_lds_fence();  // the ring is written again by the next flush
+    }
+  }
+  if constexpr (!STACKED)
+  {
+    if (merge)
+    {
+      // ---- the lines shared by two images: [tail of image l | head of image l + 1], written whole, once
+      const uint32_t m_l = ((uint32_t)lane * (uint32_t)IMG) & 127u;          // my image starts m_l bytes into a line
+      const uint32_t tail = (m_l + (uint32_t)IMG) & 127u;                      // bytes of my image in the line it ends in (0: none)
+      d2a t[7];
+#pragma unroll
+      for (int ch = 0; ch < 7; ++ch)
+      {
+        t[ch] = (d2a){0.0, 0.0};
+        if (16u * ch < tail) t[ch] = *(const d2a*)(stg + ((uint32_t)IMG - tail + 16u * ch) % (uint32_t)W);  // ring position = image offset mod W
+      }
+      wave_lds_fence();
+#pragma unroll
+      for (int ch = 0; ch < 7; ++ch)
+        if (16u * ch < tail) *(d2a*)(stg + 16 * ch) = t[ch];
+      if (m_l)  // my head completes the previous image's line (lane > 0: the wave's base is line-aligned)
+      {
+        char* const dst = stage + (lane - 1) * PITCH + m_l;
+#pragma unroll
+        for (int i = 0; i < 14; ++i)
+          if (8u * i < 128u - m_l) *(double*)(dst + 8 * i) = (i % NA == 0 && i / NA < 10) ? h0[i / NA < 10 ? i / NA : 0] : 0.0;
+      }
+      wave_lds_fence();
+      const int tsub = lane >> 3, tj = lane & 7;
+      char* yl = ywave;
+#pragma unroll
+      for (int it = 0; it < 8; ++it)
+      {
+        const int smp = it * 8 + tsub;
+        const uint32_t tl_s = (((uint32_t)smp + 1u) * (uint32_t)IMG) & 127u;  // tail of image smp
+        if (tl_s)
+        {
+          const d2a v = *(const d2a*)(stage + smp * PITCH + 16 * tj);
+          if (NT) __builtin_nontemporal_store((d2u)v, (d2u*)(yl + (uint32_t)tsub * img + ((uint32_t)IMG - tl_s) + 16u * tj));
+          else *(d2u*)(yl + (uint32_t)tsub * img + ((uint32_t)IMG - tl_s) + 16u * tj) = (d2u)v;
+        }
+        yl += (int64_t)8 * img;
+      }
     }
   }
   if (a.tau && mine)
