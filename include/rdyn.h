@@ -341,20 +341,26 @@ int rdyn_regressor_gram_multi(rdyn_multi_gpu* ctx, const rdyn_chain* chain, cons
 
 /* ---- tall-skinny QR (rdyn_tsqr.hip): the R factor of [A | b] WITHOUT forming A'A -- BASELINE.json configs[2] "regressor + TSQR".
  * The Gram route squares the condition number; this one does not.  Every wave folds row blocks into a running upper-triangular
- * factor by Householder reflections (R <- qr([R; block])), the per-wave factors are folded 4 -> 1 level by level in a fixed
+ * factor by Householder reflections (R <- qr([R; block])), the factors are folded pairwise, level by level, in a fixed
  * order (bitwise reproducible).  Output R1, DEVICE, column-major n1 x n1 with n1 = n_cols + (b != NULL):
  *   R1 = [R d; 0 rho],  A = Q R,  d = Q'b,  rho = |A x_ls - b|   (diagonal signs are not normalised)
  * accumulate != 0: R1 <- factor of [previous R1 ; new rows] (chunked batches).  Multi-GPU: every rank all-gathers its R1 and folds
  * the stack with rdyn_tsqr_combine_host.  Solve with rdyn_solve_r_factor(R1, n1, n_cols, n_cols, d = R1 + n_cols * n1, ...).
  * rdyn_tsqr: any column-major rows x n_cols device matrix (n1 <= 64).  rdyn_regressor_tsqr: the stacked regressor of the batch and
  * tau_meas (layout of batch->q), rows generated in LDS by the regressor sweep, never stored: n1 = 10 joints_number + 1; chains of
- * 2..7 joints with the input joints in chain order (else RDYN_ERR_UNSUPPORTED).  ~4-8x the time of rdyn_regressor_gram. */
+ * 2..7 joints with the input joints in chain order (else RDYN_ERR_UNSUPPORTED).  ~5x the time of rdyn_regressor_gram.
+ * rdyn_identification_tsqr: the same for the identification step's [Y | C | tau_meas] (C = the component columns of
+ * rdyn_components_regressor, K = rdyn_components_columns): n1 = 10 joints_number + K + 1, unknowns [inertial ; component]
+ * parameters; chains of 2..6 joints, 10 joints_number + 1 + K <= 16 (ceil((10 joints_number + 1) / 16) + 1). */
 size_t rdyn_tsqr_workspace_bytes(int n_cols_with_rhs);
 int rdyn_tsqr(const double* A, int64_t rows, int64_t lda, int n_cols, const double* b, double* R1, int accumulate, void* workspace,
               size_t workspace_bytes, int device, void* stream);
 size_t rdyn_regressor_tsqr_workspace_bytes(const rdyn_chain* chain);
 int rdyn_regressor_tsqr(const rdyn_chain* chain, const rdyn_batch* batch, const double* tau_meas, double* R1, int accumulate, void* workspace,
                         size_t workspace_bytes);
+size_t rdyn_identification_tsqr_workspace_bytes(const rdyn_chain* chain, const rdyn_component* comps, int n_comps);
+int rdyn_identification_tsqr(const rdyn_chain* chain, const rdyn_component* comps, int n_comps, const rdyn_batch* batch, const double* tau_meas,
+                             double* R1, int accumulate, void* workspace, size_t workspace_bytes);
 /* HOST: folds n_factors upper-triangular n x n factors (stacked, each column-major n x n) into one (Householder). */
 int rdyn_tsqr_combine_host(const double* R_stack, int n_factors, int n, double* R_out);
 

@@ -108,6 +108,8 @@ SYMBOLS = {
     "rdyn_tsqr": (_I, [_VP, C.c_int64, C.c_int64, _I, _VP, _VP, _I, _VP, C.c_size_t, _I, _VP]),
     "rdyn_regressor_tsqr_workspace_bytes": (C.c_size_t, [_VP]),
     "rdyn_regressor_tsqr": (_I, [_VP, _BP, _VP, _VP, _I, _VP, C.c_size_t]),
+    "rdyn_identification_tsqr_workspace_bytes": (C.c_size_t, [_VP, _VP, _I]),
+    "rdyn_identification_tsqr": (_I, [_VP, _VP, _I, _BP, _VP, _VP, _I, _VP, C.c_size_t]),
     "rdyn_tsqr_combine_host": (_I, [_DP, _I, _I, _DP]),
     "rdyn_solve_normal_equations": (_I, [_DP, _DP, _I, C.c_double, _DP, C.POINTER(C.c_int)]),
     "rdyn_gram_r_factor": (_I, [_DP, _I, C.c_double, _DP, C.POINTER(C.c_int32), C.POINTER(C.c_int)]),

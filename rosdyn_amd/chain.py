@@ -422,5 +422,30 @@ class Chain(object):
         return G, c, bb
 
 
+    def getIdentificationTsqr(self, components, q, Dq, DDq, tau_meas, layout="sample", out=None, accumulate=False, workspace=None):
+        """R factor of the identification step's stacked [Y | C | tau_meas] WITHOUT forming the normal equations (include/rdyn.h:
+        rdyn_identification_tsqr).  Returns R1 = [R d; 0 rho] as a (P + K + 1, P + K + 1) tensor in math layout (upper triangular);
+        solve with rosdyn_amd.gram.solve_r_factor."""
+        torch = _torch()
+        b, N, lay = self._batch(layout, q, Dq, DDq)
+        if tau_meas.shape != q.shape or tau_meas.dtype != torch.float64 or not tau_meas.is_contiguous():
+            raise ValueError("Input data dimensions mismatch")
+        arr, n_comps = (C.cast(components._arr, C.c_void_p), components.n_comps) if components is not None else (None, 0)
+        n1 = 10 * self.getJointsNumber() + (components.columns if components is not None else 0) + 1
+        buf = torch.zeros((n1, n1), dtype=torch.float64, device=q.device) if out is None else out.t().contiguous()
+        nbytes = lib().rdyn_identification_tsqr_workspace_bytes(self._h, arr, n_comps)
+        if nbytes == 0:
+            raise ValueError("rdyn_identification_tsqr: chains of 2..6 joints, component columns within one 16-column slot")
+        if workspace is None:
+            workspace = torch.empty((nbytes,), dtype=torch.uint8, device=q.device)
+        check(lib().rdyn_identification_tsqr(self._h, arr, n_comps, C.byref(b), tau_meas.data_ptr(), buf.data_ptr(), 1 if accumulate else 0,
+                                             workspace.data_ptr(), workspace.numel()))
+        R1 = buf.t()   # the library writes column-major
+        if out is not None:
+            out.copy_(R1)
+            return out
+        return R1
+
+
 def createChain(urdf_xml, base_frame, tool_frame, gravity=(0.0, 0.0, 0.0)):
     return Chain(urdf_xml, base_frame, tool_frame, gravity)

@@ -1020,36 +1020,39 @@ int rdyn_tsqr(const double* A, int64_t rows, int64_t lda, int n_cols, const doub
   return RDYN_OK;
 }
 
-size_t rdyn_regressor_tsqr_workspace_bytes(const rdyn_chain* c)
+static int regressor_tsqr_run(const rdyn_chain* c, const rdyn_component* comps, int n_comps, const rdyn_batch* b, const double* tau_meas, double* R,
+                              int accumulate, void* workspace, size_t workspace_bytes, const char* who)
 {
-  if (!c || c->n_joints() < 2 || c->n_joints() > 7) return 0;
-  const int nc = 10 * c->n_joints() + 1;
-  return rdyn_tsqr_workspace_doubles(nc, kTsqrBlocks) * sizeof(double);
-}
-
-int rdyn_regressor_tsqr(const rdyn_chain* c, const rdyn_batch* b, const double* tau_meas, double* R, int accumulate, void* workspace,
-                        size_t workspace_bytes)
-{
-  int st = check_batch(c, b, true, true, "rdyn_regressor_tsqr");
+  int st = check_batch(c, b, true, true, who);
   if (st != RDYN_OK) return st;
-  if (!R || !workspace)
+  if (!R || !workspace || n_comps < 0 || n_comps > RDYN_MAX_COMPONENTS || (n_comps > 0 && !comps))
   {
-    rdyn_set_error("rdyn_regressor_tsqr: null output or workspace");
+    rdyn_set_error("%s: null output / workspace, or more than %d components", who, RDYN_MAX_COMPONENTS);
     return RDYN_ERR_INVALID_ARGUMENT;
   }
-  const int n = c->n_active(), nJ = c->n_joints(), P1 = 10 * nJ + 1;
+  const int n = c->n_active(), nJ = c->n_joints();
+  const int K = n_comps > 0 ? rdyn_components_columns(comps, n_comps) : 0;
+  const int n1 = 10 * nJ + (K > 0 ? K : 0) + 1, nc = K < 0 ? 0 : rdyn_regressor_tsqr_cols(nJ, K);
   RdynLdsGramArgs la;
   memset(&la, 0, sizeof la);
-  const bool monotonic = nJ >= 2 && nJ <= 7 && n >= 1 && n <= 8 && build_lds_tile(c, 0, false, &la);
+  const bool monotonic = nc > 0 && nJ >= 2 && nJ <= 7 && n >= 1 && n <= 8 && build_lds_tile(c, K > 0 ? K : 0, false, &la);
   if (!monotonic || 4 * (size_t)la.tile_bytes > 160 * 1024)
   {
-    rdyn_set_error("rdyn_regressor_tsqr: chains of 2..7 joints with the input joints in chain order are supported");
+    rdyn_set_error("%s: chains of 2..7 joints (2..6 with component columns, which must fit one 16-column slot) with the input joints in chain order "
+                   "are supported", who);
     return RDYN_ERR_UNSUPPORTED;
   }
-  if (workspace_bytes < rdyn_regressor_tsqr_workspace_bytes(c))
+  if (workspace_bytes < rdyn_tsqr_workspace_doubles(nc, kTsqrBlocks) * sizeof(double))
   {
-    rdyn_set_error("rdyn_regressor_tsqr: workspace too small");
+    rdyn_set_error("%s: workspace too small", who);
     return RDYN_ERR_INVALID_ARGUMENT;
+  }
+  RdynComponentArgs ca;
+  memset(&ca, 0, sizeof ca);
+  if (n_comps > 0)
+  {
+    st = fill_components(comps, n_comps, n, &ca);
+    if (st != RDYN_OK) return st;
   }
   DeviceGuard g;
   st = g.enter(b->device);
@@ -1060,7 +1063,7 @@ int rdyn_regressor_tsqr(const rdyn_chain* c, const rdyn_batch* b, const double* 
   hipStream_t stream = (hipStream_t)b->stream;
   if (b->n_samples == 0)
   {
-    if (!accumulate) RDYN_HIP_TRY(hipMemsetAsync(R, 0, sizeof(double) * P1 * P1, stream));
+    if (!accumulate) RDYN_HIP_TRY(hipMemsetAsync(R, 0, sizeof(double) * n1 * n1, stream));
     return RDYN_OK;
   }
   la.chain = dc;
@@ -1070,10 +1073,46 @@ int rdyn_regressor_tsqr(const rdyn_chain* c, const rdyn_batch* b, const double* 
   la.bcol = tau_meas;
   la.n_samples = b->n_samples;
   rec_strides(b, n, &la.in_ss, &la.in_sj);
+  la.n_comps = n_comps;
+  la.n_comp_cols = K;
+  int col = 0;
+  for (int i = 0; i < n_comps; ++i)
+  {
+    la.comps[i] = ca.comps[i];
+    const int w = ca.comps[i].type == RDYN_COMP_FRICTION2 ? 3 : 2;
+    for (int k = 0; k < w; ++k) la.comp_col_row[col++] = (signed char)ca.comps[i].joint;
+  }
   const int64_t tiles = (b->n_samples + 15) / 16;
   const int blocks = (int)((tiles + 3) / 4 < kTsqrBlocks ? (tiles + 3) / 4 : kTsqrBlocks);
   RDYN_HIP_TRY(rdyn_launch_regressor_tsqr(nJ, la, blocks, 4 * (size_t)la.tile_bytes, (double*)workspace, R, accumulate ? 1 : 0, stream));
   return RDYN_OK;
+}
+
+size_t rdyn_regressor_tsqr_workspace_bytes(const rdyn_chain* c)
+{
+  if (!c || c->n_joints() < 2 || c->n_joints() > 7) return 0;
+  return rdyn_tsqr_workspace_doubles(rdyn_regressor_tsqr_cols(c->n_joints(), 0), kTsqrBlocks) * sizeof(double);
+}
+
+int rdyn_regressor_tsqr(const rdyn_chain* c, const rdyn_batch* b, const double* tau_meas, double* R, int accumulate, void* workspace,
+                        size_t workspace_bytes)
+{
+  return regressor_tsqr_run(c, nullptr, 0, b, tau_meas, R, accumulate, workspace, workspace_bytes, "rdyn_regressor_tsqr");
+}
+
+size_t rdyn_identification_tsqr_workspace_bytes(const rdyn_chain* c, const rdyn_component* comps, int n_comps)
+{
+  if (!c || n_comps < 0 || (n_comps > 0 && !comps)) return 0;
+  const int K = n_comps > 0 ? rdyn_components_columns(comps, n_comps) : 0;
+  const int nc = K < 0 ? 0 : rdyn_regressor_tsqr_cols(c->n_joints(), K);
+  if (nc == 0 || c->n_joints() < 2 || c->n_joints() > 7) return 0;
+  return rdyn_tsqr_workspace_doubles(nc, kTsqrBlocks) * sizeof(double);
+}
+
+int rdyn_identification_tsqr(const rdyn_chain* c, const rdyn_component* comps, int n_comps, const rdyn_batch* b, const double* tau_meas, double* R,
+                             int accumulate, void* workspace, size_t workspace_bytes)
+{
+  return regressor_tsqr_run(c, comps, n_comps, b, tau_meas, R, accumulate, workspace, workspace_bytes, "rdyn_identification_tsqr");
 }
 
 // ---- identification step: normal equations of [Y | C | tau_meas] (rigid-body regressor + component columns) -------------

@@ -149,41 +149,8 @@ __global__ __launch_bounds__(512) void k_regressor_gram_duo(const RdynLdsGramArg
       }
       if (XB > 0 || fa.n_comps > 0)
       {
-        // per-joint component columns (friction_polynomial1.h:45-52, friction_polynomial2.h:42-58, ideal_spring.h:64-70): a row of
-        // joint j only needs q_j / Dq_j, which this lane fetched if it owns the row.  The consumer has read every row group of the
-        // previous tile by now (the last link's barrier is behind us).
-        int col = 0;
-        for (int ci = 0; ci < fa.n_comps; ++ci)
-        {
-          const int type = fa.comps[ci].type, jc = fa.comps[ci].joint;
-          const int cols = type == RDYN_COMP_FRICTION2 ? 3 : 2;
-          const double qv = jc >= 4 ? qb : qa, dv = jc >= 4 ? dqb : dqa;
-          double row[3] = {0.0, 0.0, 0.0};
-          if (type == RDYN_COMP_SPRING)
-          {
-            row[0] = qv;
-            row[1] = 1.0;
-          }
-          else
-          {
-            const double vmax = fa.comps[ci].max_velocity, vmin = fa.comps[ci].min_velocity;
-            const double omega = fmin(fmax(dv, -vmax), vmax);
-            double sg;
-            if (type == RDYN_COMP_FRICTION1)
-              sg = fmin(fmax(omega / vmin, -1.0), 1.0);
-            else
-              sg = (omega == 0.0) ? 0.0 : (omega > vmin ? 1.0 : (omega < -vmin ? -1.0 : omega / vmin));
-            row[0] = sg;
-            row[1] = omega;
-            row[2] = omega * omega * sg;
-          }
-          if (k == (jc & 3))
-          {
-            char* const lc = tile + fa.lds_off_c + col * fa.comp_stride + s_loc * 8;
-            for (int e = 0; e < cols; ++e) *(double*)(lc + e * fa.comp_stride) = valid ? row[e] : 0.0;
-          }
-          col += cols;
-        }
+        // the consumer has read every row group of the previous tile by now (the last link's barrier is behind us)
+#include "rdyn_duo_comp_cols.inc"
       }
       {
         char* const lb = tile + fa.lds_off_b + s_loc * 8;

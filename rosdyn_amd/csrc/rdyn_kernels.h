@@ -175,6 +175,7 @@ hipError_t rdyn_launch_regressor_gram_duo(int n_cols, const RdynLdsGramArgs& a, 
 // tall-skinny QR (rdyn_tsqr.hip): R factor of [A | b] without forming A'A
 int rdyn_tsqr_padded_cols(int n_cols_with_rhs);              // 16 / 32 / 48 / 64, 0 = unsupported
 size_t rdyn_tsqr_workspace_doubles(int nc, int blocks);
+int rdyn_regressor_tsqr_cols(int n_joints, int n_comp_cols);  // factor width of a rdyn_launch_regressor_tsqr call (0: unsupported)
 hipError_t rdyn_launch_regressor_tsqr(int n_joints, const RdynLdsGramArgs& a, int blocks, size_t lds_bytes, double* workspace, double* R, int accumulate,
                                       hipStream_t st);
 hipError_t rdyn_launch_tsqr_rows(const double* A, const double* b, int64_t rows, int64_t lda, int n_cols, int blocks, double* workspace, double* R,

@@ -243,7 +243,7 @@ int rdyn_tsqr_combine_host(const double* R_stack, int n_factors, int n, double* 
     double sigma = 0.0;
     for (int i = k + 1; i < m; ++i) sigma += M[(size_t)k * m + i] * M[(size_t)k * m + i];
     const double alpha = M[(size_t)k * m + k];
-    if (sigma == 0.0) continue;
+    if (!(sigma > 1e-280)) continue;  // zero, or residue about to underflow (rdyn_tsqr.hip: tsqr_fold2d)
     const double norm = std::sqrt(alpha * alpha + sigma);
     const double beta = alpha > 0 ? -norm : norm;
     const double v0 = alpha - beta;

@@ -129,7 +129,10 @@ __device__ __forceinline__ void tsqr_fold2d_steps(double (&Rr)[(NC + 15) / 16][(
     for (int c = KCI; c < NCI; ++c) dp[c] = rowgroup_sum(dp[c]);
     // |y_k|^2 is the dot of column k with itself: lane kcs (row group 0) holds it in dp[KCI]
     const double sigma = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(dp[KCI]), kcs), __builtin_amdgcn_readlane(__double2loint(dp[KCI]), kcs));
-    if (sigma != 0.0)  // wave-uniform
+    // a column that is roundoff residue of earlier reflections (more columns than rows so far) shrinks by ~1e-17 per step; past
+    // ~1e-140 its square underflows, 2 / (v0^2 + sigma) overflows and the factor fills with NaN.  Such a column carries no
+    // information: it is passed like an exactly zero one (its entries stay below 1e-140 and leave with the block).
+    if (sigma > 1e-280)  // wave-uniform
     {
       const double norm = sqrt(fma(alpha, alpha, sigma));
       const double beta = alpha > 0.0 ? -norm : norm;
@@ -253,10 +256,14 @@ struct SweepRowSlots  // columns 16 c .. 16 c + 15 belong to links <= (16 c + 15
   static constexpr int of(int c) { return (16 * c + 15) / 10 + 1 < NJ ? (16 * c + 15) / 10 + 1 : NJ; }
 };
 
-template <int NJ>
+// XC: 16-column slots for the component columns of rdyn_identification_tsqr ([Y | C | tau_meas]); 0: [Y | tau_meas] with exact widths.
+// With components the factor is NC = 16 (ceil((P + 1) / 16) + XC) wide; columns P + K + 1 .. NC - 1 are zero (their steps find
+// sigma = 0 and pass).
+template <int NJ, int XC>
 __global__ __launch_bounds__(256) void k_regressor_tsqr(const RdynLdsGramArgs fa, double* __restrict__ factors)
 {
-  constexpr int P = 10 * NJ, NC = P + 1, NCI = (NC + 15) / 16, NK = (NC + 3) / 4;
+  constexpr int P = 10 * NJ, NC = XC == 0 ? P + 1 : 16 * ((P + 1 + 15) / 16 + XC), NCI = (NC + 15) / 16, NK = (NC + 3) / 4;
+  const int K = XC > 0 ? fa.n_comp_cols : 0;  // component columns sit between the regressor and tau_meas
   constexpr bool DIRECT = false;
   extern __shared__ __attribute__((aligned(32))) char lds_raw[];
   ChainPtr c = as_const(fa.chain);
@@ -269,28 +276,40 @@ __global__ __launch_bounds__(256) void k_regressor_tsqr(const RdynLdsGramArgs fa
   int fB = NJ;
   for (int f = NJ - 1; f >= 0; --f)
     if (fa.lds_m[f] >= 5) fB = f;
-  // tile column p: byte offset and row slots (joint rows; 16 samples each)
-  auto col_of = [&](int p, int& base, int& slots) {
+  // tile column p: byte offset of its row slot 0 and the row slots [lo, hi) it stores (joint rows; 16 samples each)
+  auto col_of = [&](int p, int& base, int& lo, int& hi) {
+    lo = 0;
     if (p < P)
     {
       const int f = p / 10;
       base = fa.lds_off[f] + (p - 10 * f) * fa.lds_stride[f];
-      slots = fa.lds_m[f];
+      hi = fa.lds_m[f];
+    }
+    else if (p < P + K)
+    {
+      lo = fa.comp_col_row[p - P];  // a component column is one row slot: its own joint's
+      hi = lo + 1;
+      base = fa.lds_off_c + (p - P) * fa.comp_stride - lo * 128;
+    }
+    else if (p == P + K)
+    {
+      base = fa.lds_off_b;
+      hi = n;
     }
     else
     {
-      base = fa.lds_off_b;
-      slots = n;
+      base = 0;
+      hi = 0;  // padding column
     }
   };
   // my columns of the tile (2-D distribution of tsqr_fold2d): column 16 c + cs, rows 4 rg .. 4 rg + 3 of every slot
   const int cs = lane & 15, rg = lane >> 4;
-  int yb[NCI], ys[NCI];
+  int yb[NCI], ylo[NCI], ys[NCI];
 #pragma unroll
   for (int ci = 0; ci < NCI; ++ci)
   {
     const int j = 16 * ci + cs;
-    col_of(j < NC ? j : NC - 1, yb[ci], ys[ci]);
+    col_of(j < NC ? j : NC - 1, yb[ci], ylo[ci], ys[ci]);
     yb[ci] += rg * 32;
     if (j >= NC) ys[ci] = 0;
   }
@@ -341,6 +360,10 @@ __global__ __launch_bounds__(256) void k_regressor_tsqr(const RdynLdsGramArgs fa
     {
 #include "rdyn_duo_link_body.inc"
     }
+    if (XC > 0)
+    {
+#include "rdyn_duo_comp_cols.inc"
+    }
     {
       char* const lb = tile + fa.lds_off_b + s_loc * 8;
       if (r0 < n) *(double*)(lb + r0 * 128) = tb0;
@@ -356,7 +379,7 @@ __global__ __launch_bounds__(256) void k_regressor_tsqr(const RdynLdsGramArgs fa
         if (r < SweepRowSlots<NJ>::of(ci))
         {
           d2a v0 = {0.0, 0.0}, v1 = {0.0, 0.0};
-          if (r < ys[ci])
+          if (r < ys[ci] && r >= ylo[ci])
           {
             v0 = *(const d2a*)(tile + yb[ci] + r * 128);
             v1 = *(const d2a*)(tile + yb[ci] + r * 128 + 16);
@@ -367,7 +390,10 @@ __global__ __launch_bounds__(256) void k_regressor_tsqr(const RdynLdsGramArgs fa
     tsqr_fold2d<NC, NJ, SweepRowSlots<NJ>>(Rr, Y, tile, lane);
   }
   // ---------------- the workgroup's four factors -> one
-  block_combine<NC>(Rr, [&](int w) { return lds_raw + (size_t)w * fa.tile_bytes; }, wave, lane);
+  // (two waves' regions hold one parked factor: NC * ld doubles; with component columns on a short chain a factor is larger than two
+  // tiles, the launcher then sizes the workgroup's LDS for two factors)
+  const size_t cstride = (size_t)fa.tile_bytes * 2 > (size_t)NC * lds_factor_ld(NC) * 8 ? (size_t)fa.tile_bytes : ((size_t)NC * lds_factor_ld(NC) * 8 + 63) / 64 * 32;
+  block_combine<NC>(Rr, [&](int w) { return lds_raw + (size_t)w * cstride; }, wave, lane);
   if (wave == 0) store_factor2d<NC>(Rr, factors + (int64_t)blockIdx.x * (NC * NC), NC, NC, lane);
 }
 
@@ -493,17 +519,21 @@ hipError_t combine_tree(double* slab, int count, double* scratch, double* R, int
   return hipGetLastError();
 }
 
-template <int NJ>
+template <int NJ, int XC>
 hipError_t launch_regressor_tsqr(const RdynLdsGramArgs& a, int blocks, size_t lds_bytes, double* slab, double* scratch, double* R, const double* extra,
                                  hipStream_t st)
 {
+  constexpr int NC = XC == 0 ? 10 * NJ + 1 : 16 * ((10 * NJ + 1 + 15) / 16 + XC);
   static std::atomic<uint64_t> attr{0};
-  hipError_t e = opt_in_lds(k_regressor_tsqr<NJ>, attr);
+  hipError_t e = opt_in_lds(k_regressor_tsqr<NJ, XC>, attr);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL((k_regressor_tsqr<NJ>), dim3(blocks), dim3(256), lds_bytes, st, a, slab);
+  const size_t two_factors = 2 * (((size_t)NC * lds_factor_ld(NC) * 8 + 63) / 64 * 64);
+  if (lds_bytes < two_factors) lds_bytes = two_factors;  // the block combine parks two factors side by side
+  if (lds_bytes > 160 * 1024) return hipErrorInvalidValue;
+  hipLaunchKernelGGL((k_regressor_tsqr<NJ, XC>), dim3(blocks), dim3(256), lds_bytes, st, a, slab);
   e = hipGetLastError();
   if (e != hipSuccess) return e;
-  return combine_tree<10 * NJ + 1>(slab, blocks, scratch, R, 10 * NJ + 1, extra, st);
+  return combine_tree<NC>(slab, blocks, scratch, R, 10 * NJ + (XC > 0 ? a.n_comp_cols : 0) + 1, extra, st);
 }
 
 template <int NC>
@@ -524,21 +554,41 @@ hipError_t launch_tsqr_rows(const double* A, const double* b, int64_t rows, int6
 int rdyn_tsqr_padded_cols(int n_cols_with_rhs) { return n_cols_with_rhs <= 16 ? 16 : n_cols_with_rhs <= 32 ? 32 : n_cols_with_rhs <= 48 ? 48 : n_cols_with_rhs <= 64 ? 64 : 0; }
 size_t rdyn_tsqr_workspace_doubles(int nc, int blocks) { return (size_t)(blocks + (blocks + 1) / 2 + 2) * nc * nc; }
 
+// width of the factors a launch works with: 10 nJ + 1, or (with component columns) the next multiple of 16 plus one 16-column slot
+int rdyn_regressor_tsqr_cols(int n_joints, int n_comp_cols)
+{
+  const int p1 = 10 * n_joints + 1;
+  if (n_comp_cols <= 0) return p1;
+  const int nc = 16 * ((p1 + 15) / 16 + 1);
+  return (n_joints >= 2 && n_joints <= 6 && p1 + n_comp_cols <= nc) ? nc : 0;  // 7 joints + components: the fold would not fit the register file
+}
+
 hipError_t rdyn_launch_regressor_tsqr(int n_joints, const RdynLdsGramArgs& a, int blocks, size_t lds_bytes, double* workspace, double* R, int accumulate,
                                       hipStream_t st)
 {
-  const int nc = 10 * n_joints + 1;
+  const int nc = rdyn_regressor_tsqr_cols(n_joints, a.n_comp_cols);
+  if (nc == 0) return hipErrorInvalidValue;
   double* slab = workspace;
   double* scratch = workspace + (size_t)blocks * nc * nc;
   const double* extra = accumulate ? R : nullptr;
+  if (a.n_comp_cols > 0)
+    switch (n_joints)
+    {
+    case 2: return launch_regressor_tsqr<2, 1>(a, blocks, lds_bytes, slab, scratch, R, extra, st);
+    case 3: return launch_regressor_tsqr<3, 1>(a, blocks, lds_bytes, slab, scratch, R, extra, st);
+    case 4: return launch_regressor_tsqr<4, 1>(a, blocks, lds_bytes, slab, scratch, R, extra, st);
+    case 5: return launch_regressor_tsqr<5, 1>(a, blocks, lds_bytes, slab, scratch, R, extra, st);
+    case 6: return launch_regressor_tsqr<6, 1>(a, blocks, lds_bytes, slab, scratch, R, extra, st);
+    default: return hipErrorInvalidValue;
+    }
   switch (n_joints)
   {
-  case 2: return launch_regressor_tsqr<2>(a, blocks, lds_bytes, slab, scratch, R, extra, st);
-  case 3: return launch_regressor_tsqr<3>(a, blocks, lds_bytes, slab, scratch, R, extra, st);
-  case 4: return launch_regressor_tsqr<4>(a, blocks, lds_bytes, slab, scratch, R, extra, st);
-  case 5: return launch_regressor_tsqr<5>(a, blocks, lds_bytes, slab, scratch, R, extra, st);
-  case 6: return launch_regressor_tsqr<6>(a, blocks, lds_bytes, slab, scratch, R, extra, st);
-  case 7: return launch_regressor_tsqr<7>(a, blocks, lds_bytes, slab, scratch, R, extra, st);
+  case 2: return launch_regressor_tsqr<2, 0>(a, blocks, lds_bytes, slab, scratch, R, extra, st);
+  case 3: return launch_regressor_tsqr<3, 0>(a, blocks, lds_bytes, slab, scratch, R, extra, st);
+  case 4: return launch_regressor_tsqr<4, 0>(a, blocks, lds_bytes, slab, scratch, R, extra, st);
+  case 5: return launch_regressor_tsqr<5, 0>(a, blocks, lds_bytes, slab, scratch, R, extra, st);
+  case 6: return launch_regressor_tsqr<6, 0>(a, blocks, lds_bytes, slab, scratch, R, extra, st);
+  case 7: return launch_regressor_tsqr<7, 0>(a, blocks, lds_bytes, slab, scratch, R, extra, st);
   default: return hipErrorInvalidValue;
   }
 }

@@ -474,6 +474,27 @@ public:
   {
     chk(rdyn_identification_gram(m_h, comps.data(), (int)comps.size(), &b, tau_meas, G, c, bb, accumulate ? 1 : 0, workspace, workspace_bytes));
   }
+  // the same identification step WITHOUT forming the normal equations: R1 = [R d; 0 rho] of [Y | C | tau_meas] by tall-skinny QR
+  // (condition number not squared; include/rdyn.h: rdyn_regressor_tsqr / rdyn_identification_tsqr), solved by solveRFactor
+  size_t getIdentificationTsqrWorkspaceBytes(const std::vector<rdyn_component>& comps) const
+  {
+    return rdyn_identification_tsqr_workspace_bytes(m_h, comps.data(), (int)comps.size());
+  }
+  void getIdentificationTsqrBatch(const std::vector<rdyn_component>& comps, const rdyn_batch& b, const double* tau_meas, double* R1, bool accumulate,
+                                  void* workspace, size_t workspace_bytes) const
+  {
+    chk(rdyn_identification_tsqr(m_h, comps.data(), (int)comps.size(), &b, tau_meas, R1, accumulate ? 1 : 0, workspace, workspace_bytes));
+  }
+  // minimum-norm solution from a factor R1 ((n + 1) x (n + 1), column-major, copied back to the host); returns the numerical rank
+  static int solveRFactor(const MatrixXd& R1, VectorXd& x, double rtol = 1e-10)
+  {
+    const int n = (int)R1.rows() - 1;
+    if (n < 1 || R1.cols() != n + 1) throw std::invalid_argument("Input data dimensions mismatch");
+    x.resize(n);
+    int rank = 0;
+    chk(rdyn_solve_r_factor(R1.data(), n + 1, n, n, R1.data() + (size_t)n * (n + 1), rtol, x.data(), &rank));
+    return rank;
+  }
   // minimum-norm base-parameter solve of G x = c on the host (G, c already copied back); returns the numerical rank
   static int solveNormalEquations(const MatrixXd& G, const VectorXd& c, VectorXd& x, double rtol = 1e-10)
   {

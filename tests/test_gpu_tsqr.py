@@ -111,3 +111,61 @@ def test_accumulate_and_host_combine_equal_one_shot():
     # reproducible: same launch, same bits
     again = chain.getRegressorTsqr(q, dq, ddq, tau).cpu().numpy()
     assert np.array_equal(full, again)
+
+
+@pytest.mark.parametrize("urdf,base,tool", [("ur10_like.urdf", "base_link", "wrist_3_link"), ("mixed_joints.urdf", "world", "slider"), ("panda_like.urdf", "link0", "link5")], ids=["ur10_6", "mixed", "panda5"])
+@pytest.mark.parametrize("N", [1, 33, 2000])
+def test_identification_tsqr_against_the_oracle_rows(urdf, base, tool, N):
+    """[Y | C | tau_meas] with friction / spring columns folded straight into the R factor (rdyn_identification_tsqr): the factor
+    reproduces the normal equations of the oracle's rows, accumulates over chunks, and its least-squares solution returns the
+    friction coefficients the torques were made with."""
+    torch = pytest.importorskip("torch")
+    from oracle.oracle import OracleChain, components_regressor
+    from rosdyn_amd import Chain
+    from rosdyn_amd.components import FRICTION1, FRICTION2, SPRING, ComponentSet
+    from rosdyn_amd.gram import solve_r_factor
+    from rosdyn_amd.samples import trajectory_batch
+    path = os.path.join(FIXTURES, urdf)
+    chain, ref = Chain(path, base, tool, GRAV), OracleChain(path, base, tool, GRAV)
+    n, P = chain.getActiveJointsNumber(), 10 * chain.getJointsNumber()
+    if chain.getJointsNumber() > 6:
+        pytest.skip("identification TSQR: chains of at most 6 joints")
+    q, dq, ddq = trajectory_batch(70 + N, N, n)
+    # one component per joint, the three kinds mixed (K = 2, 3, 2, 2, 3, ... columns)
+    kinds = [FRICTION1, FRICTION2, SPRING]
+    specs, dicts = [], []
+    for j in range(n):
+        ty = kinds[j % 3]
+        par = [0.5 + 0.1 * j, 1.0 + 0.2 * j] + ([0.05] if ty == FRICTION2 else [])
+        specs.append((ty, j, 1e-3, 5.0, par))
+        dicts.append(dict(type=ty, joint=j, min_velocity=1e-3, max_velocity=5.0, parameters=par))
+    comps = ComponentSet(dicts, n)
+    K = comps.columns
+    Cm, tau_c = components_regressor(specs, n, q, dq)               # (N, n, K), (N, n)
+    rng = np.random.default_rng(N)
+    Y = ref.regressor(q, dq, ddq)
+    tau = ref.joint_torque(q, dq, ddq) + tau_c + 1e-3 * rng.normal(size=(N, n))
+    M = np.column_stack([Y.reshape(-1, P), Cm.reshape(-1, K), tau.reshape(-1)])
+    tq, tdq, tddq, ttau = (torch.from_numpy(x).cuda() for x in (q, dq, ddq, tau))
+    R1 = chain.getIdentificationTsqr(comps, tq, tdq, tddq, ttau).cpu().numpy()
+    n1 = P + K + 1
+    assert R1.shape == (n1, n1) and np.allclose(np.tril(R1, -1), 0.0)
+    G = M.T @ M
+    assert np.abs(R1.T @ R1 - G).max() <= 1e-11 * np.abs(G).max()
+    # element-major inputs give the same factor (same arithmetic: bit for bit)
+    R1e = chain.getIdentificationTsqr(comps, *(x.t().contiguous() for x in (tq, tdq, tddq, ttau)), layout="element").cpu().numpy()
+    assert np.array_equal(R1, R1e)
+    if N == 2000:
+        h = 777
+        first = chain.getIdentificationTsqr(comps, *(x[:h].contiguous() for x in (tq, tdq, tddq, ttau)))
+        acc = chain.getIdentificationTsqr(comps, *(x[h:].contiguous() for x in (tq, tdq, tddq, ttau)), out=first.clone(), accumulate=True).cpu().numpy()
+        assert np.abs(acc.T @ acc - G).max() <= 1e-11 * np.abs(G).max()
+        x, rank = solve_r_factor(R1, P + K, rtol=1e-9)
+        x_ls = np.linalg.lstsq(M[:, :P + K], M[:, P + K], rcond=1e-9)[0]
+        assert np.abs(M[:, :P + K] @ (x - x_ls)).max() <= 1e-8 * np.abs(M[:, P + K]).max()
+        truth = np.concatenate([sp[4] for sp in specs])
+        assert np.abs(x[P:] - truth).max() < 0.02                   # the component parameters are identifiable: they come back
+    # without components it is the regressor TSQR
+    R0 = chain.getIdentificationTsqr(None, tq, tdq, tddq, ttau).cpu().numpy()
+    R0b = chain.getRegressorTsqr(tq, tdq, tddq, ttau).cpu().numpy()
+    assert np.array_equal(R0, R0b)
