@@ -134,6 +134,19 @@ inline void rec_strides(const rdyn_batch* b, int64_t elems, int64_t* ss, int64_t
   }
 }
 
+// Which row-contiguous regressor kernel (rdyn_image.hip) serves this layout: 0 none, 1 the per-sample image (stride_row 1, stride_col n,
+// stride_sample >= n P), 2 the stacked (N n) x P matrix (stride_sample == n).  Needs the input joints to be the first n chain joints.
+int image_route(const rdyn_chain* c, const rdyn_regressor_layout* yl, int64_t n_samples)
+{
+  const int n = c->n_active();
+  const bool lay_image = yl->stride_row == 1 && yl->stride_col == n && yl->stride_sample >= (int64_t)n * 10 * c->n_joints();
+  const bool lay_stacked = yl->stride_row == 1 && yl->stride_sample == n && yl->stride_col >= n_samples * n && !probe_env("RDYN_NO_STACKED_LDS");
+  if (!(lay_image || lay_stacked) || !rdyn_image_supported(c->n_joints(), n, yl->stride_sample) || probe_env("RDYN_NO_IMAGE")) return 0;
+  for (int j = 0; j < n; ++j)
+    if (c->active[j] != j) return 0;  // input joints = the first n chain joints, in order
+  return lay_stacked ? 2 : 1;
+}
+
 int run_local(const rdyn_chain* c, const rdyn_batch* b, int mode, double* tau, double* Y, const rdyn_regressor_layout* yl, double* M,
               bool use_dq, bool use_ddq)
 {
@@ -180,12 +193,7 @@ int run_local(const rdyn_chain* c, const rdyn_batch* b, int mode, double* tau, d
                        !probe_env("RDYN_NO_ROWPAIR");
   // the drop-in per-sample image (either input layout): one thread per sample, link blocks staged through LDS (rdyn_image.hip)
   // and the stacked column-major (N n) x P matrix (stride_sample == n): same kernel, column-major staging tile per link
-  const bool lay_image = yl && yl->stride_row == 1 && yl->stride_col == n && yl->stride_sample >= (int64_t)n * 10 * c->n_joints();
-  const bool lay_stacked = yl && yl->stride_row == 1 && yl->stride_sample == n && yl->stride_col >= b->n_samples * n &&
-                           !probe_env("RDYN_NO_STACKED_LDS");
-  bool image = mode == RDYN_MODE_REGRESSOR && (lay_image || lay_stacked) && rdyn_image_supported(c->n_joints(), n, yl->stride_sample) &&
-               !probe_env("RDYN_NO_IMAGE");
-  for (int j = 0; image && j < n; ++j) image = c->active[j] == j;  // input joints = the first n chain joints, in order
+  const bool image = mode == RDYN_MODE_REGRESSOR && yl && image_route(c, yl, b->n_samples) != 0;
   if (image)
     RDYN_HIP_TRY(rdyn_launch_image_sweep(c->n_joints(), n, a, (hipStream_t)b->stream));
   else if (rowpair)
@@ -602,6 +610,8 @@ struct rdyn_multi_plan
   struct Group
   {
     int n_joints = 0;
+    int n_active = 0;  // image / stacked groups only
+    int kind = 0;      // 0: one thread per sample, strided stores (any layout); 1: per-sample images, 2: stacked matrices (rdyn_image.hip)
     int n_items = 0;
     int64_t max_samples = 0;
     RdynSweepArgs* table = nullptr;  // device
@@ -664,14 +674,20 @@ int rdyn_multi_plan_create(const rdyn_multi_item* items, int n_items, rdyn_multi
     a.y_ss = it.y_layout.stride_sample;
     a.y_sr = it.y_layout.stride_row;
     a.y_sc = it.y_layout.stride_col;
-    const int nj = it.chain->n_joints();
-    by_nj[nj].push_back(a);
-    if (a.n_samples > max_n[nj]) max_n[nj] = a.n_samples;
+    const int nj = it.chain->n_joints(), na = it.chain->n_active();
+    // one launch per (chain joints, input joints, kernel kind): row-contiguous layouts of chains of up to 8 joints go through the
+    // LDS-staged kernels (whole-line stores), the rest keeps the strided kernel.  Key = nj | na << 8 | kind << 16.
+    const int kind = (it.batch.n_samples > 0 && nj <= 8) ? image_route(it.chain, &it.y_layout, it.batch.n_samples) : 0;
+    const int key = nj | ((kind ? na : 0) << 8) | (kind << 16);
+    by_nj[key].push_back(a);
+    if (a.n_samples > max_n[key]) max_n[key] = a.n_samples;
   }
   for (auto& kv : by_nj)
   {
     rdyn_multi_plan::Group grp;
-    grp.n_joints = kv.first;
+    grp.n_joints = kv.first & 0xFF;
+    grp.n_active = (kv.first >> 8) & 0xFF;
+    grp.kind = kv.first >> 16;
     grp.n_items = (int)kv.second.size();
     grp.max_samples = max_n[kv.first];
     RDYN_HIP_TRY(hipMalloc((void**)&grp.table, sizeof(RdynSweepArgs) * kv.second.size()));
@@ -693,7 +709,12 @@ int rdyn_multi_plan_regressor(const rdyn_multi_plan* plan, void* stream)
   int st = g.enter(plan->device);
   if (st != RDYN_OK) return st;
   for (const auto& grp : plan->groups)
-    RDYN_HIP_TRY(rdyn_launch_local_sweep_multi(grp.n_joints, RDYN_MODE_REGRESSOR, grp.table, grp.n_items, grp.max_samples, (hipStream_t)stream));
+  {
+    if (grp.kind)
+      RDYN_HIP_TRY(rdyn_launch_image_sweep_multi(grp.n_joints, grp.n_active, grp.kind == 2, grp.table, grp.n_items, grp.max_samples, (hipStream_t)stream));
+    else
+      RDYN_HIP_TRY(rdyn_launch_local_sweep_multi(grp.n_joints, RDYN_MODE_REGRESSOR, grp.table, grp.n_items, grp.max_samples, (hipStream_t)stream));
+  }
   return RDYN_OK;
 }
 

@@ -54,359 +54,21 @@ constexpr int image_flushes(int na)
 template <int NJ, int NA, bool NT, bool STACKED>
 __global__ __launch_bounds__(64, (!STACKED && NJ == NA && NJ <= 8) ? 2 : 1) void k_image_sweep(const RdynSweepArgs a)
 {
-  constexpr int RUN = 80 * NA;                       // bytes one link adds to one sample's image
-  constexpr int IMG = NJ * RUN;                      // bytes of one image
-  // the image kernel flushes a link in NF pieces of CPF columns: half the ring, twice the waves per CU (the copy-out is bound
-  // by LDS / store latency, not by instruction count: 3-4 waves per CU left one SIMD idle)
-  constexpr int NF = STACKED ? 1 : image_flushes(NA);
-  constexpr int CPF = 10 / NF;                       // columns per flush
-  constexpr int RUNF = CPF * NA * 8;                 // bytes per flush and sample
-  constexpr int W = ((RUNF + 15) / 16) * 16 + 128;   // ring: one flush's run + the < 128 bytes that wait for their line
-  // staging slot of one sample: the pitch in 16-byte units is ODD, so that the 8-byte staging writes of 16 consecutive lanes fall
-  // on different LDS banks (2-way at worst)
-  constexpr int PITCH = W + ((W / 16) % 2 ? 32 : 16);
-  constexpr int MAXC = ((RUNF + 127) / 128) * 8;     // most 16-byte chunks one sample flushes at once (whole lines)
-  constexpr int SPI = 64 / MAXC;                     // samples one copy-out instruction covers
-  constexpr int NIT = (64 + SPI - 1) / SPI;
-  extern __shared__ __attribute__((aligned(16))) char stage[];
-  ChainPtr c = as_const(a.chain);
-  const int lane = threadIdx.x;
-  const int64_t s_wave = (int64_t)blockIdx.x * 64;
-  const int64_t left = a.n_samples - s_wave;
-  const int valid = left < 64 ? (int)left : 64;
-  const bool mine = lane < valid;
-  const int64_t s = s_wave + (mine ? lane : 0);   // lanes past the batch idle along on the wave's first sample
+  const unsigned blk = blockIdx.x;
+#include "rdyn_image_body.inc"
+}
 
-  const double* __restrict__ qp = a.q + s * a.in_ss;
-  const double* __restrict__ dqp = a.dq + s * a.in_ss;
-  const double* __restrict__ ddqp = a.ddq + s * a.in_ss;
-  // staging position of element (row l, column p of link f): image kernel -> the sample's ring, stacked -> column-major tile
-  // [p][sample][row] of the link (64 NA doubles per column: exactly the bytes the wave owns in column 10 f + p of the matrix)
-  char* const stg = stage + (STACKED ? lane * (NA * 8) : lane * PITCH);
-  auto spos = [](int f, int pp, int l) { return STACKED ? pp * (64 * NA * 8) + l * 8 : (f * RUN + (pp * NA + l) * 8) % W; };
-  // copy-out role of this lane: chunk cj of sample (it * SPI + sub) in iteration it
-  const int sub = lane / MAXC, cj = lane - sub * MAXC;
-  const bool cp_lane = lane < SPI * MAXC;
-  const uint32_t img = (uint32_t)(a.y_ss * 8);
-  char* const ywave = (char*)(a.Y + s_wave * a.y_ss);
-  // misalignment (bytes past a 128-byte line) of the image of sample (it * SPI + sub): m0 + it * dm  (mod 128)
-  const uint32_t m0 = ((uint32_t)(uintptr_t)ywave + (uint32_t)sub * img) & 127u;
-  const uint32_t dm = ((uint32_t)SPI * img) & 127u;
-  const bool m_const = dm == 0;                      // natural strides at n = 6: every lane keeps one alignment class
-  // natural stride, line-aligned wave base, full wave: the 64 images are ONE contiguous run of whole lines.  The line an image's
-  // tail shares with the head of the next image is then written ONCE, whole, at the end (merge pass below) instead of as two partial
-  // lines a whole sweep apart (1 line in 22.5 at n = 6, 1.75 in 30.6 at n = 7: partial lines cost a read-modify-write in HBM)
-  const bool merge = !STACKED && img == (uint32_t)IMG && valid == 64 && (((uint32_t)(uintptr_t)ywave) & 127u) == 0;
-  double h0[10];                                     // row 0 of link 0: all that is non-zero in the first 112 bytes of an image
-#pragma unroll
-  for (int pp = 0; pp < 10; ++pp) h0[pp] = 0.0;
-  int n_phase = 1;                                   // period of the alignment class in the copy-out iteration index
-  while (((uint32_t)n_phase * dm) & 127u) ++n_phase;  // dm is a multiple of 16: at most 8
-
-  V3 w = mk(0, 0, 0), vl = mk(0, 0, 0), al = mk(0, 0, 0);
-  V3 acc = mk(-c->g[0], -c->g[1], -c->g[2]);  // base "acceleration" -g: gravity enters every link's d for free
-  V3 jl[NA], ja[NA];
-  double tau[NA];
-#pragma unroll
-  for (int l = 0; l < NA; ++l)
-  {
-    tau[l] = 0.0;
-    jl[l] = mk(0, 0, 0);
-    ja[l] = mk(0, 0, 0);
-  }
-
-#pragma unroll
-  for (int f = 0; f < NJ; ++f)
-  {
-    JointRef J = c->j[f];
-    const int type = J.type;
-    double qf = 0.0, dqf = 0.0, ddqf = 0.0;
-    if (f < NA)  // input joint f (pattern checked by the launcher); the rest are fixed
-    {
-      const int64_t o = f * a.in_sj;
-      qf = qp[o];
-      dqf = dqp[o];
-      ddqf = ddqp[o];
-    }
-    // ---- parent -> child transform (Joint::computedTpc, primitives_impl.h:38-47)
-    double R[9];
-    V3 t = ld3(J.t);
-    if (type == RDYN_REVOLUTE)
-    {
-      double sn, cs;
-      sincos(qf, &sn, &cs);
-      const double oc = 1.0 - cs;
-#pragma unroll
-      for (int i = 0; i < 9; ++i) R[i] = fma(sn, J.B[i], fma(oc, J.C[i], J.A[i]));
-    }
-    else
-    {
-#pragma unroll
-      for (int i = 0; i < 9; ++i) R[i] = J.A[i];
-      if (type == RDYN_PRISMATIC) t = axpy(t, ld3(J.up), qf);
-    }
-    {
-      const V3 wn = rotT(R, w);
-      const V3 vn = rotT(R, vl + cross(w, t));
-      const V3 aln = rotT(R, al);
-      const V3 an = rotT(R, acc + cross(al, t));
-      w = wn; vl = vn; al = aln; acc = an;
-    }
-#pragma unroll
-    for (int l = 0; l < (f < NA ? f : NA); ++l)
-    {
-      const V3 nl = rotT(R, jl[l] + cross(ja[l], t));
-      ja[l] = rotT(R, ja[l]);
-      jl[l] = nl;
-    }
-    const V3 u = ld3(J.u);
-    if (type == RDYN_REVOLUTE)
-    {
-      acc = axpy(acc, cross(vl, u), dqf);
-      al = axpy(axpy(al, cross(w, u), dqf), u, ddqf);
-      w = axpy(w, u, dqf);
-      if (f < NA)
-      {
-        jl[f < NA ? f : 0] = mk(0, 0, 0);
-        ja[f < NA ? f : 0] = u;
-      }
-    }
-    else if (type == RDYN_PRISMATIC)
-    {
-      acc = axpy(axpy(acc, cross(w, u), dqf), u, ddqf);
-      vl = axpy(vl, u, dqf);
-      if (f < NA)
-      {
-        jl[f < NA ? f : 0] = u;
-        ja[f < NA ? f : 0] = mk(0, 0, 0);
-      }
-    }
-    // ---- closed-form wrench regressor of link f + 1 in its own frame, rows of the input joints l <= f
-    const V3 d = acc + cross(w, vl);
-    const double wxy = w.x * w.y, wxz = w.x * w.z, wyz = w.y * w.z;
-    const double wxx = w.x * w.x, wyy = w.y * w.y, wzz = w.z * w.z;
-    const double b00 = -(wyy + wzz), b01 = wxy - al.z, b02 = wxz + al.y;
-    const double b10 = wxy + al.z, b11 = -(wxx + wzz), b12 = wyz - al.x;
-    const double b20 = wxz - al.y, b21 = wyz + al.x, b22 = -(wxx + wyy);
-    const RDYN_CONST_AS double* pi = J.pi;
-#pragma unroll
-    for (int hf = 0; hf < NF; ++hf)
-    {
-    const int p_lo = hf * CPF, p_hi = p_lo + CPF;  // this flush's columns (the other columns' arithmetic is dead code here)
-#pragma unroll
-    for (int l = 0; l < NA; ++l)
-    {
-      if (l <= f)
-      {
-        const V3 L = jl[l], A = ja[l];
-        const V3 dxA = cross(d, A);
-        const V3 x = cross(A, w);
-        double y[10];
-        y[0] = dot(L, d);
-        y[1] = fma(L.x, b00, fma(L.y, b10, fma(L.z, b20, dxA.x)));
-        y[2] = fma(L.x, b01, fma(L.y, b11, fma(L.z, b21, dxA.y)));
-        y[3] = fma(L.x, b02, fma(L.y, b12, fma(L.z, b22, dxA.z)));
-        y[4] = fma(A.x, al.x, x.x * w.x);
-        y[5] = fma(A.x, al.y, fma(A.y, al.x, fma(x.x, w.y, x.y * w.x)));
-        y[6] = fma(A.x, al.z, fma(A.z, al.x, fma(x.x, w.z, x.z * w.x)));
-        y[7] = fma(A.y, al.y, x.y * w.y);
-        y[8] = fma(A.y, al.z, fma(A.z, al.y, fma(x.y, w.z, x.z * w.y)));
-        y[9] = fma(A.z, al.z, x.z * w.z);
-        double tl = tau[l];
-#pragma unroll
-        for (int p = 0; p < 10; ++p)
-        {
-          if (p < p_lo || p >= p_hi) continue;
-          tl = fma(y[p], pi[p], tl);
-          *(double*)(stg + spos(f, p, l)) = y[p];
-          if (!STACKED && f == 0 && l == 0) h0[p] = y[p];
-        }
-        tau[l] = tl;
-      }
-      else
-      {
-        // structural zero block (row of a joint downstream of this link): the image is dense
-#pragma unroll
-        for (int p = 0; p < 10; ++p)
-          if (p >= p_lo && p < p_hi) *(double*)(stg + spos(f, p, l)) = 0.0;
-      }
-    }
-    // ---- copy out the lines completed by this link: image bytes [Fp, Fc), Fx = E - ((m + E) mod 128) (everything at the last link)
-    wave_lds_fence();
-    if constexpr (STACKED)
-    {
-      // the wave owns 64 NA consecutive doubles of every column: 512 NA bytes = 4 NA whole lines when the column is line aligned
-      const uint32_t lim = (uint32_t)valid * (NA * 8);
-#pragma unroll
-      for (int pp = 0; pp < 10; ++pp)
-      {
-        char* const ycol = (char*)(a.Y + (int64_t)(10 * f + pp) * a.y_sc + s_wave * NA);  // wave-uniform
-#pragma unroll
-        for (int it = 0; it < (32 * NA + 63) / 64; ++it)
-        {
-          const uint32_t off = (uint32_t)(it * 64 + lane) * 16u;
-          if (off < lim)
-          {
-            const d2a v = *(const d2a*)(stage + pp * (64 * NA * 8) + off);
-            if (off + 16u <= lim)
-            {
-              if (NT) __builtin_nontemporal_store((d2u)v, (d2u*)(ycol + off));
-              else *(d2u*)(ycol + off) = (d2u)v;
-            }
-            else
-              *(double*)(ycol + off) = v.x;  // odd number of valid doubles: the last chunk is half full
-          }
-        }
-      }
-    }
-    else
-    {
-      const int Ep = f * RUN + hf * RUNF, Ec = Ep + RUNF;  // constants after unrolling
-      const bool last = f == NJ - 1 && hf == NF - 1;
-      // one sample's piece: x = first byte this lane moves (image offset), active if x < Fc
-      auto piece = [&](uint32_t m, uint32_t j, uint32_t& x, uint32_t& pos, bool& on) {
-        const uint32_t Fp = Ep == 0 ? ((merge && m) ? 128u - m : 0u) : (uint32_t)Ep - ((m + (uint32_t)Ep) & 127u);
-        const uint32_t Fc = (last && !merge) ? (uint32_t)IMG : (uint32_t)Ec - ((m + (uint32_t)Ec) & 127u);
-        x = Fp + 16u * j;
-        on = x < Fc;
-        // ring position of image byte x in [Ep - 127, Ec): the run starts at Ep mod W
-        int pr = (int)x - Ep + (Ep % W);
-        if (pr < 0) pr += W;
-        if (pr >= W) pr -= W;
-        pos = (uint32_t)pr;
-      };
-      if (cp_lane)
-      {
-        char* yl = ywave;  // wave-uniform, advanced by SPI images per iteration
-        if (valid == 64 && m_const && 64 % SPI == 0)
-        {
-          uint32_t x, pos;
-          bool on;
-          piece(m0, (uint32_t)cj, x, pos, on);
-          const uint32_t g_off = (uint32_t)sub * img + x;
-          const char* const lsrc = stage + sub * PITCH + pos;
-          if (on)
-          {
-            // a few iterations per trip: fully unrolled (NIT up to 64 per link) the kernel body outgrows what hipcc will unroll
-            // over the links, and the per-link arrays of the sweep then live in scratch
-#pragma unroll 4
-            for (int it = 0; it < NIT; ++it)
-            {
-              const d2a v = *(const d2a*)(lsrc + it * (SPI * PITCH));
-              if (NT) __builtin_nontemporal_store((d2u)v, (d2u*)(yl + g_off));
-              else *(d2u*)(yl + g_off) = (d2u)v;
-              yl += (int64_t)SPI * img;
-            }
-          }
-        }
-        else
-        {
-          // general strides / alignments: the misalignment of sample (it * SPI + sub) repeats with a short period in `it`
-          // (n_phase <= 8: 128 / gcd(SPI * stride mod 128, 128)).  Iterations are visited phase by phase, it = ph + n_phase * k:
-          // inside a phase every lane keeps ONE alignment class, so the piece arithmetic (a dozen VALU instructions) runs once
-          // per phase and an iteration costs one address add, one LDS read and one store -- evaluated per iteration it took
-          // 1.3 ms per 1e6 evaluations at 7 joints (3 920-byte images, eight classes) against 0.62 ms for the stacked layout.
-          for (int ph = 0; ph < n_phase; ++ph)
-          {
-            uint32_t x, pos;
-            bool on;
-            piece((m0 + (uint32_t)ph * dm) & 127u, (uint32_t)cj, x, pos, on);
-            const uint32_t g_off = (uint32_t)sub * img + x;
-            uint32_t l_addr = (uint32_t)((ph * SPI + sub) * PITCH) + pos;
-            char* yp = yl + (int64_t)ph * SPI * img;  // wave-uniform
-            const int64_t g_step = (int64_t)n_phase * SPI * img;
-            const uint32_t l_step = (uint32_t)(n_phase * SPI * PITCH);
-            // the LDS read is unconditional (a slot past the wave's 64 reads as zeros, nothing is stored from it), so that several
-            // reads of the unrolled trip are in flight: one read -> wait -> store per trip exposed the LDS latency 64 times per link
-#pragma unroll 4
-            for (int it = ph; it < NIT; it += n_phase)
-            {
-              const d2a v = *(const d2a*)(stage + l_addr);
-              if (on && it * SPI + sub < valid)
-              {
-                if (NT) __builtin_nontemporal_store((d2u)v, (d2u*)(yp + g_off));
-                else *(d2u*)(yp + g_off) = (d2u)v;
-              }
-              l_addr += l_step;
-              yp += g_step;
-            }
-          }
-        }
-      }
-      if (last)
-      {
-        // the image's last link can leave more than MAXC chunks (its final partial line): 8 lanes per sample pick up the rest
-        const int tsub = lane >> 3, tj = MAXC + (lane & 7);
-        char* yl = ywave;
-#pragma unroll
-        for (int it = 0; it < 8; ++it)
-        {
-          const int smp = it * 8 + tsub;
-          const uint32_t m = ((uint32_t)(uintptr_t)ywave + (uint32_t)smp * img) & 127u;
-          uint32_t x, pos;
-          bool on;
-          piece(m, (uint32_t)tj, x, pos, on);
-          if (on && smp < valid)
-          {
-            const d2a v = *(const d2a*)(stage + smp * PITCH + pos);
-            *(d2u*)(yl + (uint32_t)tsub * img + x) = (d2u)v;
-          }
-          yl += (int64_t)8 * img;
-        }
-      }
-    }
-    wave_lds_fence();  // the ring is written again by the next flush
-    }
-  }
-  if constexpr (!STACKED)
-  {
-    if (merge)
-    {
-      // ---- the lines shared by two images: [tail of image l | head of image l + 1], written whole, once
-      const uint32_t m_l = ((uint32_t)lane * (uint32_t)IMG) & 127u;          // my image starts m_l bytes into a line
-      const uint32_t tail = (m_l + (uint32_t)IMG) & 127u;                      // bytes of my image in the line it ends in (0: none)
-      d2a t[7];
-#pragma unroll
-      for (int ch = 0; ch < 7; ++ch)
-      {
-        t[ch] = (d2a){0.0, 0.0};
-        if (16u * ch < tail) t[ch] = *(const d2a*)(stg + ((uint32_t)IMG - tail + 16u * ch) % (uint32_t)W);  // ring position = image offset mod W
-      }
-      wave_lds_fence();
-#pragma unroll
-      for (int ch = 0; ch < 7; ++ch)
-        if (16u * ch < tail) *(d2a*)(stg + 16 * ch) = t[ch];
-      if (m_l)  // my head completes the previous image's line (lane > 0: the wave's base is line-aligned)
-      {
-        char* const dst = stage + (lane - 1) * PITCH + m_l;
-#pragma unroll
-        for (int i = 0; i < 14; ++i)
-          if (8u * i < 128u - m_l) *(double*)(dst + 8 * i) = (i % NA == 0 && i / NA < 10) ? h0[i / NA < 10 ? i / NA : 0] : 0.0;
-      }
-      wave_lds_fence();
-      const int tsub = lane >> 3, tj = lane & 7;
-      char* yl = ywave;
-#pragma unroll
-      for (int it = 0; it < 8; ++it)
-      {
-        const int smp = it * 8 + tsub;
-        const uint32_t tl_s = (((uint32_t)smp + 1u) * (uint32_t)IMG) & 127u;  // tail of image smp
-        if (tl_s)
-        {
-          const d2a v = *(const d2a*)(stage + smp * PITCH + 16 * tj);
-          if (NT) __builtin_nontemporal_store((d2u)v, (d2u*)(yl + (uint32_t)tsub * img + ((uint32_t)IMG - tl_s) + 16u * tj));
-          else *(d2u*)(yl + (uint32_t)tsub * img + ((uint32_t)IMG - tl_s) + 16u * tj) = (d2u)v;
-        }
-        yl += (int64_t)8 * img;
-      }
-    }
-  }
-  if (a.tau && mine)
-  {
-    double* __restrict__ tp = a.tau + s * a.tau_ss;
-#pragma unroll
-    for (int l = 0; l < NA; ++l) tp[l * a.tau_sj] = tau[l];
-  }
+// mixed-chain plan (BASELINE.json configs[4]) in the row-contiguous layouts: blockIdx.y selects one (chain, batch) item of a device
+// table; descriptor and chain constants arrive by scalar loads, workgroups past the item's batch leave at once
+template <int NJ, int NA, bool NT, bool STACKED>
+__global__ __launch_bounds__(64, (!STACKED && NJ == NA && NJ <= 8) ? 2 : 1) void k_image_sweep_multi(const RdynSweepArgs* __restrict__ table)
+{
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wold-style-cast"
+  const RDYN_CONST_AS RdynSweepArgs& a = *((const RDYN_CONST_AS RdynSweepArgs*)table + blockIdx.y);
+#pragma clang diagnostic pop
+  const unsigned blk = blockIdx.x;
+#include "rdyn_image_body.inc"
 }
 
 template <int NJ, int NA, bool STACKED>
@@ -421,6 +83,15 @@ hipError_t launch_image(const RdynSweepArgs& a, hipStream_t st)
 #else
   hipLaunchKernelGGL((k_image_sweep<NJ, NA, true, STACKED>), grid, dim3(64), lds, st, a);
 #endif
+  return hipGetLastError();
+}
+template <int NJ, int NA, bool STACKED>
+hipError_t launch_image_multi(const RdynSweepArgs* table, int n_items, int64_t max_samples, hipStream_t st)
+{
+  const dim3 grid((unsigned)((max_samples + 63) / 64), (unsigned)n_items);
+  constexpr int runf = (10 / image_flushes(NA)) * NA * 8, w = ((runf + 15) / 16) * 16 + 128, pitch = w + ((w / 16) % 2 ? 32 : 16);
+  const size_t lds = STACKED ? (size_t)10 * 64 * NA * 8 : (size_t)64 * pitch;
+  hipLaunchKernelGGL((k_image_sweep_multi<NJ, NA, true, STACKED>), grid, dim3(64), lds, st, table);
   return hipGetLastError();
 }
 }  // namespace
@@ -443,4 +114,18 @@ hipError_t rdyn_launch_image_sweep(int n_joints, int n_active, const RdynSweepAr
   IMG(9, 8) IMG(9, 9) IMG(10, 9) IMG(10, 10)
 #undef IMG
   return hipErrorInvalidValue;
+}
+
+// every item of `table`: a chain of n_joints joints whose first n_active joints are the input joints, Y in the per-sample image
+// layout (stacked == false) or the stacked matrix layout (true); max_samples = largest batch
+hipError_t rdyn_launch_image_sweep_multi(int n_joints, int n_active, bool stacked, const RdynSweepArgs* table, int n_items, int64_t max_samples,
+                                         hipStream_t st)
+{
+  if (n_items <= 0 || max_samples <= 0) return hipSuccess;
+#define IMG(NJ_, NA_) \
+  if (n_joints == NJ_ && n_active == NA_) \
+    return stacked ? launch_image_multi<NJ_, NA_, true>(table, n_items, max_samples, st) : launch_image_multi<NJ_, NA_, false>(table, n_items, max_samples, st);
+  IMG(2, 2) IMG(3, 2) IMG(3, 3) IMG(4, 3) IMG(4, 4) IMG(5, 4) IMG(5, 5) IMG(6, 5) IMG(6, 6) IMG(7, 6) IMG(7, 7) IMG(8, 7) IMG(8, 8)
+#undef IMG
+  return hipErrorInvalidValue;  // longer chains: the plan keeps the strided kernel
 }

@@ -205,6 +205,8 @@ hipError_t rdyn_launch_rowpair_sweep(int n_joints, int n_active, const RdynSweep
 // whole 80 n-byte runs (rdyn_image.hip); input joints = the first n_active chain joints in order, at most one fixed tail joint
 bool rdyn_image_supported(int n_joints, int n_active, int64_t y_ss);
 hipError_t rdyn_launch_image_sweep(int n_joints, int n_active, const RdynSweepArgs& a, hipStream_t st);
+hipError_t rdyn_launch_image_sweep_multi(int n_joints, int n_active, bool stacked, const RdynSweepArgs* table, int n_items, int64_t max_samples,
+                                         hipStream_t st);  // 2..8 chain joints
 hipError_t rdyn_launch_local_sweep_multi(int n_joints, int mode, const RdynSweepArgs* table, int n_items, int64_t max_samples, hipStream_t st);
 
 #endif

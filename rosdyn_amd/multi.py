@@ -7,9 +7,11 @@ from ._lib import LAYOUT_ELEMENT_MAJOR, MultiItem, RegressorLayout, check, lib
 
 class MultiChainRegressor(object):
     """Freezes a list of items [(chain, q, Dq, DDq)] (element-major (n, S) float64 CUDA tensors) and allocates their
-    outputs: tau[i] (n, S) and Y[i] (P, n, S) (element-major regressor image).  run() launches; nothing is copied."""
+    outputs: tau[i] (n, S) and Y[i] -- (P, n, S) element-major (default), (S, P, n) per-sample images (y_layout="per_sample": the
+    memory image of the reference's Eigen matrix per sample) or the stacked column-major (S n) x P matrix as a (P, S n) tensor
+    (y_layout="stacked").  run() launches one kernel per (joint count, layout kind) group; nothing is copied."""
 
-    def __init__(self, items, with_torque=True):
+    def __init__(self, items, with_torque=True, y_layout="element"):
         import torch
         self._keep = []
         self.tau, self.Y = [], []
@@ -19,7 +21,9 @@ class MultiChainRegressor(object):
             for t in (q, dq, ddq):
                 assert t.is_cuda and t.dtype == torch.float64 and t.is_contiguous() and t.shape == q.shape and t.shape[0] == n
             S = q.shape[1]
-            Y = torch.empty((P, n, S), dtype=torch.float64, device=q.device)
+            shape, lay = {"element": ((P, n, S), (1, S, n * S)), "per_sample": ((S, P, n), (n * P, 1, n)),
+                          "stacked": ((P, S * n), (n, 1, S * n))}[y_layout]
+            Y = torch.empty(shape, dtype=torch.float64, device=q.device)
             tau = torch.empty((n, S), dtype=torch.float64, device=q.device) if with_torque else None
             it = arr[i]
             it.chain = chain._h
@@ -29,7 +33,7 @@ class MultiChainRegressor(object):
             it.batch.device = q.device.index if q.device.index is not None else -1
             it.tau = tau.data_ptr() if tau is not None else None
             it.Y = Y.data_ptr()
-            it.y_layout = RegressorLayout(1, S, n * S)
+            it.y_layout = RegressorLayout(*lay)
             self._keep.append((chain, q, dq, ddq))
             self.tau.append(tau)
             self.Y.append(Y)

@@ -40,3 +40,31 @@ def test_mixed_chains_match_oracle_and_single_chain_path():
         assert np.abs(tg - tr).max() <= 1e-11 * max(1.0, np.abs(tr).max())
         Y1, t1 = chain.getRegressor(tq, tdq, tddq, layout="element", with_torque=True)
         assert torch.equal(Y1, Y[i]) and torch.equal(t1, tau[i])    # same kernel body, bit identical
+
+
+@pytest.mark.parametrize("y_layout", ["per_sample", "stacked"])
+def test_mixed_chains_in_the_row_contiguous_layouts(y_layout):
+    """The drop-in per-sample images and the stacked matrices from a mixed-chain plan (k_image_sweep_multi: LDS-staged, whole-line
+    stores): bit-identical to the single-chain calls item by item, ragged batch sizes (empty waves of short items leave at once),
+    nothing written outside an item's own buffer."""
+    torch = pytest.importorskip("torch")
+    from rosdyn_amd import Chain
+    from rosdyn_amd.multi import MultiChainRegressor
+    from rosdyn_amd.samples import trajectory_batch
+    from rosdyn_amd.urdf_gen import mixed_chain_set
+    specs = mixed_chain_set(FIXTURES, n_chains=10)
+    S = [700, 256, 1, 1000, 513, 64, 63, 65, 2, 999]
+    items = []
+    for i, (xml, base, tool) in enumerate(specs):
+        chain = Chain(xml, base, tool, GRAV)
+        q, dq, ddq = trajectory_batch(2000 + i, S[i], chain.getActiveJointsNumber())
+        items.append((chain,) + tuple(torch.from_numpy(np.ascontiguousarray(x.T)).cuda() for x in (q, dq, ddq)))
+    plan = MultiChainRegressor(items, y_layout=y_layout)
+    for Y in plan.Y:
+        Y.fill_(float("nan"))
+    Y, tau = plan.run()
+    torch.cuda.synchronize()
+    for i, (chain, tq, tdq, tddq) in enumerate(items):
+        Y1, t1 = chain.getRegressor(tq, tdq, tddq, layout="element", y_layout=y_layout, with_torque=True)
+        assert not torch.isnan(Y[i]).any()
+        assert torch.equal(Y1.reshape(Y[i].shape), Y[i]) and torch.equal(t1, tau[i])

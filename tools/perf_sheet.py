@@ -45,6 +45,8 @@ row("getDTwist (all links)", lambda: chain.getDTwist(q, dq, ddq, layout=E), 144 
 row("getDDTwist (all links)", lambda: chain.getDDTwist(q, dq, ddq, dddq, layout=E), 192 + 48 * L)
 row("regressor -> Gram [A|tau]'[A|tau] fused", lambda: chain.getRegressorGram(q, dq, ddq, tau, layout=E), 192)
 row("identification Gram [Y | 6 friction comps | tau] one call", lambda: chain.getIdentificationGram(comps, q, dq, ddq, tau, layout=E), 192)
+row("regressor -> TSQR R factor of [A | tau] (no A'A)", lambda: chain.getRegressorTsqr(q, dq, ddq, tau, layout=E), 192, reps=5)
+row("identification TSQR [Y | 6 friction comps | tau]", lambda: chain.getIdentificationTsqr(comps, q, dq, ddq, tau, layout=E), 192, reps=5)
 row("friction components (6 x first order, dense n x K)", lambda: comps.getRegressor(q, dq, layout=E), 96 + 8 * n * comps.columns)
 T = chain.getTransformation(q, layout=E)
 seeds = q + 0.25 * (torch.rand_like(q) * 2 - 1)
