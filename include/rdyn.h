@@ -268,9 +268,10 @@ int rdyn_components_regressor(const rdyn_component* comps, int n_comps, int n_ac
                               const rdyn_regressor_layout* c_layout, double* tau_add);
 
 /* ---- mixed-chain batch (BASELINE.json configs[4]: 256 distinct 6-7-DOF chains x 4 096 samples) --------------
- * One launch per group of chains with equal joint count evaluates rdyn_regressor for MANY (chain, batch) items:
- * grid = (ceil(max samples / 256), items); every workgroup reads its item's descriptor and its chain's constants
- * through scalar loads.  A plan freezes the items (device pointers, layouts) so that running it allocates and
+ * One launch per group of chains with equal joint count (and output-layout kind) evaluates rdyn_regressor for MANY
+ * (chain, batch) items: grid = (ceil(max samples / workgroup), items); every workgroup reads its item's descriptor and its
+ * chain's constants through scalar loads.  Items in the per-sample image or the stacked layout (rdyn_regressor_layout presets)
+ * take the same LDS-staged whole-line kernels as rdyn_regressor; any other strides the strided one.  A plan freezes the items (device pointers, layouts) so that running it allocates and
  * copies nothing (graph-capturable).  All items must live on the same device (items[0].batch.device).  A plan holds the
  * device copies of its chains' constants: the chains must outlive the plan and must not be re-configured
  * (rdyn_chain_set_input_joints) while it exists. */
