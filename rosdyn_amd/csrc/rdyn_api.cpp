@@ -810,6 +810,9 @@ static bool build_lds_tile(const rdyn_chain* c, int n_comp_cols, bool dummy_slot
   const int n = c->n_active(), nJ = c->n_joints();
   bool monotonic = true;
   for (int j = 1; j < n; ++j) monotonic = monotonic && c->active[j] > c->active[j - 1];
+  la->all_revolute = probe_env("RDYN_DUO_NO_ALLREV") ? 0 : 1;
+  for (int f = 0; f < nJ; ++f)
+    if (c->host_const.j[f].type != RDYN_REVOLUTE) la->all_revolute = 0;
   int off = 0;
   for (int f = 0; f < nJ; ++f)
   {

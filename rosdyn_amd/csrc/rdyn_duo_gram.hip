@@ -51,7 +51,9 @@ namespace
 // XB: extra 16-column blocks for the component columns of rdyn_identification_gram (0: plain regressor Gram)
 typedef double d4h __attribute__((ext_vector_type(4), aligned(16)));  // operand quads: 16-byte aligned in the compact tile layout
 
-template <int NJ, bool DIRECT, int XB>
+// ALLREV: every chain joint is revolute (the UR / Panda arms of BASELINE.json): the sweeper drops the joint-kind selects and the
+// prismatic terms (6 % of its instructions; only instantiated with DIRECT and without component columns)
+template <int NJ, bool DIRECT, int XB, bool ALLREV>
 __global__ __launch_bounds__(512) void k_regressor_gram_duo(const RdynLdsGramArgs fa)
 {
   constexpr int NB = (10 * NJ + 1 + 15) / 16 + XB;
@@ -289,7 +291,7 @@ __global__ __launch_bounds__(512) void k_regressor_gram_duo(const RdynLdsGramArg
   }
 }
 
-template <int NJ, bool DIRECT, int XB>
+template <int NJ, bool DIRECT, int XB, bool ALLREV = false>
 hipError_t launch_duo_nj2(const RdynLdsGramArgs& a, int blocks, size_t lds_bytes, hipStream_t st)
 {
   static std::atomic<uint64_t> attr_set{0};
@@ -299,11 +301,11 @@ hipError_t launch_duo_nj2(const RdynLdsGramArgs& a, int blocks, size_t lds_bytes
   const uint64_t bit = 1ull << (dev & 63);
   if (!(attr_set.load(std::memory_order_acquire) & bit))
   {
-    e = hipFuncSetAttribute((const void*)k_regressor_gram_duo<NJ, DIRECT, XB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    e = hipFuncSetAttribute((const void*)k_regressor_gram_duo<NJ, DIRECT, XB, ALLREV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
     attr_set.fetch_or(bit, std::memory_order_release);
   }
-  hipLaunchKernelGGL((k_regressor_gram_duo<NJ, DIRECT, XB>), dim3(blocks), dim3(512), lds_bytes, st, a);
+  hipLaunchKernelGGL((k_regressor_gram_duo<NJ, DIRECT, XB, ALLREV>), dim3(blocks), dim3(512), lds_bytes, st, a);
   return hipGetLastError();
 }
 template <int NJ>
@@ -314,6 +316,7 @@ hipError_t launch_duo_nj(const RdynLdsGramArgs& a, int blocks, size_t lds_bytes,
   for (int f = 0; direct && f < NJ; ++f) direct = a.lds_m[f] == f + 1 && a.first_col[f] == 10 * f && a.lds_stride[f] == (16 * (f + 1) + 4) * 8;
   // component columns always take the XB = 1 instantiation (natural column order); without them XB = 0 (descending link order)
   const int xb = a.n_comp_cols > 0 ? 1 : 0;
+  if (xb == 0 && direct && a.all_revolute) return launch_duo_nj2<NJ, true, 0, true>(a, blocks, lds_bytes, st);
   if (xb == 0) return direct ? launch_duo_nj2<NJ, true, 0>(a, blocks, lds_bytes, st) : launch_duo_nj2<NJ, false, 0>(a, blocks, lds_bytes, st);
   if constexpr (NJ >= 5)  // identification with component columns: one extra column block, arms of 5-7 joints
   {

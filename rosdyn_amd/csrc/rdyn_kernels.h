@@ -146,6 +146,7 @@ struct RdynLdsGramArgs
   const double *q, *dq, *ddq, *bcol;   // bcol may be null
   int64_t n_samples, in_ss, in_sj;
   int n_active;
+  int all_revolute;                    // every chain joint is revolute (selects the sweeper without joint-kind selects)
   int first_col[RDYN_MAX_JOINTS];      // per input joint: 10 * chain index
   int lds_off[RDYN_MAX_JOINTS];        // per link: byte offset of its first column in the tile
   int lds_stride[RDYN_MAX_JOINTS];     // per link: bytes between its columns = (16 m_f + 4) * 8

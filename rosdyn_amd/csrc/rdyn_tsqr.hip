@@ -264,7 +264,7 @@ __global__ __launch_bounds__(256) void k_regressor_tsqr(const RdynLdsGramArgs fa
 {
   constexpr int P = 10 * NJ, NC = XC == 0 ? P + 1 : 16 * ((P + 1 + 15) / 16 + XC), NCI = (NC + 15) / 16, NK = (NC + 3) / 4;
   const int K = XC > 0 ? fa.n_comp_cols : 0;  // component columns sit between the regressor and tau_meas
-  constexpr bool DIRECT = false;
+  constexpr bool DIRECT = false, ALLREV = false;
   extern __shared__ __attribute__((aligned(32))) char lds_raw[];
   ChainPtr c = as_const(fa.chain);
   const int lane = threadIdx.x & 63;

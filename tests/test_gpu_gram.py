@@ -45,7 +45,10 @@ def test_gram_exact_integers(torch_cuda, rows, P):
 
 @pytest.mark.parametrize("urdf,base,tool,N,chunk", [("ur10_like.urdf", "base_link", "wrist_3_link", 5000, 2048),
                                                     ("panda_like.urdf", "link0", "link7", 3000, 0),
-                                                    ("mixed_joints.urdf", "world", "tip", 2500, 1000)])
+                                                    ("mixed_joints.urdf", "world", "tip", 2500, 1000),
+                                                    # prismatic + revolute, every joint an input joint: the wave-pair kernel's generic
+                                                    # (not all-revolute) unrolled sweeper
+                                                    ("mixed_joints.urdf", "pedestal", "arm", 2000, 0)])
 def test_regressor_gram_matches_oracle(torch_cuda, urdf, base, tool, N, chunk):
     from oracle.oracle import OracleChain
     from rosdyn_amd import Chain
