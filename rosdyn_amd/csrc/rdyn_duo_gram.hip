@@ -52,7 +52,7 @@ namespace
 typedef double d4h __attribute__((ext_vector_type(4), aligned(16)));  // operand quads: 16-byte aligned in the compact tile layout
 
 // ALLREV: every chain joint is revolute (the UR / Panda arms of BASELINE.json): the sweeper drops the joint-kind selects and the
-// prismatic terms (6 % of its instructions; only instantiated with DIRECT and without component columns)
+// prismatic terms (14 % of its instructions; only instantiated with DIRECT)
 template <int NJ, bool DIRECT, int XB, bool ALLREV>
 __global__ __launch_bounds__(512) void k_regressor_gram_duo(const RdynLdsGramArgs fa)
 {
@@ -320,6 +320,7 @@ hipError_t launch_duo_nj(const RdynLdsGramArgs& a, int blocks, size_t lds_bytes,
   if (xb == 0) return direct ? launch_duo_nj2<NJ, true, 0>(a, blocks, lds_bytes, st) : launch_duo_nj2<NJ, false, 0>(a, blocks, lds_bytes, st);
   if constexpr (NJ >= 5)  // identification with component columns: one extra column block, arms of 5-7 joints
   {
+    if (xb == 1 && direct && a.all_revolute) return launch_duo_nj2<NJ, true, 1, true>(a, blocks, lds_bytes, st);
     if (xb == 1) return direct ? launch_duo_nj2<NJ, true, 1>(a, blocks, lds_bytes, st) : launch_duo_nj2<NJ, false, 1>(a, blocks, lds_bytes, st);
   }
   return hipErrorInvalidValue;
