@@ -169,3 +169,23 @@ def test_identification_tsqr_against_the_oracle_rows(urdf, base, tool, N):
     R0 = chain.getIdentificationTsqr(None, tq, tdq, tddq, ttau).cpu().numpy()
     R0b = chain.getRegressorTsqr(tq, tdq, tddq, ttau).cpu().numpy()
     assert np.array_equal(R0, R0b)
+
+
+@pytest.mark.parametrize("urdf,base,tool,N", [("ur10_like.urdf", "base_link", "wrist_3_link", 1000000), ("panda_like.urdf", "link0", "link7", 4000000)],
+                         ids=["config2_size", "config3_size"])
+def test_full_size_factor_reproduces_the_mfma_normal_equations(urdf, base, tool, N):
+    """BASELINE configs[1] / configs[2] sizes: two independent reductions of the same 6e6 / 28e6 regressor rows -- Householder folds
+    on the vector units (TSQR) and the fp64-MFMA Gram -- must agree: R1'R1 = [G c; c' bb]."""
+    torch = pytest.importorskip("torch")
+    from rosdyn_amd import Chain
+    chain = Chain(os.path.join(FIXTURES, urdf), base, tool, GRAV)
+    n, P = chain.getActiveJointsNumber(), 10 * chain.getJointsNumber()
+    gen = torch.Generator(device="cuda").manual_seed(0x5EED0002)
+    q, dq, ddq, tau = (torch.rand((N, n), dtype=torch.float64, device="cuda", generator=gen) * 2 - 1 for _ in range(4))
+    R1 = chain.getRegressorTsqr(q, dq, ddq, tau)
+    G, c, bb = chain.getRegressorGram(q, dq, ddq, tau)
+    full = torch.zeros((P + 1, P + 1), dtype=torch.float64, device="cuda")
+    full[:P, :P], full[:P, P], full[P, :P], full[P, P] = G, c, c, bb[0]
+    err = (R1.t() @ R1 - full).abs().max().item()
+    assert err <= 1e-10 * full.abs().max().item(), err
+    assert torch.equal(torch.tril(R1, -1), torch.zeros_like(R1))
