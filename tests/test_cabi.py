@@ -177,3 +177,26 @@ def test_hostile_urdf_is_rejected_not_crashed():
     ok63 = xml.replace(long_name, "L" * 63)
     assert l.rdyn_chain_from_urdf(ok63.encode(), b"b", ("L" * 63).encode(), g, C.byref(h)) == 0
     l.rdyn_chain_destroy(h)
+
+
+def test_workspace_queries_reflect_what_the_tsqr_entry_points_support():
+    """Host-only: the workspace queries answer 0 for the combinations the kernels are not instantiated for (no GPU touched)."""
+    import ctypes as C
+    from rosdyn_amd import Chain
+    from rosdyn_amd._lib import lib
+    from rosdyn_amd.components import FRICTION1, FRICTION2, ComponentSet
+    ur6 = Chain(os.path.join(FIXTURES, "ur10_like.urdf"), "base_link", "wrist_3_link")
+    ur7 = Chain(os.path.join(FIXTURES, "ur10_like.urdf"), "base_link", "tool0")          # 7 chain joints (fixed flange)
+    mix8 = Chain(os.path.join(FIXTURES, "mixed_joints.urdf"), "world", "tip")            # 8 chain joints
+    L = lib()
+    assert L.rdyn_regressor_tsqr_workspace_bytes(ur6._h) > 0 and L.rdyn_regressor_tsqr_workspace_bytes(ur7._h) > 0
+    assert L.rdyn_regressor_tsqr_workspace_bytes(mix8._h) == 0
+    six = ComponentSet([dict(type=FRICTION1, joint=j, min_velocity=1e-3, max_velocity=5.0, parameters=[1.0, 1.0]) for j in range(6)], 6)
+    arr = C.cast(six._arr, C.c_void_p)
+    w6 = L.rdyn_identification_tsqr_workspace_bytes(ur6._h, arr, six.n_comps)
+    assert w6 > L.rdyn_regressor_tsqr_workspace_bytes(ur6._h)                            # one more 16-column slot: 80 x 80 factors
+    assert L.rdyn_identification_tsqr_workspace_bytes(ur7._h, arr, six.n_comps) == 0     # components: chains of at most 6 joints
+    assert L.rdyn_identification_tsqr_workspace_bytes(ur6._h, None, 0) == L.rdyn_regressor_tsqr_workspace_bytes(ur6._h)
+    many = ComponentSet([dict(type=FRICTION2, joint=j % 6, min_velocity=1e-3, max_velocity=5.0, parameters=[1.0, 1.0, 0.1]) for j in range(7)], 6)
+    assert many.columns == 21                                                            # 61 + 21 > 80: does not fit the extra slot
+    assert L.rdyn_identification_tsqr_workspace_bytes(ur6._h, C.cast(many._arr, C.c_void_p), many.n_comps) == 0
