@@ -130,6 +130,14 @@ int rdyn_chain_set_input_joints(rdyn_chain* chain, const char* const* names, int
 /* getQMax/getQMin/getDQMax/getDDQMax/getTauMax of the active joints (primitives_impl.h:85-143, 768-776);
  * any pointer may be NULL */
 int rdyn_chain_limits(const rdyn_chain* chain, double* q_max, double* q_min, double* dq_max, double* ddq_max, double* tau_max);
+/* The object tree behind a reference Chain (getJoints() / getLinks(), primitives.h:62-232), read only.
+ * Chain joint i (chain order, fixed joints included): R_pj row-major 3x3 and t_pj of parent <- joint (primitives_impl.h:54, 68), the
+ * normalised axis in the joint frame (:55-59), limits = {q_max, q_min, Dq_max, DDq_max, tau_max} (:85-143).  Joint::getTransformation(q):
+ * revolute R_pj (I + sin q K + (1 - cos q) K^2), t_pj; prismatic R_pj, t_pj + R_pj axis q (:38-47).
+ * Chain link i (0 = base link): Link::getNominalParameters [m, m c, Ixx Ixy Ixz Iyy Iyz Izz about the link origin] (:399-417), mass,
+ * centre of gravity in the link frame.  Any output may be NULL. */
+int rdyn_chain_joint_constants(const rdyn_chain* chain, int i, double R_pj[9], double t_pj[3], double axis[3], double limits[5]);
+int rdyn_chain_link_parameters(const rdyn_chain* chain, int i, double pi[10], double* mass, double cog[3]);
 /* Chain::getNominalParameters primitives_impl.h:1382 -> pi[10 * joints_number] (HOST pointer) */
 int rdyn_nominal_parameters(const rdyn_chain* chain, double* pi);
 

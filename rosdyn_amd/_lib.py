@@ -84,6 +84,8 @@ SYMBOLS = {
     "rdyn_joint_torque": (_I, [_VP, _BP, _VP]),
     "rdyn_joint_torque_nonlinear": (_I, [_VP, _BP, _VP]),
     "rdyn_regressor": (_I, [_VP, _BP, _VP, _VP, _YP]),
+    "rdyn_chain_joint_constants": (_I, [_VP, _I, _DP, _DP, _DP, _DP]),
+    "rdyn_chain_link_parameters": (_I, [_VP, _I, _DP, _DP, _DP]),
     "rdyn_joint_inertia": (_I, [_VP, _BP, _VP]),
     "rdyn_local_ik": (_I, [_VP, _BP, _VP, _DP, C.c_double, _I, _VP, _VP, _VP]),
     "rdyn_local_ik_damped": (_I, [_VP, _BP, _VP, _DP, C.c_double, C.c_double, _I, _VP, _VP, _VP]),

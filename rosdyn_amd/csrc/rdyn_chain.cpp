@@ -57,6 +57,44 @@ void skew3(const double* v, double* K)
   K[3] = v[2];  K[4] = 0;     K[5] = -v[0];
   K[6] = -v[1]; K[7] = v[0];  K[8] = 0;
 }
+// Link::fromUrdf + Link::getNominalParameters (primitives_impl.h:288-328, 399-417): [m, m c, Ixx Ixy Ixz Iyy Iyz Izz about the link origin]
+void link_parameters(const rdyn_link_desc& L, double pi[10], double* mass, double cog[3])
+{
+  double m = 0, cg[3] = {0, 0, 0}, I[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  if (L.has_inertial)
+  {
+    m = L.mass;
+    for (int i = 0; i < 3; ++i) cg[i] = L.com_xyz[i];
+    const double I0[9] = {L.ixx, L.ixy, L.ixz, L.ixy, L.iyy, L.iyz, L.ixz, L.iyz, L.izz};
+    double Rc[9], RcT[9], tmp[9];
+    quat_to_R(L.com_quat, Rc);
+    for (int a = 0; a < 3; ++a)
+      for (int b = 0; b < 3; ++b) RcT[a * 3 + b] = Rc[b * 3 + a];
+    mat3_mul(Rc, I0, tmp);
+    mat3_mul(tmp, RcT, I);  // primitives_impl.h:317
+  }
+  double cs[9], csT[9], cc[9];
+  skew3(cg, cs);
+  for (int a = 0; a < 3; ++a)
+    for (int b = 0; b < 3; ++b) csT[a * 3 + b] = cs[b * 3 + a];
+  mat3_mul(cs, csT, cc);  // spacevect_algebra.h:238
+  double Io[9];
+  for (int i = 0; i < 9; ++i) Io[i] = I[i] + m * cc[i];
+  pi[0] = m;
+  pi[1] = cg[0] * m;
+  pi[2] = cg[1] * m;
+  pi[3] = cg[2] * m;
+  pi[4] = Io[0];
+  pi[5] = Io[1];
+  pi[6] = Io[2];
+  pi[7] = Io[4];
+  pi[8] = Io[5];
+  pi[9] = Io[8];
+  if (mass) *mass = m;
+  if (cog)
+    for (int i = 0; i < 3; ++i) cog[i] = cg[i];
+}
+
 int map_type(int urdf_type)
 {
   // primitives_impl.h:74-83
@@ -117,37 +155,7 @@ void rdyn_chain_finalize(rdyn_chain* c)
     K.type = map_type(d.urdf_type);
     K.in_idx = -1;
     // child link nominal parameters (Link::fromUrdf 288-328, getNominalParameters 399-417)
-    const rdyn_link_desc& L = c->links[j + 1];
-    double m = 0, cg[3] = {0, 0, 0}, I[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-    if (L.has_inertial)
-    {
-      m = L.mass;
-      for (int i = 0; i < 3; ++i) cg[i] = L.com_xyz[i];
-      const double I0[9] = {L.ixx, L.ixy, L.ixz, L.ixy, L.iyy, L.iyz, L.ixz, L.iyz, L.izz};
-      double Rc[9], RcT[9], tmp[9];
-      quat_to_R(L.com_quat, Rc);
-      for (int a = 0; a < 3; ++a)
-        for (int b = 0; b < 3; ++b) RcT[a * 3 + b] = Rc[b * 3 + a];
-      mat3_mul(Rc, I0, tmp);
-      mat3_mul(tmp, RcT, I);  // primitives_impl.h:317
-    }
-    double cs[9], csT[9], cc[9];
-    skew3(cg, cs);
-    for (int a = 0; a < 3; ++a)
-      for (int b = 0; b < 3; ++b) csT[a * 3 + b] = cs[b * 3 + a];
-    mat3_mul(cs, csT, cc);  // spacevect_algebra.h:238
-    double Io[9];
-    for (int i = 0; i < 9; ++i) Io[i] = I[i] + m * cc[i];
-    K.pi[0] = m;
-    K.pi[1] = cg[0] * m;
-    K.pi[2] = cg[1] * m;
-    K.pi[3] = cg[2] * m;
-    K.pi[4] = Io[0];
-    K.pi[5] = Io[1];
-    K.pi[6] = Io[2];
-    K.pi[7] = Io[4];
-    K.pi[8] = Io[5];
-    K.pi[9] = Io[8];
+    link_parameters(c->links[j + 1], K.pi, nullptr, nullptr);
 
     // limits (primitives_impl.h:85-143).  Where the reference leaves a member uninitialised
     // (m_Dq_max without <limit>), 1e10 is used.
@@ -317,6 +325,40 @@ int rdyn_chain_set_input_joints(rdyn_chain* c, const char* const* names, int n_n
   c->active.swap(act);
   rdyn_chain_finalize(c);
   free_device_copies(c);
+  return RDYN_OK;
+}
+
+int rdyn_chain_joint_constants(const rdyn_chain* c, int i, double R_pj[9], double t_pj[3], double axis[3], double limits[5])
+{
+  if (!c || i < 0 || i >= c->n_joints())
+  {
+    rdyn_set_error("rdyn_chain_joint_constants: invalid argument");
+    return RDYN_ERR_INVALID_ARGUMENT;
+  }
+  const RdynJointConst& K = c->host_const.j[i];
+  if (R_pj) memcpy(R_pj, K.A, sizeof K.A);
+  if (t_pj) memcpy(t_pj, K.t, sizeof K.t);
+  if (axis) memcpy(axis, K.u, sizeof K.u);
+  if (limits)
+  {
+    limits[0] = c->q_max[i];
+    limits[1] = c->q_min[i];
+    limits[2] = c->dq_max[i];
+    limits[3] = c->ddq_max[i];
+    limits[4] = c->tau_max[i];
+  }
+  return RDYN_OK;
+}
+
+int rdyn_chain_link_parameters(const rdyn_chain* c, int i, double pi[10], double* mass, double cog[3])
+{
+  if (!c || i < 0 || i > c->n_joints())
+  {
+    rdyn_set_error("rdyn_chain_link_parameters: invalid argument");
+    return RDYN_ERR_INVALID_ARGUMENT;
+  }
+  double tmp[10];
+  link_parameters(c->links[i], pi ? pi : tmp, mass, cog);
   return RDYN_OK;
 }
 

@@ -129,6 +129,132 @@ inline void set_affine(Affine3d& T, const double* m34) { std::memcpy(T.m, m34, s
 
 class Chain;
 using ChainPtr = std::shared_ptr<Chain>;
+class Link;
+class Joint;
+using LinkPtr = std::shared_ptr<Link>;
+using JointPtr = std::shared_ptr<Joint>;
+
+// Read-only views of the object tree behind a reference Chain (rosdyn::Joint / rosdyn::Link, primitives.h:62-232), as far as the chain
+// goes: Chain::getJoints() / getLinks() (primitives.h:265-272).  The reference's objects are mutable and shared between chains; here
+// every Chain owns its views and they never change after construction.
+class Joint
+{
+public:
+  enum Type { REVOLUTE, PRISMATIC, FIXED };  // primitives.h:66
+  const std::string& getName() const { return m_name; }
+  const Type& getType() const { return m_type; }
+  bool isFixed() const { return m_type == FIXED; }
+  const double& getQMax() const { return m_limits[0]; }
+  const double& getQMin() const { return m_limits[1]; }
+  const double& getDQMax() const { return m_limits[2]; }
+  const double& getDDQMax() const { return m_limits[3]; }
+  const double& getTauMax() const { return m_limits[4]; }
+  LinkPtr getParentLink() const { return m_parent_link.lock(); }
+  LinkPtr getChildLink() const { return m_child_link.lock(); }
+  // parent <- child at joint value q (Joint::computedTpc, primitives_impl.h:38-47): revolute R_pj (I + sin q K + (1 - cos q) K^2), t_pj;
+  // prismatic R_pj, t_pj + R_pj axis q; fixed R_pj, t_pj
+  const Affine3d& getTransformation(const double& q = 0)
+  {
+    double K[9] = {0, -m_axis[2], m_axis[1], m_axis[2], 0, -m_axis[0], -m_axis[1], m_axis[0], 0}, K2[9], M[9], R[9], t[3] = {m_t[0], m_t[1], m_t[2]};
+    for (int r = 0; r < 3; ++r)
+      for (int c = 0; c < 3; ++c) K2[r * 3 + c] = K[r * 3] * K[c] + K[r * 3 + 1] * K[3 + c] + K[r * 3 + 2] * K[6 + c];
+    const double sn = m_type == REVOLUTE ? std::sin(q) : 0.0, oc = m_type == REVOLUTE ? 1.0 - std::cos(q) : 0.0;
+    for (int i = 0; i < 9; ++i) M[i] = (i % 4 == 0 ? 1.0 : 0.0) + sn * K[i] + oc * K2[i];
+    for (int r = 0; r < 3; ++r)
+      for (int c = 0; c < 3; ++c) R[r * 3 + c] = m_R[r * 3] * M[c] + m_R[r * 3 + 1] * M[3 + c] + m_R[r * 3 + 2] * M[6 + c];
+    if (m_type == PRISMATIC)
+      for (int r = 0; r < 3; ++r) t[r] += (m_R[r * 3] * m_axis[0] + m_R[r * 3 + 1] * m_axis[1] + m_R[r * 3 + 2] * m_axis[2]) * q;
+    double m34[12];
+    for (int c = 0; c < 3; ++c)
+      for (int r = 0; r < 3; ++r) m34[c * 3 + r] = R[r * 3 + c];
+    for (int r = 0; r < 3; ++r) m34[9 + r] = t[r];
+    detail::set_affine(m_last_T_pc, m34);
+    return m_last_T_pc;
+  }
+  // [linear; angular] screw of the child in the parent frame (primitives_impl.h:25-35): revolute [0; R_pj axis], prismatic [R_pj axis; 0]
+  const Vector6d& getScrew_of_child_in_parent()
+  {
+    for (int i = 0; i < 6; ++i) m_screw(i) = 0.0;
+    for (int r = 0; r < 3; ++r)
+    {
+      const double ap = m_R[r * 3] * m_axis[0] + m_R[r * 3 + 1] * m_axis[1] + m_R[r * 3 + 2] * m_axis[2];
+      if (m_type == REVOLUTE) m_screw(3 + r) = ap;
+      if (m_type == PRISMATIC) m_screw(r) = ap;
+    }
+    return m_screw;
+  }
+
+private:
+  friend class Chain;
+  std::string m_name;
+  Type m_type = FIXED;
+  double m_R[9], m_t[3], m_axis[3], m_limits[5];
+  std::weak_ptr<Link> m_parent_link, m_child_link;
+  Affine3d m_last_T_pc;
+  Vector6d m_screw;
+};
+
+class Link
+{
+public:
+  const std::string& getName() const { return m_name; }
+  const double& getMass() const { return m_mass; }
+  const Vector3d& getCog() const { return m_cog; }
+  JointPtr getParentJoint() const { return m_parent_joint.lock(); }                    // null for the chain's base link
+  std::vector<JointPtr> getChildrenJoints() const { return m_child_joints; }           // inside the chain: at most one
+  VectorXd getNominalParameters() const  // primitives_impl.h:399-417
+  {
+    VectorXd p(10);
+    for (int i = 0; i < 10; ++i) p(i) = m_pi[i];
+    return p;
+  }
+  // sum_k pi_k E_k with the reference's ten basis matrices (primitives_impl.h:337-396; spacevect_algebra.h:232-239), linear part first
+  const Matrix66d& getSpatialInertia() const { return m_inertia; }
+  const std::vector<Matrix66d>& getSpatialInertiaTerms() const { return m_terms; }
+
+private:
+  friend class Chain;
+  void build()
+  {
+    m_terms.resize(10);
+    for (auto& E : m_terms)
+      for (int i = 0; i < 6; ++i)
+        for (int j = 0; j < 6; ++j) E(i, j) = 0.0;
+    for (int i = 0; i < 3; ++i) m_terms[0](i, i) = 1.0;
+    for (int k = 0; k < 3; ++k)  // m c_k: block(3,0) = skew(e_k), block(0,3) = skew(e_k)^T
+    {
+      double e[3] = {0, 0, 0};
+      e[k] = 1.0;
+      const double S[3][3] = {{0, -e[2], e[1]}, {e[2], 0, -e[0]}, {-e[1], e[0], 0}};
+      for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j)
+        {
+          m_terms[1 + k](3 + i, j) = S[i][j];
+          m_terms[1 + k](i, 3 + j) = S[j][i];
+        }
+    }
+    const int ij[6][2] = {{0, 0}, {0, 1}, {0, 2}, {1, 1}, {1, 2}, {2, 2}};
+    for (int k = 0; k < 6; ++k)
+    {
+      m_terms[4 + k](3 + ij[k][0], 3 + ij[k][1]) = 1.0;
+      m_terms[4 + k](3 + ij[k][1], 3 + ij[k][0]) = 1.0;
+    }
+    for (int i = 0; i < 6; ++i)
+      for (int j = 0; j < 6; ++j)
+      {
+        double acc = 0.0;
+        for (int k = 0; k < 10; ++k) acc += m_pi[k] * m_terms[(size_t)k](i, j);
+        m_inertia(i, j) = acc;
+      }
+  }
+  std::string m_name;
+  double m_mass = 0.0, m_pi[10];
+  Vector3d m_cog;
+  Matrix66d m_inertia;
+  std::vector<Matrix66d> m_terms;
+  std::weak_ptr<Joint> m_parent_joint;
+  std::vector<JointPtr> m_child_joints;
+};
 
 class Chain
 {
@@ -187,6 +313,8 @@ public:
   const std::vector<std::string>& getActiveJointsName() const { return m_active_joints_name; }
   const std::string& getActiveJointName(const size_t& iAx) const { return m_active_joints_name.at(iAx); }
   const std::vector<std::string>& getLinksName() const { return m_links_name; }
+  const std::vector<LinkPtr>& getLinks() const { return m_links; }     // primitives.h:265
+  const std::vector<JointPtr>& getJoints() const { return m_joints; }  // primitives.h:269 (chain order, fixed joints included)
   const bool& isOk() const { return m_is_chain_ok; }
   const VectorXd& getQMax() const { return m_q_max; }
   const VectorXd& getQMin() const { return m_q_min; }
@@ -524,6 +652,8 @@ private:
   std::vector<std::string> m_links_name, m_moveable_joints_name, m_active_joints_name;
   std::vector<char> m_active_is_revolute;  // per input joint (getMultiplicity)
   VectorXd m_q_max, m_q_min, m_Dq_max, m_DDq_max, m_tau_max, m_active_joint_torques;
+  std::vector<LinkPtr> m_links;
+  std::vector<JointPtr> m_joints;
   Affine3d m_T_bt;
   VectorOfAffine3d m_T_bl;
   Matrix6Xd m_jacobian;
@@ -570,6 +700,31 @@ private:
     for (unsigned i = 0; i < m_active_joints_number; ++i)
       for (unsigned j = 0; j < m_joints_number; ++j)
         if (m_active_joints_name[i] == rdyn_chain_joint_name(m_h, (int)j)) m_active_is_revolute[i] = rdyn_chain_joint_type(m_h, (int)j) == RDYN_REVOLUTE;
+    m_links.clear();
+    m_joints.clear();
+    for (unsigned i = 0; i < m_links_number; ++i)
+    {
+      LinkPtr l(new Link());
+      l->m_name = m_links_name[i];
+      double cog[3];
+      rdyn_chain_link_parameters(m_h, (int)i, l->m_pi, &l->m_mass, cog);
+      for (int k = 0; k < 3; ++k) l->m_cog(k) = cog[k];
+      l->build();
+      m_links.push_back(l);
+    }
+    for (unsigned j = 0; j < m_joints_number; ++j)
+    {
+      JointPtr jt(new Joint());
+      jt->m_name = rdyn_chain_joint_name(m_h, (int)j);
+      const int ty = rdyn_chain_joint_type(m_h, (int)j);
+      jt->m_type = ty == RDYN_REVOLUTE ? Joint::REVOLUTE : (ty == RDYN_PRISMATIC ? Joint::PRISMATIC : Joint::FIXED);
+      rdyn_chain_joint_constants(m_h, (int)j, jt->m_R, jt->m_t, jt->m_axis, jt->m_limits);
+      jt->m_parent_link = m_links[j];
+      jt->m_child_link = m_links[j + 1];
+      m_links[j]->m_child_joints.push_back(jt);
+      m_links[j + 1]->m_parent_joint = jt;
+      m_joints.push_back(jt);
+    }
     const int n = (int)m_active_joints_number;
     m_q_max.resize(n); m_q_min.resize(n); m_Dq_max.resize(n); m_DDq_max.resize(n); m_tau_max.resize(n);
     rdyn_chain_limits(m_h, m_q_max.data(), m_q_min.data(), m_Dq_max.data(), m_DDq_max.data(), m_tau_max.data());

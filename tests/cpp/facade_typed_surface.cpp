@@ -86,6 +86,40 @@ int main()
   rosdyn::VectorXd q2(2);
   q2(0) = 0.1; q2(1) = 0.2;
   bad += a->getMultiplicity(q2).size() != 1;
+  // the object tree (rosdyn::Link / rosdyn::Joint views, primitives.h:62-232): names, kinds, parent / child wiring, parameters
+  const auto& links = c->getLinks();
+  const auto& joints = c->getJoints();
+  bad += links.size() != 5 || joints.size() != 4;
+  bad += links[1]->getName() != "l1" || joints[1]->getName() != "j2" || joints[1]->getType() != rosdyn::Joint::PRISMATIC || !joints[3]->isFixed();
+  bad += joints[2]->getParentLink() != links[2] || joints[2]->getChildLink() != links[3] || links[3]->getParentJoint() != joints[2];
+  bad += links[0]->getParentJoint() != nullptr || links[4]->getChildrenJoints().size() != 0 || links[1]->getChildrenJoints()[0] != joints[1];
+  bad += joints[0]->getQMax() != 2.0 || joints[0]->getDQMax() != 1.5 || joints[0]->getTauMax() != 30.0;
+  for (int l = 1; l < 5; ++l)  // Chain::getNominalParameters = the links' parameters, base link excluded (primitives_impl.h:1382-1391)
+  {
+    const rosdyn::VectorXd p = links[(size_t)l]->getNominalParameters();
+    for (int k = 0; k < 10; ++k) bad += p(k) != pc(10 * (l - 1) + k);
+  }
+  bad += links[2]->getMass() != 1.5 || links[2]->getCog()(0) != 0.2;
+  {
+    // spatial inertia about the link origin (spacevect_algebra.h:232-239): [m 1, m skew(c)^T; m skew(c), I + m skew(c) skew(c)^T]
+    const rosdyn::Matrix66d& I = links[2]->getSpatialInertia();
+    const double m2 = 1.5, cx = 0.2;
+    bad += I(0, 0) != m2 || I(1, 1) != m2 || I(2, 2) != m2;
+    bad += std::fabs(I(4, 2) - (-m2 * cx)) > 1e-15 || std::fabs(I(5, 1) - (m2 * cx)) > 1e-15 || std::fabs(I(2, 4) - I(4, 2)) > 0 || std::fabs(I(1, 5) - I(5, 1)) > 0;
+    bad += std::fabs(I(3, 3) - 0.02) > 1e-15 || std::fabs(I(4, 4) - (0.04 + m2 * cx * cx)) > 1e-15 || std::fabs(I(5, 5) - (0.06 + m2 * cx * cx)) > 1e-15;
+    bad += links[2]->getSpatialInertiaTerms().size() != 10;
+  }
+  {
+    // Joint::getTransformation (primitives_impl.h:38-47): j1 turns about z at height 0.3; j2 slides along x from x = 0.4; j3's axis is normalised
+    const rosdyn::Affine3d& T1 = joints[0]->getTransformation(0.5);
+    bad += std::fabs(T1.matrix()(0, 0) - std::cos(0.5)) > 1e-15 || std::fabs(T1.matrix()(1, 0) - std::sin(0.5)) > 1e-15 || std::fabs(T1.matrix()(2, 3) - 0.3) > 0;
+    const rosdyn::Affine3d& T2 = joints[1]->getTransformation(0.25);
+    bad += std::fabs(T2.matrix()(0, 3) - 0.65) > 1e-15 || T2.matrix()(0, 0) != 1.0;
+    const rosdyn::Vector6d& s3 = joints[2]->getScrew_of_child_in_parent();
+    bad += s3(5) != 1.0 || s3(0) != 0.0;
+    const rosdyn::Vector6d& s2 = joints[1]->getScrew_of_child_in_parent();
+    bad += s2(0) != 1.0 || s2(3) != 0.0;
+  }
   std::printf("facade typed surface: %s (%u links, %u joints, %u active, %d parameters)\n", bad ? "MISMATCH" : "ok", a->getLinksNumber(),
               a->getJointsNumber(), a->getActiveJointsNumber(), (int)pa.rows());
   return bad ? 1 : 0;

@@ -200,3 +200,50 @@ def test_workspace_queries_reflect_what_the_tsqr_entry_points_support():
     many = ComponentSet([dict(type=FRICTION2, joint=j % 6, min_velocity=1e-3, max_velocity=5.0, parameters=[1.0, 1.0, 0.1]) for j in range(7)], 6)
     assert many.columns == 21                                                            # 61 + 21 > 80: does not fit the extra slot
     assert L.rdyn_identification_tsqr_workspace_bytes(ur6._h, C.cast(many._arr, C.c_void_p), many.n_comps) == 0
+
+
+@pytest.mark.parametrize("name", ["ur10_tool0", "mixed"])
+def test_joint_constants_and_link_parameters_rebuild_the_chain(name):
+    """Host-only: the Joint / Link views behind Chain::getJoints() / getLinks() (rdyn_chain_joint_constants,
+    rdyn_chain_link_parameters).  The product of Joint::getTransformation(q_j) over the chain is the oracle's T_bt(q), and the links'
+    nominal parameters are Chain::getNominalParameters (base link excluded)."""
+    import ctypes as C
+    from oracle.oracle import OracleChain
+    from rosdyn_amd import Chain
+    from rosdyn_amd._lib import check, lib
+    urdf, base, tool = {"ur10_tool0": ("ur10_like.urdf", "base_link", "tool0"), "mixed": ("mixed_joints.urdf", "world", "tip")}[name]
+    path = os.path.join(FIXTURES, urdf)
+    chain, ref = Chain(path, base, tool), OracleChain(path, base, tool)
+    nJ = chain.getJointsNumber()
+    rng = np.random.default_rng(3)
+    q = rng.uniform(-1, 1, size=(4, ref.n))
+    T_ref = ref.fk(q)[:, -1]                                        # (4, 3, 4)
+    names = chain.getJointsName()
+    active = chain.getActiveJointsName()
+    dbl = lambda k: (C.c_double * k)()
+    for s in range(4):
+        T = np.eye(4)
+        for j in range(nJ):
+            R, t, ax, lim = dbl(9), dbl(3), dbl(3), dbl(5)
+            check(lib().rdyn_chain_joint_constants(chain._h, j, R, t, ax, lim))
+            R, t, ax = np.array(R).reshape(3, 3), np.array(t), np.array(ax)
+            ty = lib().rdyn_chain_joint_type(chain._h, j)
+            qj = q[s, active.index(names[j])] if names[j] in active else 0.0
+            K = np.array([[0, -ax[2], ax[1]], [ax[2], 0, -ax[0]], [-ax[1], ax[0], 0]])
+            Tj = np.eye(4)
+            if ty == 0:      # RDYN_REVOLUTE
+                Tj[:3, :3], Tj[:3, 3] = R @ (np.eye(3) + np.sin(qj) * K + (1 - np.cos(qj)) * K @ K), t
+            elif ty == 1:    # RDYN_PRISMATIC
+                Tj[:3, :3], Tj[:3, 3] = R, t + R @ ax * qj
+            else:
+                Tj[:3, :3], Tj[:3, 3] = R, t
+            T = T @ Tj
+        assert np.abs(T[:3] - T_ref[s]).max() < 1e-13
+    pi = chain.getNominalParameters()
+    for l in range(1, nJ + 1):
+        p, m, cg = dbl(10), C.c_double(), dbl(3)
+        check(lib().rdyn_chain_link_parameters(chain._h, l, p, C.byref(m), cg))
+        assert np.array_equal(np.array(p), pi[10 * (l - 1):10 * l])
+        assert p[0] == m.value and np.allclose(np.array(p)[1:4], m.value * np.array(cg), atol=1e-15)
+    assert lib().rdyn_chain_link_parameters(chain._h, nJ + 1, None, None, None) != 0      # out of range
+    assert lib().rdyn_chain_joint_constants(chain._h, -1, None, None, None, None) != 0
