@@ -23,16 +23,28 @@ for r in rows("trace/**/*kernel_stats.csv"):
 
 # per-dispatch durations of our kernels from the kernel trace
 dur = defaultdict(list)
+order = defaultdict(list)  # (start timestamp, duration) per kernel, to single out bench.py's timed region (its LAST --steps launches)
 meta = {}
 for r in rows("trace/**/*kernel_trace.csv"):
     name = r.get("Kernel_Name", "")
     if any(k in name for k in ("k_local_sweep", "k_base_sweep", "k_base_ext", "k_gram", "k_rowpair", "k_image_sweep", "k_regressor_gram", "k_regressor_tsqr", "k_tsqr", "k_local_ik", "k_components")):
         dur[name].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+        order[name].append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
         meta[name] = (r.get("VGPR_Count"), r.get("Accum_VGPR_Count"), r.get("SGPR_Count"), r.get("LDS_Block_Size"), r.get("Scratch_Size"), r.get("Grid_Size"), r.get("Workgroup_Size"))
 for k, v in dur.items():
     v.sort()
     print("dispatches %-60s n=%d avg_us=%.2f median_us=%.2f min_us=%.2f  vgpr/agpr/sgpr/lds/scratch/grid/wg=%s" % (
         k[:60], len(v), sum(v) / len(v) / 1e3, v[len(v) // 2] / 1e3, v[0] / 1e3, meta[k]))
+
+# bench.py probes candidate output placements before its timed region (--placements): those launches run at the speed of THEIR
+# buffers and are in the table above; the timed region is the last --steps launches of the headline kernel
+steps = int(os.environ.get("PROF_TIMED_STEPS", "20"))
+for k, v in order.items():
+    if ("k_image_sweep<" in k or "k_local_sweep<" in k) and "multi" not in k and len(v) > steps + 3:
+        v.sort()
+        last = [d for _, d in v[-steps:]]
+        print("timed region %-58s last %d of %d dispatches: avg_us=%.2f min_us=%.2f max_us=%.2f (the rest: placement probes + warm-up)" % (
+            k[:58], steps, len(v), sum(last) / len(last) / 1e3, min(last) / 1e3, max(last) / 1e3))
 
 for tag in ("fetch", "write"):
     acc = defaultdict(list)
