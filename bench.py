@@ -29,8 +29,8 @@ Beside `value` the line carries
 
 Prints ONE JSON line on rank 0.
 
-Output placement: before the timed region rank r allocates --placements (24) candidate output buffers, probes each with the launch it is
-going to time and keeps the best one (the speed of this store pattern depends on the physical backing of the allocation, reproducibly per
+Output placement: before the timed region rank r allocates candidate output buffers a dozen at a time (at most --placements = 72, at most
+three quarters of the free device memory), probes each with the launch it is going to time, stops when one stands out and keeps the best (the speed of this store pattern depends on the physical backing of the allocation, reproducibly per
 allocation: DESIGN.md section 3, profiles/r2/placement.txt); every probe time is in the JSON line (`output_placement`).
 """
 import argparse
@@ -362,7 +362,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--samples", type=int, default=1000000, help="samples per GPU")
     ap.add_argument("--y-layout", default="stacked", choices=["element", "stacked", "per_sample"])
-    ap.add_argument("--placements", type=int, default=24, help="candidate output buffers probed before the timed region (1 = take the first allocation)")
+    ap.add_argument("--placements", type=int, default=72, help="at most this many candidate output buffers are probed before the timed region (1 = take the first allocation)")
     ap.add_argument("--cpu-seconds", type=float, default=8.0, help="wall time of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-extras", action="store_true", help="skip the configs[2] / configs[4] legs after the timed region")
     ap.add_argument("--no-config4", action="store_true", help="skip the regressor -> Gram -> all-reduce block (configs[3])")
@@ -426,8 +426,21 @@ def main():
         torch.cuda.synchronize()
         return e0.elapsed_time(e1) / 3
 
-    cands = [torch.empty(y_shape, dtype=torch.float64, device=dev) for _ in range(max(1, args.placements))]
-    probe_ms = [probe(Yc) for Yc in cands]
+    # candidates are added a dozen at a time (earlier ones stay allocated, so the new ones land elsewhere) until one stands out
+    # (14 % under the median) or --placements / three quarters of the free memory are used up: the share of good placements varies
+    # from 1 in 24 to 1 in 4 from device to device (profiles/r2/placement.txt)
+    y_bytes = 8
+    for d in y_shape:
+        y_bytes *= d
+    free_b, _ = torch.cuda.mem_get_info(dev)
+    max_c = max(1, min(args.placements, int(0.75 * free_b) // y_bytes))
+    cands, probe_ms = [], []
+    while len(cands) < max_c:
+        for _ in range(min(12, max_c - len(cands))):
+            cands.append(torch.empty(y_shape, dtype=torch.float64, device=dev))
+            probe_ms.append(probe(cands[-1]))
+        if len(cands) >= 12 and min(probe_ms) <= 0.86 * sorted(probe_ms)[len(probe_ms) // 2]:
+            break
     best = min(range(len(cands)), key=lambda i: probe_ms[i])
     Y = cands[best]
     del cands
