@@ -415,36 +415,9 @@ def main():
     # against the device's physical channel / bank map; a plain sequential fill prefers the OTHER allocations).  The caller owns the
     # output buffer, so the harness does what a caller who cares would do: allocate a few candidates, probe each with the launch it is
     # going to time, keep the best placement and free the rest -- all before the timed region.  --placements 1 = first allocation.
-    def probe(Yc):
-        chain.getRegressor(q, dq, ddq, layout=in_layout, y_layout=args.y_layout, out=Yc, tau_out=tau)
-        torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(3):
-            chain.getRegressor(q, dq, ddq, layout=in_layout, y_layout=args.y_layout, out=Yc, tau_out=tau)
-        e1.record()
-        torch.cuda.synchronize()
-        return e0.elapsed_time(e1) / 3
-
-    # candidates are added a dozen at a time (earlier ones stay allocated, so the new ones land elsewhere) until one stands out
-    # (14 % under the median) or --placements / three quarters of the free memory are used up: the share of good placements varies
-    # from 1 in 24 to 1 in 4 from device to device (profiles/r2/placement.txt)
-    y_bytes = 8
-    for d in y_shape:
-        y_bytes *= d
-    free_b, _ = torch.cuda.mem_get_info(dev)
-    max_c = max(1, min(args.placements, int(0.75 * free_b) // y_bytes))
-    cands, probe_ms = [], []
-    while len(cands) < max_c:
-        for _ in range(min(12, max_c - len(cands))):
-            cands.append(torch.empty(y_shape, dtype=torch.float64, device=dev))
-            probe_ms.append(probe(cands[-1]))
-        if len(cands) >= 12 and min(probe_ms) <= 0.86 * sorted(probe_ms)[len(probe_ms) // 2]:
-            break
-    best = min(range(len(cands)), key=lambda i: probe_ms[i])
-    Y = cands[best]
-    del cands
-    torch.cuda.empty_cache()
+    from rosdyn_amd.placement import pick_output_buffer
+    Y, placement = pick_output_buffer(lambda Yc: chain.getRegressor(q, dq, ddq, layout=in_layout, y_layout=args.y_layout, out=Yc, tau_out=tau),
+                                      y_shape, dev, max_candidates=max(1, args.placements))
 
     def step():
         chain.getRegressor(q, dq, ddq, layout=in_layout, y_layout=args.y_layout, out=Y, tau_out=tau)
@@ -471,10 +444,8 @@ def main():
                      "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                      "traffic_source": "committed profile (profiles/pmc_latest.json, builder's box), not measured in this run" if traffic else None,
                      "kernel": kernel, "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": b_eval * N},
-        "output_placement": {"candidates": len(probe_ms), "chosen": best, "probe_ms": [round(t, 4) for t in probe_ms],
-                             "first_allocation_ms": round(probe_ms[0], 4), "median_ms": round(sorted(probe_ms)[len(probe_ms) // 2], 4),
-                             "note": "same launch, same device, different output allocations; the harness keeps the best placement "
-                                     "before the timed region (--placements 1 disables)"},
+        "output_placement": dict(placement, note="same launch, same device, different output allocations; the harness keeps the best placement "
+                                                 "before the timed region (--placements 1 disables); rosdyn_amd/placement.py"),
     }
     if not args.no_config4:
         # measured torques of this rank's shard: tau of the evaluation just timed (noise-free: exact normal equations)

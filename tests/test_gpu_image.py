@@ -117,3 +117,22 @@ def test_regressor_strides_are_validated():
     it[0].chain, it[0].batch, it[0].Y, it[0].y_layout = chain._h, b, Y.data_ptr(), RegressorLayout(-1, N, n * N)
     h = C.c_void_p()
     assert lib().rdyn_multi_plan_create(C.cast(it, C.c_void_p), 1, C.byref(h)) == 1
+
+
+def test_pick_output_buffer_returns_a_working_buffer():
+    """rosdyn_amd.placement.pick_output_buffer: candidates are probed with the caller's launch, the fastest is kept, results are the same."""
+    torch = pytest.importorskip("torch")
+    from rosdyn_amd.placement import pick_output_buffer
+    from rosdyn_amd.samples import trajectory_batch
+    chain, ref = _chain_and_ref(CASES[0])
+    n, P, N = chain.getActiveJointsNumber(), 10 * chain.getJointsNumber(), 20000
+    q, dq, ddq = (torch.from_numpy(x).cuda() for x in trajectory_batch(5, N, n))
+    tau = torch.empty((N, n), dtype=torch.float64, device="cuda")
+    Y, info = pick_output_buffer(lambda Yc: chain.getRegressor(q, dq, ddq, y_layout="stacked", out=Yc, tau_out=tau), (P, N * n), torch.device("cuda", 0),
+                                 max_candidates=5, batch=2)
+    assert 2 <= info["candidates"] <= 5 and len(info["probe_ms"]) == info["candidates"] and 0 <= info["chosen"] < info["candidates"]
+    assert info["probe_ms"][info["chosen"]] == min(info["probe_ms"])
+    Y2 = torch.empty_like(Y)
+    chain.getRegressor(q, dq, ddq, y_layout="stacked", out=Y2, tau_out=tau)
+    chain.getRegressor(q, dq, ddq, y_layout="stacked", out=Y, tau_out=tau)
+    assert torch.equal(Y, Y2)
