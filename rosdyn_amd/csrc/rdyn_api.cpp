@@ -12,6 +12,7 @@
 //   RDYN_GRAM_UNFUSED=1     same as RDYN_GRAM_PATH=two
 //   RDYN_FUSED_BLOCKS=n     persistent workgroups of the fused Gram kernels (default 256 = one per CU)
 //   RDYN_FUSED_DEBUG=bits   phase ablation of the fused Gram kernels (timing only: results are then wrong)
+#include <cstdint>
 #include <cstring>
 #include <map>
 #include <memory>
@@ -135,15 +136,26 @@ inline void rec_strides(const rdyn_batch* b, int64_t elems, int64_t* ss, int64_t
 }
 
 // Which row-contiguous regressor kernel (rdyn_image.hip) serves this layout: 0 none, 1 the per-sample image (stride_row 1, stride_col n,
-// stride_sample >= n P), 2 the stacked (N n) x P matrix (stride_sample == n).  Needs the input joints to be the first n chain joints.
-int image_route(const rdyn_chain* c, const rdyn_regressor_layout* yl, int64_t n_samples)
+// stride_sample >= n P), 2 the stacked (N n) x P matrix (stride_sample == n).  Needs the input joints in chain order and a compiled
+// fixed-joint pattern (*fix_mask: bit f = chain joint f is not an input joint), and a 16-byte aligned Y: the copy-out moves 16-byte
+// chunks whose addresses are Y + a multiple of 16 (an 8-byte aligned base -- a view at an odd double offset -- would put the last
+// chunk of every image 8 bytes past its end); such calls keep the row-pair / strided kernels.
+int image_route(const rdyn_chain* c, const rdyn_regressor_layout* yl, int64_t n_samples, const double* Y, bool multi, unsigned* fix_mask)
 {
-  const int n = c->n_active();
-  const bool lay_image = yl->stride_row == 1 && yl->stride_col == n && yl->stride_sample >= (int64_t)n * 10 * c->n_joints();
+  const int n = c->n_active(), nJ = c->n_joints();
+  const bool lay_image = yl->stride_row == 1 && yl->stride_col == n && yl->stride_sample >= (int64_t)n * 10 * nJ;
   const bool lay_stacked = yl->stride_row == 1 && yl->stride_sample == n && yl->stride_col >= n_samples * n && !probe_env("RDYN_NO_STACKED_LDS");
-  if (!(lay_image || lay_stacked) || !rdyn_image_supported(c->n_joints(), n, yl->stride_sample) || probe_env("RDYN_NO_IMAGE")) return 0;
+  if (!(lay_image || lay_stacked) || probe_env("RDYN_NO_IMAGE")) return 0;
+  if (((uintptr_t)Y & 15u) != 0) return 0;
+  if (lay_stacked && (yl->stride_col * 8) % 16 != 0) return 0;  // every column must start 16-byte aligned too
+  unsigned fix = (nJ >= 32) ? 0u : ((1u << nJ) - 1u);
   for (int j = 0; j < n; ++j)
-    if (c->active[j] != j) return 0;  // input joints = the first n chain joints, in order
+  {
+    if (j > 0 && c->active[j] <= c->active[j - 1]) return 0;  // input joints in chain order
+    fix &= ~(1u << c->active[j]);
+  }
+  if (!rdyn_image_supported(nJ, fix, yl->stride_sample, multi)) return 0;
+  *fix_mask = fix;
   return lay_stacked ? 2 : 1;
 }
 
@@ -193,9 +205,10 @@ int run_local(const rdyn_chain* c, const rdyn_batch* b, int mode, double* tau, d
                        !probe_env("RDYN_NO_ROWPAIR");
   // the drop-in per-sample image (either input layout): one thread per sample, link blocks staged through LDS (rdyn_image.hip)
   // and the stacked column-major (N n) x P matrix (stride_sample == n): same kernel, column-major staging tile per link
-  const bool image = mode == RDYN_MODE_REGRESSOR && yl && image_route(c, yl, b->n_samples) != 0;
+  unsigned fix_mask = 0;
+  const bool image = mode == RDYN_MODE_REGRESSOR && yl && image_route(c, yl, b->n_samples, Y, false, &fix_mask) != 0;
   if (image)
-    RDYN_HIP_TRY(rdyn_launch_image_sweep(c->n_joints(), n, a, (hipStream_t)b->stream));
+    RDYN_HIP_TRY(rdyn_launch_image_sweep(c->n_joints(), fix_mask, a, (hipStream_t)b->stream));
   else if (rowpair)
   {
     // the kernel addresses Y with a 32-bit per-lane byte offset: split so that every launch spans < 4 GB of Y
@@ -610,7 +623,7 @@ struct rdyn_multi_plan
   struct Group
   {
     int n_joints = 0;
-    int n_active = 0;  // image / stacked groups only
+    unsigned fix_mask = 0;  // image / stacked groups only: chain joints that are not input joints
     int kind = 0;      // 0: one thread per sample, strided stores (any layout); 1: per-sample images, 2: stacked matrices (rdyn_image.hip)
     int n_items = 0;
     int64_t max_samples = 0;
@@ -674,11 +687,12 @@ int rdyn_multi_plan_create(const rdyn_multi_item* items, int n_items, rdyn_multi
     a.y_ss = it.y_layout.stride_sample;
     a.y_sr = it.y_layout.stride_row;
     a.y_sc = it.y_layout.stride_col;
-    const int nj = it.chain->n_joints(), na = it.chain->n_active();
-    // one launch per (chain joints, input joints, kernel kind): row-contiguous layouts of chains of up to 8 joints go through the
-    // LDS-staged kernels (whole-line stores), the rest keeps the strided kernel.  Key = nj | na << 8 | kind << 16.
-    const int kind = (it.batch.n_samples > 0 && nj <= 8) ? image_route(it.chain, &it.y_layout, it.batch.n_samples) : 0;
-    const int key = nj | ((kind ? na : 0) << 8) | (kind << 16);
+    const int nj = it.chain->n_joints();
+    // one launch per (chain joints, fixed-joint pattern, kernel kind): row-contiguous layouts of chains of up to 8 input joints go
+    // through the LDS-staged kernels (whole-line stores), the rest keeps the strided kernel.  Key = nj | mask << 8 | kind << 24.
+    unsigned fix_mask = 0;
+    const int kind = it.batch.n_samples > 0 ? image_route(it.chain, &it.y_layout, it.batch.n_samples, it.Y, true, &fix_mask) : 0;
+    const int key = nj | ((kind ? (int)fix_mask : 0) << 8) | (kind << 24);
     by_nj[key].push_back(a);
     if (a.n_samples > max_n[key]) max_n[key] = a.n_samples;
   }
@@ -686,8 +700,8 @@ int rdyn_multi_plan_create(const rdyn_multi_item* items, int n_items, rdyn_multi
   {
     rdyn_multi_plan::Group grp;
     grp.n_joints = kv.first & 0xFF;
-    grp.n_active = (kv.first >> 8) & 0xFF;
-    grp.kind = kv.first >> 16;
+    grp.fix_mask = (unsigned)(kv.first >> 8) & 0xFFFFu;
+    grp.kind = kv.first >> 24;
     grp.n_items = (int)kv.second.size();
     grp.max_samples = max_n[kv.first];
     RDYN_HIP_TRY(hipMalloc((void**)&grp.table, sizeof(RdynSweepArgs) * kv.second.size()));
@@ -711,7 +725,7 @@ int rdyn_multi_plan_regressor(const rdyn_multi_plan* plan, void* stream)
   for (const auto& grp : plan->groups)
   {
     if (grp.kind)
-      RDYN_HIP_TRY(rdyn_launch_image_sweep_multi(grp.n_joints, grp.n_active, grp.kind == 2, grp.table, grp.n_items, grp.max_samples, (hipStream_t)stream));
+      RDYN_HIP_TRY(rdyn_launch_image_sweep_multi(grp.n_joints, grp.fix_mask, grp.kind == 2, grp.table, grp.n_items, grp.max_samples, (hipStream_t)stream));
     else
       RDYN_HIP_TRY(rdyn_launch_local_sweep_multi(grp.n_joints, RDYN_MODE_REGRESSOR, grp.table, grp.n_items, grp.max_samples, (hipStream_t)stream));
   }

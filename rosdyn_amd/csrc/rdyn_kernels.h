@@ -202,12 +202,13 @@ enum { RDYN_MODE_REGRESSOR = 0, RDYN_MODE_TORQUE = 1, RDYN_MODE_INERTIA = 2, RDY
 hipError_t rdyn_launch_local_sweep(int n_joints, int mode, const RdynSweepArgs& a, hipStream_t st);
 hipError_t rdyn_launch_base_sweep(int n_joints, const RdynKinArgs& a, hipStream_t st);
 hipError_t rdyn_launch_rowpair_sweep(int n_joints, int n_active, const RdynSweepArgs& a, hipStream_t st);
-// per-sample Eigen image (y_sr == 1, y_sc == n_active): one thread per sample, link blocks staged through LDS and written in
-// whole 80 n-byte runs (rdyn_image.hip); input joints = the first n_active chain joints in order, at most one fixed tail joint
-bool rdyn_image_supported(int n_joints, int n_active, int64_t y_ss);
-hipError_t rdyn_launch_image_sweep(int n_joints, int n_active, const RdynSweepArgs& a, hipStream_t st);
-hipError_t rdyn_launch_image_sweep_multi(int n_joints, int n_active, bool stacked, const RdynSweepArgs* table, int n_items, int64_t max_samples,
-                                         hipStream_t st);  // 2..8 chain joints
+// per-sample Eigen image (y_sr == 1, y_sc == n_active) and stacked matrix (y_ss == n_active): one thread per sample, link blocks staged
+// through LDS and written in whole lines (rdyn_image.hip / rdyn_image_impl.h).  fix_mask: bit f set = chain joint f is not an input
+// joint; the input joints are the others, in chain order.  Compiled patterns: <= 1 fixed head joint, <= 3 fixed tail joints.
+bool rdyn_image_supported(int n_joints, unsigned fix_mask, int64_t y_ss, bool multi);
+hipError_t rdyn_launch_image_sweep(int n_joints, unsigned fix_mask, const RdynSweepArgs& a, hipStream_t st);
+hipError_t rdyn_launch_image_sweep_multi(int n_joints, unsigned fix_mask, bool stacked, const RdynSweepArgs* table, int n_items, int64_t max_samples,
+                                         hipStream_t st);  // 2..8 input joints
 hipError_t rdyn_launch_local_sweep_multi(int n_joints, int mode, const RdynSweepArgs* table, int n_items, int64_t max_samples, hipStream_t st);
 
 #endif

@@ -15,18 +15,29 @@ GRAV = (0.0, 0.0, -9.806)
 CASES = [("ur10_like.urdf", "base_link", "wrist_3_link"),   # NJ = NA = 6: 2 880-byte images, two alignment classes
          ("ur10_like.urdf", "base_link", "tool0"),           # NJ = 7, NA = 6 (fixed tool frame): 3 360-byte images
          ("panda_like.urdf", "link0", "link7"),              # NJ = NA = 7: 3 920-byte images, eight alignment classes
-         ("panda_like.urdf", "link0", "link8")]              # NJ = 8, NA = 7
+         ("panda_like.urdf", "link0", "link8"),              # NJ = 8, NA = 7
+         # round 3: the reference's own chains in their public URDF form (rosdyn_speed_test.cpp:44-45, test.cpp:47-48)
+         ("ur10_public.urdf", "base_link", "wrist_3_link"),  # fixed HEAD joint base_link -> base_link_inertia: NJ = 7, NA = 6
+         ("ur10_public.urdf", "base_link", "flange"),        # fixed head + one fixed tail joint: NJ = 8
+         ("ur10_public.urdf", "base_link", "tool0"),         # fixed head + two fixed tail joints: NJ = 9, P = 90
+         ("panda_like.urdf", "link0", "hand"),               # two fixed tail joints behind 7 input joints: NJ = 9, P = 90
+         ("panda_like.urdf", "link0", "hand", ["joint1", "joint2", "joint3", "joint4", "joint5", "joint6"]),  # joint7 not an input: 3 "fixed" tail joints
+         ("ur10_public.urdf", "base_link", "tool0", ["shoulder_pan_joint", "shoulder_lift_joint", "elbow_joint", "wrist_1_joint", "wrist_2_joint"])]
+IDS = ["6of6", "6of7", "7of7", "7of8", "h1_6of7", "h1_6of8", "h1_6of9", "7of9", "6of9_t3", "h1_5of9_t3"]
 
 
 def _chain_and_ref(case):
     from oracle.oracle import OracleChain
     from rosdyn_amd import Chain
-    urdf, base, tool = case
+    urdf, base, tool = case[:3]
     path = os.path.join(FIXTURES, urdf)
-    return Chain(path, base, tool, GRAV), OracleChain(path, base, tool, GRAV)
+    chain, ref = Chain(path, base, tool, GRAV), OracleChain(path, base, tool, GRAV, input_joint_names=case[3] if len(case) > 3 else None)
+    if len(case) > 3:
+        assert chain.setInputJointsName(case[3])
+    return chain, ref
 
 
-@pytest.mark.parametrize("case", CASES, ids=["6of6", "6of7", "7of7", "7of8"])
+@pytest.mark.parametrize("case", CASES, ids=IDS)
 @pytest.mark.parametrize("N", [1, 2, 63, 64, 65, 127, 129, 1000])
 def test_image_and_stacked_match_oracle_and_element_kernel(case, N):
     torch = pytest.importorskip("torch")
@@ -78,6 +89,34 @@ def test_padded_image_stride(pad):
     Yg = h[:, :n * P].reshape(N, P, n).transpose(0, 2, 1)
     Yr = ref.regressor(q, dq, ddq)
     assert np.abs(Yg - Yr).max() <= 1e-11 * max(1.0, np.abs(Yr).max())
+
+
+@pytest.mark.parametrize("case", [CASES[0], CASES[6], CASES[7]], ids=["6of6", "h1_6of9", "7of9"])
+def test_odd_double_offset_output_is_not_overrun(case):
+    """a Y that is only 8-byte aligned (a view at an odd double offset, a C caller passing Y + 1) made the LDS-staged
+    kernels' 16-byte copy-out write 8 bytes past every image.  Such calls now keep the row-pair kernel: the result is right and the
+    doubles on either side of the output stay poisoned."""
+    torch = pytest.importorskip("torch")
+    from rosdyn_amd._lib import Batch, RegressorLayout, check, lib
+    from rosdyn_amd.samples import trajectory_batch
+    chain, ref = _chain_and_ref(case)
+    n, P, N = chain.getActiveJointsNumber(), 10 * chain.getJointsNumber(), 130
+    q, dq, ddq = trajectory_batch(77, N, n)
+    tq, tdq, tddq = (torch.from_numpy(x).cuda() for x in (q, dq, ddq))
+    Yr = ref.regressor(q, dq, ddq)
+    b = Batch()
+    b.n_samples, b.q, b.dq, b.ddq, b.layout, b.device = N, tq.data_ptr(), tdq.data_ptr(), tddq.data_ptr(), 0, 0
+    b.stream = torch.cuda.current_stream().cuda_stream
+    for yl, unpack in ((RegressorLayout(n * P, 1, n), lambda h: h.reshape(N, P, n).transpose(0, 2, 1)),
+                       (RegressorLayout(n, 1, N * n), lambda h: h.reshape(P, N, n).transpose(1, 2, 0))):
+        for off in (1, 3):
+            buf = torch.full((N * n * P + 8,), -7.0, dtype=torch.float64, device="cuda")
+            check(lib().rdyn_regressor(chain._h, C.byref(b), None, buf.data_ptr() + 8 * off, C.byref(yl)))
+            torch.cuda.synchronize()
+            h = buf.cpu().numpy()
+            assert np.all(h[:off] == -7.0) and np.all(h[off + N * n * P:] == -7.0)
+            Yg = unpack(h[off:off + N * n * P])
+            assert np.abs(Yg - Yr).max() <= 1e-11 * max(1.0, np.abs(Yr).max())
 
 
 def test_image_kernel_with_prismatic_and_fixed_joints():

@@ -10,8 +10,11 @@ OBJ=_obj/var/${NAME}_${STEM}.o
 if [[ $SRC == *.cpp ]]; then
   g++ -O3 -std=c++17 -fPIC -Wall -Wextra -Wno-unused-parameter -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include "$@" -c $SRC -o $OBJ
 else
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wextra -Wno-unused-parameter -Wno-cuda-compat -ffp-contract=on "$@" -c $SRC -o $OBJ
+  EXTRA=""
+  if [[ $SRC == rdyn_image_part.hip ]]; then EXTRA="-mllvm -pragma-unroll-threshold=1000000"; fi
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wextra -Wno-unused-parameter -Wno-cuda-compat -ffp-contract=on $EXTRA "$@" -c $SRC -o $OBJ
 fi
-OTHERS=$(ls _obj/*.o | grep -v "_obj/${STEM}.o")
+# STOCK_OBJ=<object the variant replaces> when it is not _obj/<stem>.o (the slices of rdyn_image_part.hip: _obj/rdyn_image_na6.o ...)
+OTHERS=$(ls _obj/*.o | grep -v "${STOCK_OBJ:-_obj/${STEM}.o}")
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -o ../variants/librdyn_${NAME}.so $OBJ $OTHERS
 echo built ../variants/librdyn_${NAME}.so

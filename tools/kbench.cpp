@@ -59,9 +59,10 @@ int main(int argc, char** argv)
   const std::string what = argv[1];
   const int rounds = std::atoi(argv[2]);
   const bool cfg3 = what == "gram3" || what == "ident3" || what == "tsqr3";
-  const char* urdf = cfg3 ? "tests/fixtures/panda_like.urdf" : "tests/fixtures/ur10_like.urdf";
-  const char* base = cfg3 ? "link0" : "base_link";
-  const char* tool = cfg3 ? "link7" : "wrist_3_link";
+  // KB_URDF / KB_BASE / KB_TOOL: another chain (e.g. tests/fixtures/ur10_public.urdf base_link tool0: fixed head + two fixed tail joints)
+  const char* urdf = getenv("KB_URDF") ? getenv("KB_URDF") : (cfg3 ? "tests/fixtures/panda_like.urdf" : "tests/fixtures/ur10_like.urdf");
+  const char* base = getenv("KB_BASE") ? getenv("KB_BASE") : (cfg3 ? "link0" : "base_link");
+  const char* tool = getenv("KB_TOOL") ? getenv("KB_TOOL") : (cfg3 ? "link7" : "wrist_3_link");
   const int64_t N = getenv("KB_N") ? std::atoll(getenv("KB_N")) : (cfg3 ? 4000000 : 1000000);
   const double g[3] = {0, 0, -9.806};
   const std::string xml = read_file(urdf);
