@@ -140,6 +140,16 @@ int rdyn_chain_joint_constants(const rdyn_chain* chain, int i, double R_pj[9], d
 int rdyn_chain_link_parameters(const rdyn_chain* chain, int i, double pi[10], double* mass, double cog[3]);
 /* Chain::getNominalParameters primitives_impl.h:1382 -> pi[10 * joints_number] (HOST pointer) */
 int rdyn_nominal_parameters(const rdyn_chain* chain, double* pi);
+/* Rigid-body reduction of a chain whose input joints are a subset of its joints, in chain order (fixed joints, primitives_impl.h:74-83,
+ * or joints left out of setInputJointsName): links joined by non-input joints move as one body, so the ten regressor columns of a
+ * link f + 1 hanging from a non-input joint are a CONSTANT linear image of the ten columns of the link the body's input joint
+ * carries:  Y(:, 10 f + p) = sum_a Y(:, 10 body_joint[f] + a) X[f][a][p]   (zero for links upstream of the first input joint).
+ * The regressor -> Gram / R-factor entry points use it internally (they sweep the reduced chain and expand the small result);
+ * exposed for callers that reduce the parameter vector themselves.  Returns the number of bodies (= input joints), 0 when the
+ * chain has no reduction (every joint an input joint, or input joints not in chain order), < 0 on a null chain.
+ * body_joint[n_joints]: chain index of the input joint whose child link is the body's reference frame, -1 = rides on the base;
+ * X[n_joints][10][10] row-major (a, p); pi_body[10 * bodies]: the merged nominal parameters.  HOST pointers, each may be NULL. */
+int rdyn_chain_reduction(const rdyn_chain* chain, int32_t* body_joint, double* X, double* pi_body);
 
 /* ---- batched evaluation (device pointers) ------------------------------------------------------------ */
 typedef enum rdyn_layout
@@ -335,9 +345,12 @@ int rdyn_regressor_gram(const rdyn_chain* chain, const rdyn_batch* batch, const 
  * sharded over the GPUs of a node, every GPU the fused regressor -> Gram of its shard, then ONE
  * ncclAllReduce(P*P + P + 2 doubles, ncclDouble, ncclSum) over RCCL / xGMI.  rdyn_multi_gpu_create initialises one communicator
  * (ncclCommInitAll) and one stream per device; RCCL is resolved at run time (librccl.so.1) -> RDYN_ERR_UNSUPPORTED if absent.
- * rdyn_regressor_gram_multi: batches[i] (device pointers on devices[i]; batch.device = devices[i] or -1; the stream field is
- * ignored: the context's stream of that device is used), tau_meas[i] (may be NULL as a whole or per shard), acc[i] = a device
- * buffer of P*P + P + 2 doubles on devices[i].  On return (asynchronous: rdyn_multi_gpu_synchronize, or synchronise the devices)
+ * rdyn_regressor_gram_multi: batches[i] (device pointers on devices[i]; batch.device = devices[i] or -1), tau_meas[i] (may be NULL
+ * as a whole or per shard), acc[i] = a device buffer of P*P + P + 2 doubles on devices[i].  The work runs on the CONTEXT's stream of
+ * each device, ordered BEHIND everything already queued on batches[i].stream (NULL = that device's default stream) by an event, so
+ * inputs still being produced there are safe; results are ordered for the caller by rdyn_multi_gpu_synchronize (or a device
+ * synchronise).  Calls may be queued back to back without synchronising in between (the shard size is a kernel argument, nothing
+ * host-side is re-used).  On completion
  * EVERY acc[i] holds the sums over all shards  [G = A'A (P*P, column-major) | c = A'tau_meas (P) | bb = tau_meas'tau_meas | count].
  * No reference counterpart (rosdyn_core has no multi-device code). */
 typedef struct rdyn_multi_gpu rdyn_multi_gpu;

@@ -73,6 +73,7 @@ SYMBOLS = {
     "rdyn_chain_set_input_joints": (_I, [_VP, C.POINTER(_CP), _I]),
     "rdyn_chain_limits": (_I, [_VP, _DP, _DP, _DP, _DP, _DP]),
     "rdyn_nominal_parameters": (_I, [_VP, _DP]),
+    "rdyn_chain_reduction": (_I, [_VP, _VP, _VP, _VP]),
     "rdyn_transformation": (_I, [_VP, _BP, _VP, _VP]),
     "rdyn_jacobian": (_I, [_VP, _BP, _VP]),
     "rdyn_jacobian_link": (_I, [_VP, _BP, _I, _VP]),

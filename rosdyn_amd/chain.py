@@ -108,6 +108,20 @@ class Chain(object):
         check(lib().rdyn_nominal_parameters(self._h, pi.ctypes.data_as(C.POINTER(C.c_double))))
         return pi
 
+    def getBodyReduction(self):
+        """Rigid-body reduction (include/rdyn.h: rdyn_chain_reduction; no reference counterpart): None when every chain joint is an
+        input joint, else (body_joint (nJ,), X (nJ, 10, 10), pi_body (bodies, 10)) with
+        Y[:, 10 f:10 f + 10] = Y[:, 10 b:10 b + 10] @ X[f], b = body_joint[f] (zero columns where b < 0)."""
+        nj = self.getJointsNumber()
+        body = np.zeros(nj, dtype=np.int32)
+        X = np.zeros((nj, 10, 10))
+        nb = lib().rdyn_chain_reduction(self._h, None, None, None)
+        if nb <= 0:
+            return None
+        pi = np.zeros((nb, 10))
+        lib().rdyn_chain_reduction(self._h, body.ctypes.data, X.ctypes.data, pi.ctypes.data)
+        return body, X, pi
+
     # ---- batch plumbing
     def _batch(self, layout, q, dq=None, ddq=None):
         torch = _torch()

@@ -94,6 +94,34 @@ int device_const(const rdyn_chain* c, const RdynChainConst** out)
   return RDYN_OK;
 }
 
+// device copy of the expansion blocks X_f of a chain with a reduced companion (rdyn_chain.hpp), current device
+int device_expand(const rdyn_chain* c, const double** out)
+{
+  int dev = 0;
+  RDYN_HIP_TRY(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> lk(c->mu);
+  auto it = c->dev_expand.find(dev);
+  if (it == c->dev_expand.end())
+  {
+    double* d = nullptr;
+    const size_t bytes = c->expand_X.size() * sizeof(double);
+    RDYN_HIP_TRY(hipMalloc((void**)&d, bytes));
+    hipError_t e = hipMemcpy(d, c->expand_X.data(), bytes, hipMemcpyHostToDevice);
+    if (e != hipSuccess)
+    {
+      (void)hipFree(d);
+      rdyn_set_error("HIP error: %s (upload of the expansion blocks)", hipGetErrorString(e));
+      return RDYN_ERR_HIP;
+    }
+    it = c->dev_expand.emplace(dev, d).first;
+  }
+  *out = it->second;
+  return RDYN_OK;
+}
+
+// temporary normal equations of the reduced chain at the end of a Gram workspace: G_red | c_red | bb_red
+size_t reduce_tmp_bytes(int cols_red) { return (((size_t)cols_red * cols_red + cols_red + 1) * sizeof(double) + 255) & ~(size_t)255; }
+
 int check_batch(const rdyn_chain* c, const rdyn_batch* b, bool need_dq, bool need_ddq, const char* fn)
 {
   if (!c || !b)
@@ -801,6 +829,8 @@ static int64_t default_chunk(int64_t chunk) { return chunk > 0 ? chunk : 32768; 
 // it stays in L2 / Infinity Cache): 256 workgroups x 256 samples x n x (P + 1) doubles = 192 MB at n = 6, P = 60.
 static int fused_blocks_env() { const char* e = probe_env("RDYN_FUSED_BLOCKS"); return e ? atoi(e) : 256; }
 static const int kFusedBlocks = 256;  // upper bound used for the workspace size; the launch uses fused_blocks_env()
+extern "C" int rdyn_identification_gram(const rdyn_chain* c, const rdyn_component* comps, int n_comps, const rdyn_batch* b, const double* tau_meas,
+                                        double* G, double* cvec, double* bb, int accumulate, void* workspace, size_t workspace_bytes);
 
 size_t rdyn_regressor_gram_workspace_bytes(const rdyn_chain* c, int64_t chunk_samples)
 {
@@ -810,7 +840,41 @@ size_t rdyn_regressor_gram_workspace_bytes(const rdyn_chain* c, int64_t chunk_sa
   const int64_t chunk = default_chunk(chunk_samples);
   const size_t chunked = (size_t)chunk * c->n_active() * (P + 1) * sizeof(double);
   const size_t fused = (size_t)kFusedBlocks * 256 * c->n_active() * (P + 1) * sizeof(double);  // one tile image per workgroup
-  return gram_slab_bytes(P) + (chunked > fused ? chunked : fused);
+  const size_t base = (gram_slab_bytes(P) + (chunked > fused ? chunked : fused) + 255) & ~(size_t)255;
+  // chains with joints that are not input joints: the kernels run on the reduced companion, whose normal equations wait at the end
+  return base + (c->reduced ? reduce_tmp_bytes(10 * c->reduced->n_joints()) : 0);
+}
+
+// Chains with non-input joints (default paths, chunk_samples <= 0): the regressor -> Gram kernels run on the reduced companion
+// (rdyn_chain.hpp: every joint an input joint -- the fastest instantiations, 10 n instead of 10 nJ columns), then G = E' G_red E.
+// chunk_samples > 0 keeps the chain as it is (the reference ordering of the two-kernel path).
+static int gram_through_reduced(const rdyn_chain* c, const rdyn_component* comps, int n_comps, int K, const rdyn_batch* b, const double* tau_meas,
+                                double* G, double* cvec, double* bb, int accumulate, void* workspace, size_t need_bytes)
+{
+  const rdyn_chain* r = c->reduced.get();
+  const int Cr = 10 * r->n_joints() + K;
+  const size_t tmp = reduce_tmp_bytes(Cr);
+  double* Gr = (double*)((char*)workspace + need_bytes - tmp);
+  int st = n_comps > 0 ? rdyn_identification_gram(r, comps, n_comps, b, tau_meas, Gr, Gr + (size_t)Cr * Cr, Gr + (size_t)Cr * Cr + Cr, 0, workspace, need_bytes - tmp)
+                       : rdyn_regressor_gram(r, b, tau_meas, Gr, Gr + (size_t)Cr * Cr, Gr + (size_t)Cr * Cr + Cr, 0, 0, workspace, need_bytes - tmp);
+  if (st != RDYN_OK) return st;
+  RdynGramExpandArgs ea;
+  memset(&ea, 0, sizeof ea);
+  st = device_expand(c, &ea.X);
+  if (st != RDYN_OK) return st;
+  ea.G_red = Gr;
+  ea.c_red = Gr + (size_t)Cr * Cr;
+  ea.bb_red = Gr + (size_t)Cr * Cr + Cr;
+  for (int f = 0; f < c->n_joints(); ++f) ea.red_of[f] = c->red_of[f];
+  ea.n_joints = c->n_joints();
+  ea.n_red = r->n_joints();
+  ea.n_comp_cols = K;
+  ea.add_to_output = accumulate ? 1 : 0;
+  ea.G = G;
+  ea.c = cvec;
+  ea.bb = bb;
+  RDYN_HIP_TRY(rdyn_launch_gram_expand(ea, (hipStream_t)b->stream));
+  return RDYN_OK;
 }
 
 // Tile layout of the LDS-resident regressor -> Gram kernels (rdyn_lds_gram.hip, rdyn_pipe_gram.hip, rdyn_duo_gram.hip): the columns
@@ -893,6 +957,8 @@ int rdyn_regressor_gram(const rdyn_chain* c, const rdyn_batch* b, const double* 
     }
     return RDYN_OK;
   }
+  if (c->reduced && chunk_samples <= 0 && !probe_env("RDYN_GRAM_NO_REDUCE"))
+    return gram_through_reduced(c, nullptr, 0, 0, b, tau_meas, G, cvec, bb, accumulate, workspace, rdyn_regressor_gram_workspace_bytes(c, chunk));
   // structural zero band of every row block (input joint j): columns < 10 * chain index of joint j
   int first_col[RDYN_MAX_JOINTS];
   for (int j = 0; j < n; ++j) first_col[j] = 10 * c->active[j];
@@ -1162,7 +1228,8 @@ size_t rdyn_identification_gram_workspace_bytes(const rdyn_chain* c, const rdyn_
   const int K = n_comps > 0 ? rdyn_components_columns(comps, n_comps) : 0;
   const int cols = 10 * c->n_joints() + (K > 0 ? K : 0);
   if (K < 0 || rdyn_gram_blocks_for(cols) > 7) return 0;
-  return gram_slab_bytes(cols) + (size_t)kIdentChunk * c->n_active() * (cols + 1) * sizeof(double);
+  const size_t base = (gram_slab_bytes(cols) + (size_t)kIdentChunk * c->n_active() * (cols + 1) * sizeof(double) + 255) & ~(size_t)255;
+  return base + (c->reduced ? reduce_tmp_bytes(10 * c->reduced->n_joints() + (K > 0 ? K : 0)) : 0);
 }
 
 int rdyn_identification_gram(const rdyn_chain* c, const rdyn_component* comps, int n_comps, const rdyn_batch* b, const double* tau_meas,
@@ -1212,6 +1279,9 @@ int rdyn_identification_gram(const rdyn_chain* c, const rdyn_component* comps, i
     }
     return RDYN_OK;
   }
+  if (c->reduced && !probe_env("RDYN_GRAM_NO_REDUCE"))
+    return gram_through_reduced(c, comps, n_comps, K, b, tau_meas, G, cvec, bb, accumulate, workspace,
+                                rdyn_identification_gram_workspace_bytes(c, comps, n_comps));
   // ---- fused: regressor rows AND component columns stay in LDS (rdyn_duo_gram.hip); else the chunk image below
   if (n >= 2 && n <= 8 && rdyn_regressor_gram_duo_supports_components(P, K) && !probe_env("RDYN_IDENT_UNFUSED"))
   {

@@ -115,6 +115,140 @@ void free_device_copies(rdyn_chain* c)
     }
   }
   c->dev_const.clear();
+  for (auto& kv : c->dev_expand)
+  {
+    int prev = -1;
+    if (hipGetDevice(&prev) == hipSuccess && hipSetDevice(kv.first) == hipSuccess)
+    {
+      (void)hipFree(kv.second);
+      (void)hipSetDevice(prev);
+    }
+  }
+  c->dev_expand.clear();
+  if (c->reduced) free_device_copies(c->reduced.get());
+}
+
+// inertial parameters [m, m c, Ixx Ixy Ixz Iyy Iyz Izz about the frame origin] of a body given in frame f, re-expressed in frame r,
+// where x_r = R x_f + p:  m' = m;  (m c)' = R (m c) + m p;
+// I' = R I R' + (2 p.(R mc)) 1 - (R mc) p' - p (R mc)' + m (|p|^2 1 - p p')      (parallel axes about the new origin)
+void transform_parameters(const double R[9], const double p[3], const double in[10], double out[10])
+{
+  const double m = in[0];
+  double h[3];
+  for (int i = 0; i < 3; ++i) h[i] = R[i * 3] * in[1] + R[i * 3 + 1] * in[2] + R[i * 3 + 2] * in[3];
+  const double I[9] = {in[4], in[5], in[6], in[5], in[7], in[8], in[6], in[8], in[9]};
+  double RI[9], RIRt[9], Rt[9];
+  for (int a = 0; a < 3; ++a)
+    for (int b = 0; b < 3; ++b) Rt[a * 3 + b] = R[b * 3 + a];
+  mat3_mul(R, I, RI);
+  mat3_mul(RI, Rt, RIRt);
+  const double hp = h[0] * p[0] + h[1] * p[1] + h[2] * p[2], pp = p[0] * p[0] + p[1] * p[1] + p[2] * p[2];
+  double Io[9];
+  for (int a = 0; a < 3; ++a)
+    for (int b = 0; b < 3; ++b)
+      Io[a * 3 + b] = RIRt[a * 3 + b] + (a == b ? 2 * hp + m * pp : 0.0) - h[a] * p[b] - p[a] * h[b] - m * p[a] * p[b];
+  out[0] = m;
+  out[1] = h[0] + m * p[0];
+  out[2] = h[1] + m * p[1];
+  out[3] = h[2] + m * p[2];
+  out[4] = Io[0];
+  out[5] = Io[1];
+  out[6] = Io[2];
+  out[7] = Io[4];
+  out[8] = Io[5];
+  out[9] = Io[8];
+}
+
+// see rdyn_chain.hpp: the reduced companion and the expansion blocks X_f
+void build_reduced(rdyn_chain* c)
+{
+  free_device_copies(c);  // also the old companion's
+  c->reduced.reset();
+  c->red_of.clear();
+  c->expand_X.clear();
+  const int nj = c->n_joints(), n = c->n_active();
+  if (n < 1 || n == nj) return;
+  for (int k = 1; k < n; ++k)
+    if (c->active[k] <= c->active[k - 1]) return;  // input joints not in chain order: no companion
+  const RdynChainConst& H = c->host_const;
+  std::unique_ptr<rdyn_chain> r(new rdyn_chain());
+  r->joints.resize(n);
+  r->links.resize(n + 1);
+  memset(r->joints.data(), 0, sizeof(rdyn_joint_desc) * n);
+  memset(r->links.data(), 0, sizeof(rdyn_link_desc) * (n + 1));
+  for (int i = 0; i < 3; ++i) r->gravity[i] = c->gravity[i];
+  RdynChainConst& K = r->host_const;
+  memset(&K, 0, sizeof K);
+  K.n_joints = K.n_active = n;
+  for (int i = 0; i < 3; ++i) K.g[i] = H.g[i];
+  c->red_of.assign(nj, -1);
+  c->expand_X.assign((size_t)nj * 100, 0.0);
+  // frame of the current rigid body -> frame of the link being visited: x_body = Rc x_link + pc
+  double Rc[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, pc[3] = {0, 0, 0};
+  int red = -1;  // reduced link the current body is (index of its joint in the reduced chain)
+  for (int f = 0; f < nj; ++f)
+  {
+    const RdynJointConst& J = H.j[f];
+    // compose the parent -> joint transform of chain joint f (R_pj, t_pj) onto the running transform
+    double Rn[9], pn[3];
+    mat3_mul(Rc, J.A, Rn);
+    for (int i = 0; i < 3; ++i) pn[i] = pc[i] + Rc[i * 3] * J.t[0] + Rc[i * 3 + 1] * J.t[1] + Rc[i * 3 + 2] * J.t[2];
+    if (J.in_idx >= 0)
+    {
+      // input joint: it becomes reduced joint red + 1 with everything since the previous input joint folded into its origin
+      ++red;
+      RdynJointConst& Q = K.j[red];
+      double Ks[9], K2[9];
+      skew3(J.u, Ks);
+      mat3_mul(Ks, Ks, K2);
+      memcpy(Q.A, Rn, sizeof Rn);
+      mat3_mul(Rn, Ks, Q.B);
+      mat3_mul(Rn, K2, Q.C);
+      for (int i = 0; i < 3; ++i)
+      {
+        Q.t[i] = pn[i];
+        Q.u[i] = J.u[i];
+        Q.up[i] = Rn[i * 3] * J.u[0] + Rn[i * 3 + 1] * J.u[1] + Rn[i * 3 + 2] * J.u[2];
+      }
+      Q.type = J.type;
+      Q.in_idx = red;
+      snprintf(r->joints[red].name, sizeof r->joints[red].name, "%s", c->joints[f].name);
+      snprintf(r->links[red + 1].name, sizeof r->links[red + 1].name, "%s", c->links[f + 1].name);
+      r->active.push_back(red);
+      r->moveable_names.push_back(c->joints[f].name);
+      // the child link of an input joint IS the new body's reference frame
+      const double I3[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+      memcpy(Rc, I3, sizeof I3);
+      pc[0] = pc[1] = pc[2] = 0.0;
+    }
+    else
+    {
+      memcpy(Rc, Rn, sizeof Rn);
+      memcpy(pc, pn, sizeof pn);
+    }
+    c->red_of[f] = red;
+    if (red >= 0)
+    {
+      // X_f: columns = images of the ten unit parameter vectors of link f + 1 in the body frame; the body's own parameters add up
+      double* X = c->expand_X.data() + (size_t)f * 100;
+      for (int p = 0; p < 10; ++p)
+      {
+        double e[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, img[10];
+        e[p] = 1.0;
+        transform_parameters(Rc, pc, e, img);
+        for (int a = 0; a < 10; ++a) X[a * 10 + p] = img[a];
+      }
+      double img[10];
+      transform_parameters(Rc, pc, J.pi, img);
+      for (int a = 0; a < 10; ++a) K.j[red].pi[a] += img[a];
+    }
+  }
+  r->q_max.assign(n, 1e10);
+  r->q_min.assign(n, -1e10);
+  r->dq_max.assign(n, 1e10);
+  r->ddq_max.assign(n, 1e11);
+  r->tau_max.assign(n, 1e10);
+  c->reduced = std::move(r);
 }
 }  // namespace
 
@@ -191,6 +325,7 @@ void rdyn_chain_finalize(rdyn_chain* c)
     c->tau_max[j] = taumax;
   }
   for (int k = 0; k < c->n_active(); ++k) H.j[c->active[k]].in_idx = k;
+  build_reduced(c);
 }
 
 static int build_chain(std::vector<rdyn_joint_desc>& joints, std::vector<rdyn_link_desc>& links, const double gravity[3], rdyn_chain** out)
@@ -375,6 +510,21 @@ int rdyn_chain_limits(const rdyn_chain* c, double* q_max, double* q_min, double*
     if (tau_max) tau_max[k] = c->tau_max[j];
   }
   return RDYN_OK;
+}
+
+int rdyn_chain_reduction(const rdyn_chain* c, int32_t* body_joint, double* X, double* pi_body)
+{
+  if (!c) return -1;
+  if (!c->reduced) return 0;
+  const int nj = c->n_joints(), nb = c->reduced->n_joints();
+  for (int f = 0; f < nj; ++f)
+  {
+    if (body_joint) body_joint[f] = c->red_of[f] < 0 ? -1 : c->active[c->red_of[f]];
+    if (X) memcpy(X + (size_t)f * 100, c->expand_X.data() + (size_t)f * 100, sizeof(double) * 100);
+  }
+  for (int r = 0; pi_body && r < nb; ++r)
+    for (int p = 0; p < 10; ++p) pi_body[10 * r + p] = c->reduced->host_const.j[r].pi[p];
+  return nb;
 }
 
 int rdyn_nominal_parameters(const rdyn_chain* c, double* pi)

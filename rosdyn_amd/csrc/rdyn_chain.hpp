@@ -3,6 +3,7 @@
 #define RDYN_CHAIN_HPP
 
 #include <map>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -25,6 +26,19 @@ struct rdyn_chain
   // lazily created device copies, one per HIP device ordinal; invalidated by set_input_joints
   mutable std::mutex mu;
   mutable std::map<int, RdynChainConst*> dev_const;
+
+  // "Reduced" companion for the regressor -> Gram / factor paths (rdyn_chain_finalize; null when every chain joint is an input joint
+  // or the input joints are not in chain order).  Every joint that is not an input joint (fixed, primitives_impl.h:74-83, or left
+  // out of setInputJointsName: q = 0) is a constant transform, so the links it connects move as ONE rigid body: the reduced chain
+  // keeps the input joints only, with the constant transforms folded into the next input joint's origin.  The ten columns of a
+  // link f that was folded away are a constant linear image of the columns of the body it rides on,
+  //     Y_f = Y_red(r(f)) X_f,   X_f (10 x 10) = the change of reference frame of the inertial parameters (rigid transform r -> f),
+  // and identically zero for links upstream of the first input joint.  Gram / R-factor kernels therefore run on the reduced chain
+  // (10 n columns, every joint an input joint: the fastest kernel variants) and a tiny epilogue forms G = E' G_red E.
+  std::unique_ptr<rdyn_chain> reduced;
+  std::vector<int> red_of;        // per chain link f + 1 (index f): reduced link it rides on, -1 = upstream of the first input joint
+  std::vector<double> expand_X;   // [n_joints][10][10] row-major: X_f(a, p), column p of link f = sum_a Y_red(10 r + a) X_f(a, p)
+  mutable std::map<int, double*> dev_expand;  // device copies of expand_X, one per HIP device ordinal
 
   int n_joints() const { return (int)joints.size(); }
   int n_active() const { return (int)active.size(); }

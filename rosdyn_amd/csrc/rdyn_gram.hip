@@ -182,6 +182,62 @@ __global__ __launch_bounds__(256) void k_gram_finish(const RdynGramArgs a, int n
   }
 }
 
+// Normal equations of the reduced chain -> normal equations of the chain itself (rdyn_chain.hpp: Y = Y_red E, so G = E' G_red E,
+// c = E' c_red, bb unchanged).  E is block sparse: the ten columns of link f are X_f applied to the ten columns of reduced link
+// red_of[f] (nothing for links upstream of the first input joint); component columns (K of them, behind the link columns) map
+// one to one.  One thread per entry of the output, <= 100 fmas each.
+__global__ __launch_bounds__(256) void k_gram_expand(const RdynGramExpandArgs a)
+{
+  const int P = 10 * a.n_joints, Pr = 10 * a.n_red, C = P + a.n_comp_cols, Cr = Pr + a.n_comp_cols;
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  const double prev_scale = a.add_to_output ? 1.0 : 0.0;
+  if (idx >= C * (C + 1))
+  {
+    if (idx == C * (C + 1) && a.bb) a.bb[0] = prev_scale * a.bb[0] + a.bb_red[0];
+    return;
+  }
+  const int i = idx % C, j = idx / C;  // j == C: the right-hand side c
+  // column i of the output = sum over the rows (r0 .. r0 + nr) of the reduced column space with weights wi
+  auto rows_of = [&](int col, int& r0, int& nr, const double*& w, int& wstride) {
+    if (col >= P)
+    {
+      r0 = Pr + (col - P);
+      nr = 1;
+      w = nullptr;
+      wstride = 0;
+      return;
+    }
+    const int f = col / 10, p = col - 10 * f, r = a.red_of[f];
+    r0 = 10 * (r < 0 ? 0 : r);
+    nr = r < 0 ? 0 : 10;
+    w = a.X + f * 100 + p;  // X_f(a, p), a = 0..9, stride 10
+    wstride = 10;
+  };
+  int ri, ni, si;
+  const double* wi;
+  rows_of(i, ri, ni, wi, si);
+  double s = 0.0;
+  if (j == C)
+  {
+    if (!a.c) return;
+    for (int x = 0; x < ni; ++x) s = fma(wi ? wi[x * si] : 1.0, a.c_red[ri + x], s);
+    a.c[i] = prev_scale * a.c[i] + s;
+    return;
+  }
+  int rj, nj, sj;
+  const double* wj;
+  rows_of(j, rj, nj, wj, sj);
+  for (int y = 0; y < nj; ++y)
+  {
+    double t = 0.0;
+    for (int x = 0; x < ni; ++x) t = fma(wi ? wi[x * si] : 1.0, a.G_red[(int64_t)(rj + y) * Cr + ri + x], t);
+    s = fma(wj ? wj[y * sj] : 1.0, t, s);
+  }
+  a.G[(int64_t)j * C + i] = prev_scale * a.G[(int64_t)j * C + i] + s;
+}
+
+__global__ void k_set_double(double* p, double v) { *p = v; }
+
 template <int NB>
 hipError_t launch_gram_nb(const RdynGramArgs& a, int blocks, hipStream_t st)
 {
@@ -214,5 +270,18 @@ hipError_t rdyn_launch_gram_finish(const RdynGramArgs& a, int blocks, hipStream_
   const int nb = a.slab_nb > 0 ? a.slab_nb : rdyn_gram_blocks_for(a.P);
   const int nt = nb * (nb + 1) / 2;
   hipLaunchKernelGGL(k_gram_finish, dim3((nt * 256 + 31) / 32), dim3(256), 0, st, a, nb, blocks);
+  return hipGetLastError();
+}
+
+hipError_t rdyn_launch_gram_expand(const RdynGramExpandArgs& a, hipStream_t st)
+{
+  const int C = 10 * a.n_joints + a.n_comp_cols;
+  hipLaunchKernelGGL(k_gram_expand, dim3((C * (C + 1) + 1 + 255) / 256), dim3(256), 0, st, a);
+  return hipGetLastError();
+}
+
+hipError_t rdyn_launch_set_double(double* p, double v, hipStream_t st)
+{
+  hipLaunchKernelGGL(k_set_double, dim3(1), dim3(1), 0, st, p, v);
   return hipGetLastError();
 }

@@ -119,6 +119,18 @@ struct RdynGramArgs
   int desc_nj;
   int slab_nb;  // finish only: 16-column blocks of the slabs' tile layout if it is wider than P + 1 columns need (0 = derive from P)
 };
+// normal equations of the reduced chain -> of the chain (rdyn_chain.hpp; rdyn_gram.hip: k_gram_expand)
+struct RdynGramExpandArgs
+{
+  const double *G_red, *c_red, *bb_red;  // (10 n_red + K)^2, 10 n_red + K, 1
+  const double* X;                       // device: [n_joints][10][10]
+  int red_of[RDYN_MAX_JOINTS];
+  int n_joints, n_red, n_comp_cols;
+  int add_to_output;
+  double *G, *c, *bb;                    // (10 n_joints + K)^2, 10 n_joints + K, 1 (c, bb may be null)
+};
+hipError_t rdyn_launch_gram_expand(const RdynGramExpandArgs& a, hipStream_t st);
+hipError_t rdyn_launch_set_double(double* p, double v, hipStream_t st);  // *p = v, ordered on the stream
 // fused regressor -> Gram persistent kernel (rdyn_fused_gram.hip)
 struct RdynFusedGramArgs
 {

@@ -16,6 +16,7 @@
 #include <hip/hip_runtime.h>
 
 #include "rdyn_chain.hpp"
+#include "rdyn_kernels.h"
 
 namespace
 {
@@ -96,7 +97,7 @@ struct rdyn_multi_gpu
   std::vector<hipStream_t> streams;
   std::vector<void*> workspaces;
   std::vector<size_t> workspace_bytes;
-  double* pinned_counts = nullptr;  // one double per device: the shard sizes travel inside the all-reduce payload
+  std::vector<hipEvent_t> events;  // per device: orders the context's stream behind the caller's stream (batches[i].stream)
   ~rdyn_multi_gpu()
   {
     int prev = 0;
@@ -108,8 +109,8 @@ struct rdyn_multi_gpu
       if (i < comms.size() && comms[i] && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(comms[i]);
       if (i < workspaces.size() && workspaces[i]) (void)hipFree(workspaces[i]);
       if (i < streams.size() && streams[i]) (void)hipStreamDestroy(streams[i]);
+      if (i < events.size() && events[i]) (void)hipEventDestroy(events[i]);
     }
-    if (pinned_counts) (void)hipHostFree(pinned_counts);
     (void)hipSetDevice(prev);
   }
 };
@@ -126,12 +127,15 @@ int rdyn_multi_gpu_create(const int* devices, int n_devices, rdyn_multi_gpu** ou
   }
   *out = nullptr;
   for (int i = 0; i < n_devices; ++i)
-    for (int j = 0; j < i; ++j)
-      if (devices[i] == devices[j] || devices[i] < 0)
-      {
-        rdyn_set_error("rdyn_multi_gpu_create: device ordinals must be distinct and non-negative");
-        return RDYN_ERR_INVALID_ARGUMENT;
-      }
+  {
+    bool bad = devices[i] < 0;
+    for (int j = 0; j < i; ++j) bad = bad || devices[i] == devices[j];
+    if (bad)
+    {
+      rdyn_set_error("rdyn_multi_gpu_create: device ordinals must be distinct and non-negative");
+      return RDYN_ERR_INVALID_ARGUMENT;
+    }
+  }
   int count = 0;
   if (hipGetDeviceCount(&count) != hipSuccess || count < 1)
   {
@@ -148,8 +152,14 @@ int rdyn_multi_gpu_create(const int* devices, int n_devices, rdyn_multi_gpu** ou
   if (st != RDYN_OK) return st;
   int prev = 0;
   RDYN_HIP_TRY2(hipGetDevice(&prev));
+  struct Restore  // the caller's current device comes back on EVERY exit path
+  {
+    int d;
+    ~Restore() { (void)hipSetDevice(d); }
+  } restore{prev};
   std::unique_ptr<rdyn_multi_gpu> ctx(new rdyn_multi_gpu());
   ctx->devices.assign(devices, devices + n_devices);
+  ctx->events.assign(n_devices, nullptr);
   ctx->comms.assign(n_devices, nullptr);
   ctx->streams.assign(n_devices, nullptr);
   ctx->workspaces.assign(n_devices, nullptr);
@@ -159,9 +169,8 @@ int rdyn_multi_gpu_create(const int* devices, int n_devices, rdyn_multi_gpu** ou
   {
     RDYN_HIP_TRY2(hipSetDevice(devices[i]));
     RDYN_HIP_TRY2(hipStreamCreateWithFlags(&ctx->streams[i], hipStreamNonBlocking));
+    RDYN_HIP_TRY2(hipEventCreateWithFlags(&ctx->events[i], hipEventDisableTiming));
   }
-  RDYN_HIP_TRY2(hipHostMalloc((void**)&ctx->pinned_counts, sizeof(double) * n_devices, hipHostMallocDefault));
-  RDYN_HIP_TRY2(hipSetDevice(prev));
   *out = ctx.release();
   return RDYN_OK;
 }
@@ -231,6 +240,10 @@ int rdyn_regressor_gram_multi(rdyn_multi_gpu* ctx, const rdyn_chain* chain, cons
       RDYN_HIP_TRY2(hipMalloc(&ctx->workspaces[i], need));
       ctx->workspace_bytes[i] = need;
     }
+    // the context's stream is non-blocking: order it behind whatever the caller has queued on batches[i].stream (NULL = the device's
+    // default stream) -- the inputs and acc[i] may still be in production there
+    RDYN_HIP_TRY2(hipEventRecord(ctx->events[i], (hipStream_t)batches[i].stream));
+    RDYN_HIP_TRY2(hipStreamWaitEvent(ctx->streams[i], ctx->events[i], 0));
     rdyn_batch b = batches[i];
     b.device = ctx->devices[i];
     b.stream = ctx->streams[i];
@@ -238,8 +251,9 @@ int rdyn_regressor_gram_multi(rdyn_multi_gpu* ctx, const rdyn_chain* chain, cons
     int st = rdyn_regressor_gram(chain, &b, tau_meas ? tau_meas[i] : nullptr, a, a + (size_t)P * P, a + (size_t)P * P + P, 0, 0, ctx->workspaces[i],
                                  ctx->workspace_bytes[i]);
     if (st != RDYN_OK) return st;
-    ctx->pinned_counts[i] = (double)b.n_samples;
-    RDYN_HIP_TRY2(hipMemcpyAsync(a + (size_t)P * P + P + 1, &ctx->pinned_counts[i], sizeof(double), hipMemcpyHostToDevice, ctx->streams[i]));
+    // the shard size travels as a KERNEL ARGUMENT (a pinned host word re-used by the next asynchronous call could be overwritten
+    // before this call's copy has run)
+    RDYN_HIP_TRY2(rdyn_launch_set_double(a + (size_t)P * P + P + 1, (double)b.n_samples, ctx->streams[i]));
   }
   // ---- ONE all-reduce of the accumulators (in place), all devices inside one group
   RDYN_NCCL_TRY(g_rccl.GroupStart());

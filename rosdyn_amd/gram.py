@@ -194,9 +194,11 @@ class MultiGpuGram(object):
             lib().rdyn_multi_gpu_destroy(h)
             self._h = None
 
-    def regressor_gram(self, chain, shards, layout="sample"):
+    def regressor_gram(self, chain, shards, layout="sample", acc=None, sync=True):
         """shards[i] = (q, Dq, DDq, tau_meas) float64 CUDA tensors on devices[i].  Returns the list of per-device accumulators
-        (P*P + P + 2,): after synchronisation every one holds the sums over all shards."""
+        (P*P + P + 2,) (acc= re-uses the caller's): once the context is synchronised every one holds the sums over all shards.
+        The library orders its streams behind torch's current stream of every device; sync=False returns without waiting
+        (call synchronize() before reading)."""
         import torch
         from ._lib import Batch, LAYOUT_ELEMENT_MAJOR, LAYOUT_SAMPLE_MAJOR
         assert len(shards) == len(self.devices)
@@ -215,12 +217,16 @@ class MultiGpuGram(object):
             b.q, b.dq, b.ddq = q.data_ptr(), dq.data_ptr(), ddq.data_ptr()
             b.layout = LAYOUT_ELEMENT_MAJOR if layout == "element" else LAYOUT_SAMPLE_MAJOR
             b.device = self.devices[i]
+            b.stream = torch.cuda.current_stream(q.device).cuda_stream      # the library waits for what is queued here
             taus[i] = tau.data_ptr()
-            a = torch.empty((P * P + P + 2,), dtype=torch.float64, device=q.device)
+            a = acc[i] if acc is not None else torch.empty((P * P + P + 2,), dtype=torch.float64, device=q.device)
+            assert a.is_cuda and a.device.index == self.devices[i] and a.dtype == torch.float64 and a.numel() == P * P + P + 2 and a.is_contiguous()
             accs[i] = a.data_ptr()
             out.append(a)
-        for d in self.devices:
-            torch.cuda.synchronize(d)      # the inputs were produced on torch's streams; the library uses its own
         check(lib().rdyn_regressor_gram_multi(self._h, chain._h, batches, taus, accs))
-        check(lib().rdyn_multi_gpu_synchronize(self._h))
+        if sync:
+            self.synchronize()
         return out
+
+    def synchronize(self):
+        check(lib().rdyn_multi_gpu_synchronize(self._h))
