@@ -12,10 +12,18 @@ copy-out); --y-layout element selects the SoA form (k_local_sweep<6, REGRESSOR>)
 Multi-GPU: the batch shards trivially (i.i.d. samples) -> every rank evaluates its own 1e6 samples, no
 data-path collective ("weak" scaling); the only exchange is the max-over-ranks of the elapsed time.
 
+`value` is measured into the FIRST output allocation the process gets -- what a rosdyn::Chain caller has.  The speed of the
+stacked store pattern depends on the physical backing of the 2.88 GB output; the best of a few probed
+allocations is reported beside it as "tuned_output_placement" and is never `value`.
+
 Beside `value` the line carries
   * "config4": BASELINE.json configs[3] -- every rank's regressor -> fp64 Gram of its shard (the regressor never reaches
-    HBM) followed by ONE all-reduce of [G | c | bb | count] (P*P + P + 2 doubles, RCCL over xGMI), timed as its own
+    HBM) written straight into the packed payload [G | c | bb | count], followed by ONE in-place all-reduce of it
+    (P*P + P + 2 doubles, RCCL over xGMI; no packing kernels, no host synchronisation inside a step), timed as its own
     barrier-bracketed region (max over ranks), with the all-reduce latency separately;
+  * "config4_library": the same exchange through the library's own multi-device path (rdyn_regressor_gram_multi: one process,
+    ncclCommInitAll over the N devices, one stream per device, one grouped ncclAllReduce) -- measured by a child process
+    `bench.py --single-process --gpus N` that rank 0 starts after the torch.distributed legs are done and torn down;
   * "extras" (rank 0's GPU, outside every timed region of the headline): configs[2] (7-DOF, N = 4e6, Gram) and configs[4]
     (256 distinct chains x 4 096 samples) once each with their own roofline blocks;
   * "cpu_baseline": the C oracle on rank 0's host cores (every line, also for N > 1).
@@ -26,12 +34,9 @@ Beside `value` the line carries
       (before anything touches the GPU), relays rank 0's JSON line and exits with the child's return code.
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...      (what the driver runs)
   python bench.py --gpus 2 --backend gloo --dry     launcher / process-group / all-reduce plumbing only, no GPU (CPU tests)
+  python bench.py --single-process --gpus N         configs[3] through the library's in-process RCCL path only (one JSON line)
 
 Prints ONE JSON line on rank 0.
-
-Output placement: before the timed region rank r allocates candidate output buffers a dozen at a time (at most --placements = 72, at most
-three quarters of the free device memory), probes each with the launch it is going to time, stops when one stands out and keeps the best (the speed of this store pattern depends on the physical backing of the allocation, reproducibly per
-allocation: DESIGN.md section 3, profiles/r2/placement.txt); every probe time is in the JSON line (`output_placement`).
 """
 import argparse
 import json
@@ -172,39 +177,95 @@ def time_region(fn, steps, warmup, world, dist, dev):
 
 def config4_block(chain, q, dq, ddq, tau, in_layout, N, n, P, world, dist, dev, steps, warmup):
     """BASELINE.json configs[3]: the 6-DOF batch sharded over the ranks (weak: N per rank), every rank's normal equations
-    on the fp64 matrix cores without the regressor leaving the chip, then ONE all-reduce of P*P + P + 2 doubles."""
+    on the fp64 matrix cores without the regressor leaving the chip, written straight into the packed payload, then ONE in-place
+    all-reduce of P*P + P + 2 doubles.  Nothing in a step touches the host."""
     import torch
     from rosdyn_amd._lib import lib
-    from rosdyn_amd.gram import allreduce_normal_equations
+    from rosdyn_amd.gram import allreduce_packed, packed_buffer, unpack_normal_equations
     d = dist if world > 1 else None
     ws = torch.empty((lib().rdyn_regressor_gram_workspace_bytes(chain._h, 0),), dtype=torch.uint8, device=dev)
-    acc = chain.getRegressorGram(q, dq, ddq, tau, layout=in_layout, workspace=ws)
-    result = {}
-
-    def step():
-        chain.getRegressorGram(q, dq, ddq, tau, layout=in_layout, out=acc, workspace=ws)
-        result["sum"] = allreduce_normal_equations(acc[0], acc[1], acc[2], N, d)
+    buf = packed_buffer(P, N, dev)
 
     def gram_only():
-        chain.getRegressorGram(q, dq, ddq, tau, layout=in_layout, out=acc, workspace=ws)
+        chain.getRegressorGram(q, dq, ddq, tau, layout=in_layout, packed_out=buf, workspace=ws)
+
+    def step():
+        gram_only()
+        allreduce_packed(buf, d, count=N if world > 1 else None)   # world 1: nothing to reduce, the count slot stays N
 
     def allreduce_only():
-        allreduce_normal_equations(acc[0], acc[1], acc[2], N, d)
+        allreduce_packed(buf, d)
 
     wall, _ = time_region(step, steps, warmup, world, dist, dev)
+    count = unpack_normal_equations(buf, P)[3]                     # after the timed region: one host read
     _, gram_ms = time_region(gram_only, steps, 1, world, dist, dev)
     ar_wall, _ = time_region(allreduce_only, 20, 3, world, dist, dev)
-    count = result["sum"][3]
     f_eval = gram_flop_per_eval(n, P)
     kernel_ms = gram_ms / steps
     tf = f_eval * N / (kernel_ms * 1e-3) / 1e12
     return {"workload": "configs[3]: 6-DOF chain, %d samples per GPU x %d GPUs, getRegressor -> Gram [A'A | A'tau | tau'tau] per rank "
-                        "(regressor stays on chip) + one all-reduce of %d doubles" % (N, world, P * P + P + 2),
+                        "(regressor stays on chip) + one in-place all-reduce of %d doubles" % (N, world, P * P + P + 2),
             "value": N * world * steps / wall, "unit": "evals/s", "ms_per_step": wall / steps * 1e3,
             "regressor_gram_ms_per_rank": kernel_ms, "allreduce_us": ar_wall / 20 * 1e6, "allreduce_doubles": P * P + P + 2,
-            "samples_reduced": count, "backend": "nccl(RCCL)" if world > 1 else "none (1 rank)",
+            "samples_reduced": count, "backend": "torch.distributed nccl(RCCL)" if world > 1 else "none (1 rank)",
             "roofline": {"bound": "fp64-matrix", "achieved": tf, "peak": FP64_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": tf / FP64_MATRIX_PEAK_TFLOPS, "flop_per_eval_dense_syrk": f_eval, "kernel_ms": kernel_ms}}
+
+
+def config4_library(n_dev, N, steps, warmup):
+    """BASELINE.json configs[3] through the library's OWN multi-device path: one process, rdyn_multi_gpu_create (ncclCommInitAll over
+    the n_dev devices, one stream and one event per device) and rdyn_regressor_gram_multi per step -- every device the fused
+    regressor -> Gram of its shard, ONE grouped ncclAllReduce of P*P + P + 2 doubles in place.  Steps are queued back to back
+    (asynchronous C-ABI), the context is synchronised at both ends of the timed region."""
+    import torch
+    from rosdyn_amd import Chain
+    from rosdyn_amd.gram import MultiGpuGram
+    chain = Chain(os.path.join(ROOT, "tests", "fixtures", "ur10_like.urdf"), "base_link", "wrist_3_link", GRAVITY)
+    n, P = chain.getActiveJointsNumber(), 10 * chain.getJointsNumber()
+    shards = []
+    for d in range(n_dev):
+        dev = torch.device("cuda", d)
+        gen = torch.Generator(device=dev).manual_seed(0x5EED0002 + d)
+        shards.append(tuple(torch.rand((N, n), dtype=torch.float64, device=dev, generator=gen) * 2 - 1 for _ in range(4)))
+    ctx = MultiGpuGram(list(range(n_dev)))
+    acc = ctx.regressor_gram(chain, shards)
+    for _ in range(warmup):
+        ctx.regressor_gram(chain, shards, acc=acc, sync=False)
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        ctx.regressor_gram(chain, shards, acc=acc, sync=False)
+    ctx.synchronize()
+    wall = time.perf_counter() - t0
+    count = float(acc[0][-1].item())
+    # every device must hold the same sums
+    same = all(bool(torch.equal(acc[0].cpu(), a.cpu())) for a in acc[1:])
+    f_eval = gram_flop_per_eval(n, P)
+    tf = f_eval * N * n_dev * steps / wall / 1e12
+    return {"workload": "configs[3] in the library: 6-DOF chain, %d samples per GPU x %d GPUs in ONE process, rdyn_regressor_gram_multi "
+                        "(regressor -> Gram per device + one grouped ncclAllReduce of %d doubles)" % (N, n_dev, P * P + P + 2),
+            "value": N * n_dev * steps / wall, "unit": "evals/s", "ms_per_step": wall / steps * 1e3, "n_gpus": n_dev, "steps": steps,
+            "samples_reduced": count, "all_devices_agree": same, "backend": "rccl-in-library (ncclCommInitAll, single process)",
+            "roofline": {"bound": "fp64-matrix", "achieved": tf, "peak": FP64_MATRIX_PEAK_TFLOPS * n_dev, "unit": "TFLOP/s",
+                         "frac": tf / (FP64_MATRIX_PEAK_TFLOPS * n_dev), "flop_per_eval_dense_syrk": f_eval}}
+
+
+def config4_library_child(n_dev, N, steps, timeout_s=240):
+    """Runs config4_library in a CHILD process (`bench.py --single-process`): a fresh process owns all n_dev devices and its own RCCL
+    communicator, and a failure or hang there cannot take the bench line with it."""
+    cmd = [sys.executable, os.path.abspath(__file__), "--single-process", "--gpus", str(n_dev), "--samples", str(N), "--steps", str(steps)]
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "GROUP_RANK", "LOCAL_WORLD_SIZE", "ROLE_RANK", "TORCHELASTIC_RUN_ID"):
+        env.pop(k, None)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    try:
+        p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, timeout=timeout_s)
+    except subprocess.TimeoutExpired:
+        return {"error": "child timed out after %d s" % timeout_s}
+    lines = [l for l in p.stdout.splitlines() if l.strip().startswith("{")]
+    if p.returncode != 0 or not lines:
+        return {"error": "child rc %d: %s" % (p.returncode, p.stderr[-400:])}
+    return json.loads(lines[-1])
 
 
 def extras_config3(dev, steps=5):
@@ -238,10 +299,65 @@ def extras_config3(dev, steps=5):
     tsqr_ms = ev0.elapsed_time(ev1) / 2
     f_eval = gram_flop_per_eval(n, P)
     tf = f_eval * N / (ms * 1e-3) / 1e12
+    # dense Householder convention for the factor of the (n N) x (P + 1) matrix [A | tau]: 2 rows cols^2
+    qr_flop = 2.0 * n * N * (P + 1) ** 2
+    qr_tf = qr_flop / (tsqr_ms * 1e-3) / 1e12
     return {"workload": "configs[2]: 7-DOF panda_like link0->link7 (n=7, P=70), N=%d, getRegressor -> Gram" % N,
             "value": N / (ms * 1e-3), "unit": "evals/s", "ms_per_step": ms, "tsqr_ms_per_step": tsqr_ms,
             "roofline": {"bound": "fp64-matrix", "achieved": tf, "peak": FP64_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": tf / FP64_MATRIX_PEAK_TFLOPS, "flop_per_eval_dense_syrk": f_eval, "kernel_ms": ms}}
+                         "frac": tf / FP64_MATRIX_PEAK_TFLOPS, "flop_per_eval_dense_syrk": f_eval, "kernel_ms": ms},
+            "tsqr_roofline": {"bound": "fp64-matrix", "achieved": qr_tf, "peak": FP64_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
+                              "frac": qr_tf / FP64_MATRIX_PEAK_TFLOPS, "flop_dense_householder": qr_flop, "ms": tsqr_ms,
+                              "route": "rdyn_regressor_tsqr (R factor of [A | tau] without the normal equations)"}}
+
+
+def extras_real_chains(dev, steps=5, N=1000000):
+    """The reference's own benchmark chains in their public URDF form (rosdyn_speed_test.cpp:44-45, test.cpp:47-48): ur10
+    base_link -> tool0 with the fixed base_link_inertia joint in front and the fixed flange / tool0 joints behind (9 chain joints,
+    6 input joints, P = 90) and a Panda link0 -> hand (9 joints, 7 input joints, P = 90): dense regressor (per-sample drop-in
+    image and stacked matrix) and the regressor -> Gram, 1e6 samples each."""
+    import torch
+    from rosdyn_amd import Chain
+    out = {}
+    for name, urdf, base, tool in (("ur10_public_base_link_tool0", "ur10_public.urdf", "base_link", "tool0"),
+                                   ("panda_link0_hand", "panda_like.urdf", "link0", "hand")):
+        chain = Chain(os.path.join(ROOT, "tests", "fixtures", urdf), base, tool, GRAVITY)
+        n, nJ = chain.getActiveJointsNumber(), chain.getJointsNumber()
+        P = 10 * nJ
+        gen = torch.Generator(device=dev).manual_seed(0x5EED0006)
+        q, dq, ddq, tau = (torch.rand((N, n), dtype=torch.float64, device=dev, generator=gen) * 2 - 1 for _ in range(4))
+        tau_o = torch.empty((N, n), dtype=torch.float64, device=dev)
+        res = {"n_active": n, "chain_joints": nJ, "n_params": P}
+        for lay, shape in (("stacked", (P, N * n)), ("per_sample", (N, P, n))):
+            Y = torch.empty(shape, dtype=torch.float64, device=dev)
+            chain.getRegressor(q, dq, ddq, y_layout=lay, out=Y, tau_out=tau_o)
+            torch.cuda.synchronize()
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record()
+            for _ in range(steps):
+                chain.getRegressor(q, dq, ddq, y_layout=lay, out=Y, tau_out=tau_o)
+            ev1.record()
+            torch.cuda.synchronize()
+            ms = ev0.elapsed_time(ev1) / steps
+            gbps = algorithmic_bytes_per_eval(n, P) * N / (ms * 1e-3) / 1e9
+            res["regressor_" + lay] = {"ms": ms, "evals_per_s": N / (ms * 1e-3), "GBps": gbps, "hbm_frac": gbps / HBM_PEAK_GBPS}
+            del Y
+        acc = chain.getRegressorGram(q, dq, ddq, tau)
+        torch.cuda.synchronize()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+        for _ in range(steps):
+            chain.getRegressorGram(q, dq, ddq, tau, out=acc)
+        ev1.record()
+        torch.cuda.synchronize()
+        ms = ev0.elapsed_time(ev1) / steps
+        # flops actually multiplied: the kernels sweep the reduced chain (10 n columns, fixed links folded in; DESIGN.md section 3)
+        f_red = gram_flop_per_eval(n, 10 * n)
+        res["regressor_gram"] = {"ms": ms, "evals_per_s": N / (ms * 1e-3), "TFLOPs_reduced_chain_dense_syrk": f_red * N / (ms * 1e-3) / 1e12,
+                                 "note": "normal equations of all %d columns = E' G_red E from the %d columns of the reduced chain" % (P, 10 * n)}
+        out[name] = res
+        torch.cuda.empty_cache()
+    return out
 
 
 def extras_config5(dev, steps=5, n_chains=256, S=4096):
@@ -285,6 +401,12 @@ def extras_config5(dev, steps=5, n_chains=256, S=4096):
             "ms_per_step_per_sample_images": ms_image, "ms_per_step_element_major": ms_element,
             "roofline": {"bound": "hbm", "achieved": gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": gbps / HBM_PEAK_GBPS,
                          "algorithmic_bytes_per_step": nbytes, "kernel_ms": ms, "traffic": None}}
+
+
+def step_into(chain, q, dq, ddq, in_layout, y_layout, Y, tau):
+    def step():
+        chain.getRegressor(q, dq, ddq, layout=in_layout, y_layout=y_layout, out=Y, tau_out=tau)
+    return step
 
 
 def guarded(fn, *a, **k):
@@ -362,7 +484,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--samples", type=int, default=1000000, help="samples per GPU")
     ap.add_argument("--y-layout", default="stacked", choices=["element", "stacked", "per_sample"])
-    ap.add_argument("--placements", type=int, default=72, help="at most this many candidate output buffers are probed before the timed region (1 = take the first allocation)")
+    ap.add_argument("--placements", type=int, default=12, help="candidate output buffers probed for the tuned_output_placement side block AFTER the headline (0 or 1 = skip); never affects `value`")
+    ap.add_argument("--single-process", action="store_true", help="configs[3] through the library's in-process RCCL path (rdyn_regressor_gram_multi over --gpus devices) only")
+    ap.add_argument("--no-library-config4", action="store_true", help="skip the config4_library child process")
     ap.add_argument("--cpu-seconds", type=float, default=8.0, help="wall time of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-extras", action="store_true", help="skip the configs[2] / configs[4] legs after the timed region")
     ap.add_argument("--no-config4", action="store_true", help="skip the regressor -> Gram -> all-reduce block (configs[3])")
@@ -370,6 +494,13 @@ def main():
     ap.add_argument("--dry", action="store_true", help="no GPU work: launcher + process group + all-reduce plumbing (CPU tests)")
     args = ap.parse_args()
 
+    if args.single_process:
+        # one process, every device: the library's own communicator (nothing of torch.distributed is initialised)
+        if args.dry:
+            print(json.dumps({"metric": "config4_library", "dry": True, "n_gpus": args.gpus, "steps": args.steps, "samples_per_gpu": args.samples}))
+            sys.exit(0)
+        print(json.dumps(config4_library(args.gpus, args.samples, max(1, args.steps), 3)))
+        sys.exit(0)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args, sys.argv[1:]))   # before anything touches the GPU
 
@@ -410,14 +541,9 @@ def main():
     y_shape = {"element": (P, n, N), "stacked": (P, N * n), "per_sample": (N, P, n)}[args.y_layout]
     tau = torch.empty(shape, dtype=torch.float64, device=dev)
 
-    # Where the 2.88 GB output lands in HBM matters: the SAME launch on the SAME device runs at 0.45 ms into some allocations and at
-    # 0.53 ms into others, reproducibly per allocation (profiles/r2/placement.txt: the 60 concurrent column streams
-    # against the device's physical channel / bank map; a plain sequential fill prefers the OTHER allocations).  The caller owns the
-    # output buffer, so the harness does what a caller who cares would do: allocate a few candidates, probe each with the launch it is
-    # going to time, keep the best placement and free the rest -- all before the timed region.  --placements 1 = first allocation.
-    from rosdyn_amd.placement import pick_output_buffer
-    Y, placement = pick_output_buffer(lambda Yc: chain.getRegressor(q, dq, ddq, layout=in_layout, y_layout=args.y_layout, out=Yc, tau_out=tau),
-                                      y_shape, dev, max_candidates=max(1, args.placements))
+    # HEADLINE = the first allocation (what a caller gets).  Where the 2.88 GB output lands in HBM matters for this store pattern
+    # (profiles/r2/placement.txt): the best of a few probed allocations is a SIDE block further down.
+    Y = torch.empty(y_shape, dtype=torch.float64, device=dev)
 
     def step():
         chain.getRegressor(q, dq, ddq, layout=in_layout, y_layout=args.y_layout, out=Y, tau_out=tau)
@@ -444,25 +570,43 @@ def main():
                      "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                      "traffic_source": "committed profile (profiles/pmc_latest.json, builder's box), not measured in this run" if traffic else None,
                      "kernel": kernel, "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": b_eval * N},
-        "output_placement": dict(placement, note="same launch, same device, different output allocations; the harness keeps the best placement "
-                                                 "before the timed region (--placements 1 disables); rosdyn_amd/placement.py"),
     }
-    if not args.no_config4:
-        # measured torques of this rank's shard: tau of the evaluation just timed (noise-free: exact normal equations)
-        out["config4"] = guarded(config4_block, chain, q, dq, ddq, tau, in_layout, N, n, P, world, dist, dev,
-                                 max(1, min(args.steps, 10)), 2)
-    del Y
-    if rank == 0 and not args.no_extras:
+    if args.placements > 1:
+        # side block, never `value`: the same launch into the best of a few candidate output allocations (rosdyn_amd/placement.py)
+        del Y
         torch.cuda.empty_cache()
-        out["extras"] = {"config3": guarded(extras_config3, dev), "config5": guarded(extras_config5, dev)}
-    if rank == 0 and args.cpu_seconds > 0:
+        from rosdyn_amd.placement import pick_output_buffer
+        Y, placement = pick_output_buffer(lambda Yc: chain.getRegressor(q, dq, ddq, layout=in_layout, y_layout=args.y_layout, out=Yc, tau_out=tau),
+                                          y_shape, dev, max_candidates=args.placements)
+        t_wall, t_ms = time_region(step_into(chain, q, dq, ddq, in_layout, args.y_layout, Y, tau), args.steps, 1, world, dist, dev)
+        t_kernel_ms = t_ms / args.steps
+        out["tuned_output_placement"] = {"value": total_evals / t_wall, "ms_per_step": t_wall / args.steps * 1e3,
+                                         "frac": b_eval * N / (t_kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "probe_ms": placement["probe_ms"],
+                                         "candidates": placement["candidates"], "chosen": placement["chosen"],
+                                         "note": "same launch, same device, best of the probed output allocations; NOT the headline"}
+    if not args.no_config4:
+        # measured torques of this rank's shard: tau of the evaluation just timed (noise-free: exact normal equations).
+        # NOT guarded per rank when world > 1: this leg holds collectives -- a rank that swallowed an exception here would leave
+        # the others waiting inside the all-reduce; an error must take the whole job down instead.
+        c4 = (config4_block, chain, q, dq, ddq, tau, in_layout, N, n, P, world, dist, dev, max(50, args.steps), 3)
+        out["config4"] = guarded(*c4) if world == 1 else c4[0](*c4[1:])
+    del Y
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()   # everything collective is done: the other ranks leave, rank 0 goes on alone
+    if rank != 0:
+        return
+    del q, dq, ddq, tau
+    torch.cuda.empty_cache()
+    if not args.no_extras:
+        out["extras"] = {"config3": guarded(extras_config3, dev), "config5": guarded(extras_config5, dev),
+                         "real_chains": guarded(extras_real_chains, dev)}
+        torch.cuda.empty_cache()
+    if not args.no_config4 and not args.no_library_config4:
+        out["config4_library"] = config4_library_child(world, N, max(50, args.steps))
+    if args.cpu_seconds > 0:
         out["cpu_baseline"] = guarded(cpu_baseline, urdf, base, tool, n, args.cpu_seconds)
-    if world > 1:
-        dist.barrier()   # the other ranks wait for rank 0's informational legs before the group is torn down
-    if rank == 0:
-        print(json.dumps(out))
-    if world > 1:
-        dist.destroy_process_group()
+    print(json.dumps(out))
 
 
 if __name__ == "__main__":

@@ -370,14 +370,23 @@ class Chain(object):
 
 
     def getRegressorGram(self, q, Dq, DDq, tau_meas=None, layout="sample", chunk_samples=0, out=None, accumulate=False,
-                         workspace=None):
+                         workspace=None, packed_out=None):
         """Normal equations of the stacked regressor of this batch without leaving Y in HBM:
-        returns (G = A^T A (P, P), c = A^T tau_meas (P,), bb = tau_meas^T tau_meas (1,)).  include/rdyn.h: rdyn_regressor_gram."""
+        returns (G = A^T A (P, P), c = A^T tau_meas (P,), bb = tau_meas^T tau_meas (1,)).  include/rdyn.h: rdyn_regressor_gram.
+        packed_out: a (P*P + P + 2,) float64 buffer [G | c | bb | count] -- the all-reduce payload of the multi-GPU path; G, c, bb are
+        written straight into it (the returned tensors are views), the count slot is the caller's (rosdyn_amd.gram.packed_buffer)."""
         torch = _torch()
         b, N, lay = self._batch(layout, q, Dq, DDq)
         P = 10 * self.getJointsNumber()
         if tau_meas is not None and (tau_meas.shape != q.shape or tau_meas.dtype != torch.float64 or not tau_meas.is_contiguous()):
             raise ValueError("Input data dimensions mismatch")
+        if packed_out is not None:
+            if out is not None:
+                raise ValueError("packed_out and out are exclusive")
+            if packed_out.dtype != torch.float64 or packed_out.numel() != P * P + P + 2 or not packed_out.is_contiguous() or packed_out.device != q.device:
+                raise ValueError("packed_out must be a contiguous float64 tensor of P*P + P + 2 elements on the batch's device")
+            flat = packed_out.view(-1)
+            out = (flat[:P * P].view(P, P), flat[P * P:P * P + P], flat[P * P + P:P * P + P + 1])
         if out is None:
             out = (torch.empty((P, P), dtype=torch.float64, device=q.device), torch.empty((P,), dtype=torch.float64, device=q.device),
                    torch.empty((1,), dtype=torch.float64, device=q.device))
@@ -408,6 +417,9 @@ class Chain(object):
             workspace = torch.empty((nbytes,), dtype=torch.uint8, device=q.device)
         check(lib().rdyn_regressor_tsqr(self._h, C.byref(b), tau_meas.data_ptr() if tau_meas is not None else None, buf.data_ptr(),
                                         1 if accumulate else 0, workspace.data_ptr(), workspace.numel()))
+        if out is not None:           # the C side is column-major: `buf` was a transposed copy of `out`
+            out.copy_(buf.t())
+            return out
         return buf.t()
 
     def getIdentificationGram(self, components, q, Dq, DDq, tau_meas, layout="sample", out=None, accumulate=False, workspace=None):

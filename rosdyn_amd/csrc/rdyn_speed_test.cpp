@@ -59,6 +59,11 @@ int main(int argc, char** argv)
   };
   if (argc > 5 && std::string(argv[5]) == "dump")
   {
+#ifdef RDYN_FACADE_HAS_EIGEN
+    std::printf("# types: Eigen (VectorXd / MatrixXd / Matrix<double, 6, Dynamic> / Affine3d: the signatures of primitives.h:452-547)\n");
+#else
+    std::printf("# types: facade stand-ins (no <Eigen/Core> on the include path)\n");
+#endif
     // numerical dump of single-sample facade calls for the parity test (tests/test_facade.py):
     // q = 0.1 (i+1), Dq = -0.05 (i+1), DDq = 0.3 - 0.02 i
     for (unsigned i = 0; i < n_joints; ++i)
@@ -114,6 +119,23 @@ int main(int argc, char** argv)
       for (int i = 0; i < 6; ++i) std::printf(" %.17g", jlc(i) + jn(i));
       const rosdyn::Vector6d& jt = chain->getDDTwistTool(q, Dq, DDq, DDDq);
       for (int i = 0; i < 6; ++i) std::printf(" %.17g", jt(i));
+      std::printf("\n");
+    }
+    {
+      // getTwist (primitives.h:457): twists of every link, base first; getDTwist likewise; getNominalParameters (primitives.h:548)
+      const rosdyn::VectorOfVector6d tw = chain->getTwist(q, Dq);
+      std::printf("V");
+      for (size_t l = 0; l < tw.size(); ++l)
+        for (int i = 0; i < 6; ++i) std::printf(" %.17g", tw[l](i));
+      std::printf("\n");
+      const rosdyn::VectorOfVector6d dtw = chain->getDTwist(q, Dq, DDq);
+      std::printf("D");
+      for (size_t l = 0; l < dtw.size(); ++l)
+        for (int i = 0; i < 6; ++i) std::printf(" %.17g", dtw[l](i));
+      std::printf("\n");
+      const rosdyn::VectorXd par = chain->getNominalParameters();
+      std::printf("N");
+      for (int i = 0; i < (int)par.rows(); ++i) std::printf(" %.17g", par(i));
       std::printf("\n");
     }
     const std::string mid = chain->getLinksName().at(chain->getLinksNumber() / 2);

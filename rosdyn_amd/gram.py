@@ -48,6 +48,26 @@ def unpack_normal_equations(buf, P):
     return buf[:P * P].reshape(P, P), buf[P * P:P * P + P], buf[P * P + P:P * P + P + 1], float(buf[P * P + P + 1].item())
 
 
+def packed_buffer(P, count, device):
+    """The all-reduce payload [G (P*P) | c (P) | bb | count] as one zeroed fp64 buffer with the count slot filled ONCE (the shard
+    size does not change from step to step); pass it as getRegressorGram(packed_out=...) and reduce it with allreduce_packed."""
+    import torch
+    buf = torch.zeros((P * P + P + 2,), dtype=torch.float64, device=device)
+    buf[P * P + P + 1] = float(count)
+    return buf
+
+
+def allreduce_packed(buf, dist=None, count=None):
+    """ONE in-place all-reduce of a packed accumulator (RCCL over xGMI on GPUs, gloo in the CPU tests): no packing kernels, no host
+    synchronisation.  The kernels overwrite G, c, bb every step; the count slot holds the SUM after a reduction, so a caller that
+    re-uses the buffer passes its shard size again (`count`: one fill kernel, still no synchronisation)."""
+    if count is not None:
+        buf[-1] = float(count)
+    if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+    return buf
+
+
 def allreduce_normal_equations(G, c, bb, count, dist=None):
     """Sum of every rank's accumulators: one all-reduce (RCCL over xGMI on GPUs, gloo in the CPU tests).
     ~29 KB for P = 60: latency-bound, independent of the batch size."""
@@ -152,7 +172,10 @@ def tsqr(A, b=None, out=None, accumulate=False, workspace=None):
     check(lib().rdyn_tsqr(A.data_ptr(), rows, rows, P, b.data_ptr() if b is not None else None, buf.data_ptr(), 1 if accumulate else 0,
                           workspace.data_ptr(), workspace.numel(), A.device.index if A.device.index is not None else -1,
                           torch.cuda.current_stream(A.device).cuda_stream))
-    return buf.t()          # the C side is column-major
+    if out is not None:     # the C side is column-major: `buf` was a transposed copy of `out`
+        out.copy_(buf.t())
+        return out
+    return buf.t()
 
 
 def tsqr_combine_host(factors):

@@ -41,3 +41,16 @@ def test_world_size_mismatch_is_an_error_not_an_assert():
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry", "--backend", "gloo"],
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, timeout=120)
     assert p.returncode == 2 and "WORLD_SIZE=3" in p.stderr
+
+
+def test_single_process_argument_path_dry():
+    """`bench.py --single-process --gpus N` = configs[3] through the library's in-process RCCL path (one process, no torch.distributed,
+    no launcher); on the CPU box only the argument path can run."""
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--single-process", "--gpus", "8", "--dry", "--samples", "1000"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, timeout=120)
+    assert p.returncode == 0, p.stderr[-2000:]
+    d = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][0])
+    assert d == {"metric": "config4_library", "dry": True, "n_gpus": 8, "steps": 20, "samples_per_gpu": 1000}

@@ -42,6 +42,16 @@ def _worker(rank, world, port, q):
                                                torch.tensor([br @ br]), rows, dist)
     ok = (np.allclose(G.numpy(), A.T @ A, rtol=1e-13, atol=1e-13) and np.allclose(c.numpy(), A.T @ b, rtol=1e-13, atol=1e-13)
           and abs(float(bb.item()) - b @ b) < 1e-12 and cnt == world * rows and t == float(world))
+    # the packed payload reduced IN PLACE (what bench.py's config4 does every step: no packing kernels, no host read)
+    from rosdyn_amd.gram import allreduce_packed, packed_buffer, unpack_normal_equations
+    buf = packed_buffer(P, rows, torch.device("cpu"))
+    for _ in range(2):                       # the buffer is re-used: the count slot is refilled, G / c / bb are overwritten
+        buf[:P * P] = torch.from_numpy(Ar.T @ Ar).reshape(-1)
+        buf[P * P:P * P + P] = torch.from_numpy(Ar.T @ br)
+        buf[P * P + P] = float(br @ br)
+        assert allreduce_packed(buf, dist, count=rows) is buf
+        G2, c2, bb2, cnt2 = unpack_normal_equations(buf, P)
+        ok = ok and torch.equal(G2, G) and torch.equal(c2, c) and cnt2 == world * rows
     q.put((rank, ok))
     dist.destroy_process_group()
 
