@@ -370,7 +370,13 @@ int rdyn_regressor_gram_multi(rdyn_multi_gpu* ctx, const rdyn_chain* chain, cons
  * the stack with rdyn_tsqr_combine_host.  Solve with rdyn_solve_r_factor(R1, n1, n_cols, n_cols, d = R1 + n_cols * n1, ...).
  * rdyn_tsqr: any column-major rows x n_cols device matrix (n1 <= 64).  rdyn_regressor_tsqr: the stacked regressor of the batch and
  * tau_meas (layout of batch->q), rows generated in LDS by the regressor sweep, never stored: n1 = 10 joints_number + 1; chains of
- * 2..7 joints with the input joints in chain order (else RDYN_ERR_UNSUPPORTED).  ~5x the time of rdyn_regressor_gram.
+ * 2..7 INPUT joints in chain order (else RDYN_ERR_UNSUPPORTED); joints that are not input joints are folded away (the reduced chain
+ * of rdyn_chain_reduction is swept and the factor expanded by a small QR: up to RDYN_MAX_JOINTS chain joints).
+ * Two routes, chosen by the batch size: Householder folds on the vector units (rdyn_tsqr.hip; ~5x the time of rdyn_regressor_gram),
+ * and from 327 680 samples on preconditioned CholeskyQR with the heavy pass on the fp64 matrix cores (rdyn_cholqr.hip: Householder
+ * factor R1 of a row subsample, W = R1^-1 without its null columns, G2 = (A W)'(A W) over all rows by MFMA, R = chol(G2) R1 with a
+ * pivot check and an automatic second round; ~2.3x the time of rdyn_regressor_gram; rows of R at structurally dependent columns
+ * are exactly zero).  Both return R1 with R1'R1 = [A b]'[A b] to rounding and the small singular values to ~cond * eps.
  * rdyn_identification_tsqr: the same for the identification step's [Y | C | tau_meas] (C = the component columns of
  * rdyn_components_regressor, K = rdyn_components_columns): n1 = 10 joints_number + K + 1, unknowns [inertial ; component]
  * parameters; chains of 2..6 joints, 10 joints_number + 1 + K <= 16 (ceil((10 joints_number + 1) / 16) + 1). */

@@ -12,6 +12,7 @@
 //   RDYN_GRAM_UNFUSED=1     same as RDYN_GRAM_PATH=two
 //   RDYN_FUSED_BLOCKS=n     persistent workgroups of the fused Gram kernels (default 256 = one per CU)
 //   RDYN_FUSED_DEBUG=bits   phase ablation of the fused Gram kernels (timing only: results are then wrong)
+#include <cmath>
 #include <cstdint>
 #include <cstring>
 #include <map>
@@ -1124,6 +1125,39 @@ int rdyn_tsqr(const double* A, int64_t rows, int64_t lda, int n_cols, const doub
   return RDYN_OK;
 }
 
+// ---- layout of the factor workspaces.  Region 1: the Householder route's leaves + tree levels (rdyn_tsqr.hip) for the chain that is
+// swept (the reduced companion when the chain has one).  Region 2 (regressor factor only): the preconditioned route's slabs, W, the
+// intermediate factors and the second-round flag (rdyn_cholqr.hip).
+struct TsqrLayout
+{
+  size_t householder_doubles = 0;  // region 1
+  size_t slabs = 0, w = 0, r_sub = 0, r1p = 0, g2 = 0, r_swept = 0, flag = 0, total_doubles = 0;  // offsets (doubles) of region 2
+};
+static const int kCholqrBlocks = 256;
+static TsqrLayout tsqr_layout(int n_joints_swept)
+{
+  TsqrLayout L;
+  const int n1 = 10 * n_joints_swept + 1, nb = (n1 + 15) / 16, nt = nb * (nb + 1) / 2;
+  L.householder_doubles = rdyn_tsqr_workspace_doubles(n1, kTsqrBlocks);
+  size_t off = (L.householder_doubles + 31) & ~(size_t)31;
+  auto take = [&](size_t doubles) {
+    const size_t at = off;
+    off = (off + doubles + 31) & ~(size_t)31;
+    return at;
+  };
+  L.slabs = take((size_t)kCholqrBlocks * nt * 256);
+  L.w = take((size_t)nt * 256);
+  L.r_sub = take((size_t)n1 * n1);
+  L.r1p = take((size_t)n1 * n1);
+  L.g2 = take((size_t)n1 * n1 + 1);
+  L.r_swept = take((size_t)n1 * n1);
+  L.flag = take(64);  // ints: [0] the second-round flag, [16 ..] the null set of the columns
+  L.total_doubles = off;
+  return L;
+}
+// the chain whose rows are swept: the reduced companion when the chain has non-input joints (no component columns in that case)
+static const rdyn_chain* swept_chain(const rdyn_chain* c, int n_comps) { return (c->reduced && n_comps == 0) ? c->reduced.get() : c; }
+
 static int regressor_tsqr_run(const rdyn_chain* c, const rdyn_component* comps, int n_comps, const rdyn_batch* b, const double* tau_meas, double* R,
                               int accumulate, void* workspace, size_t workspace_bytes, const char* who)
 {
@@ -1134,19 +1168,24 @@ static int regressor_tsqr_run(const rdyn_chain* c, const rdyn_component* comps, 
     rdyn_set_error("%s: null output / workspace, or more than %d components", who, RDYN_MAX_COMPONENTS);
     return RDYN_ERR_INVALID_ARGUMENT;
   }
-  const int n = c->n_active(), nJ = c->n_joints();
+  const rdyn_chain* cs = swept_chain(c, n_comps);  // chains with fixed joints: the reduced companion is swept, the factor expanded
+  const bool expand = cs != c;
+  const int n = cs->n_active(), nJ = cs->n_joints();
   const int K = n_comps > 0 ? rdyn_components_columns(comps, n_comps) : 0;
-  const int n1 = 10 * nJ + (K > 0 ? K : 0) + 1, nc = K < 0 ? 0 : rdyn_regressor_tsqr_cols(nJ, K);
+  const int n1s = 10 * nJ + (K > 0 ? K : 0) + 1, n1 = 10 * c->n_joints() + (K > 0 ? K : 0) + 1;
+  const int nc = K < 0 ? 0 : rdyn_regressor_tsqr_cols(nJ, K);
   RdynLdsGramArgs la;
   memset(&la, 0, sizeof la);
-  const bool monotonic = nc > 0 && nJ >= 2 && nJ <= 7 && n >= 1 && n <= 8 && build_lds_tile(c, K > 0 ? K : 0, false, &la);
+  const bool monotonic = nc > 0 && nJ >= 2 && nJ <= 7 && n >= 1 && n <= 8 && build_lds_tile(cs, K > 0 ? K : 0, false, &la);
   if (!monotonic || 4 * (size_t)la.tile_bytes > 160 * 1024)
   {
-    rdyn_set_error("%s: chains of 2..7 joints (2..6 with component columns, which must fit one 16-column slot) with the input joints in chain order "
+    rdyn_set_error("%s: chains of 2..7 input joints in chain order (2..6 chain joints with component columns, which must fit one 16-column slot) "
                    "are supported", who);
     return RDYN_ERR_UNSUPPORTED;
   }
-  if (workspace_bytes < rdyn_tsqr_workspace_doubles(nc, kTsqrBlocks) * sizeof(double))
+  const TsqrLayout L = tsqr_layout(nJ);
+  const size_t need = n_comps > 0 ? rdyn_tsqr_workspace_doubles(nc, kTsqrBlocks) * sizeof(double) : L.total_doubles * sizeof(double);
+  if (workspace_bytes < need)
   {
     rdyn_set_error("%s: workspace too small", who);
     return RDYN_ERR_INVALID_ARGUMENT;
@@ -1162,7 +1201,7 @@ static int regressor_tsqr_run(const rdyn_chain* c, const rdyn_component* comps, 
   st = g.enter(b->device);
   if (st != RDYN_OK) return st;
   const RdynChainConst* dc = nullptr;
-  st = device_const(c, &dc);
+  st = device_const(cs, &dc);
   if (st != RDYN_OK) return st;
   hipStream_t stream = (hipStream_t)b->stream;
   if (b->n_samples == 0)
@@ -1186,16 +1225,79 @@ static int regressor_tsqr_run(const rdyn_chain* c, const rdyn_component* comps, 
     const int w = ca.comps[i].type == RDYN_COMP_FRICTION2 ? 3 : 2;
     for (int k = 0; k < w; ++k) la.comp_col_row[col++] = (signed char)ca.comps[i].joint;
   }
+  double* const ws = (double*)workspace;
   const int64_t tiles = (b->n_samples + 15) / 16;
-  const int blocks = (int)((tiles + 3) / 4 < kTsqrBlocks ? (tiles + 3) / 4 : kTsqrBlocks);
-  RDYN_HIP_TRY(rdyn_launch_regressor_tsqr(nJ, la, blocks, 4 * (size_t)la.tile_bytes, (double*)workspace, R, accumulate ? 1 : 0, stream));
+  // ---- which route.  Preconditioned CholeskyQR (rdyn_cholqr.hip: the heavy pass on the matrix cores) for large batches of chains
+  // whose swept form has every joint as an input joint; the Householder folds (rdyn_tsqr.hip) otherwise.
+  const char* route_env = probe_env("RDYN_TSQR_ROUTE");  // A/B builds only: "householder" / "cholqr"
+  const int pairs = (n_comps == 0 && n == nJ) ? rdyn_cholqr_pairs(nJ, la.tile_bytes) : 0;
+  // ~1.0 ms of fixed cost (subsample leaves + tree + the two small dense kernels) against 0.9 / 1.4 ms per 1e6 samples (6 / 7 joints);
+  // the Householder route: 0.4 ms + 2.8 / 3.8 ms per 1e6 samples -> break-even near 3e5 samples
+  const int64_t kCholqrMinTiles = 20480;  // 327 680 samples
+  bool cholqr = pairs != 0 && tiles >= kCholqrMinTiles;
+  if (route_env && pairs != 0) cholqr = !strcmp(route_env, "cholqr");
+  // where the factor of the swept chain goes: straight into R when nothing follows
+  double* const R_swept = (expand || (cholqr && accumulate)) ? ws + L.r_swept : R;
+  if (cholqr)
+  {
+    // pass A: Householder factor of every S-th tile (about 2 048 tiles whatever the batch size)
+    RdynLdsGramArgs sub = la;
+    sub.tile_stride = (int)(tiles / 2048 > 1 ? tiles / 2048 : 1);
+    const int64_t sub_tiles = (tiles + sub.tile_stride - 1) / sub.tile_stride;
+    const int sub_blocks = (int)((sub_tiles + 3) / 4 < kTsqrBlocks ? (sub_tiles + 3) / 4 : kTsqrBlocks);
+    RDYN_HIP_TRY(rdyn_launch_regressor_tsqr(nJ, sub, sub_blocks, 4 * (size_t)la.tile_bytes, ws, ws + L.r_sub, 0, stream));
+    la.slabs = ws + L.slabs;
+    const int np = pairs < 0 ? -pairs : pairs;
+    const int blocks = (int)((tiles + np - 1) / np < kCholqrBlocks ? (tiles + np - 1) / np : kCholqrBlocks);
+    int* const flag = (int*)(ws + L.flag);
+    const int n_rounds = probe_env("RDYN_CHOLQR_ROUNDS") ? atoi(probe_env("RDYN_CHOLQR_ROUNDS")) : 2;  // A/B builds only
+    for (int round = 0; round < n_rounds; ++round)
+    {
+      // round 0: W from the subsample's factor.  Round 1 (CholeskyQR2 on top): W from round 0's factor; its kernels leave at once
+      // unless round 0 found a pivot of its Cholesky factor outside [1/2, 2]
+      const int* const run = round == 0 ? nullptr : flag;
+      const double row_scale = round == 0 ? sqrt((double)tiles / (double)sub_tiles) : 1.0;
+      RDYN_HIP_TRY(rdyn_launch_cholqr_precond(round == 0 ? ws + L.r_sub : R_swept, n1s, row_scale, ws + L.r1p, ws + L.w, flag + 16, round, run, stream));
+      RDYN_HIP_TRY(rdyn_launch_regressor_pgram(nJ, la, ws + L.w, run, blocks, pairs, stream));
+      RdynGramArgs ga;
+      memset(&ga, 0, sizeof ga);
+      ga.P = n1s - 1;
+      ga.slabs = la.slabs;
+      ga.G = ws + L.g2;
+      ga.c = ws + L.g2 + (size_t)(n1s - 1) * (n1s - 1);
+      ga.bb = ga.c + (n1s - 1);
+      ga.run_flag = run;
+      RDYN_HIP_TRY(rdyn_launch_gram_finish(ga, blocks, stream));
+      RDYN_HIP_TRY(rdyn_launch_cholqr_factor(ga.G, ga.c, ga.bb, n1s, tau_meas ? 1 : 0, ws + L.r1p, flag + 16, R_swept, round == 0 ? flag : nullptr, run, stream));
+    }
+    if (!expand && accumulate) RDYN_HIP_TRY(rdyn_launch_tsqr_fold_factor(nJ, R_swept, R, stream));
+  }
+  else
+  {
+    const int blocks = (int)((tiles + 3) / 4 < kTsqrBlocks ? (tiles + 3) / 4 : kTsqrBlocks);
+    RDYN_HIP_TRY(rdyn_launch_regressor_tsqr(nJ, la, blocks, 4 * (size_t)la.tile_bytes, ws, R_swept, (accumulate && !expand) ? 1 : 0, stream));
+  }
+  if (expand)
+  {
+    // [A b] = [A_red b] diag(E, 1): R = qr([R_prev ; R_red diag(E, 1)])
+    RdynGramExpandArgs ea;
+    memset(&ea, 0, sizeof ea);
+    st = device_expand(c, &ea.X);
+    if (st != RDYN_OK) return st;
+    for (int f = 0; f < c->n_joints(); ++f) ea.red_of[f] = c->red_of[f];
+    ea.n_joints = c->n_joints();
+    ea.n_red = nJ;
+    RDYN_HIP_TRY(rdyn_launch_cholqr_expand(ea, R_swept, accumulate ? R : nullptr, R, stream));
+  }
   return RDYN_OK;
 }
 
 size_t rdyn_regressor_tsqr_workspace_bytes(const rdyn_chain* c)
 {
-  if (!c || c->n_joints() < 2 || c->n_joints() > 7) return 0;
-  return rdyn_tsqr_workspace_doubles(rdyn_regressor_tsqr_cols(c->n_joints(), 0), kTsqrBlocks) * sizeof(double);
+  if (!c) return 0;
+  const rdyn_chain* cs = swept_chain(c, 0);
+  if (cs->n_joints() < 2 || cs->n_joints() > 7) return 0;
+  return tsqr_layout(cs->n_joints()).total_doubles * sizeof(double);
 }
 
 int rdyn_regressor_tsqr(const rdyn_chain* c, const rdyn_batch* b, const double* tau_meas, double* R, int accumulate, void* workspace,
@@ -1207,6 +1309,7 @@ int rdyn_regressor_tsqr(const rdyn_chain* c, const rdyn_batch* b, const double* 
 size_t rdyn_identification_tsqr_workspace_bytes(const rdyn_chain* c, const rdyn_component* comps, int n_comps)
 {
   if (!c || n_comps < 0 || (n_comps > 0 && !comps)) return 0;
+  if (n_comps == 0) return rdyn_regressor_tsqr_workspace_bytes(c);  // without components it is the regressor factor (and its routes)
   const int K = n_comps > 0 ? rdyn_components_columns(comps, n_comps) : 0;
   const int nc = K < 0 ? 0 : rdyn_regressor_tsqr_cols(c->n_joints(), K);
   if (nc == 0 || c->n_joints() < 2 || c->n_joints() > 7) return 0;

@@ -1,0 +1,660 @@
+// rdyn_cholqr.hip -- the robust R factor of the stacked regressor [A | tau_meas] with the heavy pass on the fp64 MATRIX cores
+// (BASELINE.json configs[2]: "regressor + TSQR Gram ..., MFMA path"; no reference counterpart: /root/reference/README.md:15).
+//
+// rdyn_tsqr.hip folds Householder reflections on the vector units: rank-1 updates, a ~1 400-cycle dependent chain per column step,
+// 15.8 ms at config 3 (7 joints, 4e6 samples) with the matrix pipe idle.  The plain Gram route (rdyn_duo_gram.hip + Cholesky) runs
+// at 2.8 ms but squares the condition number.  This file sits between the two -- preconditioned CholeskyQR:
+//
+//   pass A   R1 = Householder factor (rdyn_tsqr.hip, unchanged) of a ROW SUBSAMPLE: every S-th 16-sample tile, ~2 000 tiles whatever
+//            the batch size (~0.5 ms).  Backward stable; for a batch whose rows are exchangeable (trajectory samples) R1 differs from
+//            the factor of all rows by a well-conditioned factor.
+//   inverse  W = R1^-1 (back substitution, one thread per column, one workgroup), pivots below 1e-13 x their column's norm lifted to
+//            that level first (structurally dependent regressor columns: exact rank deficiency).
+//   pass B   k_regressor_pgram: ALL rows.  The wave-pair design of rdyn_duo_gram.hip: the sweeper wave drops every finished link's
+//            regressor rows into the pair's LDS tile; the consumer wave multiplies each 16-row group by W (v_mfma_f64_16x16x4_f64,
+//            W in LDS in operand order) and accumulates the Gram of the PRODUCT straight from the result registers (the D layout of
+//            the first MFMA is the A/B operand layout of the second: no transposition, no LDS round trip).  Q = A W is never stored.
+//            Block-triangular zero band of a row group: preserved by the upper-triangular W, skipped in both stages.
+//   factor   G2 = Q'Q is well conditioned (cond(Q) ~ 1): R2 = chol(G2 + 1e-14 max diag), R = R2 R1.  R'R = [A b]'[A b] to rounding,
+//            whatever the quality of R1; the ACCURACY of R is that of CholeskyQR on Q, u cond(Q)^2 -- so the factor kernel
+//            checks the pivots of R2: all within [1/2, 2] (cond(Q) <= 4) or a SECOND round runs with W = R^-1 (CholeskyQR2 on top of
+//            the preconditioner; the round's kernels are always queued and leave at once when the device flag says "not needed").
+//
+// fp64 throughout.  The multiplication by an explicit inverse (instead of a triangular solve) keeps every step a matrix product;
+// its rounding enters as |A| |W| u per row, which the pivot check of the second factorisation sees like any other loss.
+#include <hip/hip_runtime.h>
+#include <atomic>
+#include <cstdint>
+#include "rdyn_device.h"
+#include "rdyn_devmath.h"
+#include "rdyn_kernels.h"
+#include "rdyn_gram_common.h"
+#include "rdyn_duo_common.h"
+
+#ifndef RDYN_CHOLQR_AHEAD
+#define RDYN_CHOLQR_AHEAD 2  // rows of W operands requested ahead of their MFMAs when W is read from global memory (1 / 2 / 3: 6.47 / 6.33 / 6.36 ms at config 3)
+#endif
+#define DUO_BARRIER_LDS() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#define DUO_BARRIER() asm volatile("s_barrier" ::: "memory")
+
+namespace
+{
+
+// pass B.  NPAIR wave pairs per workgroup (4, or 3 when four LDS tiles do not fit beside W: 7 joints).  Waves are dealt to the four
+// SIMDs cyclically: with 8 waves pair p = (wave p, wave p + 4) shares SIMD p; with 6 waves the pairs are (0, 4), (1, 5) and (2, 3).
+// Every chain joint is an input joint, in chain order (the reduced companion of a chain with fixed joints qualifies).
+// WGLOBAL: W stays in global memory (30 KB at 7 joints: L1 / L2 resident) and the consumer loads its operands from there -- the LDS
+// then holds four tiles again where W + four tiles exceed 160 KB (7 joints).
+template <int NJ, bool ALLREV, int NPAIR, bool WGLOBAL>
+__global__ __launch_bounds__(128 * NPAIR) void k_regressor_pgram(const RdynLdsGramArgs fa, const double* __restrict__ Wg, const int* __restrict__ run_flag)
+{
+  constexpr bool DIRECT = true;
+  constexpr int NB = (10 * NJ + 1 + 15) / 16, NT = NB * (NB + 1) / 2, P = 10 * NJ;
+  constexpr int WB = WGLOBAL ? 0 : NT * 2048;  // W in operand order: per (cb1 <= cb2) block four k-steps of 64 doubles
+  if (run_flag && *run_flag == 0) return;  // second round not needed (uniform: every wave leaves)
+  extern __shared__ __attribute__((aligned(32))) char lds_raw[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const bool sweeper = wave < (NPAIR == 4 ? 4 : 3);
+  const int pair = NPAIR == 4 ? (wave & 3) : (wave < 3 ? wave : (wave == 3 ? 2 : wave - 4));
+  if constexpr (!WGLOBAL)
+  {
+    double* const wl = (double*)lds_raw;
+    for (int i = threadIdx.x; i < NT * 256; i += 128 * NPAIR) wl[i] = Wg[i];
+    __syncthreads();
+  }
+  char* const tile = lds_raw + WB + (size_t)pair * fa.tile_bytes;  // shared by the pair
+  const int n = fa.n_active;
+  const int64_t n_tiles = (fa.n_samples + 15) / 16;
+  const int64_t t_step = (int64_t)gridDim.x * NPAIR;
+  const int64_t t_first = (int64_t)blockIdx.x * NPAIR + pair;
+  const int64_t trips_raw = (n_tiles - (int64_t)blockIdx.x * NPAIR + t_step - 1) / t_step;
+  const int64_t trips = trips_raw > 0 ? trips_raw : 0;
+
+  if (sweeper)
+  {
+    // ================================================================ sweeper: as in rdyn_duo_gram.hip (16 samples x 4 lanes)
+    ChainPtr c = as_const(fa.chain);
+    const int s_loc = lane >> 2, k = lane & 3;
+    const int r0 = k, r1 = k + 4;
+    const int fB = 4;
+    double nqa = 0.0, ndqa = 0.0, nddqa = 0.0, nqb = 0.0, ndqb = 0.0, nddqb = 0.0, nb0 = 0.0, nb1 = 0.0;
+    auto fetch = [&](int64_t tile_index) {
+      int64_t sx = tile_index * 16 + s_loc;
+      if (sx >= fa.n_samples) sx = fa.n_samples - 1;
+      const int64_t o = sx * fa.in_ss;
+      if (fa.bcol)
+      {
+        if (r0 < n) nb0 = fa.bcol[o + r0 * fa.in_sj];
+        if (r1 < n) nb1 = fa.bcol[o + r1 * fa.in_sj];
+      }
+      if (k < n)
+      {
+        nqa = fa.q[o + k * fa.in_sj];
+        ndqa = fa.dq[o + k * fa.in_sj];
+        nddqa = fa.ddq[o + k * fa.in_sj];
+      }
+      if (k + 4 < n)
+      {
+        nqb = fa.q[o + (k + 4) * fa.in_sj];
+        ndqb = fa.dq[o + (k + 4) * fa.in_sj];
+        nddqb = fa.ddq[o + (k + 4) * fa.in_sj];
+      }
+    };
+    if (t_first < n_tiles) fetch(t_first);
+    for (int64_t it = 0; it < trips; ++it)
+    {
+      const int64_t tl = t_first + it * t_step;
+      const bool valid = tl < n_tiles && tl * 16 + s_loc < fa.n_samples;
+      const int m0idx = valid ? r0 : -2, m1idx = valid ? r1 : -2;
+      const double qa = nqa, dqa = ndqa, ddqa = nddqa, qb = nqb, dqb = ndqb, ddqb = nddqb;
+      const double tb0 = valid ? nb0 : 0.0, tb1 = valid ? nb1 : 0.0;
+      if (tl + t_step < n_tiles) fetch(tl + t_step);
+      double sna, csa, snb, csb;
+      sincos(qa, &sna, &csa);
+      sincos(qb, &snb, &csb);
+      const double oca = 1.0 - csa, ocb = 1.0 - csb;
+      V3 w = mk(0, 0, 0), vl = mk(0, 0, 0), al = mk(0, 0, 0);
+      V3 lin = mk(-c->g[0], -c->g[1], -c->g[2]);
+      V3 L0 = mk(0, 0, 0), A0 = mk(0, 0, 0), L1 = mk(0, 0, 0), A1 = mk(0, 0, 0);
+#pragma unroll
+      for (int f = 0; f < NJ; ++f)
+      {
+#include "rdyn_duo_link_body.inc"
+      }
+      {
+        char* const lb = tile + fa.lds_off_b + s_loc * 8;
+        if (r0 < n) *(double*)(lb + r0 * 128) = tb0;
+        if (r1 < n) *(double*)(lb + r1 * 128) = tb1;
+      }
+      DUO_BARRIER_LDS();  // the tile is complete
+    }
+  }
+  else
+  {
+    // ================================================================ consumer: row group x W, then the Gram of the product
+    const int cl = lane & 15, g = lane >> 4;
+    // stage 1 operand A: lane (cl, g) supplies X[sample cl][column 16 cb1 + 4 kk + g] of the row group.  Direct chains: link f's first
+    // column sits at byte 640 f^2 + 960 f of the tile, its columns are 128 f + 160 bytes apart and hold row groups 0 .. f; the measured
+    // torque (column P) holds every row group, columns beyond are padding.  Computed per operand (a handful of 32-bit instructions
+    // under the MFMAs) instead of kept in 20 registers.
+    auto a_operand = [&](int cb1, int kk, int j) -> double {
+      const int col = 16 * cb1 + 4 * kk + g;
+      const int f = (col * 205) >> 11;  // col / 10 for col < 1024
+      const int off = col < P ? f * (640 * f + 960) + (col - 10 * f) * (128 * f + 160) : fa.lds_off_b;
+      const bool stored = col < P ? j <= f : col == P;
+      double a = 0.0;
+      if (stored) a = *(const double*)(tile + off + cl * 8 + j * 128);
+      return a;
+    };
+    d4 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = (d4){0.0, 0.0, 0.0, 0.0};
+    const char* const wl = lds_raw + lane * 8;   // W in LDS
+    // W in global memory: uniform base (laundered per row group: hoisted out of the tile loop, the ~250 operand addresses of a tile
+    // become 64-bit VGPR pairs and spill) + lane index
+    const double* wgp = Wg;
+    auto wglob = [&](int blk_kk) -> double { return (wgp + blk_kk * 64)[lane]; };
+    d4 D[NB];
+    // Q(rows of group j, :) = X(rows of group j, :) W;  D[cb2] register r of lane (cl, g) = Q[sample g + 4 r][16 cb2 + cl]
+    auto stage1 = [&](int j, int band) {
+#pragma unroll
+      for (int cb = 0; cb < NB; ++cb) D[cb] = (d4){0.0, 0.0, 0.0, 0.0};
+      if constexpr (!WGLOBAL)
+      {
+#pragma unroll
+        for (int cb1 = 0; cb1 < NB; ++cb1)
+        {
+          if (cb1 < band) continue;
+#pragma unroll
+          for (int kk = 0; kk < 4; ++kk)
+          {
+            const double a = a_operand(cb1, kk, j);
+#pragma unroll
+            for (int cb2 = cb1; cb2 < NB; ++cb2)
+            {
+              const double b = *(const double*)(wl + ((cb2 * (cb2 + 1) / 2 + cb1) * 4 + kk) * 512);
+              D[cb2] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, D[cb2], 0, 0, 0);
+            }
+          }
+        }
+      }
+      else
+      {
+        // W from global memory: the operands of row (cb1, kk + 1) are requested before the MFMAs of row (cb1, kk) are issued, and no
+        // further ahead (compiler barrier): left alone the scheduler hoists every load of the group and spills the accumulators
+        // rows (cb1, kk) of W in the order they are used, from the first block row of the band; RDYN_CHOLQR_AHEAD rows in flight
+        constexpr int AH = RDYN_CHOLQR_AHEAD;
+        double ring[AH + 1][NB];
+        asm volatile("" : "+s"(wgp));
+        auto load_row = [&](int r, double (&dst)[NB]) {  // r = flat row index from the band's first row
+          const int c1 = band + (r >> 2), k4 = r & 3;
+#pragma unroll
+          for (int cb2 = 0; cb2 < NB; ++cb2)
+          {
+            dst[cb2] = 0.0;
+            if (c1 < NB && cb2 >= c1) dst[cb2] = wglob((cb2 * (cb2 + 1) / 2 + c1) * 4 + k4);
+          }
+        };
+#pragma unroll
+        for (int r = 0; r < AH; ++r) load_row(r, ring[r]);
+#pragma unroll
+        for (int cb1 = 0; cb1 < NB; ++cb1)
+        {
+          if (cb1 < band) continue;
+#pragma unroll
+          for (int kk = 0; kk < 4; ++kk)
+          {
+            const int r = (cb1 - band) * 4 + kk;
+            load_row(r + AH, ring[(r + AH) % (AH + 1)]);
+            asm volatile("" ::: "memory");
+            const double a = a_operand(cb1, kk, j);
+#pragma unroll
+            for (int cb2 = cb1; cb2 < NB; ++cb2) D[cb2] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, ring[r % (AH + 1)][cb2], D[cb2], 0, 0, 0);
+          }
+        }
+      }
+    };
+    // acc(rb, cb) += Q(:, block rb)' Q(:, block cb): register r of D is k-step r (which rows share a k-step is irrelevant to the sum)
+    auto stage2 = [&](int band) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+      {
+        int ti = 0;
+#pragma unroll
+        for (int cb = 0; cb < NB; ++cb)
+#pragma unroll
+          for (int rb = 0; rb <= cb; ++rb)
+          {
+            if (rb >= band) acc[ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(D[rb][t], D[cb][t], acc[ti], 0, 0, 0);
+            ++ti;
+          }
+      }
+    };
+    for (int64_t it = 0; it <= trips; ++it)
+    {
+      const bool have = it > 0;  // the tile in LDS is complete (nothing to consume while the first tile is being swept)
+#pragma unroll
+      for (int f = 0; f < NJ; ++f)
+      {
+        if (have) stage1(f, (10 * f) >> 4);
+        // my reads of row group f have returned -> the sweeper may overwrite link f's columns (no later group reads them)
+        if (it < trips) DUO_BARRIER_LDS();
+        else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (have) stage2((10 * f) >> 4);
+      }
+      if (it < trips) DUO_BARRIER_LDS();  // end of the sweeper's tile
+    }
+    // ---- block reduction of the consumers (fixed order); the reduction area overlays W (every consumer is done with it)
+    DUO_BARRIER_LDS();
+    double* red = (double*)lds_raw;
+    for (int w = 0; w < NPAIR; ++w)
+    {
+      if (pair == w)
+      {
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+          {
+            const int idx = t * 256 + ((g + 4 * r) * 16 + cl);
+            red[idx] = (w == 0) ? acc[t][r] : red[idx] + acc[t][r];
+          }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
+  }
+  if (sweeper)
+    for (int w = 0; w < NPAIR + 1; ++w) __builtin_amdgcn_s_barrier();  // the sweepers take part in the barriers of the reduction
+  asm volatile("" ::: "memory");
+  {
+    const double* red = (const double*)lds_raw;
+    double* slab = fa.slabs + (int64_t)blockIdx.x * (NT * 256);
+    for (int i = threadIdx.x; i < NT * 256; i += 128 * NPAIR) slab[i] = red[i];
+  }
+}
+
+// ---------------------------------------------------------------- the small dense steps (one workgroup each, n1 <= 81)
+constexpr int kMaxN1 = 81;
+
+// Householder QR of the m x nc matrix B (column-major, leading dimension m) in LDS, in place (R in the upper triangle, zeros below),
+// by the 256 threads of the workgroup; v = m doubles of LDS, s_part / s_beta / s_v0 = workgroup-shared scratch.
+__device__ __forceinline__ void small_qr_lds(double* B, int m, int nc, double* v, double* s_part, double* s_beta, double* s_v0, int tid)
+{
+  const int steps = nc < m ? nc : m;
+  for (int k = 0; k < steps; ++k)
+  {
+    double part = 0.0;
+    for (int r = k + 1 + tid; r < m; r += 256) part = fma(B[k * m + r], B[k * m + r], part);
+    s_part[tid] = part;
+    __syncthreads();
+    if (tid < 64)
+    {
+      double t = s_part[tid] + s_part[tid + 64] + s_part[tid + 128] + s_part[tid + 192];
+      for (int o = 32; o > 0; o >>= 1) t += __shfl_down(t, o);
+      if (tid == 0)
+      {
+        const double alpha = B[k * m + k], sigma = t;
+        if (sigma > 1e-280)
+        {
+          const double norm = sqrt(fma(alpha, alpha, sigma));
+          const double beta = alpha > 0.0 ? -norm : norm;
+          *s_v0 = alpha - beta;
+          *s_beta = 2.0 / fma(*s_v0, *s_v0, sigma);
+          B[k * m + k] = beta;
+        }
+        else
+          *s_beta = 0.0;  // nothing below the diagonal: no reflection
+      }
+    }
+    __syncthreads();
+    const double scale = *s_beta, v0 = *s_v0;
+    if (scale != 0.0)
+    {
+      for (int r = k + 1 + tid; r < m; r += 256) v[r] = B[k * m + r];
+      __syncthreads();
+      // columns j > k: four threads per column share the rows
+      const int ncol = nc - k - 1;
+      for (int e = tid; e < ((ncol * 4 + 255) & ~255); e += 256)
+      {
+        const bool on = e < ncol * 4;
+        const int j = on ? k + 1 + (e >> 2) : k, q = e & 3;
+        double d = (on && q == 0) ? v0 * B[j * m + k] : 0.0;
+        if (on)
+          for (int r = k + 1 + q; r < m; r += 4) d = fma(v[r], B[j * m + r], d);
+        d += __shfl_xor(d, 1);
+        d += __shfl_xor(d, 2);
+        const double f = scale * d;
+        if (on)
+        {
+          if (q == 0) B[j * m + k] = fma(-f, v0, B[j * m + k]);
+          for (int r = k + 1 + q; r < m; r += 4) B[j * m + r] = fma(-f, v[r], B[j * m + r]);
+        }
+      }
+      __syncthreads();
+      for (int r = k + 1 + tid; r < m; r += 256) B[k * m + r] = 0.0;
+    }
+    __syncthreads();
+  }
+}
+
+// The preconditioner of a round.  In: an upper-triangular factor R1 (n1 x n1) of (a subsample of) the rows.  A regressor is
+// structurally rank deficient: the pivot of a column that depends on the columns to its left is rounding residue -- and a Householder
+// factor keeps real information of LATER columns in that pivot's row.  Inverting R1 as it stands (pivot lifted to something tiny)
+// puts 1e12-sized entries into W whose effects cancel in Q = A W only in exact arithmetic.  So:
+//   null set Z   round 0: pivots below 1e-13 x their column's norm; round 1: the set of round 0 (zmask)
+//   T            the factor re-triangularised WITHOUT the null columns (Householder QR of R1(:, not Z), in LDS), embedded back at the
+//                positions of the kept columns; a null column gets its norm on the diagonal and nothing else.
+//   W = T^-1     back substitution, one thread per column; written in the MFMA operand order of k_regressor_pgram.
+// Any invertible upper-triangular T serves: R = chol((A W)'(A W)) T satisfies R'R = A'A exactly; T only has to make Q = A W well
+// conditioned on its range, which the factor kernel checks.  Kept columns of Q are orthonormal on the rows T came from, null
+// columns are unit vectors inside their span (G2 singular there: the factor kernel skips those pivots).
+__global__ __launch_bounds__(256) void k_cholqr_precond(const double* __restrict__ R1, int n1, double row_scale, double* __restrict__ Tout,
+                                                        double* __restrict__ W, int* __restrict__ zmask, int zmask_given, const int* __restrict__ run_flag)
+{
+  if (run_flag && *run_flag == 0) return;
+  extern __shared__ __attribute__((aligned(16))) double sh[];
+  double* const A0 = sh;                // [n1][n1] column-major: R1, then T
+  double* const B = sh + n1 * n1;       // [nc][n1]: the kept columns, then V = T^-1
+  double* const v = sh + 2 * n1 * n1;   // [n1]
+  __shared__ double s_part[256], s_beta, s_v0, s_norm[kMaxN1];
+  __shared__ int s_z[kMaxN1], s_cmap[kMaxN1], s_nc;
+  const int tid = threadIdx.x;
+  for (int i = tid; i < n1 * n1; i += 256)
+  {
+    const int r = i % n1, c = i / n1;
+    A0[i] = r <= c ? row_scale * R1[i] : 0.0;  // a factor of 1 row in row_scale^2: the factor of all rows is row_scale x larger
+  }
+  __syncthreads();
+  if (tid < n1)
+  {
+    double s = 0.0;
+    for (int r = 0; r <= tid; ++r) s = fma(A0[tid * n1 + r], A0[tid * n1 + r], s);
+    const double nrm = sqrt(s);
+    s_norm[tid] = nrm > 0.0 ? nrm : 1.0;
+    s_z[tid] = zmask_given ? zmask[tid] : ((nrm > 0.0 && fabs(A0[tid * n1 + tid]) >= 1e-13 * nrm) ? 0 : 1);
+  }
+  __syncthreads();
+  if (tid == 0)
+  {
+    int nc = 0;
+    for (int c = 0; c < n1; ++c)
+      if (!s_z[c]) s_cmap[nc++] = c;
+    s_nc = nc;
+  }
+  __syncthreads();
+  const int nc = s_nc;
+  for (int i = tid; i < nc * n1; i += 256) B[i] = A0[s_cmap[i / n1] * n1 + (i % n1)];
+  __syncthreads();
+  small_qr_lds(B, n1, nc, v, s_part, &s_beta, &s_v0, tid);
+  // T: kept columns at their positions, null columns diagonal
+  for (int i = tid; i < n1 * n1; i += 256) A0[i] = 0.0;
+  __syncthreads();
+  for (int i = tid; i < nc * nc; i += 256)
+  {
+    const int a = i % nc, bcol = i / nc;
+    if (a <= bcol) A0[s_cmap[bcol] * n1 + s_cmap[a]] = B[bcol * n1 + a];
+  }
+  if (tid < n1 && s_z[tid]) A0[tid * n1 + tid] = s_norm[tid];
+  __syncthreads();
+  for (int i = tid; i < n1 * n1; i += 256)
+  {
+    Tout[i] = A0[i];
+    B[i] = 0.0;  // V
+  }
+  if (tid < n1 && !zmask_given) zmask[tid] = s_z[tid];
+  __syncthreads();
+  if (tid < n1)
+  {
+    // column c of the inverse: T x = e_c by back substitution (T is nonsingular: full-rank kept block, norms on the null diagonal)
+    const int c = tid;
+    B[c * n1 + c] = 1.0 / A0[c * n1 + c];
+    for (int i = c - 1; i >= 0; --i)
+    {
+      double s = 0.0;
+      for (int k = i + 1; k <= c; ++k) s = fma(A0[k * n1 + i], B[c * n1 + k], s);
+      B[c * n1 + i] = -s / A0[i * n1 + i];
+    }
+  }
+  __syncthreads();
+  const int nb = (n1 + 15) / 16, nt = nb * (nb + 1) / 2;
+  for (int i = tid; i < nt * 256; i += 256)
+  {
+    const int blk = i >> 8, kk = (i >> 6) & 3, ln = i & 63;
+    int cb2 = 0;
+    while ((cb2 + 1) * (cb2 + 2) / 2 <= blk) ++cb2;
+    const int cb1 = blk - cb2 * (cb2 + 1) / 2;
+    const int r = 16 * cb1 + 4 * kk + (ln >> 4), c = 16 * cb2 + (ln & 15);
+    W[i] = (r < n1 && c < n1 && r <= c) ? B[c * n1 + r] : 0.0;
+  }
+}
+
+// G2 = [G c; c' bb] (the Gram of Q = [A b] W) -> R = chol(G2) T; the pivots of the null set are skipped (their rows of R are exactly
+// zero: the rank deficiency is reported as such); *flag_out = 1 when a kept pivot of the Cholesky factor left [1/2, 2] (cond(Q) > 4)
+__global__ __launch_bounds__(256) void k_cholqr_factor(const double* __restrict__ G, const double* __restrict__ cvec, const double* __restrict__ bb, int n1,
+                                                       int has_b, const double* __restrict__ T_in, const int* __restrict__ zmask, double* __restrict__ Rout,
+                                                       int* __restrict__ flag_out, const int* __restrict__ run_flag)
+{
+  if (run_flag && *run_flag == 0) return;
+  extern __shared__ __attribute__((aligned(16))) double sh[];
+  double* const M = sh;             // [n1][n1] column-major, upper triangle = the running Cholesky factor
+  double* const T = sh + n1 * n1;
+  __shared__ double s_piv;
+  __shared__ int s_flag, s_z[kMaxN1];
+  const int tid = threadIdx.x, P = n1 - 1;
+  for (int i = tid; i < n1 * n1; i += 256)
+  {
+    const int r = i % n1, c = i / n1;
+    double v;
+    if (r < P && c < P) v = G[(int64_t)c * P + r];
+    else if (r == P && c == P) v = bb[0];
+    else v = cvec[r < P ? r : c];
+    M[i] = v;
+    T[i] = T_in[i];
+  }
+  if (tid < n1) s_z[tid] = zmask[tid] || (!has_b && tid == P);  // no measured torque: the last column is null by construction
+  if (tid == 0) s_flag = 0;
+  __syncthreads();
+  for (int k = 0; k < n1; ++k)
+  {
+    if (s_z[k])
+    {
+      // null direction: its Schur complement is rounding residue -- row k of the factor is zero, nothing is eliminated
+      for (int j = k + tid; j < n1; j += 256) M[j * n1 + k] = 0.0;
+      __syncthreads();
+      continue;
+    }
+    if (tid == 0)
+    {
+      const double d = M[k * n1 + k];
+      s_piv = sqrt(d > 1e-30 ? d : 1e-30);
+      M[k * n1 + k] = s_piv;
+      if (s_piv < 0.5 || s_piv > 2.0) s_flag = 1;
+    }
+    __syncthreads();
+    const double inv = 1.0 / s_piv;
+    for (int j = k + 1 + tid; j < n1; j += 256) M[j * n1 + k] *= inv;  // row k of the factor: M(k, j), stored in column j
+    __syncthreads();
+    const int m = n1 - k - 1;  // trailing update of the upper triangle: M(i, j) -= M(k, i) M(k, j), k < i <= j
+    for (int e = tid; e < m * m; e += 256)
+    {
+      const int i = k + 1 + e % m, j = k + 1 + e / m;
+      if (i <= j) M[j * n1 + i] = fma(-M[i * n1 + k], M[j * n1 + k], M[j * n1 + i]);
+    }
+    __syncthreads();
+  }
+  // R = R2 T (upper x upper)
+  for (int e = tid; e < n1 * n1; e += 256)
+  {
+    const int i = e % n1, j = e / n1;
+    double s = 0.0;
+    if (i <= j)
+      for (int k = i; k <= j; ++k) s = fma(M[k * n1 + i], T[j * n1 + k], s);
+    Rout[e] = s;
+  }
+  if (tid == 0 && flag_out) *flag_out = s_flag;
+}
+
+// Factor of the reduced chain -> factor of the chain (rdyn_chain.hpp: [A b] = [A_red b] E_aug, E_aug = diag(E, 1)):
+// R = qr([R_prev ; R_red E_aug]) by Householder reflections in LDS, one workgroup.  R_prev (n1 x n1, the caller's running factor)
+// only when accumulating.  The product has nr = 10 n_red + 1 rows and n1 = 10 n_joints + 1 columns; rows beyond the rank stay zero.
+__global__ __launch_bounds__(256) void k_cholqr_expand(const RdynGramExpandArgs a, const double* __restrict__ R_red, const double* __restrict__ R_prev,
+                                                       double* __restrict__ Rout)
+{
+  extern __shared__ __attribute__((aligned(16))) double sh[];
+  const int P = 10 * a.n_joints, n1 = P + 1, Pr = 10 * a.n_red, nr = Pr + 1;
+  const int m = nr + (R_prev ? n1 : 0);
+  double* const B = sh;            // [n1][m] column-major (leading dimension m)
+  double* const v = sh + n1 * m;   // the reflector of the current step
+  __shared__ double s_part[256], s_beta, s_v0;
+  const int tid = threadIdx.x;
+  // rows 0 .. nr - 1: R_red E_aug; rows nr ..: R_prev
+  for (int e = tid; e < n1 * m; e += 256)
+  {
+    const int r = e % m, col = e / m;
+    double s = 0.0;
+    if (r < nr)
+    {
+      if (col == P)
+        s = R_red[(int64_t)Pr * nr + r];
+      else
+      {
+        const int f = col / 10, p = col - 10 * f, rb = a.red_of[f];
+        if (rb >= 0)
+          for (int x = 0; x < 10; ++x)
+          {
+            const int cr = 10 * rb + x;
+            if (r <= cr) s = fma(R_red[(int64_t)cr * nr + r], a.X[f * 100 + x * 10 + p], s);
+          }
+      }
+    }
+    else
+    {
+      const int rp = r - nr;
+      s = rp <= col ? R_prev[(int64_t)col * n1 + rp] : 0.0;
+    }
+    B[e] = s;
+  }
+  __syncthreads();
+  small_qr_lds(B, m, n1, v, s_part, &s_beta, &s_v0, tid);
+  for (int e = tid; e < n1 * n1; e += 256)
+  {
+    const int r = e % n1, col = e / n1;
+    Rout[e] = (r <= col && r < m) ? B[col * m + r] : 0.0;
+  }
+}
+
+// max_bytes: dynamic LDS the kernel may ask for (kernels with static __shared__ variables must leave room for them inside 160 KB)
+template <class K>
+hipError_t opt_in_lds_once(K kernel, std::atomic<uint64_t>& done, int max_bytes = 160 * 1024)
+{
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  const uint64_t bit = 1ull << (dev & 63);
+  if (!(done.load(std::memory_order_acquire) & bit))
+  {
+    e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, max_bytes);
+    if (e != hipSuccess) return e;
+    done.fetch_or(bit, std::memory_order_release);
+  }
+  return hipSuccess;
+}
+
+template <int NJ, bool ALLREV, int NPAIR, bool WGLOBAL>
+hipError_t launch_pgram3(const RdynLdsGramArgs& a, const double* W, const int* run_flag, int blocks, hipStream_t st)
+{
+  static std::atomic<uint64_t> attr{0};
+  hipError_t e = opt_in_lds_once(k_regressor_pgram<NJ, ALLREV, NPAIR, WGLOBAL>, attr);
+  if (e != hipSuccess) return e;
+  constexpr int NB = (10 * NJ + 1 + 15) / 16, NT = NB * (NB + 1) / 2;
+  size_t lds = (WGLOBAL ? 0 : (size_t)NT * 2048) + (size_t)NPAIR * a.tile_bytes;
+  if (lds < (size_t)NT * 2048) lds = (size_t)NT * 2048;  // the final reduction area
+  hipLaunchKernelGGL((k_regressor_pgram<NJ, ALLREV, NPAIR, WGLOBAL>), dim3(blocks), dim3(128 * NPAIR), lds, st, a, W, run_flag);
+  return hipGetLastError();
+}
+// pairs: 4 = W in LDS beside four tiles; 3 = W in LDS beside three tiles; -4 = four tiles, W read from global memory
+template <int NJ>
+hipError_t launch_pgram(const RdynLdsGramArgs& a, const double* W, const int* run_flag, int blocks, int pairs, hipStream_t st)
+{
+  if (pairs == 4)
+    return a.all_revolute ? launch_pgram3<NJ, true, 4, false>(a, W, run_flag, blocks, st) : launch_pgram3<NJ, false, 4, false>(a, W, run_flag, blocks, st);
+  if constexpr (NJ >= 7)
+  {
+    if (pairs == 3)
+      return a.all_revolute ? launch_pgram3<NJ, true, 3, false>(a, W, run_flag, blocks, st) : launch_pgram3<NJ, false, 3, false>(a, W, run_flag, blocks, st);
+    if (pairs == -4)
+      return a.all_revolute ? launch_pgram3<NJ, true, 4, true>(a, W, run_flag, blocks, st) : launch_pgram3<NJ, false, 4, true>(a, W, run_flag, blocks, st);
+  }
+  return hipErrorInvalidValue;
+}
+}  // namespace
+
+size_t rdyn_cholqr_w_doubles(int n_joints)
+{
+  const int nb = (10 * n_joints + 1 + 15) / 16;
+  return (size_t)(nb * (nb + 1) / 2) * 256;
+}
+
+int rdyn_cholqr_pairs(int n_joints, int tile_bytes)
+{
+  if (n_joints < 2 || n_joints > 7) return 0;
+  const size_t wb = rdyn_cholqr_w_doubles(n_joints) * 8;
+  if (wb + 4 * (size_t)tile_bytes <= 160 * 1024) return 4;
+#ifdef RDYN_CHOLQR_W_LDS3
+  if (wb + 3 * (size_t)tile_bytes <= 160 * 1024) return 3;
+#else
+  if (4 * (size_t)tile_bytes <= 160 * 1024) return -4;  // W from global memory (7 joints)
+#endif
+  return 0;
+}
+
+hipError_t rdyn_launch_regressor_pgram(int n_joints, const RdynLdsGramArgs& a, const double* W, const int* run_flag, int blocks, int pairs, hipStream_t st)
+{
+  switch (n_joints)
+  {
+  case 2: return launch_pgram<2>(a, W, run_flag, blocks, pairs, st);
+  case 3: return launch_pgram<3>(a, W, run_flag, blocks, pairs, st);
+  case 4: return launch_pgram<4>(a, W, run_flag, blocks, pairs, st);
+  case 5: return launch_pgram<5>(a, W, run_flag, blocks, pairs, st);
+  case 6: return launch_pgram<6>(a, W, run_flag, blocks, pairs, st);
+  case 7: return launch_pgram<7>(a, W, run_flag, blocks, pairs, st);
+  default: return hipErrorInvalidValue;
+  }
+}
+
+hipError_t rdyn_launch_cholqr_precond(const double* R1, int n1, double row_scale, double* T, double* W, int* zmask, int zmask_given, const int* run_flag,
+                                      hipStream_t st)
+{
+  if (n1 < 1 || n1 > kMaxN1) return hipErrorInvalidValue;
+  static std::atomic<uint64_t> attr{0};
+  hipError_t e = opt_in_lds_once(k_cholqr_precond, attr, 128 * 1024);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(k_cholqr_precond, dim3(1), dim3(256), ((size_t)2 * n1 * n1 + n1) * sizeof(double), st, R1, n1, row_scale, T, W, zmask, zmask_given, run_flag);
+  return hipGetLastError();
+}
+
+hipError_t rdyn_launch_cholqr_factor(const double* G, const double* c, const double* bb, int n1, int has_b, const double* T, const int* zmask, double* R,
+                                     int* flag_out, const int* run_flag, hipStream_t st)
+{
+  if (n1 < 2 || n1 > kMaxN1) return hipErrorInvalidValue;
+  static std::atomic<uint64_t> attr{0};
+  hipError_t e = opt_in_lds_once(k_cholqr_factor, attr, 128 * 1024);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(k_cholqr_factor, dim3(1), dim3(256), (size_t)2 * n1 * n1 * sizeof(double), st, G, c, bb, n1, has_b, T, zmask, R, flag_out, run_flag);
+  return hipGetLastError();
+}
+
+// a.G_red / c_red / bb_red / G / c / bb are unused here: the factors travel as separate arguments (R_prev null = not accumulating)
+hipError_t rdyn_launch_cholqr_expand(const RdynGramExpandArgs& a, const double* R_red, const double* R_prev, double* R, hipStream_t st)
+{
+  const int n1 = 10 * a.n_joints + 1, nr = 10 * a.n_red + 1, m = nr + (R_prev ? n1 : 0);
+  const size_t lds = ((size_t)n1 * m + m) * sizeof(double);
+  if (lds > 156 * 1024) return hipErrorInvalidValue;
+  static std::atomic<uint64_t> attr{0};
+  hipError_t e = opt_in_lds_once(k_cholqr_expand, attr, 156 * 1024);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(k_cholqr_expand, dim3(1), dim3(256), lds, st, a, R_red, R_prev, R);
+  return hipGetLastError();
+}

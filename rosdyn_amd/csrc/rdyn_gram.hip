@@ -137,6 +137,7 @@ __global__ __launch_bounds__(256) void k_gram(const RdynGramArgs a)
 // One workgroup per 32 tile elements: 8 slab groups x 32 elements, slab groups reduced through LDS in fixed order.
 __global__ __launch_bounds__(256) void k_gram_finish(const RdynGramArgs a, int nb, int n_slabs)
 {
+  if (a.run_flag && *a.run_flag == 0) return;
   const int nt = nb * (nb + 1) / 2;
   const int e_loc = threadIdx.x & 31, grp = threadIdx.x >> 5;
   const int i = blockIdx.x * 32 + e_loc;

@@ -118,6 +118,7 @@ struct RdynGramArgs
   // (rdyn_duo_gram.hip: the zero band of every row group then ends at a 16-column boundary more often); 0 = natural order
   int desc_nj;
   int slab_nb;  // finish only: 16-column blocks of the slabs' tile layout if it is wider than P + 1 columns need (0 = derive from P)
+  const int* run_flag;  // finish only, may be null: device word; 0 = leave at once (conditional second round of rdyn_cholqr.hip)
 };
 // normal equations of the reduced chain -> of the chain (rdyn_chain.hpp; rdyn_gram.hip: k_gram_expand)
 struct RdynGramExpandArgs
@@ -168,6 +169,7 @@ struct RdynLdsGramArgs
   int tile_bytes;                      // one wave's tile
   double* slabs;
   int debug;                           // timing experiments only (RDYN_FUSED_DEBUG): bit 0 sweep only the first tile, bit 1 no Gram phase
+  int tile_stride;                     // k_regressor_tsqr only: sweep every tile_stride-th 16-sample tile (0 / 1 = all): the subsample pass of the preconditioned route
   // wave-pair kernel only (rdyn_duo_gram.hip): the per-joint component columns [Y | C | tau_meas] of rdyn_identification_gram.
   // Column P + k of the tile belongs to component comp_col_comp[k] and is non-zero only in the rows of that component's joint:
   // it is stored as ONE 16-row group (stride 160 bytes) at lds_off_c + 160 k; the measured torque moves to column P + n_comp_cols.
@@ -185,6 +187,23 @@ bool rdyn_regressor_gram_duo_supported(int n_cols);
 // n_cols = 10 * chain joints; a.n_comp_cols extra component columns may add at most one 16-column block
 bool rdyn_regressor_gram_duo_supports_components(int n_cols, int n_comp_cols);
 hipError_t rdyn_launch_regressor_gram_duo(int n_cols, const RdynLdsGramArgs& a, int blocks, size_t lds_bytes, hipStream_t st);
+// preconditioned CholeskyQR (rdyn_cholqr.hip): R factor of [A | b] with the heavy pass on the fp64 matrix cores.
+//   W = R1^-1 of a Householder factor R1 of a row SUBSAMPLE (rdyn_tsqr.hip);  G2 = (A W)'(A W) over ALL rows: sweep -> LDS tile -> the
+//   consumer wave multiplies every 16-row group by W (MFMA) and accumulates the Gram of the product (MFMA);  R = chol(G2) R1.
+int rdyn_cholqr_pairs(int n_joints, int tile_bytes);          // wave pairs per workgroup that fit 160 KB of LDS next to W (0: unsupported)
+size_t rdyn_cholqr_w_doubles(int n_joints);                   // W in MFMA operand order
+hipError_t rdyn_launch_regressor_pgram(int n_joints, const RdynLdsGramArgs& a, const double* W, const int* run_flag, int blocks, int pairs, hipStream_t st);
+// R1 (n1 x n1 upper, column-major) -> T = R1 re-triangularised without its null columns (zmask: found when !zmask_given, else used),
+// W = T^-1 in MFMA operand order.  row_scale: R1 is the factor of one row in row_scale^2 (the subsample), T is scaled to all rows.
+hipError_t rdyn_launch_cholqr_precond(const double* R1, int n1, double row_scale, double* T, double* W, int* zmask, int zmask_given, const int* run_flag,
+                                      hipStream_t st);
+// G2 = [G c; c' bb] -> R = chol(G2) T (n1 x n1 upper, column-major; zero rows at the null set); *flag_out = 1 when the preconditioner was poor
+hipError_t rdyn_launch_cholqr_factor(const double* G, const double* c, const double* bb, int n1, int has_b, const double* T, const int* zmask, double* R,
+                                     int* flag_out, const int* run_flag, hipStream_t st);
+// factor of the reduced chain -> factor of the chain: R = qr([R_prev ; R_red diag(E, 1)]) (a.X, a.red_of, a.n_joints, a.n_red used)
+hipError_t rdyn_launch_cholqr_expand(const RdynGramExpandArgs& a, const double* R_red, const double* R_prev, double* R, hipStream_t st);
+// one more factor folded into a running one: R <- qr([R ; R_new]) (both n1 x n1 upper, column-major; n1 = 10 n_joints + 1, <= 7 joints)
+hipError_t rdyn_launch_tsqr_fold_factor(int n_joints, const double* R_new, double* R, hipStream_t st);
 // tall-skinny QR (rdyn_tsqr.hip): R factor of [A | b] without forming A'A
 int rdyn_tsqr_padded_cols(int n_cols_with_rhs);              // 16 / 32 / 48 / 64, 0 = unsupported
 size_t rdyn_tsqr_workspace_doubles(int nc, int blocks);

@@ -319,12 +319,14 @@ __global__ __launch_bounds__(256) void k_regressor_tsqr(const RdynLdsGramArgs fa
 #pragma unroll
     for (int i = 0; i < NK; ++i) Rr[ci][i] = 0.0;
 
-  const int64_t n_tiles = (fa.n_samples + 15) / 16;
+  // tile_stride > 1: only every tile_stride-th tile (the subsample pass of rdyn_cholqr.hip)
+  const int64_t t_mul = fa.tile_stride > 1 ? fa.tile_stride : 1;
+  const int64_t n_tiles = ((fa.n_samples + 15) / 16 + t_mul - 1) / t_mul;
   const int64_t t_first = (int64_t)blockIdx.x * 4 + wave, t_step = (int64_t)gridDim.x * 4;
   for (int64_t tl = t_first; tl < n_tiles; tl += t_step)
   {
     // ---------------- sweep (row-pair lanes, as the sweeper of rdyn_duo_gram.hip): my sample's rows k and k + 4 -> LDS tile
-    int64_t sx = tl * 16 + s_loc;
+    int64_t sx = tl * t_mul * 16 + s_loc;
     const bool valid = sx < fa.n_samples;
     if (!valid) sx = fa.n_samples - 1;
     const int64_t o = sx * fa.in_ss;
@@ -591,6 +593,21 @@ hipError_t rdyn_launch_regressor_tsqr(int n_joints, const RdynLdsGramArgs& a, in
   case 7: return launch_regressor_tsqr<7, 0>(a, blocks, lds_bytes, slab, scratch, R, extra, st);
   default: return hipErrorInvalidValue;
   }
+}
+
+hipError_t rdyn_launch_tsqr_fold_factor(int n_joints, const double* R_new, double* R, hipStream_t st)
+{
+  const int n1 = 10 * n_joints + 1;
+#define FOLD(NJ_) \
+  case NJ_: \
+    hipLaunchKernelGGL((k_tsqr_combine<10 * NJ_ + 1>), dim3(1), dim3(64), 0, st, R_new, 1, R, n1, n1, R, n1); \
+    return hipGetLastError();
+  switch (n_joints)
+  {
+    FOLD(2) FOLD(3) FOLD(4) FOLD(5) FOLD(6) FOLD(7)
+  default: return hipErrorInvalidValue;
+  }
+#undef FOLD
 }
 
 hipError_t rdyn_launch_tsqr_rows(const double* A, const double* b, int64_t rows, int64_t lda, int n_cols, int blocks, double* workspace, double* R,

@@ -103,7 +103,9 @@ def test_accumulate_and_host_combine_equal_one_shot():
     h = 1234
     first = chain.getRegressorTsqr(q[:h].contiguous(), dq[:h].contiguous(), ddq[:h].contiguous(), tau[:h].contiguous())
     second = chain.getRegressorTsqr(q[h:].contiguous(), dq[h:].contiguous(), ddq[h:].contiguous(), tau[h:].contiguous())
-    acc = chain.getRegressorTsqr(q[h:].contiguous(), dq[h:].contiguous(), ddq[h:].contiguous(), tau[h:].contiguous(), out=first.clone(), accumulate=True)
+    out = first.clone()
+    acc = chain.getRegressorTsqr(q[h:].contiguous(), dq[h:].contiguous(), ddq[h:].contiguous(), tau[h:].contiguous(), out=out, accumulate=True)
+    assert acc is out                                    # out= is written, not only returned
     ref = full.T @ full
     for R in (acc.cpu().numpy(), tsqr_combine_host([first.cpu().numpy(), second.cpu().numpy()])):
         assert np.allclose(np.tril(R, -1), 0.0)
@@ -189,3 +191,86 @@ def test_full_size_factor_reproduces_the_mfma_normal_equations(urdf, base, tool,
     err = (R1.t() @ R1 - full).abs().max().item()
     assert err <= 1e-10 * full.abs().max().item(), err
     assert torch.equal(torch.tril(R1, -1), torch.zeros_like(R1))
+
+
+# ---- the preconditioned CholeskyQR route (rdyn_cholqr.hip): batches of >= 327 680 samples, the heavy pass on the matrix cores
+CHOLQR_N = 330000
+CHOLQR_CASES = [("ur10_like.urdf", "base_link", "wrist_3_link"),      # 6 joints: W in LDS beside the four tiles
+                ("panda_like.urdf", "link0", "link7"),                # 7 joints: W read from global memory (four tiles fill the LDS)
+                ("ur10_public.urdf", "base_link", "tool0"),           # fixed head + two fixed tail joints: reduced chain swept, factor expanded (P = 90)
+                ("panda_like.urdf", "link0", "hand")]
+
+
+def _oracle_rows(ref, q, dq, ddq, tau):
+    Y = ref.regressor(q, dq, ddq)
+    return np.column_stack([Y.reshape(-1, ref.P), tau.reshape(-1)])
+
+
+@pytest.mark.parametrize("urdf,base,tool", CHOLQR_CASES, ids=["ur10_6", "panda_7", "ur10_public_tool0", "panda_hand"])
+def test_cholqr_route_against_numpy_qr_of_the_oracle_rows(urdf, base, tool):
+    """N = 330 000 (above the 327 680-sample threshold of the route): upper triangular, R'R = M'M, the singular values of R equal those of numpy's
+    Householder factor of the oracle's rows, same minimum-norm least-squares solution; accumulation folds a second factor in."""
+    torch = pytest.importorskip("torch")
+    from oracle.oracle import OracleChain
+    from rosdyn_amd import Chain
+    from rosdyn_amd.gram import solve_r_factor
+    from rosdyn_amd.samples import trajectory_batch
+    path = os.path.join(FIXTURES, urdf)
+    chain, ref = Chain(path, base, tool, GRAV), OracleChain(path, base, tool, GRAV)
+    n, P, N = ref.n, ref.P, CHOLQR_N
+    q, dq, ddq = trajectory_batch(2024, N, n)
+    rng = np.random.default_rng(7)
+    tau = ref.joint_torque(q, dq, ddq) + 1e-3 * rng.normal(size=(N, n))
+    M = _oracle_rows(ref, q, dq, ddq, tau)
+    args = [torch.from_numpy(x).cuda() for x in (q, dq, ddq, tau)]
+    R1 = chain.getRegressorTsqr(*args).cpu().numpy()
+    assert R1.shape == (P + 1, P + 1) and np.allclose(np.tril(R1, -1), 0.0)
+    G = M.T @ M
+    assert np.abs(R1.T @ R1 - G).max() <= 1e-11 * np.abs(G).max()
+    Rq = np.linalg.qr(M, mode="r")
+    s_gpu, s_ref = np.linalg.svd(R1, compute_uv=False), np.linalg.svd(Rq, compute_uv=False)
+    keep = s_ref > 1e-9 * s_ref[0]
+    assert np.abs(s_gpu[keep] / s_ref[keep] - 1.0).max() <= 1e-9
+    assert np.all(s_gpu[~keep] <= 1e-8 * s_ref[0])
+    x, rank = solve_r_factor(R1, P, rtol=1e-9)
+    x_ls = np.linalg.lstsq(M[:, :P], M[:, P], rcond=1e-9)[0]
+    assert rank == int(keep[: P + 1].sum()) - 1 or rank == np.linalg.matrix_rank(M[:, :P], tol=1e-9 * s_ref[0])
+    assert np.abs(M[:, :P] @ (x - x_ls)).max() <= 1e-8 * np.abs(M[:, P]).max()
+    # accumulate: the factor of twice the rows
+    R2 = chain.getRegressorTsqr(*args, out=torch.from_numpy(R1).cuda(), accumulate=True).cpu().numpy()
+    assert np.allclose(np.tril(R2, -1), 0.0)
+    assert np.abs(R2.T @ R2 - 2 * G).max() <= 1e-11 * np.abs(G).max()
+    # reproducible
+    assert np.array_equal(R1, chain.getRegressorTsqr(*args).cpu().numpy())
+
+
+def test_cholqr_route_keeps_small_singular_values():
+    """A slow trajectory (velocities and accelerations scaled by 1e-5): ten gravity directions at O(1), the other 26 identifiable
+    directions at 1e-6 .. 6e-8 of that -- cond(A) ~ 2e7 on the identifiable subspace, cond^2 eps ~ 0.03.  The normal equations lose the small singular values (error ~ cond^2 eps relative to themselves); the preconditioned
+    route must return them like numpy's Householder QR of the same rows does."""
+    torch = pytest.importorskip("torch")
+    from oracle.oracle import OracleChain
+    from rosdyn_amd import Chain
+    from rosdyn_amd.samples import trajectory_batch
+    path = os.path.join(FIXTURES, "ur10_like.urdf")
+    chain, ref = Chain(path, "base_link", "wrist_3_link", GRAV), OracleChain(path, "base_link", "wrist_3_link", GRAV)
+    n, P, N = 6, 60, CHOLQR_N
+    q, dq, ddq = trajectory_batch(99, N, n)
+    dq *= 1e-5
+    ddq *= 1e-5
+    tau = ref.joint_torque(q, dq, ddq)
+    M = _oracle_rows(ref, q, dq, ddq, tau)
+    args = [torch.from_numpy(x).cuda() for x in (q, dq, ddq, tau)]
+    R1 = chain.getRegressorTsqr(*args).cpu().numpy()
+    s_ref = np.linalg.svd(np.linalg.qr(M, mode="r"), compute_uv=False)
+    s_gpu = np.linalg.svd(R1, compute_uv=False)
+    G, c, bb = chain.getRegressorGram(*args)
+    full = np.zeros((P + 1, P + 1))
+    full[:P, :P], full[:P, P], full[P, :P], full[P, P] = G.cpu().numpy(), c.cpu().numpy(), c.cpu().numpy(), float(bb.item())
+    s_ne = np.sqrt(np.abs(np.linalg.eigvalsh(full))[::-1])
+    keep = s_ref > 1e-11 * s_ref[0]                      # everything a cond-1e11 factor can hold
+    assert s_ref[keep].min() < 1e-6 * s_ref[0]           # the case is as ill conditioned as it claims
+    err_qr = np.abs(s_gpu[keep] / s_ref[keep] - 1.0).max()
+    err_ne = np.abs(s_ne[keep] / s_ref[keep] - 1.0).max()
+    assert err_qr <= 1e-5, (err_qr, err_ne)
+    assert err_ne > 100 * err_qr, (err_qr, err_ne)
