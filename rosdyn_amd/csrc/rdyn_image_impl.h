@@ -28,6 +28,7 @@
 #ifndef RDYN_IMAGE_IMPL_H
 #define RDYN_IMAGE_IMPL_H
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include "rdyn_device.h"
 #include "rdyn_devmath.h"
 #include "rdyn_kernels.h"
@@ -62,10 +63,26 @@ constexpr int image_flushes(int na)
 #ifndef RDYN_IMAGE_WAVES
 #define RDYN_IMAGE_WAVES(STACKED_, FIX_, NJ_) ((!(STACKED_) && (FIX_) == 0 && (NJ_) <= 8) ? 2 : 1)
 #endif
+#ifndef RDYN_STACKED_FLUSHES
+#define RDYN_STACKED_FLUSHES 1  // pieces a link's ten columns are staged and copied out in (stacked layout): 1, 2 or 5
+#endif
+#ifdef RDYN_STACKED_WG256
+#define RDYN_IMAGE_WG_WAVES(STACKED_) ((STACKED_) ? 4 : 1)
+#else
+#define RDYN_IMAGE_WG_WAVES(STACKED_) 1
+#endif
 template <int NJ, unsigned FIX, bool NT, bool STACKED>
-__global__ __launch_bounds__(64, RDYN_IMAGE_WAVES(STACKED, FIX, NJ)) void k_image_sweep(const RdynSweepArgs a)
+__global__ __launch_bounds__(64 * RDYN_IMAGE_WG_WAVES(STACKED), RDYN_IMAGE_WG_WAVES(STACKED) > 1 ? 1 : RDYN_IMAGE_WAVES(STACKED, FIX, NJ)) void k_image_sweep(const RdynSweepArgs a)
 {
-  const unsigned blk = blockIdx.x;
+  constexpr int IMAGE_WAVES = RDYN_IMAGE_WG_WAVES(STACKED);
+#ifdef RDYN_STACKED_XCD_REMAP
+  // A/B variant: workgroups are dealt to the 8 XCDs round-robin; give every XCD one contiguous eighth of the batch instead
+  const unsigned per = (gridDim.x + 7u) / 8u;
+  const unsigned bx = (blockIdx.x & 7u) * per + (blockIdx.x >> 3);
+#else
+  const unsigned bx = blockIdx.x;
+#endif
+  const unsigned blk = bx * IMAGE_WAVES + (IMAGE_WAVES > 1 ? (threadIdx.x >> 6) : 0);
 #include "rdyn_image_body.inc"
 }
 
@@ -78,6 +95,7 @@ __global__ __launch_bounds__(64, RDYN_IMAGE_WAVES(STACKED, FIX, NJ)) void k_imag
 #pragma clang diagnostic ignored "-Wold-style-cast"
   const RDYN_CONST_AS RdynSweepArgs& a = *((const RDYN_CONST_AS RdynSweepArgs*)table + blockIdx.y);
 #pragma clang diagnostic pop
+  constexpr int IMAGE_WAVES = 1;
   const unsigned blk = blockIdx.x;
 #include "rdyn_image_body.inc"
 }
@@ -86,15 +104,30 @@ template <int NJ, unsigned FIX, bool STACKED>
 hipError_t launch_image(const RdynSweepArgs& a, hipStream_t st)
 {
   constexpr int NA = NJ - __builtin_popcount(FIX);
-  const dim3 grid((unsigned)((a.n_samples + 63) / 64));
+  constexpr int WV = RDYN_IMAGE_WG_WAVES(STACKED);
+  const dim3 grid((unsigned)((a.n_samples + 64 * WV - 1) / (64 * WV)));
   constexpr int runf = (10 / image_flushes(NA)) * NA * 8, w = ((runf + 15) / 16) * 16 + 128, pitch = w + ((w / 16) % 2 ? 32 : 16);
-  const size_t lds = STACKED ? (size_t)10 * 64 * NA * 8 : (size_t)64 * pitch;
+  const size_t lds = (STACKED ? (size_t)(10 / RDYN_STACKED_FLUSHES) * 64 * NA * 8 : (size_t)64 * pitch) * WV;
   // nontemporal copy-out: the lines are written whole, once, and never re-read (A/B, same box: 0.55 ms vs 0.72 ms per 1e6)
 #ifdef RDYN_IMAGE_PLAIN_STORES
-  hipLaunchKernelGGL((k_image_sweep<NJ, FIX, false, STACKED>), grid, dim3(64), lds, st, a);
+  constexpr bool kNT = false;
 #else
-  hipLaunchKernelGGL((k_image_sweep<NJ, FIX, true, STACKED>), grid, dim3(64), lds, st, a);
+  constexpr bool kNT = true;
 #endif
+  if constexpr (WV > 1)
+  {
+    static std::atomic<uint64_t> attr{0};
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (!(attr.load() & (1ull << (dev & 63))))
+    {
+      e = hipFuncSetAttribute((const void*)k_image_sweep<NJ, FIX, kNT, STACKED>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      if (e != hipSuccess) return e;
+      attr.fetch_or(1ull << (dev & 63));
+    }
+  }
+  hipLaunchKernelGGL((k_image_sweep<NJ, FIX, kNT, STACKED>), grid, dim3(64 * WV), lds, st, a);
   return hipGetLastError();
 }
 template <int NJ, unsigned FIX, bool STACKED>
@@ -103,7 +136,7 @@ hipError_t launch_image_multi(const RdynSweepArgs* table, int n_items, int64_t m
   constexpr int NA = NJ - __builtin_popcount(FIX);
   const dim3 grid((unsigned)((max_samples + 63) / 64), (unsigned)n_items);
   constexpr int runf = (10 / image_flushes(NA)) * NA * 8, w = ((runf + 15) / 16) * 16 + 128, pitch = w + ((w / 16) % 2 ? 32 : 16);
-  const size_t lds = STACKED ? (size_t)10 * 64 * NA * 8 : (size_t)64 * pitch;
+  const size_t lds = STACKED ? (size_t)(10 / RDYN_STACKED_FLUSHES) * 64 * NA * 8 : (size_t)64 * pitch;
   hipLaunchKernelGGL((k_image_sweep_multi<NJ, FIX, true, STACKED>), grid, dim3(64), lds, st, table);
   return hipGetLastError();
 }

@@ -143,9 +143,19 @@ int main(int argc, char** argv)
     }
     CHECK(hipMalloc(&d_ws, ws_bytes));
   }
-  else
+  // KB_BUFFERS=k (regressor modes): k output allocations kept alive, every library timed into each of them (the output-placement
+  // lottery of DESIGN.md section 3: is a store schedule sensitive to WHERE the 2.88 GB land?)
+  std::vector<double*> y_bufs;
+  if (!(gram || ident || tsqr))
   {
-    CHECK(hipMalloc((void**)&d_Y, sizeof(double) * (size_t)N * n * P));
+    const int nbuf = getenv("KB_BUFFERS") ? std::atoi(getenv("KB_BUFFERS")) : 1;
+    for (int i = 0; i < nbuf; ++i)
+    {
+      double* p = nullptr;
+      CHECK(hipMalloc((void**)&p, sizeof(double) * (size_t)N * n * P));
+      y_bufs.push_back(p);
+    }
+    d_Y = y_bufs[0];
     CHECK(hipMalloc((void**)&d_tau, sizeof(double) * (size_t)N * n));
   }
   rdyn_regressor_layout yl;
@@ -166,8 +176,11 @@ int main(int argc, char** argv)
   };
   std::printf("%s: n = %d, P = %d, N = %lld\n", what.c_str(), n, P, (long long)N);
   for (int r = 0; r < rounds; ++r)
+   for (size_t bi = 0; bi < (y_bufs.empty() ? 1 : y_bufs.size()); ++bi)
     for (auto& l : libs)
     {
+      if (!y_bufs.empty()) d_Y = y_bufs[bi];
+      if (y_bufs.size() > 1) std::printf("  [buffer %zu] ", bi);
       for (int w = 0; w < 2; ++w)
         if (call(l) != RDYN_OK) { std::printf("%s: %s\n", l.path.c_str(), l.last_error()); return 1; }
       CHECK(hipDeviceSynchronize());
