@@ -395,12 +395,14 @@ def extras_config5(dev, steps=5, n_chains=256, S=4096):
     ms_image = t["per_sample"]   # the drop-in layout: one Eigen image per sample
     ms_element = t["element"]
     gbps = nbytes / (ms * 1e-3) / 1e9
+    traffic = committed_traffic("config5_stacked") if (n_chains, S) == (256, 4096) else None
     return {"workload": "configs[4]: %d distinct 6-/7-DOF chains x %d samples, getJointTorque + dense getRegressor, "
                         "one stacked column-major (S n) x P matrix per chain, one launch per joint-count group" % (n_chains, S),
             "value": n_chains * S / (ms * 1e-3), "unit": "evals/s", "ms_per_step": ms,
             "ms_per_step_per_sample_images": ms_image, "ms_per_step_element_major": ms_element,
             "roofline": {"bound": "hbm", "achieved": gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": gbps / HBM_PEAK_GBPS,
-                         "algorithmic_bytes_per_step": nbytes, "kernel_ms": ms, "traffic": None}}
+                         "algorithmic_bytes_per_step": nbytes, "kernel_ms": ms, "traffic": traffic,
+                         "traffic_source": "committed profile (profiles/pmc_latest.json, builder's box), not measured in this run" if traffic else None}}
 
 
 def step_into(chain, q, dq, ddq, in_layout, y_layout, Y, tau):
