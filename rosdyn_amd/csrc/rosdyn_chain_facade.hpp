@@ -613,6 +613,27 @@ public:
   {
     chk(rdyn_identification_tsqr(m_h, comps.data(), (int)comps.size(), &b, tau_meas, R1, accumulate ? 1 : 0, workspace, workspace_bytes));
   }
+  // the R factor of the stacked [regressor | tau_meas] of a batch without the normal equations (include/rdyn.h: rdyn_regressor_tsqr:
+  // Householder folds, from 327 680 samples on preconditioned CholeskyQR on the matrix cores); R1 = (10 joints + 1)^2 doubles, device
+  size_t getRegressorTsqrWorkspaceBytes() const { return rdyn_regressor_tsqr_workspace_bytes(m_h); }
+  void getRegressorTsqrBatch(const rdyn_batch& b, const double* tau_meas, double* R1, bool accumulate, void* workspace, size_t workspace_bytes) const
+  {
+    chk(rdyn_regressor_tsqr(m_h, &b, tau_meas, R1, accumulate ? 1 : 0, workspace, workspace_bytes));
+  }
+  // rigid-body reduction of a chain whose input joints are a subset of its joints (include/rdyn.h: rdyn_chain_reduction): returns the
+  // number of bodies (0: no reduction); body_joint[f] = chain index of the input joint link f + 1 rides on (-1: on the base),
+  // X = [joints][10][10] row-major with Y(:, 10 f + p) = sum_a Y(:, 10 body_joint[f] + a) X[f][a][p], pi_body = merged parameters
+  int getBodyReduction(std::vector<int32_t>& body_joint, std::vector<double>& X, VectorXd& pi_body) const
+  {
+    const int nb = rdyn_chain_reduction(m_h, nullptr, nullptr, nullptr);
+    if (nb <= 0) return 0;
+    const int nj = rdyn_chain_joints_number(m_h);
+    body_joint.assign((size_t)nj, -1);
+    X.assign((size_t)nj * 100, 0.0);
+    pi_body.resize(10 * nb);
+    rdyn_chain_reduction(m_h, body_joint.data(), X.data(), pi_body.data());
+    return nb;
+  }
   // minimum-norm solution from a factor R1 ((n + 1) x (n + 1), column-major, copied back to the host); returns the numerical rank
   static int solveRFactor(const MatrixXd& R1, VectorXd& x, double rtol = 1e-10)
   {

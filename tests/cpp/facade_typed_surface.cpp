@@ -120,6 +120,17 @@ int main()
     const rosdyn::Vector6d& s2 = joints[1]->getScrew_of_child_in_parent();
     bad += s2(0) != 1.0 || s2(3) != 0.0;
   }
+  {
+    // rigid-body reduction through the facade: the fixed tool joint folds "tool" into the body of j3 (chain index 2); X of a link that
+    // is its body's own reference frame is the identity, the merged parameters of the last body include the (massless) tool link
+    std::vector<int32_t> body;
+    std::vector<double> X;
+    rosdyn::VectorXd pib;
+    bad += c->getBodyReduction(body, X, pib) != 3 || body.size() != 4 || body[0] != 0 || body[1] != 1 || body[2] != 2 || body[3] != 2;
+    for (int a = 0; a < 10 && !bad; ++a)
+      for (int p = 0; p < 10; ++p) bad += X[(size_t)2 * 100 + a * 10 + p] != (a == p ? 1.0 : 0.0);
+    for (int k = 0; k < 10 && !bad; ++k) bad += std::fabs(pib(20 + k) - pc(20 + k)) > 1e-15;   // tool has no inertia: body 3 = link l3
+  }
   std::printf("facade typed surface: %s (%u links, %u joints, %u active, %d parameters)\n", bad ? "MISMATCH" : "ok", a->getLinksNumber(),
               a->getJointsNumber(), a->getActiveJointsNumber(), (int)pa.rows());
   return bad ? 1 : 0;

@@ -1,7 +1,8 @@
 #!/bin/bash
 # Host-side sanitizer run (CPU only; GPU sanitizers are not available on the pool): the URDF reader and chain ingest
 # (rdyn_urdf.cpp, rdyn_chain.cpp) under ASan + UBSan over 300 fuzzed chains (tests/test_gpu_fuzz.py generator) and 400
-# malformed variants of a fixture (truncations, byte flips, deleted / duplicated chunks).  Expected: no report.
+# malformed variants of a fixture (truncations, byte flips, deleted / duplicated chunks); round 3: plus the rigid-body reduction of
+# every parsed chain (as parsed, with every other input joint dropped, on a clone).  Expected: no report.
 set -e
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 W=$(mktemp -d)
@@ -52,8 +53,25 @@ int main(int argc, char** argv)
       rdyn_nominal_parameters(c, pi);
       rdyn_chain_limits(c, lim[0], lim[1], lim[2], lim[3], lim[4]);
       for (int k = 0; k < rdyn_chain_links_number(c); ++k) (void)rdyn_chain_link_name(c, k);
+      // round 3: the rigid-body reduction (rdyn_chain.cpp: build_reduced) on the chain as parsed and after dropping every other
+      // input joint (non-input moving joints fold like fixed ones)
+      int32_t body[16];
+      double X[16 * 100], pib[160];
+      (void)rdyn_chain_reduction(c, body, X, pib);
+      const int na = rdyn_chain_active_joints_number(c);
+      if (na >= 2)
+      {
+        const char* keep[16];
+        int nk = 0;
+        for (int k = 0; k < na; k += 2) keep[nk++] = rdyn_chain_active_joint_name(c, k);
+        std::string names[16];
+        for (int k = 0; k < nk; ++k) names[k] = keep[k];   // the pointers die with the re-finalised chain
+        for (int k = 0; k < nk; ++k) keep[k] = names[k].c_str();
+        if (rdyn_chain_set_input_joints(c, keep, nk) == RDYN_OK) (void)rdyn_chain_reduction(c, body, X, pib);
+      }
       rdyn_chain* d = nullptr;
       rdyn_chain_clone(c, &d);
+      if (d) (void)rdyn_chain_reduction(d, body, X, pib);
       rdyn_chain_destroy(d);
       rdyn_chain_destroy(c);
     }

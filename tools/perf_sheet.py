@@ -52,6 +52,14 @@ T = chain.getTransformation(q, layout=E)
 seeds = q + 0.25 * (torch.rand_like(q) * 2 - 1)
 row("computeLocalIk, <= 8 updates, seeds within 0.25 rad", lambda: chain.computeLocalIk(T, seeds, toll=1e-6, max_iterations=8, layout=E), 96 + 48 + 48 + 8, reps=5)
 
-print("%-52s %10s %14s %10s %10s" % ("entry point (N = 1e6 per call)", "us / call", "evals/s", "B / eval", "GB/s"))
+# round 3: the reference's own benchmark chain in its public URDF form (fixed head joint, fixed flange + tool0: 9 joints, 6 inputs, P = 90)
+pub = Chain(os.path.join(ROOT, "tests/fixtures/ur10_public.urdf"), "base_link", "tool0", (0, 0, -9.806))
+Bp = 3 * 48 + 48 + 6 * 90 * 8
+row("ur10_public base_link->tool0: getRegressor + tau (stacked)", lambda: pub.getRegressor(qs, dqs, ddqs, y_layout="stacked", with_torque=True), Bp)
+row("ur10_public base_link->tool0: getRegressor + tau (images)", lambda: pub.getRegressor(qs, dqs, ddqs, with_torque=True), Bp)
+row("ur10_public base_link->tool0: regressor -> Gram (P = 90)", lambda: pub.getRegressorGram(q, dq, ddq, tau, layout=E), 192)
+row("ur10_public base_link->tool0: R factor of [A | tau]", lambda: pub.getRegressorTsqr(q, dq, ddq, tau, layout=E), 192, reps=5)
+
+print("%-60s %10s %14s %10s %10s" % ("entry point (N = 1e6 per call)", "us / call", "evals/s", "B / eval", "GB/s"))
 for r in rows:
-    print("%-52s %10.1f %14.3e %10d %10.0f" % r)
+    print("%-60s %10.1f %14.3e %10d %10.0f" % r)
