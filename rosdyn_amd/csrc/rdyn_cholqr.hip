@@ -280,9 +280,10 @@ constexpr int kMaxN1 = 81;
 
 // Householder QR of the m x nc matrix B (column-major, leading dimension m) in LDS, in place (R in the upper triangle, zeros below),
 // by the 256 threads of the workgroup; v = m doubles of LDS, s_part / s_beta / s_v0 = workgroup-shared scratch.
-__device__ __forceinline__ void small_qr_lds(double* B, int m, int nc, double* v, double* s_part, double* s_beta, double* s_v0, int tid)
+// n_steps: columns that are reduced (the remaining ones only have the reflections applied to them); < 0: min(nc, m)
+__device__ __forceinline__ void small_qr_lds(double* B, int m, int nc, double* v, double* s_part, double* s_beta, double* s_v0, int tid, int n_steps = -1)
 {
-  const int steps = nc < m ? nc : m;
+  const int steps = n_steps >= 0 ? n_steps : (nc < m ? nc : m);
   for (int k = 0; k < steps; ++k)
   {
     double part = 0.0;
@@ -343,13 +344,17 @@ __device__ __forceinline__ void small_qr_lds(double* B, int m, int nc, double* v
 // structurally rank deficient: the pivot of a column that depends on the columns to its left is rounding residue -- and a Householder
 // factor keeps real information of LATER columns in that pivot's row.  Inverting R1 as it stands (pivot lifted to something tiny)
 // puts 1e12-sized entries into W whose effects cancel in Q = A W only in exact arithmetic.  So:
-//   null set Z   round 0: pivots below 1e-13 x their column's norm; round 1: the set of round 0 (zmask)
+//   null set Z   round 0: pivots below 1e-13 x their column's norm; round 1: the set the factor kernel of round 0 confirmed (zmask)
 //   T            the factor re-triangularised WITHOUT the null columns (Householder QR of R1(:, not Z), in LDS), embedded back at the
-//                positions of the kept columns; a null column gets its norm on the diagonal and nothing else.
+//                positions of the kept columns.  A null column k rides through the same reflections: its coefficients on the kept
+//                directions to its LEFT go into T(:, k), its diagonal is 1e-13 x its norm.  If the column is null in ALL rows, its
+//                column of Q = A W is the rounding residue / 1e-13: O(1e-3), and the factor kernel zeroes its row; if the subsample
+//                merely missed it (or it is nearly dependent: cond 1e9), its column of Q is huge, the factor kernel sees a pivot far
+//                above 1/10, keeps it and calls for the second round, which starts from a factor that holds it properly.
 //   W = T^-1     back substitution, one thread per column; written in the MFMA operand order of k_regressor_pgram.
 // Any invertible upper-triangular T serves: R = chol((A W)'(A W)) T satisfies R'R = A'A exactly; T only has to make Q = A W well
-// conditioned on its range, which the factor kernel checks.  Kept columns of Q are orthonormal on the rows T came from, null
-// columns are unit vectors inside their span (G2 singular there: the factor kernel skips those pivots).
+// conditioned on its range, which the factor kernel checks.  The rows of T at null positions hold the diagonal only, so W has no
+// large ROWS (large rows cancel in Q only in exact arithmetic); the large column W(:, k) touches nothing but the null column itself.
 __global__ __launch_bounds__(256) void k_cholqr_precond(const double* __restrict__ R1, int n1, double row_scale, double* __restrict__ Tout,
                                                         double* __restrict__ W, int* __restrict__ zmask, int zmask_given, const int* __restrict__ run_flag)
 {
@@ -385,9 +390,16 @@ __global__ __launch_bounds__(256) void k_cholqr_precond(const double* __restrict
   }
   __syncthreads();
   const int nc = s_nc;
-  for (int i = tid; i < nc * n1; i += 256) B[i] = A0[s_cmap[i / n1] * n1 + (i % n1)];
+  if (tid == 0)  // the null columns behind the kept ones
+  {
+    int nz = nc;
+    for (int c = 0; c < n1; ++c)
+      if (s_z[c]) s_cmap[nz++] = c;
+  }
   __syncthreads();
-  small_qr_lds(B, n1, nc, v, s_part, &s_beta, &s_v0, tid);
+  for (int i = tid; i < n1 * n1; i += 256) B[i] = A0[s_cmap[i / n1] * n1 + (i % n1)];
+  __syncthreads();
+  small_qr_lds(B, n1, n1, v, s_part, &s_beta, &s_v0, tid, nc);
   // T: kept columns at their positions, null columns diagonal
   for (int i = tid; i < n1 * n1; i += 256) A0[i] = 0.0;
   __syncthreads();
@@ -396,7 +408,13 @@ __global__ __launch_bounds__(256) void k_cholqr_precond(const double* __restrict
     const int a = i % nc, bcol = i / nc;
     if (a <= bcol) A0[s_cmap[bcol] * n1 + s_cmap[a]] = B[bcol * n1 + a];
   }
-  if (tid < n1 && s_z[tid]) A0[tid * n1 + tid] = s_norm[tid];
+  for (int i = tid; i < (n1 - nc) * nc; i += 256)
+  {
+    // null column k = s_cmap[nc + z]: its coefficient on kept direction a, if that direction's column lies to its left
+    const int z = i / (nc > 0 ? nc : 1), a = i - z * nc, k = s_cmap[nc + z];
+    if (s_cmap[a] < k) A0[k * n1 + s_cmap[a]] = B[(nc + z) * n1 + a];
+  }
+  if (tid < n1 && s_z[tid]) A0[tid * n1 + tid] = 1e-13 * s_norm[tid];
   __syncthreads();
   for (int i = tid; i < n1 * n1; i += 256)
   {
@@ -433,14 +451,14 @@ __global__ __launch_bounds__(256) void k_cholqr_precond(const double* __restrict
 // G2 = [G c; c' bb] (the Gram of Q = [A b] W) -> R = chol(G2) T; the pivots of the null set are skipped (their rows of R are exactly
 // zero: the rank deficiency is reported as such); *flag_out = 1 when a kept pivot of the Cholesky factor left [1/2, 2] (cond(Q) > 4)
 __global__ __launch_bounds__(256) void k_cholqr_factor(const double* __restrict__ G, const double* __restrict__ cvec, const double* __restrict__ bb, int n1,
-                                                       int has_b, const double* __restrict__ T_in, const int* __restrict__ zmask, double* __restrict__ Rout,
+                                                       int has_b, const double* __restrict__ T_in, int* __restrict__ zmask, double* __restrict__ Rout,
                                                        int* __restrict__ flag_out, const int* __restrict__ run_flag)
 {
   if (run_flag && *run_flag == 0) return;
   extern __shared__ __attribute__((aligned(16))) double sh[];
   double* const M = sh;             // [n1][n1] column-major, upper triangle = the running Cholesky factor
   double* const T = sh + n1 * n1;
-  __shared__ double s_piv;
+  __shared__ double s_piv, s_g0[kMaxN1];
   __shared__ int s_flag, s_z[kMaxN1];
   const int tid = threadIdx.x, P = n1 - 1;
   for (int i = tid; i < n1 * n1; i += 256)
@@ -456,8 +474,39 @@ __global__ __launch_bounds__(256) void k_cholqr_factor(const double* __restrict_
   if (tid < n1) s_z[tid] = zmask[tid] || (!has_b && tid == P);  // no measured torque: the last column is null by construction
   if (tid == 0) s_flag = 0;
   __syncthreads();
+  if (tid < n1) s_g0[tid] = M[tid * n1 + tid];  // |Q(:, k)|^2 before anything is eliminated
+  __syncthreads();
   for (int k = 0; k < n1; ++k)
   {
+    if (tid == 0)
+    {
+      const double d = M[k * n1 + k];
+      const double rel = d / s_g0[k];  // squared distance of Q(:, k) from the columns to its left, relative to its own length
+      s_piv = sqrt(d > 1e-30 ? d : 1e-30);
+      if (s_z[k])
+      {
+        // a column the preconditioner declared null: scaled by 1e13 / its norm, its pivot is O(1e-3) if it is rounding residue in
+        // ALL rows -- and far above 1/10 if it is not (the subsample missed it, or it is a real direction at 1e-13 .. 1e-9 of its
+        // column): then it is a pivot like any other, the set is corrected and the second round is called for.  Unless what is left
+        // of it is rounding residue of ITS OWN elimination (rel ~ 1e-16: it depends on a column to its left that the subsample missed
+        // as well -- both are huge here, and so is the residue): that stays null; a direction between 1e-8 and rounding level is
+        // left to the second round, whose preconditioner has orthogonalised it first
+        if (s_piv >= 0.1 && rel >= 1e-8)
+        {
+          s_z[k] = 0;
+          s_flag = 1;
+        }
+      }
+      else if (!(rel >= 1e-12))
+      {
+        s_z[k] = 1;  // a kept column that turns out to be numerically dependent on its left neighbours in the whole batch
+        s_flag = 1;
+      }
+      else if (s_piv < 0.5 || s_piv > 2.0)
+        s_flag = 1;
+      M[k * n1 + k] = s_piv;
+    }
+    __syncthreads();
     if (s_z[k])
     {
       // null direction: its Schur complement is rounding residue -- row k of the factor is zero, nothing is eliminated
@@ -465,14 +514,6 @@ __global__ __launch_bounds__(256) void k_cholqr_factor(const double* __restrict_
       __syncthreads();
       continue;
     }
-    if (tid == 0)
-    {
-      const double d = M[k * n1 + k];
-      s_piv = sqrt(d > 1e-30 ? d : 1e-30);
-      M[k * n1 + k] = s_piv;
-      if (s_piv < 0.5 || s_piv > 2.0) s_flag = 1;
-    }
-    __syncthreads();
     const double inv = 1.0 / s_piv;
     for (int j = k + 1 + tid; j < n1; j += 256) M[j * n1 + k] *= inv;  // row k of the factor: M(k, j), stored in column j
     __syncthreads();
@@ -494,6 +535,7 @@ __global__ __launch_bounds__(256) void k_cholqr_factor(const double* __restrict_
     Rout[e] = s;
   }
   if (tid == 0 && flag_out) *flag_out = s_flag;
+  if (flag_out && tid < n1) zmask[tid] = s_z[tid];  // round 0 hands the confirmed set to round 1
 }
 
 // Factor of the reduced chain -> factor of the chain (rdyn_chain.hpp: [A b] = [A_red b] E_aug, E_aug = diag(E, 1)):
@@ -635,7 +677,7 @@ hipError_t rdyn_launch_cholqr_precond(const double* R1, int n1, double row_scale
   return hipGetLastError();
 }
 
-hipError_t rdyn_launch_cholqr_factor(const double* G, const double* c, const double* bb, int n1, int has_b, const double* T, const int* zmask, double* R,
+hipError_t rdyn_launch_cholqr_factor(const double* G, const double* c, const double* bb, int n1, int has_b, const double* T, int* zmask, double* R,
                                      int* flag_out, const int* run_flag, hipStream_t st)
 {
   if (n1 < 2 || n1 > kMaxN1) return hipErrorInvalidValue;

@@ -198,7 +198,7 @@ hipError_t rdyn_launch_regressor_pgram(int n_joints, const RdynLdsGramArgs& a, c
 hipError_t rdyn_launch_cholqr_precond(const double* R1, int n1, double row_scale, double* T, double* W, int* zmask, int zmask_given, const int* run_flag,
                                       hipStream_t st);
 // G2 = [G c; c' bb] -> R = chol(G2) T (n1 x n1 upper, column-major; zero rows at the null set); *flag_out = 1 when the preconditioner was poor
-hipError_t rdyn_launch_cholqr_factor(const double* G, const double* c, const double* bb, int n1, int has_b, const double* T, const int* zmask, double* R,
+hipError_t rdyn_launch_cholqr_factor(const double* G, const double* c, const double* bb, int n1, int has_b, const double* T, int* zmask, double* R,
                                      int* flag_out, const int* run_flag, hipStream_t st);
 // factor of the reduced chain -> factor of the chain: R = qr([R_prev ; R_red diag(E, 1)]) (a.X, a.red_of, a.n_joints, a.n_red used)
 hipError_t rdyn_launch_cholqr_expand(const RdynGramExpandArgs& a, const double* R_red, const double* R_prev, double* R, hipStream_t st);

@@ -274,3 +274,37 @@ def test_cholqr_route_keeps_small_singular_values():
     err_ne = np.abs(s_ne[keep] / s_ref[keep] - 1.0).max()
     assert err_qr <= 1e-5, (err_qr, err_ne)
     assert err_ne > 100 * err_qr, (err_qr, err_ne)
+
+
+def test_cholqr_route_survives_an_unrepresentative_subsample():
+    """The preconditioner comes from every S-th 16-sample tile.  Here exactly those tiles are STATIC poses (zero velocities and
+    accelerations): the subsample only sees the gravity columns and its factor declares every inertia column null although the other
+    90 % of the rows excite them.  The factor kernel must
+    notice (their pivots are far above the rounding level), keep them and run the second round: same singular values as numpy's
+    Householder factor of all rows."""
+    torch = pytest.importorskip("torch")
+    from oracle.oracle import OracleChain
+    from rosdyn_amd import Chain
+    from rosdyn_amd.samples import trajectory_batch
+    path = os.path.join(FIXTURES, "ur10_like.urdf")
+    chain, ref = Chain(path, "base_link", "wrist_3_link", GRAV), OracleChain(path, "base_link", "wrist_3_link", GRAV)
+    n, P, N = 6, 60, CHOLQR_N
+    q, dq, ddq = trajectory_batch(4711, N, n)
+    tiles = (N + 15) // 16
+    stride = max(1, tiles // 2048)                       # rdyn_api.cpp: the subsample pass sweeps tiles 0, stride, 2 stride, ...
+    sub = (np.arange(N) // 16) % stride == 0
+    dq[sub] = 0.0
+    ddq[sub] = 0.0
+    tau = ref.joint_torque(q, dq, ddq) + 1e-3 * np.random.default_rng(3).normal(size=(N, n))   # a residual: the last column counts too
+    M = _oracle_rows(ref, q, dq, ddq, tau)
+    R1 = chain.getRegressorTsqr(*(torch.from_numpy(x).cuda() for x in (q, dq, ddq, tau))).cpu().numpy()
+    assert np.allclose(np.tril(R1, -1), 0.0)
+    G = M.T @ M
+    assert np.abs(R1.T @ R1 - G).max() <= 1e-11 * np.abs(G).max()
+    s_ref = np.linalg.svd(np.linalg.qr(M, mode="r"), compute_uv=False)
+    s_gpu = np.linalg.svd(R1, compute_uv=False)
+    keep = s_ref > 1e-9 * s_ref[0]
+    assert np.abs(s_gpu[keep] / s_ref[keep] - 1.0).max() <= 1e-9
+    assert np.all(s_gpu[~keep] <= 1e-8 * s_ref[0])
+    # and the subsample really was blind: its own rows have a smaller rank than the whole batch
+    assert np.linalg.matrix_rank(M[np.repeat(sub, n), :P], tol=1e-9 * s_ref[0]) < np.linalg.matrix_rank(M[:, :P], tol=1e-9 * s_ref[0])
