@@ -1240,9 +1240,11 @@ static int regressor_tsqr_run(const rdyn_chain* c, const rdyn_component* comps, 
   double* const R_swept = (expand || (cholqr && accumulate)) ? ws + L.r_swept : R;
   if (cholqr)
   {
-    // pass A: Householder factor of every S-th tile (about 2 048 tiles whatever the batch size)
+    // pass A: Householder factor of every S-th tile (about 1 024 tiles whatever the batch size: one fold per wave + the block combine
+    // + the tree; 16 384 samples = 115 000 rows for <= 71 columns put the pivots of the second factorisation within a few % of 1)
     RdynLdsGramArgs sub = la;
-    sub.tile_stride = (int)(tiles / 2048 > 1 ? tiles / 2048 : 1);
+    const int64_t kSubTiles = probe_env("RDYN_CHOLQR_SUBTILES") ? atoll(probe_env("RDYN_CHOLQR_SUBTILES")) : 1024;
+    sub.tile_stride = (int)(tiles / kSubTiles > 1 ? tiles / kSubTiles : 1);
     const int64_t sub_tiles = (tiles + sub.tile_stride - 1) / sub.tile_stride;
     const int sub_blocks = (int)((sub_tiles + 3) / 4 < kTsqrBlocks ? (sub_tiles + 3) / 4 : kTsqrBlocks);
     RDYN_HIP_TRY(rdyn_launch_regressor_tsqr(nJ, sub, sub_blocks, 4 * (size_t)la.tile_bytes, ws, ws + L.r_sub, 0, stream));

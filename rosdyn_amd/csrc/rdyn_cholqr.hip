@@ -133,6 +133,9 @@ __global__ __launch_bounds__(128 * NPAIR) void k_regressor_pgram(const RdynLdsGr
   else
   {
     // ================================================================ consumer: row group x W, then the Gram of the product
+#ifdef RDYN_CHOLQR_MFMA_PRIO
+    __builtin_amdgcn_s_setprio(RDYN_CHOLQR_MFMA_PRIO);  // A/B: the consumer is the bound of this kernel
+#endif
     const int cl = lane & 15, g = lane >> 4;
     // stage 1 operand A: lane (cl, g) supplies X[sample cl][column 16 cb1 + 4 kk + g] of the row group.  Direct chains: link f's first
     // column sits at byte 640 f^2 + 960 f of the tile, its columns are 128 f + 160 bytes apart and hold row groups 0 .. f; the measured

@@ -107,7 +107,10 @@ hipError_t launch_image(const RdynSweepArgs& a, hipStream_t st)
   constexpr int WV = RDYN_IMAGE_WG_WAVES(STACKED);
   const dim3 grid((unsigned)((a.n_samples + 64 * WV - 1) / (64 * WV)));
   constexpr int runf = (10 / image_flushes(NA)) * NA * 8, w = ((runf + 15) / 16) * 16 + 128, pitch = w + ((w / 16) % 2 ? 32 : 16);
-  const size_t lds = (STACKED ? (size_t)(10 / RDYN_STACKED_FLUSHES) * 64 * NA * 8 : (size_t)64 * pitch) * WV;
+  size_t lds = (STACKED ? (size_t)(10 / RDYN_STACKED_FLUSHES) * 64 * NA * 8 : (size_t)64 * pitch) * WV;
+#ifdef RDYN_IMAGE_LDS_FORCE
+  lds = RDYN_IMAGE_LDS_FORCE;  // timing experiment: limits the waves per CU through the LDS request
+#endif
   // nontemporal copy-out: the lines are written whole, once, and never re-read (A/B, same box: 0.55 ms vs 0.72 ms per 1e6)
 #ifdef RDYN_IMAGE_PLAIN_STORES
   constexpr bool kNT = false;

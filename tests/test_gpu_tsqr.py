@@ -291,7 +291,7 @@ def test_cholqr_route_survives_an_unrepresentative_subsample():
     n, P, N = 6, 60, CHOLQR_N
     q, dq, ddq = trajectory_batch(4711, N, n)
     tiles = (N + 15) // 16
-    stride = max(1, tiles // 2048)                       # rdyn_api.cpp: the subsample pass sweeps tiles 0, stride, 2 stride, ...
+    stride = max(1, tiles // 1024)                       # rdyn_api.cpp: the subsample pass sweeps tiles 0, stride, 2 stride, ...
     sub = (np.arange(N) // 16) % stride == 0
     dq[sub] = 0.0
     ddq[sub] = 0.0
