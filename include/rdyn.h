@@ -377,6 +377,7 @@ int rdyn_regressor_gram_multi(rdyn_multi_gpu* ctx, const rdyn_chain* chain, cons
  * factor R1 of a row subsample, W = R1^-1 without its null columns, G2 = (A W)'(A W) over all rows by MFMA, R = chol(G2) R1 with a
  * pivot check and an automatic second round; ~2.3x the time of rdyn_regressor_gram; rows of R at structurally dependent columns
  * are exactly zero).  Both return R1 with R1'R1 = [A b]'[A b] to rounding and the small singular values to ~cond * eps.
+ * rdyn_identification_tsqr takes the same two routes (the component columns ride in the LDS tile as one more 16-column block).
  * rdyn_identification_tsqr: the same for the identification step's [Y | C | tau_meas] (C = the component columns of
  * rdyn_components_regressor, K = rdyn_components_columns): n1 = 10 joints_number + K + 1, unknowns [inertial ; component]
  * parameters; chains of 2..6 joints, 10 joints_number + 1 + K <= 16 (ceil((10 joints_number + 1) / 16) + 1). */

@@ -1134,10 +1134,12 @@ struct TsqrLayout
   size_t slabs = 0, w = 0, r_sub = 0, r1p = 0, g2 = 0, r_swept = 0, flag = 0, total_doubles = 0;  // offsets (doubles) of region 2
 };
 static const int kCholqrBlocks = 256;
-static TsqrLayout tsqr_layout(int n_joints_swept)
+// xb = 1: with component columns (one more 16-column block; the factors are sized for the padded width 16 nb)
+static TsqrLayout tsqr_layout(int n_joints_swept, int xb = 0)
 {
   TsqrLayout L;
-  const int n1 = 10 * n_joints_swept + 1, nb = (n1 + 15) / 16, nt = nb * (nb + 1) / 2;
+  const int nb = (10 * n_joints_swept + 1 + 15) / 16 + xb, nt = nb * (nb + 1) / 2;
+  const int n1 = xb ? 16 * nb : 10 * n_joints_swept + 1;
   L.householder_doubles = rdyn_tsqr_workspace_doubles(n1, kTsqrBlocks);
   size_t off = (L.householder_doubles + 31) & ~(size_t)31;
   auto take = [&](size_t doubles) {
@@ -1183,8 +1185,8 @@ static int regressor_tsqr_run(const rdyn_chain* c, const rdyn_component* comps, 
                    "are supported", who);
     return RDYN_ERR_UNSUPPORTED;
   }
-  const TsqrLayout L = tsqr_layout(nJ);
-  const size_t need = n_comps > 0 ? rdyn_tsqr_workspace_doubles(nc, kTsqrBlocks) * sizeof(double) : L.total_doubles * sizeof(double);
+  const TsqrLayout L = tsqr_layout(nJ, n_comps > 0 ? 1 : 0);
+  const size_t need = L.total_doubles * sizeof(double);
   if (workspace_bytes < need)
   {
     rdyn_set_error("%s: workspace too small", who);
@@ -1230,7 +1232,7 @@ static int regressor_tsqr_run(const rdyn_chain* c, const rdyn_component* comps, 
   // ---- which route.  Preconditioned CholeskyQR (rdyn_cholqr.hip: the heavy pass on the matrix cores) for large batches of chains
   // whose swept form has every joint as an input joint; the Householder folds (rdyn_tsqr.hip) otherwise.
   const char* route_env = probe_env("RDYN_TSQR_ROUTE");  // A/B builds only: "householder" / "cholqr"
-  const int pairs = (n_comps == 0 && n == nJ) ? rdyn_cholqr_pairs(nJ, la.tile_bytes) : 0;
+  const int pairs = n == nJ ? rdyn_cholqr_pairs(nJ, la.tile_bytes, n_comps > 0 ? 1 : 0) : 0;
   // ~1.0 ms of fixed cost (subsample leaves + tree + the two small dense kernels) against 0.9 / 1.4 ms per 1e6 samples (6 / 7 joints);
   // the Householder route: 0.4 ms + 2.8 / 3.8 ms per 1e6 samples -> break-even near 3e5 samples
   const int64_t kCholqrMinTiles = 20480;  // 327 680 samples
@@ -1272,7 +1274,7 @@ static int regressor_tsqr_run(const rdyn_chain* c, const rdyn_component* comps, 
       RDYN_HIP_TRY(rdyn_launch_gram_finish(ga, blocks, stream));
       RDYN_HIP_TRY(rdyn_launch_cholqr_factor(ga.G, ga.c, ga.bb, n1s, tau_meas ? 1 : 0, ws + L.r1p, flag + 16, R_swept, round == 0 ? flag : nullptr, run, stream));
     }
-    if (!expand && accumulate) RDYN_HIP_TRY(rdyn_launch_tsqr_fold_factor(nJ, R_swept, R, stream));
+    if (!expand && accumulate) RDYN_HIP_TRY(rdyn_launch_cholqr_fold(R_swept, R, n1s, stream));
   }
   else
   {
@@ -1315,7 +1317,7 @@ size_t rdyn_identification_tsqr_workspace_bytes(const rdyn_chain* c, const rdyn_
   const int K = n_comps > 0 ? rdyn_components_columns(comps, n_comps) : 0;
   const int nc = K < 0 ? 0 : rdyn_regressor_tsqr_cols(c->n_joints(), K);
   if (nc == 0 || c->n_joints() < 2 || c->n_joints() > 7) return 0;
-  return rdyn_tsqr_workspace_doubles(nc, kTsqrBlocks) * sizeof(double);
+  return tsqr_layout(c->n_joints(), 1).total_doubles * sizeof(double);
 }
 
 int rdyn_identification_tsqr(const rdyn_chain* c, const rdyn_component* comps, int n_comps, const rdyn_batch* b, const double* tau_meas, double* R,

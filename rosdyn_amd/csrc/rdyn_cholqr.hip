@@ -45,11 +45,13 @@ namespace
 // Every chain joint is an input joint, in chain order (the reduced companion of a chain with fixed joints qualifies).
 // WGLOBAL: W stays in global memory (30 KB at 7 joints: L1 / L2 resident) and the consumer loads its operands from there -- the LDS
 // then holds four tiles again where W + four tiles exceed 160 KB (7 joints).
-template <int NJ, bool ALLREV, int NPAIR, bool WGLOBAL>
+// XB = 1: the per-joint component columns of rdyn_identification_tsqr ride in the tile ([Y | C | tau_meas], one more 16-column block), as
+// in rdyn_duo_gram.hip: a component column is stored as ONE 16-row group, that of its own joint.
+template <int NJ, bool ALLREV, int NPAIR, bool WGLOBAL, int XB>
 __global__ __launch_bounds__(128 * NPAIR) void k_regressor_pgram(const RdynLdsGramArgs fa, const double* __restrict__ Wg, const int* __restrict__ run_flag)
 {
   constexpr bool DIRECT = true;
-  constexpr int NB = (10 * NJ + 1 + 15) / 16, NT = NB * (NB + 1) / 2, P = 10 * NJ;
+  constexpr int NB = (10 * NJ + 1 + 15) / 16 + XB, NT = NB * (NB + 1) / 2, P = 10 * NJ;
   constexpr int WB = WGLOBAL ? 0 : NT * 2048;  // W in operand order: per (cb1 <= cb2) block four k-steps of 64 doubles
   if (run_flag && *run_flag == 0) return;  // second round not needed (uniform: every wave leaves)
   extern __shared__ __attribute__((aligned(32))) char lds_raw[];
@@ -122,6 +124,11 @@ __global__ __launch_bounds__(128 * NPAIR) void k_regressor_pgram(const RdynLdsGr
       {
 #include "rdyn_duo_link_body.inc"
       }
+      if constexpr (XB > 0)
+      {
+        // the consumer has read every row group of the previous tile by now (the last link's barrier is behind us)
+#include "rdyn_duo_comp_cols.inc"
+      }
       {
         char* const lb = tile + fa.lds_off_b + s_loc * 8;
         if (r0 < n) *(double*)(lb + r0 * 128) = tb0;
@@ -141,13 +148,43 @@ __global__ __launch_bounds__(128 * NPAIR) void k_regressor_pgram(const RdynLdsGr
     // column sits at byte 640 f^2 + 960 f of the tile, its columns are 128 f + 160 bytes apart and hold row groups 0 .. f; the measured
     // torque (column P) holds every row group, columns beyond are padding.  Computed per operand (a handful of 32-bit instructions
     // under the MFMAs) instead of kept in 20 registers.
+    // columns from P on ([C (K) | tau_meas | padding]; K = 0 without components): per-lane offset and row group of the (cb1, kk)
+    // operands that can reach them, looked up once (the component table is a kernel argument indexed by a lane-dependent column)
+    constexpr int X0 = P / 4, NX = 4 * NB - X0;  // operand ids 4 cb1 + kk >= X0 touch columns >= P
+    const int K = XB > 0 ? fa.n_comp_cols : 0;
+    int xoff[NX], xrow[NX];  // xrow: the one row group stored, -1 = every row group (tau_meas), -2 = nothing (padding / a link column)
+#pragma unroll
+    for (int i = 0; i < NX; ++i)
+    {
+      const int col = 4 * (X0 + i) + g;
+      int off = 0, row = -2;
+      if (col >= P && col < P + K)
+      {
+        row = fa.comp_col_row[col - P];
+        off = fa.lds_off_c + (col - P) * fa.comp_stride - row * 128;
+      }
+      else if (col == P + K)
+      {
+        off = fa.lds_off_b;
+        row = -1;
+      }
+      xoff[i] = off + cl * 8;
+      xrow[i] = row;
+    }
     auto a_operand = [&](int cb1, int kk, int j) -> double {
-      const int col = 16 * cb1 + 4 * kk + g;
-      const int f = (col * 205) >> 11;  // col / 10 for col < 1024
-      const int off = col < P ? f * (640 * f + 960) + (col - 10 * f) * (128 * f + 160) : fa.lds_off_b;
-      const bool stored = col < P ? j <= f : col == P;
+      const int id = 4 * cb1 + kk, col = 4 * id + g;
       double a = 0.0;
-      if (stored) a = *(const double*)(tile + off + cl * 8 + j * 128);
+      if (id < X0 || (4 * id < P && col < P))  // a link column (the second test: an operand that straddles P)
+      {
+        const int f = (col * 205) >> 11;  // col / 10 for col < 1024
+        const int off = f * (640 * f + 960) + (col - 10 * f) * (128 * f + 160);
+        if (j <= f) a = *(const double*)(tile + off + cl * 8 + j * 128);
+      }
+      else
+      {
+        const int i = id - X0;
+        if (xrow[i] == -1 || xrow[i] == j) a = *(const double*)(tile + xoff[i] + j * 128);
+      }
       return a;
     };
     d4 acc[NT];
@@ -591,6 +628,29 @@ __global__ __launch_bounds__(256) void k_cholqr_expand(const RdynGramExpandArgs 
 }
 
 // max_bytes: dynamic LDS the kernel may ask for (kernels with static __shared__ variables must leave room for them inside 160 KB)
+// R <- qr([R ; R_new]): both n1 x n1 upper triangular, column-major (the accumulate step of the preconditioned route: any width)
+__global__ __launch_bounds__(256) void k_cholqr_fold(const double* __restrict__ R_new, double* __restrict__ R, int n1)
+{
+  extern __shared__ __attribute__((aligned(16))) double sh[];
+  const int m = 2 * n1;
+  double* const B = sh;
+  double* const v = sh + n1 * m;
+  __shared__ double s_part[256], s_beta, s_v0;
+  const int tid = threadIdx.x;
+  for (int e = tid; e < n1 * m; e += 256)
+  {
+    const int r = e % m, col = e / m;
+    B[e] = r < n1 ? (r <= col ? R[(int64_t)col * n1 + r] : 0.0) : (r - n1 <= col ? R_new[(int64_t)col * n1 + r - n1] : 0.0);
+  }
+  __syncthreads();
+  small_qr_lds(B, m, n1, v, s_part, &s_beta, &s_v0, tid);
+  for (int e = tid; e < n1 * n1; e += 256)
+  {
+    const int r = e % n1, col = e / n1;
+    R[e] = r <= col ? B[col * m + r] : 0.0;
+  }
+}
+
 template <class K>
 hipError_t opt_in_lds_once(K kernel, std::atomic<uint64_t>& done, int max_bytes = 160 * 1024)
 {
@@ -607,22 +667,34 @@ hipError_t opt_in_lds_once(K kernel, std::atomic<uint64_t>& done, int max_bytes 
   return hipSuccess;
 }
 
-template <int NJ, bool ALLREV, int NPAIR, bool WGLOBAL>
+template <int NJ, bool ALLREV, int NPAIR, bool WGLOBAL, int XB = 0>
 hipError_t launch_pgram3(const RdynLdsGramArgs& a, const double* W, const int* run_flag, int blocks, hipStream_t st)
 {
   static std::atomic<uint64_t> attr{0};
-  hipError_t e = opt_in_lds_once(k_regressor_pgram<NJ, ALLREV, NPAIR, WGLOBAL>, attr);
+  hipError_t e = opt_in_lds_once(k_regressor_pgram<NJ, ALLREV, NPAIR, WGLOBAL, XB>, attr);
   if (e != hipSuccess) return e;
-  constexpr int NB = (10 * NJ + 1 + 15) / 16, NT = NB * (NB + 1) / 2;
+  constexpr int NB = (10 * NJ + 1 + 15) / 16 + XB, NT = NB * (NB + 1) / 2;
   size_t lds = (WGLOBAL ? 0 : (size_t)NT * 2048) + (size_t)NPAIR * a.tile_bytes;
   if (lds < (size_t)NT * 2048) lds = (size_t)NT * 2048;  // the final reduction area
-  hipLaunchKernelGGL((k_regressor_pgram<NJ, ALLREV, NPAIR, WGLOBAL>), dim3(blocks), dim3(128 * NPAIR), lds, st, a, W, run_flag);
+  hipLaunchKernelGGL((k_regressor_pgram<NJ, ALLREV, NPAIR, WGLOBAL, XB>), dim3(blocks), dim3(128 * NPAIR), lds, st, a, W, run_flag);
   return hipGetLastError();
 }
 // pairs: 4 = W in LDS beside four tiles; 3 = W in LDS beside three tiles; -4 = four tiles, W read from global memory
 template <int NJ>
 hipError_t launch_pgram(const RdynLdsGramArgs& a, const double* W, const int* run_flag, int blocks, int pairs, hipStream_t st)
 {
+  if (a.n_comp_cols > 0)
+  {
+    // [Y | C | tau_meas]: chains of up to 6 joints (as the Householder route), W beside the four tiles or in global memory
+    if constexpr (NJ <= 6)
+    {
+      if (pairs == 4)
+        return a.all_revolute ? launch_pgram3<NJ, true, 4, false, 1>(a, W, run_flag, blocks, st) : launch_pgram3<NJ, false, 4, false, 1>(a, W, run_flag, blocks, st);
+      if (pairs == -4)
+        return a.all_revolute ? launch_pgram3<NJ, true, 4, true, 1>(a, W, run_flag, blocks, st) : launch_pgram3<NJ, false, 4, true, 1>(a, W, run_flag, blocks, st);
+    }
+    return hipErrorInvalidValue;
+  }
   if (pairs == 4)
     return a.all_revolute ? launch_pgram3<NJ, true, 4, false>(a, W, run_flag, blocks, st) : launch_pgram3<NJ, false, 4, false>(a, W, run_flag, blocks, st);
   if constexpr (NJ >= 7)
@@ -636,16 +708,16 @@ hipError_t launch_pgram(const RdynLdsGramArgs& a, const double* W, const int* ru
 }
 }  // namespace
 
-size_t rdyn_cholqr_w_doubles(int n_joints)
+size_t rdyn_cholqr_w_doubles(int n_joints, int xb)
 {
-  const int nb = (10 * n_joints + 1 + 15) / 16;
+  const int nb = (10 * n_joints + 1 + 15) / 16 + xb;
   return (size_t)(nb * (nb + 1) / 2) * 256;
 }
 
-int rdyn_cholqr_pairs(int n_joints, int tile_bytes)
+int rdyn_cholqr_pairs(int n_joints, int tile_bytes, int xb)
 {
-  if (n_joints < 2 || n_joints > 7) return 0;
-  const size_t wb = rdyn_cholqr_w_doubles(n_joints) * 8;
+  if (n_joints < 2 || n_joints > (xb ? 6 : 7)) return 0;
+  const size_t wb = rdyn_cholqr_w_doubles(n_joints, xb) * 8;
   if (wb + 4 * (size_t)tile_bytes <= 160 * 1024) return 4;
 #ifdef RDYN_CHOLQR_W_LDS3
   if (wb + 3 * (size_t)tile_bytes <= 160 * 1024) return 3;
@@ -701,5 +773,15 @@ hipError_t rdyn_launch_cholqr_expand(const RdynGramExpandArgs& a, const double* 
   hipError_t e = opt_in_lds_once(k_cholqr_expand, attr, 156 * 1024);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(k_cholqr_expand, dim3(1), dim3(256), lds, st, a, R_red, R_prev, R);
+  return hipGetLastError();
+}
+
+hipError_t rdyn_launch_cholqr_fold(const double* R_new, double* R, int n1, hipStream_t st)
+{
+  if (n1 < 1 || n1 > kMaxN1) return hipErrorInvalidValue;
+  static std::atomic<uint64_t> attr{0};
+  hipError_t e = opt_in_lds_once(k_cholqr_fold, attr, 128 * 1024);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(k_cholqr_fold, dim3(1), dim3(256), ((size_t)2 * n1 * n1 + 2 * n1) * sizeof(double), st, R_new, R, n1);
   return hipGetLastError();
 }

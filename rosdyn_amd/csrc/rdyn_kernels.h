@@ -190,8 +190,10 @@ hipError_t rdyn_launch_regressor_gram_duo(int n_cols, const RdynLdsGramArgs& a, 
 // preconditioned CholeskyQR (rdyn_cholqr.hip): R factor of [A | b] with the heavy pass on the fp64 matrix cores.
 //   W = R1^-1 of a Householder factor R1 of a row SUBSAMPLE (rdyn_tsqr.hip);  G2 = (A W)'(A W) over ALL rows: sweep -> LDS tile -> the
 //   consumer wave multiplies every 16-row group by W (MFMA) and accumulates the Gram of the product (MFMA);  R = chol(G2) R1.
-int rdyn_cholqr_pairs(int n_joints, int tile_bytes);          // wave pairs per workgroup that fit 160 KB of LDS next to W (0: unsupported)
-size_t rdyn_cholqr_w_doubles(int n_joints);                   // W in MFMA operand order
+// xb = 1: one more 16-column block for the component columns of rdyn_identification_tsqr (chains of <= 6 joints)
+int rdyn_cholqr_pairs(int n_joints, int tile_bytes, int xb);  // 4: W in LDS beside four tiles; -4: four tiles, W in global memory; 0: unsupported
+size_t rdyn_cholqr_w_doubles(int n_joints, int xb);           // W in MFMA operand order
+hipError_t rdyn_launch_cholqr_fold(const double* R_new, double* R, int n1, hipStream_t st);  // R <- qr([R ; R_new]), n1 <= 81
 hipError_t rdyn_launch_regressor_pgram(int n_joints, const RdynLdsGramArgs& a, const double* W, const int* run_flag, int blocks, int pairs, hipStream_t st);
 // R1 (n1 x n1 upper, column-major) -> T = R1 re-triangularised without its null columns (zmask: found when !zmask_given, else used),
 // W = T^-1 in MFMA operand order.  row_scale: R1 is the factor of one row in row_scale^2 (the subsample), T is scaled to all rows.
@@ -202,8 +204,6 @@ hipError_t rdyn_launch_cholqr_factor(const double* G, const double* c, const dou
                                      int* flag_out, const int* run_flag, hipStream_t st);
 // factor of the reduced chain -> factor of the chain: R = qr([R_prev ; R_red diag(E, 1)]) (a.X, a.red_of, a.n_joints, a.n_red used)
 hipError_t rdyn_launch_cholqr_expand(const RdynGramExpandArgs& a, const double* R_red, const double* R_prev, double* R, hipStream_t st);
-// one more factor folded into a running one: R <- qr([R ; R_new]) (both n1 x n1 upper, column-major; n1 = 10 n_joints + 1, <= 7 joints)
-hipError_t rdyn_launch_tsqr_fold_factor(int n_joints, const double* R_new, double* R, hipStream_t st);
 // tall-skinny QR (rdyn_tsqr.hip): R factor of [A | b] without forming A'A
 int rdyn_tsqr_padded_cols(int n_cols_with_rhs);              // 16 / 32 / 48 / 64, 0 = unsupported
 size_t rdyn_tsqr_workspace_doubles(int nc, int blocks);

@@ -595,21 +595,6 @@ hipError_t rdyn_launch_regressor_tsqr(int n_joints, const RdynLdsGramArgs& a, in
   }
 }
 
-hipError_t rdyn_launch_tsqr_fold_factor(int n_joints, const double* R_new, double* R, hipStream_t st)
-{
-  const int n1 = 10 * n_joints + 1;
-#define FOLD(NJ_) \
-  case NJ_: \
-    hipLaunchKernelGGL((k_tsqr_combine<10 * NJ_ + 1>), dim3(1), dim3(64), 0, st, R_new, 1, R, n1, n1, R, n1); \
-    return hipGetLastError();
-  switch (n_joints)
-  {
-    FOLD(2) FOLD(3) FOLD(4) FOLD(5) FOLD(6) FOLD(7)
-  default: return hipErrorInvalidValue;
-  }
-#undef FOLD
-}
-
 hipError_t rdyn_launch_tsqr_rows(const double* A, const double* b, int64_t rows, int64_t lda, int n_cols, int blocks, double* workspace, double* R,
                                  int accumulate, hipStream_t st)
 {

@@ -308,3 +308,47 @@ def test_cholqr_route_survives_an_unrepresentative_subsample():
     assert np.all(s_gpu[~keep] <= 1e-8 * s_ref[0])
     # and the subsample really was blind: its own rows have a smaller rank than the whole batch
     assert np.linalg.matrix_rank(M[np.repeat(sub, n), :P], tol=1e-9 * s_ref[0]) < np.linalg.matrix_rank(M[:, :P], tol=1e-9 * s_ref[0])
+
+
+def test_cholqr_route_with_component_columns():
+    """rdyn_identification_tsqr above the route's threshold: [Y | friction / spring columns | tau_meas] through the preconditioned
+    CholeskyQR route (the component columns ride in the LDS tile as one more 16-column block): R'R = M'M, the singular values of
+    numpy's Householder factor of the oracle's rows, the friction coefficients come back from the factor, accumulation."""
+    torch = pytest.importorskip("torch")
+    from oracle.oracle import OracleChain, components_regressor
+    from rosdyn_amd import Chain
+    from rosdyn_amd.components import FRICTION1, FRICTION2, SPRING, ComponentSet
+    from rosdyn_amd.gram import solve_r_factor
+    from rosdyn_amd.samples import trajectory_batch
+    path = os.path.join(FIXTURES, "ur10_like.urdf")
+    chain, ref = Chain(path, "base_link", "wrist_3_link", GRAV), OracleChain(path, "base_link", "wrist_3_link", GRAV)
+    n, P, N = 6, 60, CHOLQR_N
+    q, dq, ddq = trajectory_batch(808, N, n)
+    kinds = [FRICTION1, FRICTION2, SPRING]
+    specs, dicts = [], []
+    for j in range(n):
+        ty = kinds[j % 3]
+        par = [0.5 + 0.1 * j, 1.0 + 0.2 * j] + ([0.05] if ty == FRICTION2 else [])
+        specs.append((ty, j, 1e-3, 5.0, par))
+        dicts.append(dict(type=ty, joint=j, min_velocity=1e-3, max_velocity=5.0, parameters=par))
+    comps = ComponentSet(dicts, n)
+    K = comps.columns
+    Cm, tau_c = components_regressor(specs, n, q, dq)
+    rng = np.random.default_rng(11)
+    tau = ref.joint_torque(q, dq, ddq) + tau_c + 1e-3 * rng.normal(size=(N, n))
+    M = np.column_stack([ref.regressor(q, dq, ddq).reshape(-1, P), Cm.reshape(-1, K), tau.reshape(-1)])
+    args = [torch.from_numpy(x).cuda() for x in (q, dq, ddq, tau)]
+    R1 = chain.getIdentificationTsqr(comps, *args).cpu().numpy()
+    n1 = P + K + 1
+    assert R1.shape == (n1, n1) and np.allclose(np.tril(R1, -1), 0.0)
+    G = M.T @ M
+    assert np.abs(R1.T @ R1 - G).max() <= 1e-11 * np.abs(G).max()
+    s_ref = np.linalg.svd(np.linalg.qr(M, mode="r"), compute_uv=False)
+    s_gpu = np.linalg.svd(R1, compute_uv=False)
+    keep = s_ref > 1e-9 * s_ref[0]
+    assert np.abs(s_gpu[keep] / s_ref[keep] - 1.0).max() <= 1e-9
+    x, rank = solve_r_factor(R1, P + K, rtol=1e-9)
+    truth = np.concatenate([sp[4] for sp in specs])
+    assert np.abs(x[P:] - truth).max() < 0.01
+    R2 = chain.getIdentificationTsqr(comps, *args, out=torch.from_numpy(R1).cuda(), accumulate=True).cpu().numpy()
+    assert np.allclose(np.tril(R2, -1), 0.0) and np.abs(R2.T @ R2 - 2 * G).max() <= 1e-11 * np.abs(G).max()
