@@ -133,21 +133,22 @@ def test_chain_from_desc_equals_chain_from_urdf():
     assert np.array_equal(a.getGravity(), b.getGravity())
 
 
-def _build_c_example(tmp_path):
+def _build_c_example(tmp_path, name="regressor_batch"):
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    exe = str(tmp_path / "regressor_batch")
+    exe = str(tmp_path / name)
     cmd = ["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-I" + os.path.join(root, "include"),
-           os.path.join(root, "examples", "regressor_batch.c"), "-L" + os.path.join(root, "rosdyn_amd"), "-lrdyn_hip", "-L/opt/rocm/lib",
-           "-lamdhip64", "-Wl,-rpath," + os.path.join(root, "rosdyn_amd"), "-Wl,-rpath,/opt/rocm/lib", "-o", exe]
+           os.path.join(root, "examples", name + ".c"), "-L" + os.path.join(root, "rosdyn_amd"), "-lrdyn_hip", "-L/opt/rocm/lib",
+           "-lamdhip64", "-lm", "-Wl,-rpath," + os.path.join(root, "rosdyn_amd"), "-Wl,-rpath,/opt/rocm/lib", "-o", exe]
     r = subprocess.run(cmd, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     return exe
 
 
 def test_header_is_plain_c_and_the_c_example_links(tmp_path):
-    """include/rdyn.h compiles as C99 (no C++-isms cross the ABI) and examples/regressor_batch.c links against the library."""
+    """include/rdyn.h compiles as C99 (no C++-isms cross the ABI) and the examples link against the library."""
     _build_c_example(tmp_path)
+    _build_c_example(tmp_path, "identify")
 
 
 @pytest.mark.gpu
@@ -158,6 +159,18 @@ def test_c_example_runs(tmp_path):
                        timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "n = 6, P = 60" in r.stdout
+
+
+@pytest.mark.gpu
+def test_c_identification_example_runs(tmp_path):
+    """examples/identify.c: the reference's benchmark chain in its public URDF form (9 joints, 6 input joints, P = 90) from plain C --
+    torques -> fused Gram and R factor (400 000 samples: the preconditioned CholeskyQR route, reduced chain + expansion) -> parameters
+    that reproduce the torques; both solves agree on the rank."""
+    import subprocess
+    exe = _build_c_example(tmp_path, "identify")
+    r = subprocess.run([exe, os.path.join(FIXTURES, "ur10_public.urdf"), "base_link", "tool0", "400000"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "n = 6, P = 90 (6 rigid bodies)" in r.stdout
 
 
 def test_hostile_urdf_is_rejected_not_crashed():
