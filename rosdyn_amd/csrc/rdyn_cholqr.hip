@@ -5,23 +5,27 @@
 // 15.8 ms at config 3 (7 joints, 4e6 samples) with the matrix pipe idle.  The plain Gram route (rdyn_duo_gram.hip + Cholesky) runs
 // at 2.8 ms but squares the condition number.  This file sits between the two -- preconditioned CholeskyQR:
 //
-//   pass A   R1 = Householder factor (rdyn_tsqr.hip, unchanged) of a ROW SUBSAMPLE: every S-th 16-sample tile, ~2 000 tiles whatever
+//   pass A   R1 = Householder factor (rdyn_tsqr.hip, unchanged) of a ROW SUBSAMPLE: every S-th 16-sample tile, ~1 000 tiles whatever
 //            the batch size (~0.5 ms).  Backward stable; for a batch whose rows are exchangeable (trajectory samples) R1 differs from
 //            the factor of all rows by a well-conditioned factor.
-//   inverse  W = R1^-1 (back substitution, one thread per column, one workgroup), pivots below 1e-13 x their column's norm lifted to
-//            that level first (structurally dependent regressor columns: exact rank deficiency).
+//   precond  k_cholqr_precond: T = R1 scaled to all rows and re-triangularised without its NULL columns (a regressor is structurally
+//            rank deficient: pivots below 1e-13 x their column's norm; those columns ride through the reflections and get 1e-13 x their
+//            norm on the diagonal), W = T^-1 by back substitution, written in MFMA operand order.
 //   pass B   k_regressor_pgram: ALL rows.  The wave-pair design of rdyn_duo_gram.hip: the sweeper wave drops every finished link's
 //            regressor rows into the pair's LDS tile; the consumer wave multiplies each 16-row group by W (v_mfma_f64_16x16x4_f64,
 //            W in LDS in operand order) and accumulates the Gram of the PRODUCT straight from the result registers (the D layout of
 //            the first MFMA is the A/B operand layout of the second: no transposition, no LDS round trip).  Q = A W is never stored.
 //            Block-triangular zero band of a row group: preserved by the upper-triangular W, skipped in both stages.
-//   factor   G2 = Q'Q is well conditioned (cond(Q) ~ 1): R2 = chol(G2 + 1e-14 max diag), R = R2 R1.  R'R = [A b]'[A b] to rounding,
-//            whatever the quality of R1; the ACCURACY of R is that of CholeskyQR on Q, u cond(Q)^2 -- so the factor kernel
-//            checks the pivots of R2: all within [1/2, 2] (cond(Q) <= 4) or a SECOND round runs with W = R^-1 (CholeskyQR2 on top of
-//            the preconditioner; the round's kernels are always queued and leave at once when the device flag says "not needed").
+//   factor   k_cholqr_factor: G2 = Q'Q is well conditioned (cond(Q) ~ 1): R2 = chol(G2), R = R2 T.  R'R = [A b]'[A b] to rounding,
+//            whatever the quality of T; the ACCURACY of R is that of CholeskyQR on Q, u cond(Q)^2 -- so the kernel checks the
+//            pivots of R2: all kept ones within [1/2, 2] (cond(Q) <= 4), and the null set is validated against ALL rows (a null
+//            column's pivot is O(1e-3); a large one is a direction the subsample missed) -- or a SECOND round runs with W = R^-1
+//            (CholeskyQR2 on top of the preconditioner; the round's kernels are always queued and leave at once when the device
+//            flag says "not needed").  Rows of R at confirmed null columns are exactly zero.
 //
 // fp64 throughout.  The multiplication by an explicit inverse (instead of a triangular solve) keeps every step a matrix product;
 // its rounding enters as |A| |W| u per row, which the pivot check of the second factorisation sees like any other loss.
+// k_cholqr_expand: factor of the reduced chain -> factor of a chain with fixed joints; k_cholqr_fold: the accumulate step.
 #include <hip/hip_runtime.h>
 #include <atomic>
 #include <cstdint>
