@@ -30,12 +30,19 @@ CASES = {
     "ur10_permuted":   ("ur10_like.urdf", "base_link", "tool0", GRAV,
                         ["wrist_3_joint", "shoulder_pan_joint", "elbow_joint", "wrist_1_joint"], 0x5EED0024),
     "planar_2r":       ("planar_2r.urdf", "base", "l2", GRAV, None, 0x5EED0034),
+    # round 3: the reference's own chains in the topology of the public ur_description (test.cpp:47-48, rosdyn_speed_test.cpp:44-45):
+    # a fixed joint in front of the six revolute ones, flange and tool0 behind them
+    "ur10_public_tool0":  ("ur10_public.urdf", "base_link", "tool0", GRAV, None, 0x5EED0044),
+    "ur10_public_flange": ("ur10_public.urdf", "base_link", "flange", (0.1, 0.2, -9.7), None, 0x5EED0054),
 }
 N = 16
 
 
 def main():
+    only = set(sys.argv[1:])   # names to (re)generate; none = all
     for name, (urdf, base, tool, g, inputs, seed) in CASES.items():
+        if only and name not in only:
+            continue
         c = NpChain(os.path.join(FIX, urdf), base, tool, g, inputs)
         q, dq, ddq = trajectory_batch(seed, N, c.n)
         # a few special rows: zero state, zero velocity, large angles (argument reduction of sin/cos)
