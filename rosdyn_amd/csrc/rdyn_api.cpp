@@ -1261,7 +1261,9 @@ static int regressor_tsqr_run(const rdyn_chain* c, const rdyn_component* comps, 
       // unless round 0 found a pivot of its Cholesky factor outside [1/2, 2]
       const int* const run = round == 0 ? nullptr : flag;
       const double row_scale = round == 0 ? sqrt((double)tiles / (double)sub_tiles) : 1.0;
-      RDYN_HIP_TRY(rdyn_launch_cholqr_precond(round == 0 ? ws + L.r_sub : R_swept, n1s, row_scale, ws + L.r1p, ws + L.w, flag + 16, round, run, stream));
+      const int col_shift = rdyn_cholqr_col_shift(nJ, n_comps > 0 ? 1 : 0);
+      RDYN_HIP_TRY(rdyn_launch_cholqr_precond(round == 0 ? ws + L.r_sub : R_swept, n1s, col_shift, row_scale, ws + L.r1p, ws + L.w, flag + 16, round, run,
+                                              stream));
       RDYN_HIP_TRY(rdyn_launch_regressor_pgram(nJ, la, ws + L.w, run, blocks, pairs, stream));
       RdynGramArgs ga;
       memset(&ga, 0, sizeof ga);
@@ -1271,6 +1273,8 @@ static int regressor_tsqr_run(const rdyn_chain* c, const rdyn_component* comps, 
       ga.c = ws + L.g2 + (size_t)(n1s - 1) * (n1s - 1);
       ga.bb = ga.c + (n1s - 1);
       ga.run_flag = run;
+      ga.col_shift = col_shift;
+      ga.slab_nb = n_comps > 0 ? (10 * nJ + 1 + 15) / 16 + 1 : 0;
       RDYN_HIP_TRY(rdyn_launch_gram_finish(ga, blocks, stream));
       RDYN_HIP_TRY(rdyn_launch_cholqr_factor(ga.G, ga.c, ga.bb, n1s, tau_meas ? 1 : 0, ws + L.r1p, flag + 16, R_swept, round == 0 ? flag : nullptr, run, stream));
     }

@@ -56,6 +56,13 @@ __global__ __launch_bounds__(128 * NPAIR) void k_regressor_pgram(const RdynLdsGr
 {
   constexpr bool DIRECT = true;
   constexpr int NB = (10 * NJ + 1 + 15) / 16 + XB, NT = NB * (NB + 1) / 2, P = 10 * NJ;
+  // The consumer's column space is the natural order [links | tau_meas] SHIFTED RIGHT by SH: the padding of the last 16-column block
+  // sits in front, where it joins the zero band of every row group (row group j is zero in the 10 j columns of the links upstream of
+  // its joint): floor((SH + 10 j) / 16) whole blocks are skipped instead of floor(10 j / 16) -- 384 instead of 496 MFMAs per tile at
+  // 7 joints (SH = 9), 264 instead of 288 at 6 (SH = 3) -- and W stays upper triangular (the descending order of rdyn_duo_gram.hip
+  // buys the same blocks for a Gram, but a triangular factor fills a zero band on the right).  With component columns (K known at
+  // run time only) SH = 0.
+  constexpr int SH = XB > 0 ? 0 : 16 * NB - (P + 1);
   constexpr int WB = WGLOBAL ? 0 : NT * 2048;  // W in operand order: per (cb1 <= cb2) block four k-steps of 64 doubles
   if (run_flag && *run_flag == 0) return;  // second round not needed (uniform: every wave leaves)
   extern __shared__ __attribute__((aligned(32))) char lds_raw[];
@@ -154,13 +161,13 @@ __global__ __launch_bounds__(128 * NPAIR) void k_regressor_pgram(const RdynLdsGr
     // under the MFMAs) instead of kept in 20 registers.
     // columns from P on ([C (K) | tau_meas | padding]; K = 0 without components): per-lane offset and row group of the (cb1, kk)
     // operands that can reach them, looked up once (the component table is a kernel argument indexed by a lane-dependent column)
-    constexpr int X0 = P / 4, NX = 4 * NB - X0;  // operand ids 4 cb1 + kk >= X0 touch columns >= P
+    constexpr int X0 = (P + SH) / 4, NX = 4 * NB - X0;  // operand ids 4 cb1 + kk >= X0 touch (natural) columns >= P
     const int K = XB > 0 ? fa.n_comp_cols : 0;
     int xoff[NX], xrow[NX];  // xrow: the one row group stored, -1 = every row group (tau_meas), -2 = nothing (padding / a link column)
 #pragma unroll
     for (int i = 0; i < NX; ++i)
     {
-      const int col = 4 * (X0 + i) + g;
+      const int col = 4 * (X0 + i) + g - SH;
       int off = 0, row = -2;
       if (col >= P && col < P + K)
       {
@@ -176,10 +183,11 @@ __global__ __launch_bounds__(128 * NPAIR) void k_regressor_pgram(const RdynLdsGr
       xrow[i] = row;
     }
     auto a_operand = [&](int cb1, int kk, int j) -> double {
-      const int id = 4 * cb1 + kk, col = 4 * id + g;
+      const int id = 4 * cb1 + kk, col = 4 * id + g - SH;  // natural column; < 0: the padding in front
       double a = 0.0;
-      if (id < X0 || (4 * id < P && col < P))  // a link column (the second test: an operand that straddles P)
+      if (id < X0 || (4 * id - SH < P && col < P))  // a link column (the second test: an operand that straddles P)
       {
+        if (col < 0) return 0.0;
         const int f = (col * 205) >> 11;  // col / 10 for col < 1024
         const int off = f * (640 * f + 960) + (col - 10 * f) * (128 * f + 160);
         if (j <= f) a = *(const double*)(tile + off + cl * 8 + j * 128);
@@ -281,11 +289,11 @@ __global__ __launch_bounds__(128 * NPAIR) void k_regressor_pgram(const RdynLdsGr
 #pragma unroll
       for (int f = 0; f < NJ; ++f)
       {
-        if (have) stage1(f, (10 * f) >> 4);
+        if (have) stage1(f, (SH + 10 * f) >> 4);
         // my reads of row group f have returned -> the sweeper may overwrite link f's columns (no later group reads them)
         if (it < trips) DUO_BARRIER_LDS();
         else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (have) stage2((10 * f) >> 4);
+        if (have) stage2((SH + 10 * f) >> 4);
       }
       if (it < trips) DUO_BARRIER_LDS();  // end of the sweeper's tile
     }
@@ -399,7 +407,7 @@ __device__ __forceinline__ void small_qr_lds(double* B, int m, int nc, double* v
 // Any invertible upper-triangular T serves: R = chol((A W)'(A W)) T satisfies R'R = A'A exactly; T only has to make Q = A W well
 // conditioned on its range, which the factor kernel checks.  The rows of T at null positions hold the diagonal only, so W has no
 // large ROWS (large rows cancel in Q only in exact arithmetic); the large column W(:, k) touches nothing but the null column itself.
-__global__ __launch_bounds__(256) void k_cholqr_precond(const double* __restrict__ R1, int n1, double row_scale, double* __restrict__ Tout,
+__global__ __launch_bounds__(256) void k_cholqr_precond(const double* __restrict__ R1, int n1, int col_shift, double row_scale, double* __restrict__ Tout,
                                                         double* __restrict__ W, int* __restrict__ zmask, int zmask_given, const int* __restrict__ run_flag)
 {
   if (run_flag && *run_flag == 0) return;
@@ -480,15 +488,16 @@ __global__ __launch_bounds__(256) void k_cholqr_precond(const double* __restrict
     }
   }
   __syncthreads();
-  const int nb = (n1 + 15) / 16, nt = nb * (nb + 1) / 2;
+  // operand order of k_regressor_pgram, in its column space (natural order shifted right by col_shift)
+  const int nb = (n1 + col_shift + 15) / 16, nt = nb * (nb + 1) / 2;
   for (int i = tid; i < nt * 256; i += 256)
   {
     const int blk = i >> 8, kk = (i >> 6) & 3, ln = i & 63;
     int cb2 = 0;
     while ((cb2 + 1) * (cb2 + 2) / 2 <= blk) ++cb2;
     const int cb1 = blk - cb2 * (cb2 + 1) / 2;
-    const int r = 16 * cb1 + 4 * kk + (ln >> 4), c = 16 * cb2 + (ln & 15);
-    W[i] = (r < n1 && c < n1 && r <= c) ? B[c * n1 + r] : 0.0;
+    const int r = 16 * cb1 + 4 * kk + (ln >> 4) - col_shift, c = 16 * cb2 + (ln & 15) - col_shift;
+    W[i] = (r >= 0 && c >= 0 && r < n1 && c < n1 && r <= c) ? B[c * n1 + r] : 0.0;
   }
 }
 
@@ -745,14 +754,14 @@ hipError_t rdyn_launch_regressor_pgram(int n_joints, const RdynLdsGramArgs& a, c
   }
 }
 
-hipError_t rdyn_launch_cholqr_precond(const double* R1, int n1, double row_scale, double* T, double* W, int* zmask, int zmask_given, const int* run_flag,
-                                      hipStream_t st)
+hipError_t rdyn_launch_cholqr_precond(const double* R1, int n1, int col_shift, double row_scale, double* T, double* W, int* zmask, int zmask_given,
+                                      const int* run_flag, hipStream_t st)
 {
   if (n1 < 1 || n1 > kMaxN1) return hipErrorInvalidValue;
   static std::atomic<uint64_t> attr{0};
   hipError_t e = opt_in_lds_once(k_cholqr_precond, attr, 128 * 1024);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(k_cholqr_precond, dim3(1), dim3(256), ((size_t)2 * n1 * n1 + n1) * sizeof(double), st, R1, n1, row_scale, T, W, zmask, zmask_given, run_flag);
+  hipLaunchKernelGGL(k_cholqr_precond, dim3(1), dim3(256), ((size_t)2 * n1 * n1 + n1) * sizeof(double), st, R1, n1, col_shift, row_scale, T, W, zmask, zmask_given, run_flag);
   return hipGetLastError();
 }
 
@@ -789,3 +798,6 @@ hipError_t rdyn_launch_cholqr_fold(const double* R_new, double* R, int n1, hipSt
   hipLaunchKernelGGL(k_cholqr_fold, dim3(1), dim3(256), ((size_t)2 * n1 * n1 + 2 * n1) * sizeof(double), st, R_new, R, n1);
   return hipGetLastError();
 }
+
+// columns the consumer of k_regressor_pgram keeps in front of the natural order (the padding of its last 16-column block)
+int rdyn_cholqr_col_shift(int n_joints, int xb) { return xb ? 0 : 16 * ((10 * n_joints + 1 + 15) / 16) - (10 * n_joints + 1); }

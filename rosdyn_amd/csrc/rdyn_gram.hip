@@ -159,6 +159,7 @@ __global__ __launch_bounds__(256) void k_gram_finish(const RdynGramArgs a, int n
   const int P = a.P;
   // slab column -> regressor column (P = the measured-torque column, > P = padding)
   auto col_of = [&](int pp) -> int {
+    if (a.col_shift > 0) return pp < a.col_shift ? P + 1 : pp - a.col_shift;  // padding in front of the natural order
     if (a.desc_nj <= 0) return pp;
     if (pp == 0) return P;
     if (pp > P) return P + 1;

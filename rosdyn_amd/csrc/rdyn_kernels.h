@@ -119,6 +119,7 @@ struct RdynGramArgs
   int desc_nj;
   int slab_nb;  // finish only: 16-column blocks of the slabs' tile layout if it is wider than P + 1 columns need (0 = derive from P)
   const int* run_flag;  // finish only, may be null: device word; 0 = leave at once (conditional second round of rdyn_cholqr.hip)
+  int col_shift;        // finish only: the slabs' column space is the natural order shifted right by col_shift (rdyn_cholqr.hip)
 };
 // normal equations of the reduced chain -> of the chain (rdyn_chain.hpp; rdyn_gram.hip: k_gram_expand)
 struct RdynGramExpandArgs
@@ -197,8 +198,10 @@ hipError_t rdyn_launch_cholqr_fold(const double* R_new, double* R, int n1, hipSt
 hipError_t rdyn_launch_regressor_pgram(int n_joints, const RdynLdsGramArgs& a, const double* W, const int* run_flag, int blocks, int pairs, hipStream_t st);
 // R1 (n1 x n1 upper, column-major) -> T = R1 re-triangularised without its null columns (zmask: found when !zmask_given, else used),
 // W = T^-1 in MFMA operand order.  row_scale: R1 is the factor of one row in row_scale^2 (the subsample), T is scaled to all rows.
-hipError_t rdyn_launch_cholqr_precond(const double* R1, int n1, double row_scale, double* T, double* W, int* zmask, int zmask_given, const int* run_flag,
-                                      hipStream_t st);
+// col_shift: columns of padding in FRONT of the natural order in the consumer's column space (rdyn_cholqr_col_shift)
+hipError_t rdyn_launch_cholqr_precond(const double* R1, int n1, int col_shift, double row_scale, double* T, double* W, int* zmask, int zmask_given,
+                                      const int* run_flag, hipStream_t st);
+int rdyn_cholqr_col_shift(int n_joints, int xb);
 // G2 = [G c; c' bb] -> R = chol(G2) T (n1 x n1 upper, column-major; zero rows at the null set); *flag_out = 1 when the preconditioner was poor
 hipError_t rdyn_launch_cholqr_factor(const double* G, const double* c, const double* bb, int n1, int has_b, const double* T, int* zmask, double* R,
                                      int* flag_out, const int* run_flag, hipStream_t st);
