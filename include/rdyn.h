@@ -373,7 +373,7 @@ int rdyn_regressor_gram_multi(rdyn_multi_gpu* ctx, const rdyn_chain* chain, cons
  * 2..7 INPUT joints in chain order (else RDYN_ERR_UNSUPPORTED); joints that are not input joints are folded away (the reduced chain
  * of rdyn_chain_reduction is swept and the factor expanded by a small QR: up to RDYN_MAX_JOINTS chain joints).
  * Two routes, chosen by the batch size: Householder folds on the vector units (rdyn_tsqr.hip; ~5x the time of rdyn_regressor_gram),
- * and from 327 680 samples on preconditioned CholeskyQR with the heavy pass on the fp64 matrix cores (rdyn_cholqr.hip: Householder
+ * and from 196 608 samples on preconditioned CholeskyQR with the heavy pass on the fp64 matrix cores (rdyn_cholqr.hip: Householder
  * factor R1 of a row subsample, W = R1^-1 without its null columns, G2 = (A W)'(A W) over all rows by MFMA, R = chol(G2) R1 with a
  * pivot check and an automatic second round; ~2.3x the time of rdyn_regressor_gram; rows of R at structurally dependent columns
  * are exactly zero).  Both return R1 with R1'R1 = [A b]'[A b] to rounding and the small singular values to ~cond * eps.
