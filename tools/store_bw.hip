@@ -430,6 +430,89 @@ int run(int argc, char** argv)
 }
 }  // namespace probe5
 
+
+// probe 6 (round 3) -- the EXACT copy-out instruction shapes of k_image_sweep<6, 0>, stores only (no sweep, no input reads), into K
+// output allocations kept alive: what the store schedule alone reaches in the fast and in the slow placement state.
+//   stacked     wave w owns samples 64 w ..: per link 10 columns x 3 (64 lanes x 16 B = 1 KiB) nontemporal stores at column offset 3072 w
+//   per-sample  wave w owns 64 images of 2 880 B (one contiguous 184 320-byte region): per link, for every image the whole 128-byte
+//               lines completed by that link, 2 images x 32 lanes x 16 B per instruction
+namespace probe6
+{
+#define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { std::printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); std::exit(1); } } while (0)
+typedef double d2u __attribute__((ext_vector_type(2), aligned(8)));
+__global__ __launch_bounds__(64) void k_stacked(double* __restrict__ out, size_t N)
+{
+  const size_t w = blockIdx.x;
+  const int lane = threadIdx.x;
+  const d2u v = {1.0, 2.0};
+  for (int f = 0; f < 6; ++f)
+    for (int pp = 0; pp < 10; ++pp)
+    {
+      char* col = (char*)(out + (size_t)(10 * f + pp) * (N * 6) + w * 64 * 6);
+#pragma unroll
+      for (int it = 0; it < 3; ++it) __builtin_nontemporal_store(v, (d2u*)(col + (it * 64 + lane) * 16));
+    }
+}
+__global__ __launch_bounds__(64) void k_images(double* __restrict__ out, size_t N)
+{
+  const size_t w = blockIdx.x;
+  const int lane = threadIdx.x, sub = lane >> 5, ch = lane & 31;
+  char* const base = (char*)out + w * (64 * 2880);
+  const d2u v = {1.0, 2.0};
+  for (int f = 0; f < 6; ++f)
+    for (int it = 0; it < 32; ++it)
+    {
+      const unsigned i = 2 * it + sub;
+      const unsigned lo = (i * 2880u + 480u * f) & ~127u;
+      const unsigned hi = (f == 5 && i == 63) ? 64u * 2880u : ((i * 2880u + 480u * (f + 1)) & ~127u);
+      const unsigned x = lo + 16u * ch;
+      if (x < hi) __builtin_nontemporal_store(v, (d2u*)(base + x));
+    }
+}
+template <class F>
+static double time_ms(F&& launch, int reps)
+{
+  hipEvent_t a, b;
+  CHECK(hipEventCreate(&a));
+  CHECK(hipEventCreate(&b));
+  launch();
+  launch();
+  CHECK(hipDeviceSynchronize());
+  CHECK(hipEventRecord(a, nullptr));
+  for (int i = 0; i < reps; ++i) launch();
+  CHECK(hipEventRecord(b, nullptr));
+  CHECK(hipEventSynchronize(b));
+  float ms = 0;
+  CHECK(hipEventElapsedTime(&ms, a, b));
+  return ms / reps;
+}
+int run(int argc, char** argv)
+{
+  const size_t N = 1000000 - 1000000 % 64;  // whole waves
+  const int K = argc > 1 ? std::atoi(argv[1]) : 8;
+  std::vector<double*> bufs;
+  for (int i = 0; i < K; ++i)
+  {
+    double* d = nullptr;
+    CHECK(hipMalloc((void**)&d, (size_t)1000000 * 360 * sizeof(double)));
+    bufs.push_back(d);
+  }
+  const unsigned g = (unsigned)(N / 64);
+  const double bytes = (double)N * 2880.0;
+  for (int i = 0; i < K; ++i)
+  {
+    double* d = bufs[(size_t)i];
+    const double ms_s = time_ms([&] { hipLaunchKernelGGL(k_stacked, dim3(g), dim3(64), 0, nullptr, d, N); }, 10);
+    const double ms_i = time_ms([&] { hipLaunchKernelGGL(k_images, dim3(g), dim3(64), 0, nullptr, d, N); }, 10);
+    const double ms_f = time_ms([&] { CHECK(hipMemsetAsync(d, 0, (size_t)bytes, nullptr)); }, 10);
+    std::printf("buffer %d: stacked pattern %7.1f us %6.3f TB/s | per-sample pattern %7.1f us %6.3f TB/s | hipMemset %7.1f us %6.3f TB/s\n", i, ms_s * 1e3,
+                bytes / ms_s * 1e-9, ms_i * 1e3, bytes / ms_i * 1e-9, ms_f * 1e3, bytes / ms_f * 1e-9);
+  }
+  for (double* d : bufs) CHECK(hipFree(d));
+  return 0;
+}
+}  // namespace probe6
+
 int main(int argc, char** argv)
 {
   const int which = argc > 1 ? std::atoi(argv[1]) : 1;
@@ -441,6 +524,7 @@ int main(int argc, char** argv)
   case 3: return probe3::run(argc, argv);
   case 4: return probe4::run(argc, argv);
   case 5: return probe5::run(argc, argv);
-  default: std::fprintf(stderr, "usage: store_bw [1-5]\n"); return 2;
+  case 6: return probe6::run(argc, argv);
+  default: std::fprintf(stderr, "usage: store_bw [1-6]\n"); return 2;
   }
 }
