@@ -137,6 +137,19 @@ def test_fuzzed_chain_all_entry_points(seed):
             assert np.linalg.norm(G.cpu().numpy() - Gr) <= 1e-10 * max(np.linalg.norm(Gr), 1e-300), ("G", chunk)
             assert np.linalg.norm(c.cpu().numpy() - cr) <= 1e-10 * max(np.linalg.norm(cr), 1e-300), ("c", chunk)
             assert abs(bb.item() - (tau ** 2).sum()) <= 1e-10 * max((tau ** 2).sum(), 1e-300)
+        # the R factor of [A | tau] (round 3: chains with non-input joints are swept through their reduced companion and the factor
+        # expanded by a small QR): R'R = [G c; c' bb] wherever the entry point serves the chain (2..7 input joints in chain order)
+        from rosdyn_amd._lib import RdynError, lib
+        if lib().rdyn_regressor_tsqr_workspace_bytes(chain._h) > 0:
+            try:
+                R1 = chain.getRegressorTsqr(eq, edq, eddq, etau, layout="element").cpu().numpy()
+            except RdynError as e:
+                assert e.status == 5, e                        # RDYN_ERR_UNSUPPORTED: input joints not in chain order
+            else:
+                full = np.zeros((P + 1, P + 1))
+                full[:P, :P], full[:P, P], full[P, :P], full[P, P] = Gr, cr, cr, (tau ** 2).sum()
+                assert np.allclose(np.tril(R1, -1), 0.0)
+                assert np.abs(R1.T @ R1 - full).max() <= 1e-10 * max(np.abs(full).max(), 1e-300), "R factor"
 
 
 @pytest.mark.parametrize("N", [1, 2, 15, 16, 17, 63, 64, 65, 255, 256, 257, 1023])
