@@ -453,6 +453,19 @@ __global__ __launch_bounds__(64) void k_stacked(double* __restrict__ out, size_t
       for (int it = 0; it < 3; ++it) __builtin_nontemporal_store(v, (d2u*)(col + (it * 64 + lane) * 16));
     }
 }
+// the same 3 KB per column and wave with 8 B per lane (six 512-byte stores) -- "dwordx4 stores are slower than dwordx2" for a plain fill
+__global__ __launch_bounds__(64) void k_stacked8(double* __restrict__ out, size_t N)
+{
+  const size_t w = blockIdx.x;
+  const int lane = threadIdx.x;
+  for (int f = 0; f < 6; ++f)
+    for (int pp = 0; pp < 10; ++pp)
+    {
+      double* col = out + (size_t)(10 * f + pp) * (N * 6) + w * 64 * 6;
+#pragma unroll
+      for (int it = 0; it < 6; ++it) __builtin_nontemporal_store(1.0, col + it * 64 + lane);
+    }
+}
 __global__ __launch_bounds__(64) void k_images(double* __restrict__ out, size_t N)
 {
   const size_t w = blockIdx.x;
@@ -504,9 +517,10 @@ int run(int argc, char** argv)
     double* d = bufs[(size_t)i];
     const double ms_s = time_ms([&] { hipLaunchKernelGGL(k_stacked, dim3(g), dim3(64), 0, nullptr, d, N); }, 10);
     const double ms_i = time_ms([&] { hipLaunchKernelGGL(k_images, dim3(g), dim3(64), 0, nullptr, d, N); }, 10);
+    const double ms_8 = time_ms([&] { hipLaunchKernelGGL(k_stacked8, dim3(g), dim3(64), 0, nullptr, d, N); }, 10);
     const double ms_f = time_ms([&] { CHECK(hipMemsetAsync(d, 0, (size_t)bytes, nullptr)); }, 10);
-    std::printf("buffer %d: stacked pattern %7.1f us %6.3f TB/s | per-sample pattern %7.1f us %6.3f TB/s | hipMemset %7.1f us %6.3f TB/s\n", i, ms_s * 1e3,
-                bytes / ms_s * 1e-9, ms_i * 1e3, bytes / ms_i * 1e-9, ms_f * 1e3, bytes / ms_f * 1e-9);
+    std::printf("buffer %d: stacked pattern %7.1f us %6.3f TB/s (8 B per lane: %7.1f us) | per-sample pattern %7.1f us %6.3f TB/s | hipMemset %7.1f us %6.3f TB/s\n", i,
+                ms_s * 1e3, bytes / ms_s * 1e-9, ms_8 * 1e3, ms_i * 1e3, bytes / ms_i * 1e-9, ms_f * 1e3, bytes / ms_f * 1e-9);
   }
   for (double* d : bufs) CHECK(hipFree(d));
   return 0;
