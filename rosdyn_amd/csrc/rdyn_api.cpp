@@ -1248,6 +1248,7 @@ static int regressor_tsqr_run(const rdyn_chain* c, const rdyn_component* comps, 
     RdynLdsGramArgs sub = la;
     const int64_t kSubTiles = probe_env("RDYN_CHOLQR_SUBTILES") ? atoll(probe_env("RDYN_CHOLQR_SUBTILES")) : 1024;
     sub.tile_stride = (int)(tiles / kSubTiles > 1 ? tiles / kSubTiles : 1);
+    if (sub.tile_stride > 1 && sub.tile_stride % 2 == 0) ++sub.tile_stride;  // odd: does not lock onto power-of-two periods of a trajectory
     const int64_t sub_tiles = (tiles + sub.tile_stride - 1) / sub.tile_stride;
     const int sub_blocks = (int)((sub_tiles + 3) / 4 < kTsqrBlocks ? (sub_tiles + 3) / 4 : kTsqrBlocks);
     RDYN_HIP_TRY(rdyn_launch_regressor_tsqr(nJ, sub, sub_blocks, 4 * (size_t)la.tile_bytes, ws, ws + L.r_sub, 0, stream));
