@@ -1131,7 +1131,7 @@ int rdyn_tsqr(const double* A, int64_t rows, int64_t lda, int n_cols, const doub
 struct TsqrLayout
 {
   size_t householder_doubles = 0;  // region 1
-  size_t slabs = 0, w = 0, r_sub = 0, r1p = 0, g2 = 0, r_swept = 0, flag = 0, total_doubles = 0;  // offsets (doubles) of region 2
+  size_t slabs = 0, w = 0, v = 0, r_sub = 0, r1p = 0, g2 = 0, r_swept = 0, flag = 0, total_doubles = 0;  // offsets (doubles) of region 2
 };
 static const int kCholqrBlocks = 256;
 // xb = 1: with component columns (one more 16-column block; the factors are sized for the padded width 16 nb)
@@ -1153,7 +1153,9 @@ static TsqrLayout tsqr_layout(int n_joints_swept, int xb = 0)
   L.r1p = take((size_t)n1 * n1);
   L.g2 = take((size_t)n1 * n1 + 1);
   L.r_swept = take((size_t)n1 * n1);
-  L.flag = take(64);  // ints: [0] the second-round flag, [16 ..] the null set of the columns
+  L.v = take((size_t)n1 * n1);
+  L.flag = take(64);  // ints: [0] run round 1, [1] run the stand-by (Householder) call, [2] run round 0, [16 ..] the deferred columns;
+                      // doubles [50 .. 55]: gamma (preconditioner), rho, gamma (factor kernel) of the two rounds (diagnostics)
   L.total_doubles = off;
   return L;
 }
@@ -1260,12 +1262,12 @@ static int regressor_tsqr_run(const rdyn_chain* c, const rdyn_component* comps, 
     for (int round = 0; round < n_rounds; ++round)
     {
       // round 0: W from the subsample's factor.  Round 1 (CholeskyQR2 on top): W from round 0's factor; its kernels leave at once
-      // unless round 0 found a pivot of its Cholesky factor outside [1/2, 2]
-      const int* const run = round == 0 ? nullptr : flag;
+      // unless round 0's factor kernel asked for it (flag[0]).  Round 0 itself runs when its preconditioner is fit for it (flag[2]).
+      const int* const run = round == 0 ? flag + 2 : flag;
       const double row_scale = round == 0 ? sqrt((double)tiles / (double)sub_tiles) : 1.0;
       const int col_shift = rdyn_cholqr_col_shift(nJ, n_comps > 0 ? 1 : 0);
-      RDYN_HIP_TRY(rdyn_launch_cholqr_precond(round == 0 ? ws + L.r_sub : R_swept, n1s, col_shift, row_scale, ws + L.r1p, ws + L.w, flag + 16, round, run,
-                                              stream));
+      RDYN_HIP_TRY(rdyn_launch_cholqr_precond(round == 0 ? ws + L.r_sub : R_swept, n1s, col_shift, row_scale, ws + L.r1p, ws + L.w, ws + L.v, flag + 16, flag, round,
+                                              round == 0 ? nullptr : flag, ws + L.flag + 50 + round, stream));
       RDYN_HIP_TRY(rdyn_launch_regressor_pgram(nJ, la, ws + L.w, run, blocks, pairs, stream));
       RdynGramArgs ga;
       memset(&ga, 0, sizeof ga);
@@ -1278,7 +1280,18 @@ static int regressor_tsqr_run(const rdyn_chain* c, const rdyn_component* comps, 
       ga.col_shift = col_shift;
       ga.slab_nb = n_comps > 0 ? (10 * nJ + 1 + 15) / 16 + 1 : 0;
       RDYN_HIP_TRY(rdyn_launch_gram_finish(ga, blocks, stream));
-      RDYN_HIP_TRY(rdyn_launch_cholqr_factor(ga.G, ga.c, ga.bb, n1s, tau_meas ? 1 : 0, ws + L.r1p, flag + 16, R_swept, round == 0 ? flag : nullptr, run, stream));
+      RDYN_HIP_TRY(rdyn_launch_cholqr_factor(ga.G, ga.c, ga.bb, n1s, tau_meas ? 1 : 0, ws + L.r1p, ws + L.v, flag + 16, R_swept, flag, round, run, ws + L.flag + 52 + round,
+                                             stream));
+    }
+    {
+      // stand-by: the Householder factorisation of ALL rows, queued behind the two rounds and started by the device only when a
+      // preconditioner was unfit (growth factor) or round 1 was not accepted either (flag[1]; three launches that leave at once
+      // otherwise).  It asks nothing of the batch, so the call as a whole is as robust as the Householder route whatever the
+      // subsample looked like.
+      RdynLdsGramArgs all = la;
+      all.run_flag = flag + 1;
+      const int hblocks = (int)((tiles + 3) / 4 < kTsqrBlocks ? (tiles + 3) / 4 : kTsqrBlocks);
+      RDYN_HIP_TRY(rdyn_launch_regressor_tsqr(nJ, all, hblocks, 4 * (size_t)la.tile_bytes, ws, R_swept, 0, stream, 16));
     }
     if (!expand && accumulate) RDYN_HIP_TRY(rdyn_launch_cholqr_fold(R_swept, R, n1s, stream));
   }

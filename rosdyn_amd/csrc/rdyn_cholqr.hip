@@ -392,30 +392,37 @@ __device__ __forceinline__ void small_qr_lds(double* B, int m, int nc, double* v
   }
 }
 
-// The preconditioner of a round.  In: an upper-triangular factor R1 (n1 x n1) of (a subsample of) the rows.  A regressor is
-// structurally rank deficient: the pivot of a column that depends on the columns to its left is rounding residue -- and a Householder
-// factor keeps real information of LATER columns in that pivot's row.  Inverting R1 as it stands (pivot lifted to something tiny)
-// puts 1e12-sized entries into W whose effects cancel in Q = A W only in exact arithmetic.  So:
-//   null set Z   round 0: pivots below 1e-13 x their column's norm; round 1: the set the factor kernel of round 0 confirmed (zmask)
-//   T            the factor re-triangularised WITHOUT the null columns (Householder QR of R1(:, not Z), in LDS), embedded back at the
-//                positions of the kept columns.  A null column k rides through the same reflections: its coefficients on the kept
-//                directions to its LEFT go into T(:, k), its diagonal is 1e-13 x its norm.  If the column is null in ALL rows, its
-//                column of Q = A W is the rounding residue / 1e-13: O(1e-3), and the factor kernel zeroes its row; if the subsample
-//                merely missed it (or it is nearly dependent: cond 1e9), its column of Q is huge, the factor kernel sees a pivot far
-//                above 1/10, keeps it and calls for the second round, which starts from a factor that holds it properly.
-//   W = T^-1     back substitution, one thread per column; written in the MFMA operand order of k_regressor_pgram.
-// Any invertible upper-triangular T serves: R = chol((A W)'(A W)) T satisfies R'R = A'A exactly; T only has to make Q = A W well
-// conditioned on its range, which the factor kernel checks.  The rows of T at null positions hold the diagonal only, so W has no
-// large ROWS (large rows cancel in Q only in exact arithmetic); the large column W(:, k) touches nothing but the null column itself.
+// The preconditioner of a round.  In: an upper-triangular factor R1 (n1 x n1): round 0 the Householder factor of the row subsample,
+// round 1 the factor round 0 produced.  W = T^-1 for a triangular T that makes Q = A W well conditioned -- ANY invertible upper-
+// triangular T gives R = chol((A W)'(A W)) T with R'R = A'A in exact arithmetic.  In floating point Q = A W carries a rounding error
+// u |A| |W| per row, which T multiplies back: column j of A is reproduced with a relative error of about
+//     u gamma_j,   gamma_j = sum_l g_l |T(l, j)| / |a_j|,   g_l = sum_i |a_i| |W(i, l)|
+// and a pivot T(k, k) that is tiny against its own column while later columns have components in its row puts 1 / T(k, k) into gamma.
+// A regressor always has such pivots (it is structurally rank deficient: the pivot of a dependent column is rounding residue), and a
+// subsample can have more of them than the batch.  So:
+//   deferred set Z   column k is NOT used to eliminate later columns when its pivot is below 1e-13 x the largest column norm to its
+//                    left (rounding residue of a dependent column: relative to what it depends on, not to itself) or below 1e-5 x its
+//                    own norm (the last column -- the measured torque, nothing to its right -- excepted)
+//   T                the factor re-triangularised WITHOUT the deferred columns (Householder QR of R1(:, not Z), in LDS), embedded back
+//                    at the positions of the kept columns.  A deferred column k rides through the same reflections: its coefficients on
+//                    the kept directions to its LEFT go into T(:, k), its diagonal is its own pivot (or the 1e-13 floor).  Row k of T
+//                    holds the diagonal only, so W has no large rows; the large column W(:, k) touches nothing but column k itself.
+//                    What the later columns keep of direction k is left to the Cholesky factorisation of Q'Q over ALL rows.
+//   gamma            max_j gamma_j is evaluated on the finished T, W.  Above 1e4 the round is not run: flags say so and the
+//                    Householder factorisation of all rows (the stand-by call of rdyn_api.cpp) takes over.
+// flags: [0] run round 1, [1] run the stand-by, [2] run round 0 (written here in round 0).  zmask <- Z (for the factor kernel).
+// W is written in the MFMA operand order of k_regressor_pgram.
+constexpr double kCholqrGammaMax = 1e4;
 __global__ __launch_bounds__(256) void k_cholqr_precond(const double* __restrict__ R1, int n1, int col_shift, double row_scale, double* __restrict__ Tout,
-                                                        double* __restrict__ W, int* __restrict__ zmask, int zmask_given, const int* __restrict__ run_flag)
+                                                        double* __restrict__ W, double* __restrict__ Vout, int* __restrict__ zmask, int* __restrict__ flags,
+                                                        int round, const int* __restrict__ run_flag, double* __restrict__ gamma_out)
 {
   if (run_flag && *run_flag == 0) return;
   extern __shared__ __attribute__((aligned(16))) double sh[];
   double* const A0 = sh;                // [n1][n1] column-major: R1, then T
   double* const B = sh + n1 * n1;       // [nc][n1]: the kept columns, then V = T^-1
   double* const v = sh + 2 * n1 * n1;   // [n1]
-  __shared__ double s_part[256], s_beta, s_v0, s_norm[kMaxN1];
+  __shared__ double s_part[256], s_beta, s_v0, s_norm[kMaxN1], s_lift[kMaxN1], s_g[kMaxN1];
   __shared__ int s_z[kMaxN1], s_cmap[kMaxN1], s_nc;
   const int tid = threadIdx.x;
   for (int i = tid; i < n1 * n1; i += 256)
@@ -428,9 +435,19 @@ __global__ __launch_bounds__(256) void k_cholqr_precond(const double* __restrict
   {
     double s = 0.0;
     for (int r = 0; r <= tid; ++r) s = fma(A0[tid * n1 + r], A0[tid * n1 + r], s);
-    const double nrm = sqrt(s);
-    s_norm[tid] = nrm > 0.0 ? nrm : 1.0;
-    s_z[tid] = zmask_given ? zmask[tid] : ((nrm > 0.0 && fabs(A0[tid * n1 + tid]) >= 1e-13 * nrm) ? 0 : 1);
+    s_norm[tid] = sqrt(s);
+  }
+  __syncthreads();
+  if (tid < n1)
+  {
+    double mx = 0.0;
+    for (int c = 0; c <= tid; ++c) mx = fmax(mx, s_norm[c]);
+    const double piv = fabs(A0[tid * n1 + tid]);
+    const double floor_k = mx > 0.0 ? 1e-13 * mx : 1.0;  // (nothing but zero columns so far: any diagonal serves)
+    const bool residue = !(piv >= floor_k);
+    const bool tiny = tid + 1 < n1 && piv < 1e-5 * s_norm[tid];
+    s_z[tid] = (residue || tiny) ? 1 : 0;
+    s_lift[tid] = residue ? floor_k : piv;
   }
   __syncthreads();
   if (tid == 0)
@@ -439,20 +456,15 @@ __global__ __launch_bounds__(256) void k_cholqr_precond(const double* __restrict
     for (int c = 0; c < n1; ++c)
       if (!s_z[c]) s_cmap[nc++] = c;
     s_nc = nc;
+    for (int c = 0; c < n1; ++c)  // the deferred columns behind the kept ones
+      if (s_z[c]) s_cmap[nc++] = c;
   }
   __syncthreads();
   const int nc = s_nc;
-  if (tid == 0)  // the null columns behind the kept ones
-  {
-    int nz = nc;
-    for (int c = 0; c < n1; ++c)
-      if (s_z[c]) s_cmap[nz++] = c;
-  }
-  __syncthreads();
   for (int i = tid; i < n1 * n1; i += 256) B[i] = A0[s_cmap[i / n1] * n1 + (i % n1)];
   __syncthreads();
   small_qr_lds(B, n1, n1, v, s_part, &s_beta, &s_v0, tid, nc);
-  // T: kept columns at their positions, null columns diagonal
+  // T: kept columns at their positions, deferred columns: coefficients + diagonal
   for (int i = tid; i < n1 * n1; i += 256) A0[i] = 0.0;
   __syncthreads();
   for (int i = tid; i < nc * nc; i += 256)
@@ -462,22 +474,22 @@ __global__ __launch_bounds__(256) void k_cholqr_precond(const double* __restrict
   }
   for (int i = tid; i < (n1 - nc) * nc; i += 256)
   {
-    // null column k = s_cmap[nc + z]: its coefficient on kept direction a, if that direction's column lies to its left
+    // deferred column k = s_cmap[nc + z]: its coefficient on kept direction a, if that direction's column lies to its left
     const int z = i / (nc > 0 ? nc : 1), a = i - z * nc, k = s_cmap[nc + z];
     if (s_cmap[a] < k) A0[k * n1 + s_cmap[a]] = B[(nc + z) * n1 + a];
   }
-  if (tid < n1 && s_z[tid]) A0[tid * n1 + tid] = 1e-13 * s_norm[tid];
+  if (tid < n1 && s_z[tid]) A0[tid * n1 + tid] = s_lift[tid];
   __syncthreads();
   for (int i = tid; i < n1 * n1; i += 256)
   {
     Tout[i] = A0[i];
     B[i] = 0.0;  // V
   }
-  if (tid < n1 && !zmask_given) zmask[tid] = s_z[tid];
+  if (tid < n1) zmask[tid] = s_z[tid];
   __syncthreads();
   if (tid < n1)
   {
-    // column c of the inverse: T x = e_c by back substitution (T is nonsingular: full-rank kept block, norms on the null diagonal)
+    // column c of the inverse: T x = e_c by back substitution (T is nonsingular: full-rank kept block, lifts on the deferred diagonal)
     const int c = tid;
     B[c * n1 + c] = 1.0 / A0[c * n1 + c];
     for (int i = c - 1; i >= 0; --i)
@@ -488,6 +500,34 @@ __global__ __launch_bounds__(256) void k_cholqr_precond(const double* __restrict
     }
   }
   __syncthreads();
+  for (int i = tid; i < n1 * n1; i += 256) Vout[i] = B[i];  // T^-1 in natural order: the factor kernel re-evaluates gamma on the norms of ALL rows
+  if (tid < n1)
+  {
+    double g = 0.0;
+    for (int i = 0; i <= tid; ++i) g = fma(s_norm[i], fabs(B[tid * n1 + i]), g);
+    s_g[tid] = g;
+  }
+  __syncthreads();
+  if (tid < n1)
+  {
+    double g = 0.0;
+    for (int l = 0; l <= tid; ++l) g = fma(s_g[l], fabs(A0[tid * n1 + l]), g);
+    s_part[tid] = s_norm[tid] > 0.0 ? g / s_norm[tid] : 0.0;
+  }
+  __syncthreads();
+  if (tid == 0)
+  {
+    double gamma = 0.0;
+    for (int j = 0; j < n1; ++j) gamma = fmax(gamma, s_part[j]);
+    const bool safe = gamma <= kCholqrGammaMax;  // (false for NaN)
+    if (gamma_out) *gamma_out = gamma;
+    if (round == 0) flags[2] = safe ? 1 : 0;
+    if (!safe)
+    {
+      flags[0] = 0;  // the kernels of this round (round 1: flags[0]; round 0: flags[2]) and of the next leave at once
+      flags[1] = 1;  // the stand-by runs
+    }
+  }
   // operand order of k_regressor_pgram, in its column space (natural order shifted right by col_shift)
   const int nb = (n1 + col_shift + 15) / 16, nt = nb * (nb + 1) / 2;
   for (int i = tid; i < nt * 256; i += 256)
@@ -501,18 +541,27 @@ __global__ __launch_bounds__(256) void k_cholqr_precond(const double* __restrict
   }
 }
 
-// G2 = [G c; c' bb] (the Gram of Q = [A b] W) -> R = chol(G2) T; the pivots of the null set are skipped (their rows of R are exactly
-// zero: the rank deficiency is reported as such); *flag_out = 1 when a kept pivot of the Cholesky factor left [1/2, 2] (cond(Q) > 4)
+// G2 = [G c; c' bb] (the Gram of Q = [A b] W over ALL rows) -> R = chol(G2) T.
+//   Columns the preconditioner deferred (zmask): whether they hold anything is decided HERE, on all rows.  Rounding residue of a dependent
+//   column reads O(1e-3) in units of its lift (1e-13 x the largest column to its left) and has nothing left after its own elimination
+//   either way: its pivot is SKIPPED -- row k of R is exactly zero, the rank deficiency is reported as such.  Anything else is a pivot
+//   like any other (a direction the subsample missed, or a nearly dependent one).
+//   Accuracy: R = chol(Q'Q) T is as good as cond(Q D^-1)^2 u for the column-equilibrated Q (Cholesky does not see column scales: a
+//   preconditioner that is off by a factor per column costs nothing).  The kernel measures it: rho = |Re^-1|_F / sqrt(k) for the factor
+//   Re of the equilibrated Gram of the k pivoted columns (1 for orthogonal columns; |Re^-1|_2 <= rho sqrt(k)); rho > 4, or a kept
+//   column that turns out dependent on its left neighbours, and the round is not accepted: flags[round] = 1 (flags[0] starts round 1,
+//   flags[1] starts the stand-by Householder factorisation).  Round 0 also clears flags[1].
 __global__ __launch_bounds__(256) void k_cholqr_factor(const double* __restrict__ G, const double* __restrict__ cvec, const double* __restrict__ bb, int n1,
-                                                       int has_b, const double* __restrict__ T_in, int* __restrict__ zmask, double* __restrict__ Rout,
-                                                       int* __restrict__ flag_out, const int* __restrict__ run_flag)
+                                                       int has_b, const double* __restrict__ T_in, const double* __restrict__ V, const int* __restrict__ zmask,
+                                                       double* __restrict__ Rout, int* __restrict__ flags, int round, const int* __restrict__ run_flag,
+                                                       double* __restrict__ rho_out)
 {
   if (run_flag && *run_flag == 0) return;
   extern __shared__ __attribute__((aligned(16))) double sh[];
   double* const M = sh;             // [n1][n1] column-major, upper triangle = the running Cholesky factor
-  double* const T = sh + n1 * n1;
-  __shared__ double s_piv, s_g0[kMaxN1];
-  __shared__ int s_flag, s_z[kMaxN1];
+  double* const T = sh + n1 * n1;   // T, later the inverse of the equilibrated factor
+  __shared__ double s_piv, s_g0[kMaxN1], s_sc[kMaxN1], s_part[kMaxN1], s_gam[kMaxN1];
+  __shared__ int s_flag, s_z[kMaxN1], s_skip[kMaxN1];
   const int tid = threadIdx.x, P = n1 - 1;
   for (int i = tid; i < n1 * n1; i += 256)
   {
@@ -534,33 +583,26 @@ __global__ __launch_bounds__(256) void k_cholqr_factor(const double* __restrict_
     if (tid == 0)
     {
       const double d = M[k * n1 + k];
-      const double rel = d / s_g0[k];  // squared distance of Q(:, k) from the columns to its left, relative to its own length
+      const double rel = d / s_g0[k];  // squared sine of the angle between Q(:, k) and the columns to its left
       s_piv = sqrt(d > 1e-30 ? d : 1e-30);
+      int skip = 0;
       if (s_z[k])
       {
-        // a column the preconditioner declared null: scaled by 1e13 / its norm, its pivot is O(1e-3) if it is rounding residue in
-        // ALL rows -- and far above 1/10 if it is not (the subsample missed it, or it is a real direction at 1e-13 .. 1e-9 of its
-        // column): then it is a pivot like any other, the set is corrected and the second round is called for.  Unless what is left
-        // of it is rounding residue of ITS OWN elimination (rel ~ 1e-16: it depends on a column to its left that the subsample missed
-        // as well -- both are huge here, and so is the residue): that stays null; a direction between 1e-8 and rounding level is
-        // left to the second round, whose preconditioner has orthogonalised it first
-        if (s_piv >= 0.1 && rel >= 1e-8)
-        {
-          s_z[k] = 0;
-          s_flag = 1;
-        }
+        // residue in all rows (in units of the lift)?  Or nothing left after its own elimination: null as far as this round can tell --
+        // but if the column was large (its elimination's own rounding, u |Q(:, k)|^2, is above the 1/10 mark), that proves nothing
+        skip = !(s_piv >= 0.1 && rel >= 1e-12);
+        if (s_piv >= 0.1 && !(rel >= 1e-12)) s_flag = 1;
       }
       else if (!(rel >= 1e-12))
       {
-        s_z[k] = 1;  // a kept column that turns out to be numerically dependent on its left neighbours in the whole batch
+        skip = 1;  // a kept column that turns out to be numerically dependent on its left neighbours in the whole batch
         s_flag = 1;
       }
-      else if (s_piv < 0.5 || s_piv > 2.0)
-        s_flag = 1;
+      s_skip[k] = skip;
       M[k * n1 + k] = s_piv;
     }
     __syncthreads();
-    if (s_z[k])
+    if (s_skip[k])
     {
       // null direction: its Schur complement is rounding residue -- row k of the factor is zero, nothing is eliminated
       for (int j = k + tid; j < n1; j += 256) M[j * n1 + k] = 0.0;
@@ -587,8 +629,77 @@ __global__ __launch_bounds__(256) void k_cholqr_factor(const double* __restrict_
       for (int k = i; k <= j; ++k) s = fma(M[k * n1 + i], T[j * n1 + k], s);
     Rout[e] = s;
   }
-  if (tid == 0 && flag_out) *flag_out = s_flag;
-  if (flag_out && tid < n1) zmask[tid] = s_z[tid];  // round 0 hands the confirmed set to round 1
+  if (tid < n1) s_sc[tid] = sqrt(s_g0[tid]);
+  __syncthreads();
+  // the growth factor of the round on the column norms of ALL rows (|a_j| = |R(:, j)|; the preconditioner's own figure used the norms
+  // of its input factor: the subsample's in round 0, which may say little about the batch)
+  if (tid < n1)
+  {
+    double q = 0.0;
+    for (int i = 0; i <= tid; ++i) q = fma(Rout[tid * n1 + i], Rout[tid * n1 + i], q);
+    s_part[tid] = sqrt(q);
+  }
+  __syncthreads();
+  double g_own = 0.0;
+  if (tid < n1)
+    for (int i = 0; i <= tid; ++i) g_own = fma(s_part[i], fabs(V[tid * n1 + i]), g_own);
+  __syncthreads();
+  const double norm_own = tid < n1 ? s_part[tid] : 0.0;
+  __syncthreads();
+  if (tid < n1) s_part[tid] = g_own;
+  __syncthreads();
+  if (tid < n1)
+  {
+    double g = 0.0;
+    for (int l = 0; l <= tid; ++l) g = fma(s_part[l], fabs(T[tid * n1 + l]), g);
+    s_gam[tid] = norm_own > 0.0 ? g / norm_own : 0.0;
+  }
+  __syncthreads();
+  // the inverse of Re = R2 diag(1 / |Q(:, j)|) over the pivoted columns (skipped rows / columns left out): column c by back substitution
+  if (tid < n1)
+  {
+    const int c = tid;
+    double fro = 0.0;
+    if (!s_skip[c])
+    {
+      const double xc = s_sc[c] / M[c * n1 + c];  // Re(i, j) = M(i, j) / sqrt(g0(j))
+      T[c * n1 + c] = xc;
+      fro = xc * xc;
+      for (int i = c - 1; i >= 0; --i)
+      {
+        if (s_skip[i]) continue;
+        double s = 0.0;
+        for (int k = i + 1; k <= c; ++k)
+          if (!s_skip[k]) s = fma(M[k * n1 + i] / s_sc[k], T[c * n1 + k], s);
+        const double x = -s * s_sc[i] / M[i * n1 + i];
+        T[c * n1 + i] = x;
+        fro = fma(x, x, fro);
+      }
+    }
+    s_part[c] = fro;
+  }
+  __syncthreads();
+  if (tid == 0)
+  {
+    double fro = 0.0;
+    int kept = 0;
+    for (int c = 0; c < n1; ++c)
+    {
+      fro += s_part[c];
+      kept += s_skip[c] ? 0 : 1;
+    }
+    const double rho = kept > 0 ? sqrt(fro / kept) : 1.0;
+    double gamma = 0.0;
+    for (int c = 0; c < n1; ++c) gamma = fmax(gamma, s_gam[c]);
+    if (!(rho <= 4.0) || !(gamma <= kCholqrGammaMax)) s_flag = 1;
+    if (rho_out)
+    {
+      rho_out[0] = rho;
+      rho_out[2] = gamma;
+    }
+    flags[round] = s_flag;
+    if (round == 0) flags[1] = 0;
+  }
 }
 
 // Factor of the reduced chain -> factor of the chain (rdyn_chain.hpp: [A b] = [A_red b] E_aug, E_aug = diag(E, 1)):
@@ -754,25 +865,25 @@ hipError_t rdyn_launch_regressor_pgram(int n_joints, const RdynLdsGramArgs& a, c
   }
 }
 
-hipError_t rdyn_launch_cholqr_precond(const double* R1, int n1, int col_shift, double row_scale, double* T, double* W, int* zmask, int zmask_given,
-                                      const int* run_flag, hipStream_t st)
+hipError_t rdyn_launch_cholqr_precond(const double* R1, int n1, int col_shift, double row_scale, double* T, double* W, double* V, int* zmask, int* flags,
+                                      int round, const int* run_flag, double* gamma_out, hipStream_t st)
 {
   if (n1 < 1 || n1 > kMaxN1) return hipErrorInvalidValue;
   static std::atomic<uint64_t> attr{0};
   hipError_t e = opt_in_lds_once(k_cholqr_precond, attr, 128 * 1024);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(k_cholqr_precond, dim3(1), dim3(256), ((size_t)2 * n1 * n1 + n1) * sizeof(double), st, R1, n1, col_shift, row_scale, T, W, zmask, zmask_given, run_flag);
+  hipLaunchKernelGGL(k_cholqr_precond, dim3(1), dim3(256), ((size_t)2 * n1 * n1 + n1) * sizeof(double), st, R1, n1, col_shift, row_scale, T, W, V, zmask, flags, round, run_flag, gamma_out);
   return hipGetLastError();
 }
 
-hipError_t rdyn_launch_cholqr_factor(const double* G, const double* c, const double* bb, int n1, int has_b, const double* T, int* zmask, double* R,
-                                     int* flag_out, const int* run_flag, hipStream_t st)
+hipError_t rdyn_launch_cholqr_factor(const double* G, const double* c, const double* bb, int n1, int has_b, const double* T, const double* V, const int* zmask,
+                                     double* R, int* flags, int round, const int* run_flag, double* rho_out, hipStream_t st)
 {
-  if (n1 < 2 || n1 > kMaxN1) return hipErrorInvalidValue;
+  if (n1 < 2 || n1 > kMaxN1 || round < 0 || round > 1) return hipErrorInvalidValue;
   static std::atomic<uint64_t> attr{0};
   hipError_t e = opt_in_lds_once(k_cholqr_factor, attr, 128 * 1024);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(k_cholqr_factor, dim3(1), dim3(256), (size_t)2 * n1 * n1 * sizeof(double), st, G, c, bb, n1, has_b, T, zmask, R, flag_out, run_flag);
+  hipLaunchKernelGGL(k_cholqr_factor, dim3(1), dim3(256), (size_t)2 * n1 * n1 * sizeof(double), st, G, c, bb, n1, has_b, T, V, zmask, R, flags, round, run_flag, rho_out);
   return hipGetLastError();
 }
 

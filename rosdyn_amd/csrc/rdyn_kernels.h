@@ -171,6 +171,7 @@ struct RdynLdsGramArgs
   double* slabs;
   int debug;                           // timing experiments only (RDYN_FUSED_DEBUG): bit 0 sweep only the first tile, bit 1 no Gram phase
   int tile_stride;                     // k_regressor_tsqr only: sweep every tile_stride-th 16-sample tile (0 / 1 = all): the subsample pass of the preconditioned route
+  const int* run_flag;                 // k_regressor_tsqr and its tree only: null, or a device word -- 0 = leave at once
   // wave-pair kernel only (rdyn_duo_gram.hip): the per-joint component columns [Y | C | tau_meas] of rdyn_identification_gram.
   // Column P + k of the tile belongs to component comp_col_comp[k] and is non-zero only in the rows of that component's joint:
   // it is stored as ONE 16-row group (stride 160 bytes) at lds_off_c + 160 k; the measured torque moves to column P + n_comp_cols.
@@ -196,23 +197,31 @@ int rdyn_cholqr_pairs(int n_joints, int tile_bytes, int xb);  // 4: W in LDS bes
 size_t rdyn_cholqr_w_doubles(int n_joints, int xb);           // W in MFMA operand order
 hipError_t rdyn_launch_cholqr_fold(const double* R_new, double* R, int n1, hipStream_t st);  // R <- qr([R ; R_new]), n1 <= 81
 hipError_t rdyn_launch_regressor_pgram(int n_joints, const RdynLdsGramArgs& a, const double* W, const int* run_flag, int blocks, int pairs, hipStream_t st);
-// R1 (n1 x n1 upper, column-major) -> T = R1 re-triangularised without its null columns (zmask: found when !zmask_given, else used),
-// W = T^-1 in MFMA operand order.  row_scale: R1 is the factor of one row in row_scale^2 (the subsample), T is scaled to all rows.
-// col_shift: columns of padding in FRONT of the natural order in the consumer's column space (rdyn_cholqr_col_shift)
-hipError_t rdyn_launch_cholqr_precond(const double* R1, int n1, int col_shift, double row_scale, double* T, double* W, int* zmask, int zmask_given,
-                                      const int* run_flag, hipStream_t st);
+// R1 (n1 x n1 upper, column-major) -> T = R1 re-triangularised without its deferred columns (zmask <- that set), W = T^-1 in MFMA
+// operand order.  row_scale: R1 is the factor of one row in row_scale^2 (the subsample), T is scaled to all rows.
+// col_shift: columns of padding in FRONT of the natural order in the consumer's column space (rdyn_cholqr_col_shift).
+// flags (device ints): [0] run round 1, [1] run the stand-by Householder factorisation, [2] run round 0.  The preconditioner of a
+// round whose growth factor gamma (Q T reproduces the columns of A with a relative error of about u gamma; *gamma_out, may be null)
+// exceeds 1e4 calls the round off and the stand-by in.
+// V: T^-1 in natural order (n1 x n1, for the factor kernel's own evaluation of gamma)
+hipError_t rdyn_launch_cholqr_precond(const double* R1, int n1, int col_shift, double row_scale, double* T, double* W, double* V, int* zmask, int* flags,
+                                      int round, const int* run_flag, double* gamma_out, hipStream_t st);
 int rdyn_cholqr_col_shift(int n_joints, int xb);
-// G2 = [G c; c' bb] -> R = chol(G2) T (n1 x n1 upper, column-major; zero rows at the null set); *flag_out = 1 when the preconditioner was poor
-hipError_t rdyn_launch_cholqr_factor(const double* G, const double* c, const double* bb, int n1, int has_b, const double* T, int* zmask, double* R,
-                                     int* flag_out, const int* run_flag, hipStream_t st);
+// G2 = [G c; c' bb] -> R = chol(G2) T (n1 x n1 upper, column-major; zero rows at the confirmed null columns); flags[round] = 1 when the
+// round is not accepted (rho_out, may be null: [0] the conditioning measure of the equilibrated Q, [2] gamma on the norms of all rows);
+// round 0 clears flags[1]
+hipError_t rdyn_launch_cholqr_factor(const double* G, const double* c, const double* bb, int n1, int has_b, const double* T, const double* V, const int* zmask,
+                                     double* R, int* flags, int round, const int* run_flag, double* rho_out, hipStream_t st);
 // factor of the reduced chain -> factor of the chain: R = qr([R_prev ; R_red diag(E, 1)]) (a.X, a.red_of, a.n_joints, a.n_red used)
 hipError_t rdyn_launch_cholqr_expand(const RdynGramExpandArgs& a, const double* R_red, const double* R_prev, double* R, hipStream_t st);
 // tall-skinny QR (rdyn_tsqr.hip): R factor of [A | b] without forming A'A
 int rdyn_tsqr_padded_cols(int n_cols_with_rhs);              // 16 / 32 / 48 / 64, 0 = unsupported
 size_t rdyn_tsqr_workspace_doubles(int nc, int blocks);
 int rdyn_regressor_tsqr_cols(int n_joints, int n_comp_cols);  // factor width of a rdyn_launch_regressor_tsqr call (0: unsupported)
+// a.run_flag (device int, may be null): every kernel of the call leaves at once when it reads 0; tree_fan: factors folded per wave and
+// tree level (2: the shallowest dependent chain; 16: three launches in all -- the stand-by call of the preconditioned route)
 hipError_t rdyn_launch_regressor_tsqr(int n_joints, const RdynLdsGramArgs& a, int blocks, size_t lds_bytes, double* workspace, double* R, int accumulate,
-                                      hipStream_t st);
+                                      hipStream_t st, int tree_fan = 2);
 hipError_t rdyn_launch_tsqr_rows(const double* A, const double* b, int64_t rows, int64_t lda, int n_cols, int blocks, double* workspace, double* R,
                                  int accumulate, hipStream_t st);
 int rdyn_gram_blocks_for(int P);

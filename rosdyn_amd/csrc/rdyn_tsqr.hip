@@ -265,6 +265,7 @@ __global__ __launch_bounds__(256) void k_regressor_tsqr(const RdynLdsGramArgs fa
   constexpr int P = 10 * NJ, NC = XC == 0 ? P + 1 : 16 * ((P + 1 + 15) / 16 + XC), NCI = (NC + 15) / 16, NK = (NC + 3) / 4;
   const int K = XC > 0 ? fa.n_comp_cols : 0;  // component columns sit between the regressor and tau_meas
   constexpr bool DIRECT = false, ALLREV = false;
+  if (fa.run_flag && *fa.run_flag == 0) return;  // stand-by call, not needed (uniform: every wave leaves)
   extern __shared__ __attribute__((aligned(32))) char lds_raw[];
   ChainPtr c = as_const(fa.chain);
   const int lane = threadIdx.x & 63;
@@ -458,20 +459,22 @@ __global__ __launch_bounds__(256) void k_tsqr_rows(const double* __restrict__ A,
   if (wave == 0) store_factor2d<NC>(Rr, factors + (int64_t)blockIdx.x * (NC * NC), NC, NC, lane);
 }
 
-// ---------------------------------------------------------------- tree: every wave folds two factors into one
-// (2 : 1 -- a fold is 61 .. 71 dependent column steps whatever the block holds, so the DEPTH of the tree is its cost: 4 : 1 levels
-// fold three blocks one after the other per level)
+// ---------------------------------------------------------------- tree: every wave folds `fan` factors into one
+// (2 : 1 by default -- a fold is 61 .. 71 dependent column steps whatever the block holds, so the DEPTH of the tree is its cost: 4 : 1
+// levels fold three blocks one after the other per level.  A larger fan trades time for launches: the stand-by call of rdyn_api.cpp)
 template <int NC>
-__global__ __launch_bounds__(64) void k_tsqr_combine(const double* __restrict__ in, int count, double* __restrict__ out, int out_ld, int out_cols,
-                                                     const double* __restrict__ extra /* one more factor (accumulate), or null */, int extra_ld)
+__global__ __launch_bounds__(64) void k_tsqr_combine(const double* __restrict__ in, int count, int fan, double* __restrict__ out, int out_ld, int out_cols,
+                                                     const double* __restrict__ extra /* one more factor (accumulate), or null */, int extra_ld,
+                                                     const int* __restrict__ run_flag)
 {
   constexpr int NCI = (NC + 15) / 16, NK = (NC + 3) / 4;
+  if (run_flag && *run_flag == 0) return;
   __shared__ __attribute__((aligned(32))) char buf[2 * NCI * 128];
   const int lane = threadIdx.x;
-  const int first = blockIdx.x * 2;
+  const int first = blockIdx.x * fan;
   double Rr[NCI][NK];
   load_factor2d<NC>(Rr, in + (int64_t)first * (NC * NC), NC, NC, lane);
-  const int n_more = first + 1 < count ? 1 : 0;
+  const int n_more = count - first - 1 < fan - 1 ? count - first - 1 : fan - 1;
   for (int t = 1; t <= n_more + (extra && blockIdx.x == 0 ? 1 : 0); ++t)
   {
     const bool is_extra = t > n_more;
@@ -479,7 +482,7 @@ __global__ __launch_bounds__(64) void k_tsqr_combine(const double* __restrict__ 
     if (is_extra)
       load_tri_block<NC>(Y, extra, extra_ld, out_cols, lane);
     else
-      load_tri_block<NC>(Y, in + (int64_t)(first + 1) * (NC * NC), NC, NC, lane);
+      load_tri_block<NC>(Y, in + (int64_t)(first + t) * (NC * NC), NC, NC, lane);
     tsqr_fold2d<NC, NCI, TriRowSlots>(Rr, Y, buf, lane);
   }
   store_factor2d<NC>(Rr, out + (int64_t)blockIdx.x * (NC * NC), out_ld, out_cols, lane);  // the last level is one wave: offset 0
@@ -503,27 +506,28 @@ hipError_t opt_in_lds(K kernel, std::atomic<uint64_t>& done)
 
 // folds `count` NC x NC factors at `slab` down to one, written to R (ld_out x n_out, column-major); scratch = second slab region
 template <int NC>
-hipError_t combine_tree(double* slab, int count, double* scratch, double* R, int n_out, const double* extra, hipStream_t st)
+hipError_t combine_tree(double* slab, int count, double* scratch, double* R, int n_out, const double* extra, hipStream_t st, int fan = 2,
+                        const int* run_flag = nullptr)
 {
   double* in = slab;
   double* out = scratch;
-  while (count > 2)
+  while (count > fan)
   {
-    const int nout = (count + 1) / 2;
-    hipLaunchKernelGGL((k_tsqr_combine<NC>), dim3(nout), dim3(64), 0, st, in, count, out, NC, NC, nullptr, 0);
+    const int nout = (count + fan - 1) / fan;
+    hipLaunchKernelGGL((k_tsqr_combine<NC>), dim3(nout), dim3(64), 0, st, in, count, fan, out, NC, NC, nullptr, 0, run_flag);
     count = nout;
     double* t = in;
     in = out;
     out = t;
   }
   // last level: straight into the caller's buffer (compact n_out x n_out), folding the caller's previous factor if accumulating
-  hipLaunchKernelGGL((k_tsqr_combine<NC>), dim3(1), dim3(64), 0, st, in, count, R, n_out, n_out, extra, n_out);
+  hipLaunchKernelGGL((k_tsqr_combine<NC>), dim3(1), dim3(64), 0, st, in, count, fan, R, n_out, n_out, extra, n_out, run_flag);
   return hipGetLastError();
 }
 
 template <int NJ, int XC>
 hipError_t launch_regressor_tsqr(const RdynLdsGramArgs& a, int blocks, size_t lds_bytes, double* slab, double* scratch, double* R, const double* extra,
-                                 hipStream_t st)
+                                 hipStream_t st, int fan)
 {
   constexpr int NC = XC == 0 ? 10 * NJ + 1 : 16 * ((10 * NJ + 1 + 15) / 16 + XC);
   static std::atomic<uint64_t> attr{0};
@@ -535,7 +539,7 @@ hipError_t launch_regressor_tsqr(const RdynLdsGramArgs& a, int blocks, size_t ld
   hipLaunchKernelGGL((k_regressor_tsqr<NJ, XC>), dim3(blocks), dim3(256), lds_bytes, st, a, slab);
   e = hipGetLastError();
   if (e != hipSuccess) return e;
-  return combine_tree<NC>(slab, blocks, scratch, R, 10 * NJ + (XC > 0 ? a.n_comp_cols : 0) + 1, extra, st);
+  return combine_tree<NC>(slab, blocks, scratch, R, 10 * NJ + (XC > 0 ? a.n_comp_cols : 0) + 1, extra, st, fan, a.run_flag);
 }
 
 template <int NC>
@@ -566,31 +570,31 @@ int rdyn_regressor_tsqr_cols(int n_joints, int n_comp_cols)
 }
 
 hipError_t rdyn_launch_regressor_tsqr(int n_joints, const RdynLdsGramArgs& a, int blocks, size_t lds_bytes, double* workspace, double* R, int accumulate,
-                                      hipStream_t st)
+                                      hipStream_t st, int tree_fan)
 {
   const int nc = rdyn_regressor_tsqr_cols(n_joints, a.n_comp_cols);
-  if (nc == 0) return hipErrorInvalidValue;
+  if (nc == 0 || tree_fan < 2) return hipErrorInvalidValue;
   double* slab = workspace;
   double* scratch = workspace + (size_t)blocks * nc * nc;
   const double* extra = accumulate ? R : nullptr;
   if (a.n_comp_cols > 0)
     switch (n_joints)
     {
-    case 2: return launch_regressor_tsqr<2, 1>(a, blocks, lds_bytes, slab, scratch, R, extra, st);
-    case 3: return launch_regressor_tsqr<3, 1>(a, blocks, lds_bytes, slab, scratch, R, extra, st);
-    case 4: return launch_regressor_tsqr<4, 1>(a, blocks, lds_bytes, slab, scratch, R, extra, st);
-    case 5: return launch_regressor_tsqr<5, 1>(a, blocks, lds_bytes, slab, scratch, R, extra, st);
-    case 6: return launch_regressor_tsqr<6, 1>(a, blocks, lds_bytes, slab, scratch, R, extra, st);
+    case 2: return launch_regressor_tsqr<2, 1>(a, blocks, lds_bytes, slab, scratch, R, extra, st, tree_fan);
+    case 3: return launch_regressor_tsqr<3, 1>(a, blocks, lds_bytes, slab, scratch, R, extra, st, tree_fan);
+    case 4: return launch_regressor_tsqr<4, 1>(a, blocks, lds_bytes, slab, scratch, R, extra, st, tree_fan);
+    case 5: return launch_regressor_tsqr<5, 1>(a, blocks, lds_bytes, slab, scratch, R, extra, st, tree_fan);
+    case 6: return launch_regressor_tsqr<6, 1>(a, blocks, lds_bytes, slab, scratch, R, extra, st, tree_fan);
     default: return hipErrorInvalidValue;
     }
   switch (n_joints)
   {
-  case 2: return launch_regressor_tsqr<2, 0>(a, blocks, lds_bytes, slab, scratch, R, extra, st);
-  case 3: return launch_regressor_tsqr<3, 0>(a, blocks, lds_bytes, slab, scratch, R, extra, st);
-  case 4: return launch_regressor_tsqr<4, 0>(a, blocks, lds_bytes, slab, scratch, R, extra, st);
-  case 5: return launch_regressor_tsqr<5, 0>(a, blocks, lds_bytes, slab, scratch, R, extra, st);
-  case 6: return launch_regressor_tsqr<6, 0>(a, blocks, lds_bytes, slab, scratch, R, extra, st);
-  case 7: return launch_regressor_tsqr<7, 0>(a, blocks, lds_bytes, slab, scratch, R, extra, st);
+  case 2: return launch_regressor_tsqr<2, 0>(a, blocks, lds_bytes, slab, scratch, R, extra, st, tree_fan);
+  case 3: return launch_regressor_tsqr<3, 0>(a, blocks, lds_bytes, slab, scratch, R, extra, st, tree_fan);
+  case 4: return launch_regressor_tsqr<4, 0>(a, blocks, lds_bytes, slab, scratch, R, extra, st, tree_fan);
+  case 5: return launch_regressor_tsqr<5, 0>(a, blocks, lds_bytes, slab, scratch, R, extra, st, tree_fan);
+  case 6: return launch_regressor_tsqr<6, 0>(a, blocks, lds_bytes, slab, scratch, R, extra, st, tree_fan);
+  case 7: return launch_regressor_tsqr<7, 0>(a, blocks, lds_bytes, slab, scratch, R, extra, st, tree_fan);
   default: return hipErrorInvalidValue;
   }
 }

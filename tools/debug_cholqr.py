@@ -9,7 +9,7 @@ def layout(nJ):
     hh = (256 + 128 + 2) * n1 * n1
     off = (hh + 31) & ~31
     L = {}
-    for name, d in (("slabs", 256 * nt * 256), ("w", nt * 256), ("r_sub", n1 * n1), ("r1p", n1 * n1), ("g2", n1 * n1 + 1), ("r_swept", n1 * n1), ("flag", 64)):
+    for name, d in (("slabs", 256 * nt * 256), ("w", nt * 256), ("r_sub", n1 * n1), ("r1p", n1 * n1), ("g2", n1 * n1 + 1), ("r_swept", n1 * n1), ("v", n1 * n1), ("flag", 64)):
         L[name] = off; off = (off + d + 31) & ~31
     L["total"] = off
     return L, n1
