@@ -1245,43 +1245,50 @@ static int regressor_tsqr_run(const rdyn_chain* c, const rdyn_component* comps, 
   double* const R_swept = (expand || (cholqr && accumulate)) ? ws + L.r_swept : R;
   if (cholqr)
   {
-    // pass A: Householder factor of every S-th tile (about 1 024 tiles whatever the batch size: one fold per wave + the block combine
-    // + the tree; 16 384 samples = 115 000 rows for <= 71 columns put the pivots of the second factorisation within a few % of 1)
+    // pass A: the Gram matrix of every S-th tile (about 1 024 tiles whatever the batch size: one tile per wave pair of the pass-B kernel
+    // run with W = I; 16 384 samples = 115 000 rows for <= 81 columns put the pivots of the second factorisation within a few % of 1).
+    // A preconditioner does not have to be a backward-stable factor -- what it is worth is measured on all rows afterwards.
     RdynLdsGramArgs sub = la;
     const int64_t kSubTiles = probe_env("RDYN_CHOLQR_SUBTILES") ? atoll(probe_env("RDYN_CHOLQR_SUBTILES")) : 1024;
     sub.tile_stride = (int)(tiles / kSubTiles > 1 ? tiles / kSubTiles : 1);
     if (sub.tile_stride > 1 && sub.tile_stride % 2 == 0) ++sub.tile_stride;  // odd: does not lock onto power-of-two periods of a trajectory
     const int64_t sub_tiles = (tiles + sub.tile_stride - 1) / sub.tile_stride;
-    const int sub_blocks = (int)((sub_tiles + 3) / 4 < kTsqrBlocks ? (sub_tiles + 3) / 4 : kTsqrBlocks);
-    RDYN_HIP_TRY(rdyn_launch_regressor_tsqr(nJ, sub, sub_blocks, 4 * (size_t)la.tile_bytes, ws, ws + L.r_sub, 0, stream));
     la.slabs = ws + L.slabs;
+    sub.slabs = la.slabs;
     const int np = pairs < 0 ? -pairs : pairs;
     const int blocks = (int)((tiles + np - 1) / np < kCholqrBlocks ? (tiles + np - 1) / np : kCholqrBlocks);
+    const int sub_blocks = (int)((sub_tiles + np - 1) / np < kCholqrBlocks ? (sub_tiles + np - 1) / np : kCholqrBlocks);
     int* const flag = (int*)(ws + L.flag);
+    const int col_shift = rdyn_cholqr_col_shift(nJ, n_comps > 0 ? 1 : 0);
+    RdynGramArgs ga;
+    memset(&ga, 0, sizeof ga);
+    ga.P = n1s - 1;
+    ga.slabs = la.slabs;
+    ga.G = ws + L.g2;
+    ga.c = ws + L.g2 + (size_t)(n1s - 1) * (n1s - 1);
+    ga.bb = ga.c + (n1s - 1);
+    ga.col_shift = col_shift;
+    ga.slab_nb = n_comps > 0 ? (10 * nJ + 1 + 15) / 16 + 1 : 0;
+    RDYN_HIP_TRY(rdyn_launch_cholqr_identity_w(ws + L.w, n1s, col_shift, stream));
+    RDYN_HIP_TRY(rdyn_launch_regressor_pgram(nJ, sub, ws + L.w, nullptr, sub_blocks, pairs, stream));
+    RDYN_HIP_TRY(rdyn_launch_gram_finish(ga, sub_blocks, stream));
     const int n_rounds = probe_env("RDYN_CHOLQR_ROUNDS") ? atoi(probe_env("RDYN_CHOLQR_ROUNDS")) : 2;  // A/B builds only
     for (int round = 0; round < n_rounds; ++round)
     {
-      // round 0: W from the subsample's factor.  Round 1 (CholeskyQR2 on top): W from round 0's factor; its kernels leave at once
+      // round 0: W from the subsample's Gram matrix.  Round 1 (CholeskyQR2 on top): W from round 0's factor; its kernels leave at once
       // unless round 0's factor kernel asked for it (flag[0]).  Round 0 itself runs when its preconditioner is fit for it (flag[2]).
       const int* const run = round == 0 ? flag + 2 : flag;
-      const double row_scale = round == 0 ? sqrt((double)tiles / (double)sub_tiles) : 1.0;
-      const int col_shift = rdyn_cholqr_col_shift(nJ, n_comps > 0 ? 1 : 0);
-      RDYN_HIP_TRY(rdyn_launch_cholqr_precond(round == 0 ? ws + L.r_sub : R_swept, n1s, col_shift, row_scale, ws + L.r1p, ws + L.w, ws + L.v, flag + 16, flag, round,
-                                              round == 0 ? nullptr : flag, ws + L.flag + 50 + round, stream));
+      if (round == 0)
+        RDYN_HIP_TRY(rdyn_launch_cholqr_precond(nullptr, ga.G, ga.c, ga.bb, n1s, col_shift, sqrt((double)tiles / (double)sub_tiles), ws + L.r1p, ws + L.w,
+                                                ws + L.v, flag + 16, flag, 0, nullptr, ws + L.flag + 50, stream));
+      else
+        RDYN_HIP_TRY(rdyn_launch_cholqr_precond(R_swept, nullptr, nullptr, nullptr, n1s, col_shift, 1.0, ws + L.r1p, ws + L.w, ws + L.v, flag + 16, flag, 1,
+                                                flag, ws + L.flag + 51, stream));
       RDYN_HIP_TRY(rdyn_launch_regressor_pgram(nJ, la, ws + L.w, run, blocks, pairs, stream));
-      RdynGramArgs ga;
-      memset(&ga, 0, sizeof ga);
-      ga.P = n1s - 1;
-      ga.slabs = la.slabs;
-      ga.G = ws + L.g2;
-      ga.c = ws + L.g2 + (size_t)(n1s - 1) * (n1s - 1);
-      ga.bb = ga.c + (n1s - 1);
       ga.run_flag = run;
-      ga.col_shift = col_shift;
-      ga.slab_nb = n_comps > 0 ? (10 * nJ + 1 + 15) / 16 + 1 : 0;
       RDYN_HIP_TRY(rdyn_launch_gram_finish(ga, blocks, stream));
-      RDYN_HIP_TRY(rdyn_launch_cholqr_factor(ga.G, ga.c, ga.bb, n1s, tau_meas ? 1 : 0, ws + L.r1p, ws + L.v, flag + 16, R_swept, flag, round, run, ws + L.flag + 52 + round,
-                                             stream));
+      RDYN_HIP_TRY(rdyn_launch_cholqr_factor(ga.G, ga.c, ga.bb, n1s, tau_meas ? 1 : 0, ws + L.r1p, ws + L.v, flag + 16, R_swept, flag, round, run,
+                                             ws + L.flag + 52 + round, stream));
     }
     {
       // stand-by: the Householder factorisation of ALL rows, queued behind the two rounds and started by the device only when a

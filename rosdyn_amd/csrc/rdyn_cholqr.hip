@@ -78,7 +78,9 @@ __global__ __launch_bounds__(128 * NPAIR) void k_regressor_pgram(const RdynLdsGr
   }
   char* const tile = lds_raw + WB + (size_t)pair * fa.tile_bytes;  // shared by the pair
   const int n = fa.n_active;
-  const int64_t n_tiles = (fa.n_samples + 15) / 16;
+  // tile_stride > 1: only every tile_stride-th 16-sample tile (the subsample pass); tile index t below counts the tiles that are swept
+  const int64_t t_mul = fa.tile_stride > 1 ? fa.tile_stride : 1;
+  const int64_t n_tiles = ((fa.n_samples + 15) / 16 + t_mul - 1) / t_mul;
   const int64_t t_step = (int64_t)gridDim.x * NPAIR;
   const int64_t t_first = (int64_t)blockIdx.x * NPAIR + pair;
   const int64_t trips_raw = (n_tiles - (int64_t)blockIdx.x * NPAIR + t_step - 1) / t_step;
@@ -93,7 +95,7 @@ __global__ __launch_bounds__(128 * NPAIR) void k_regressor_pgram(const RdynLdsGr
     const int fB = 4;
     double nqa = 0.0, ndqa = 0.0, nddqa = 0.0, nqb = 0.0, ndqb = 0.0, nddqb = 0.0, nb0 = 0.0, nb1 = 0.0;
     auto fetch = [&](int64_t tile_index) {
-      int64_t sx = tile_index * 16 + s_loc;
+      int64_t sx = tile_index * t_mul * 16 + s_loc;
       if (sx >= fa.n_samples) sx = fa.n_samples - 1;
       const int64_t o = sx * fa.in_ss;
       if (fa.bcol)
@@ -118,7 +120,7 @@ __global__ __launch_bounds__(128 * NPAIR) void k_regressor_pgram(const RdynLdsGr
     for (int64_t it = 0; it < trips; ++it)
     {
       const int64_t tl = t_first + it * t_step;
-      const bool valid = tl < n_tiles && tl * 16 + s_loc < fa.n_samples;
+      const bool valid = tl < n_tiles && tl * t_mul * 16 + s_loc < fa.n_samples;
       const int m0idx = valid ? r0 : -2, m1idx = valid ? r1 : -2;
       const double qa = nqa, dqa = ndqa, ddqa = nddqa, qb = nqb, dqb = ndqb, ddqb = nddqb;
       const double tb0 = valid ? nb0 : 0.0, tb1 = valid ? nb1 : 0.0;
@@ -329,66 +331,100 @@ __global__ __launch_bounds__(128 * NPAIR) void k_regressor_pgram(const RdynLdsGr
 
 // ---------------------------------------------------------------- the small dense steps (one workgroup each, n1 <= 81)
 constexpr int kMaxN1 = 81;
+#ifndef RDYN_CHOLQR_DENSE_THREADS
+#define RDYN_CHOLQR_DENSE_THREADS 1024
+#endif
+constexpr int NTD = RDYN_CHOLQR_DENSE_THREADS;  // threads of the single-workgroup dense kernels (256 / 512 / 1024: 1.45 / 1.41 / 1.40 ms for the whole call at config-2 size; >= 128)
 
-// Householder QR of the m x nc matrix B (column-major, leading dimension m) in LDS, in place (R in the upper triangle, zeros below),
-// by the 256 threads of the workgroup; v = m doubles of LDS, s_part / s_beta / s_v0 = workgroup-shared scratch.
-// n_steps: columns that are reduced (the remaining ones only have the reflections applied to them); < 0: min(nc, m)
-__device__ __forceinline__ void small_qr_lds(double* B, int m, int nc, double* v, double* s_part, double* s_beta, double* s_v0, int tid, int n_steps = -1)
+// Householder QR of the m x nc matrix B (column-major, leading dimension m) in LDS, in place, by the NTD threads of the workgroup:
+// R in the upper triangle; what is left BELOW the diagonal is the reflectors, not zeros -- callers read the upper triangle only.
+// One barrier per column step: every wave forms the column's norm by itself (the same sum in the same order: the waves agree to the
+// bit), the reflector is read in place, the new diagonal is written behind the step's barrier.
+// n_steps: columns that are reduced (the remaining ones only have the reflections applied to them); < 0: min(nc, m).
+// row_end (LDS, may be null): per reduced column k, one past the last row that can be non-zero below the diagonal (a triangular factor
+// with columns removed: the reflector of step k ends at the original index of its column).
+__device__ __forceinline__ void small_qr_lds(double* B, int m, int nc, int tid, int n_steps = -1, const int* row_end = nullptr)
 {
   const int steps = n_steps >= 0 ? n_steps : (nc < m ? nc : m);
+  const int lane = tid & 63;
   for (int k = 0; k < steps; ++k)
   {
-    double part = 0.0;
-    for (int r = k + 1 + tid; r < m; r += 256) part = fma(B[k * m + r], B[k * m + r], part);
-    s_part[tid] = part;
-    __syncthreads();
-    if (tid < 64)
+    const int rend = row_end ? (row_end[k] < m ? row_end[k] : m) : m;
+    double sigma = 0.0;
+    for (int r = k + 1 + lane; r < rend; r += 64) sigma = fma(B[k * m + r], B[k * m + r], sigma);
+    for (int o = 32; o > 0; o >>= 1) sigma += __shfl_xor(sigma, o);
+    const double alpha = B[k * m + k];
+    double scale = 0.0, v0 = 0.0, beta = alpha;
+    if (sigma > 1e-280)  // (else: nothing below the diagonal, no reflection)
     {
-      double t = s_part[tid] + s_part[tid + 64] + s_part[tid + 128] + s_part[tid + 192];
-      for (int o = 32; o > 0; o >>= 1) t += __shfl_down(t, o);
-      if (tid == 0)
-      {
-        const double alpha = B[k * m + k], sigma = t;
-        if (sigma > 1e-280)
-        {
-          const double norm = sqrt(fma(alpha, alpha, sigma));
-          const double beta = alpha > 0.0 ? -norm : norm;
-          *s_v0 = alpha - beta;
-          *s_beta = 2.0 / fma(*s_v0, *s_v0, sigma);
-          B[k * m + k] = beta;
-        }
-        else
-          *s_beta = 0.0;  // nothing below the diagonal: no reflection
-      }
-    }
-    __syncthreads();
-    const double scale = *s_beta, v0 = *s_v0;
-    if (scale != 0.0)
-    {
-      for (int r = k + 1 + tid; r < m; r += 256) v[r] = B[k * m + r];
-      __syncthreads();
+      const double norm = sqrt(fma(alpha, alpha, sigma));
+      beta = alpha > 0.0 ? -norm : norm;
+      v0 = alpha - beta;
+      scale = 2.0 / fma(v0, v0, sigma);
       // columns j > k: four threads per column share the rows
       const int ncol = nc - k - 1;
-      for (int e = tid; e < ((ncol * 4 + 255) & ~255); e += 256)
+      for (int e = tid; e < (ncol * 4 + NTD - 1) / NTD * NTD; e += NTD)
       {
         const bool on = e < ncol * 4;
         const int j = on ? k + 1 + (e >> 2) : k, q = e & 3;
         double d = (on && q == 0) ? v0 * B[j * m + k] : 0.0;
         if (on)
-          for (int r = k + 1 + q; r < m; r += 4) d = fma(v[r], B[j * m + r], d);
+          for (int r = k + 1 + q; r < rend; r += 4) d = fma(B[k * m + r], B[j * m + r], d);
         d += __shfl_xor(d, 1);
         d += __shfl_xor(d, 2);
         const double f = scale * d;
         if (on)
         {
           if (q == 0) B[j * m + k] = fma(-f, v0, B[j * m + k]);
-          for (int r = k + 1 + q; r < m; r += 4) B[j * m + r] = fma(-f, v[r], B[j * m + r]);
+          for (int r = k + 1 + q; r < rend; r += 4) B[j * m + r] = fma(-f, B[k * m + r], B[j * m + r]);
         }
       }
-      __syncthreads();
-      for (int r = k + 1 + tid; r < m; r += 256) B[k * m + r] = 0.0;
     }
     __syncthreads();
+    if (tid == 0) B[k * m + k] = beta;
+  }
+  __syncthreads();
+}
+
+// X = U^-1 for an upper-triangular U (n x n, column-major, leading dimension n, in LDS; rdiag = 1 / diag(U), in LDS); X in LDS, its
+// strict lower triangle untouched.  Four lanes per column: lane q of a column owns the entries x(k), k = q mod 4 (it writes and later
+// reads them itself: no exchange through LDS inside the wave), the inner sums meet by two shuffles.  Long columns first.
+// fro2 (LDS, may be null): per column the sum of squares of its entries of X.  Callers put barriers around the call.
+__device__ __forceinline__ void tri_inverse_lds(const double* U, const double* rdiag, double* X, int n, int tid, double* fro2)
+{
+  const int q = tid & 3, lane = tid & 63;
+  for (int c0 = 0; c0 < n; c0 += NTD / 4)
+  {
+    const int c = n - 1 - c0 - (tid >> 2);  // this lane's column (< 0: none)
+    const int c_top = n - 1 - c0 - ((tid - lane) >> 2);  // the longest column of the wave: its trip count for everyone (uniform shuffles)
+    double own2 = 0.0;
+    if (c >= 0 && (c & 3) == q)
+    {
+      const double x = rdiag[c];
+      X[c * n + c] = x;
+      own2 = x * x;
+    }
+    for (int i = c_top - 1; i >= 0; --i)
+    {
+      const bool on = c >= 0 && i < c;
+      double s = 0.0;
+      if (on)
+      {
+        int k = i + 1 + ((q - (i + 1)) & 3);  // the first k > i with k = q mod 4
+        for (; k <= c; k += 4) s = fma(U[k * n + i], X[c * n + k], s);
+      }
+      s += __shfl_xor(s, 1);
+      s += __shfl_xor(s, 2);
+      if (on && (i & 3) == q)
+      {
+        const double x = -s * rdiag[i];
+        X[c * n + i] = x;
+        own2 = fma(x, x, own2);
+      }
+    }
+    own2 += __shfl_xor(own2, 1);
+    own2 += __shfl_xor(own2, 2);
+    if (fro2 && c >= 0 && q == 0) fro2[c] = own2;
   }
 }
 
@@ -413,19 +449,78 @@ __device__ __forceinline__ void small_qr_lds(double* B, int m, int nc, double* v
 // flags: [0] run round 1, [1] run the stand-by, [2] run round 0 (written here in round 0).  zmask <- Z (for the factor kernel).
 // W is written in the MFMA operand order of k_regressor_pgram.
 constexpr double kCholqrGammaMax = 1e4;
-__global__ __launch_bounds__(256) void k_cholqr_precond(const double* __restrict__ R1, int n1, int col_shift, double row_scale, double* __restrict__ Tout,
-                                                        double* __restrict__ W, double* __restrict__ Vout, int* __restrict__ zmask, int* __restrict__ flags,
-                                                        int round, const int* __restrict__ run_flag, double* __restrict__ gamma_out)
+__global__ __launch_bounds__(NTD) void k_cholqr_precond(const double* __restrict__ R1, const double* __restrict__ Gs, const double* __restrict__ cs,
+                                                        const double* __restrict__ bbs, int n1, int col_shift, double row_scale,
+                                                        double* __restrict__ Tout, double* __restrict__ W, double* __restrict__ Vout, int* __restrict__ zmask,
+                                                        int* __restrict__ flags, int round, const int* __restrict__ run_flag,
+                                                        double* __restrict__ gamma_out)
 {
   if (run_flag && *run_flag == 0) return;
   extern __shared__ __attribute__((aligned(16))) double sh[];
   double* const A0 = sh;                // [n1][n1] column-major: R1, then T
-  double* const B = sh + n1 * n1;       // [nc][n1]: the kept columns, then V = T^-1
-  double* const v = sh + 2 * n1 * n1;   // [n1]
-  __shared__ double s_part[256], s_beta, s_v0, s_norm[kMaxN1], s_lift[kMaxN1], s_g[kMaxN1];
-  __shared__ int s_z[kMaxN1], s_cmap[kMaxN1], s_nc;
+  double* const B = sh + n1 * n1;       // [nc][n1]: the kept columns (or the Gram matrix being factorised), then V = T^-1
+  __shared__ double s_part[kMaxN1], s_norm[kMaxN1], s_lift[kMaxN1], s_g[kMaxN1];
+  __shared__ int s_z[kMaxN1], s_cmap[kMaxN1], s_rend[kMaxN1], s_nc;
   const int tid = threadIdx.x;
-  for (int i = tid; i < n1 * n1; i += 256)
+  if (Gs)
+  {
+    // ---- from the Gram matrix [G c; c' bb] of the subsample: Cholesky in which a deferred pivot eliminates nothing.  Row k of T is
+    // M(k, :) / pivot (the coefficients of the later columns, deferred ones included, on direction k); a deferred row holds its lift.
+    // One barrier per pivot: everybody evaluates the (uniform) pivot decision, the scaled row goes to T, the trailing update works
+    // from the unscaled one.
+    const int P = n1 - 1;
+    const double sc2 = row_scale * row_scale;  // the Gram matrix of all rows is row_scale^2 x that of the subsample
+    for (int i = tid; i < n1 * n1; i += NTD)
+    {
+      const int r = i % n1, c = i / n1;
+      double v;
+      if (r < P && c < P) v = Gs[(int64_t)c * P + r];
+      else if (r == P && c == P) v = bbs[0];
+      else v = cs[r < P ? r : c];
+      B[i] = sc2 * v;
+      A0[i] = 0.0;
+    }
+    __syncthreads();
+    if (tid < n1) s_norm[tid] = sqrt(fmax(B[tid * n1 + tid], 0.0));
+    __syncthreads();
+    if (tid < n1)
+    {
+      double mx = 0.0;
+      for (int c = 0; c <= tid; ++c) mx = fmax(mx, s_norm[c]);
+      s_lift[tid] = mx > 0.0 ? 1e-13 * mx : 1.0;
+    }
+    __syncthreads();
+    for (int k = 0; k < n1; ++k)
+    {
+      const double d = B[k * n1 + k], rel = d / (s_norm[k] * s_norm[k]);
+      // the squared sine of the angle to the columns on the left: a Gram matrix resolves it down to ~1e-14; below 1e-10 (sine 1e-5, the
+      // own-norm rule of the other branch) or below the residue floor the column is deferred.  The last column eliminates nothing.
+      const bool defer = !(rel >= (k + 1 < n1 ? 1e-10 : 1e-14)) || !(d >= s_lift[k] * s_lift[k]);
+      if (defer)
+      {
+        if (tid == 0)
+        {
+          s_z[k] = 1;
+          A0[k * n1 + k] = s_lift[k];
+        }
+        continue;
+      }
+      const double piv = sqrt(d), inv_p = 1.0 / piv, inv_d = 1.0 / d;
+      const int m = n1 - k - 1;
+      for (int e = tid; e < m * m; e += NTD)
+      {
+        const int i = k + 1 + e % m, j = k + 1 + e / m;
+        if (i <= j) B[j * n1 + i] = fma(-B[i * n1 + k] * inv_d, B[j * n1 + k], B[j * n1 + i]);
+      }
+      for (int j = k + tid; j < n1; j += NTD) A0[j * n1 + k] = j == k ? piv : B[j * n1 + k] * inv_p;
+      if (tid == 0) s_z[k] = 0;
+      __syncthreads();
+    }
+    __syncthreads();
+  }
+  else
+  {
+  for (int i = tid; i < n1 * n1; i += NTD)
   {
     const int r = i % n1, c = i / n1;
     A0[i] = r <= c ? row_scale * R1[i] : 0.0;  // a factor of 1 row in row_scale^2: the factor of all rows is row_scale x larger
@@ -458,21 +553,22 @@ __global__ __launch_bounds__(256) void k_cholqr_precond(const double* __restrict
     s_nc = nc;
     for (int c = 0; c < n1; ++c)  // the deferred columns behind the kept ones
       if (s_z[c]) s_cmap[nc++] = c;
+    for (int c = 0; c < n1; ++c) s_rend[c] = s_cmap[c] + 1;  // column c of the compacted matrix is zero below its original index
   }
   __syncthreads();
   const int nc = s_nc;
-  for (int i = tid; i < n1 * n1; i += 256) B[i] = A0[s_cmap[i / n1] * n1 + (i % n1)];
+  for (int i = tid; i < n1 * n1; i += NTD) B[i] = A0[s_cmap[i / n1] * n1 + (i % n1)];
   __syncthreads();
-  small_qr_lds(B, n1, n1, v, s_part, &s_beta, &s_v0, tid, nc);
+  small_qr_lds(B, n1, n1, tid, nc, s_rend);
   // T: kept columns at their positions, deferred columns: coefficients + diagonal
-  for (int i = tid; i < n1 * n1; i += 256) A0[i] = 0.0;
+  for (int i = tid; i < n1 * n1; i += NTD) A0[i] = 0.0;
   __syncthreads();
-  for (int i = tid; i < nc * nc; i += 256)
+  for (int i = tid; i < nc * nc; i += NTD)
   {
     const int a = i % nc, bcol = i / nc;
     if (a <= bcol) A0[s_cmap[bcol] * n1 + s_cmap[a]] = B[bcol * n1 + a];
   }
-  for (int i = tid; i < (n1 - nc) * nc; i += 256)
+  for (int i = tid; i < (n1 - nc) * nc; i += NTD)
   {
     // deferred column k = s_cmap[nc + z]: its coefficient on kept direction a, if that direction's column lies to its left
     const int z = i / (nc > 0 ? nc : 1), a = i - z * nc, k = s_cmap[nc + z];
@@ -480,27 +576,20 @@ __global__ __launch_bounds__(256) void k_cholqr_precond(const double* __restrict
   }
   if (tid < n1 && s_z[tid]) A0[tid * n1 + tid] = s_lift[tid];
   __syncthreads();
-  for (int i = tid; i < n1 * n1; i += 256)
+  }
+  for (int i = tid; i < n1 * n1; i += NTD)
   {
     Tout[i] = A0[i];
     B[i] = 0.0;  // V
   }
   if (tid < n1) zmask[tid] = s_z[tid];
   __syncthreads();
-  if (tid < n1)
-  {
-    // column c of the inverse: T x = e_c by back substitution (T is nonsingular: full-rank kept block, lifts on the deferred diagonal)
-    const int c = tid;
-    B[c * n1 + c] = 1.0 / A0[c * n1 + c];
-    for (int i = c - 1; i >= 0; --i)
-    {
-      double s = 0.0;
-      for (int k = i + 1; k <= c; ++k) s = fma(A0[k * n1 + i], B[c * n1 + k], s);
-      B[c * n1 + i] = -s / A0[i * n1 + i];
-    }
-  }
+  // V = T^-1 (T is nonsingular: full-rank kept block, lifts on the deferred diagonal)
+  if (tid < n1) s_g[tid] = 1.0 / A0[tid * n1 + tid];
   __syncthreads();
-  for (int i = tid; i < n1 * n1; i += 256) Vout[i] = B[i];  // T^-1 in natural order: the factor kernel re-evaluates gamma on the norms of ALL rows
+  tri_inverse_lds(A0, s_g, B, n1, tid, nullptr);
+  __syncthreads();
+  for (int i = tid; i < n1 * n1; i += NTD) Vout[i] = B[i];  // T^-1 in natural order: the factor kernel re-evaluates gamma on the norms of ALL rows
   if (tid < n1)
   {
     double g = 0.0;
@@ -530,7 +619,7 @@ __global__ __launch_bounds__(256) void k_cholqr_precond(const double* __restrict
   }
   // operand order of k_regressor_pgram, in its column space (natural order shifted right by col_shift)
   const int nb = (n1 + col_shift + 15) / 16, nt = nb * (nb + 1) / 2;
-  for (int i = tid; i < nt * 256; i += 256)
+  for (int i = tid; i < nt * 256; i += NTD)
   {
     const int blk = i >> 8, kk = (i >> 6) & 3, ln = i & 63;
     int cb2 = 0;
@@ -538,6 +627,21 @@ __global__ __launch_bounds__(256) void k_cholqr_precond(const double* __restrict
     const int cb1 = blk - cb2 * (cb2 + 1) / 2;
     const int r = 16 * cb1 + 4 * kk + (ln >> 4) - col_shift, c = 16 * cb2 + (ln & 15) - col_shift;
     W[i] = (r >= 0 && c >= 0 && r < n1 && c < n1 && r <= c) ? B[c * n1 + r] : 0.0;
+  }
+}
+
+// W = identity in the operand order of k_regressor_pgram (the subsample pass: the Gram matrix of the rows themselves)
+__global__ __launch_bounds__(256) void k_cholqr_identity_w(double* __restrict__ W, int n1, int col_shift)
+{
+  const int nb = (n1 + col_shift + 15) / 16, nt = nb * (nb + 1) / 2;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < nt * 256; i += gridDim.x * 256)
+  {
+    const int blk = i >> 8, kk = (i >> 6) & 3, ln = i & 63;
+    int cb2 = 0;
+    while ((cb2 + 1) * (cb2 + 2) / 2 <= blk) ++cb2;
+    const int cb1 = blk - cb2 * (cb2 + 1) / 2;
+    const int r = 16 * cb1 + 4 * kk + (ln >> 4) - col_shift, c = 16 * cb2 + (ln & 15) - col_shift;
+    W[i] = (r == c && r >= 0 && r < n1) ? 1.0 : 0.0;
   }
 }
 
@@ -551,7 +655,7 @@ __global__ __launch_bounds__(256) void k_cholqr_precond(const double* __restrict
 //   Re of the equilibrated Gram of the k pivoted columns (1 for orthogonal columns; |Re^-1|_2 <= rho sqrt(k)); rho > 4, or a kept
 //   column that turns out dependent on its left neighbours, and the round is not accepted: flags[round] = 1 (flags[0] starts round 1,
 //   flags[1] starts the stand-by Householder factorisation).  Round 0 also clears flags[1].
-__global__ __launch_bounds__(256) void k_cholqr_factor(const double* __restrict__ G, const double* __restrict__ cvec, const double* __restrict__ bb, int n1,
+__global__ __launch_bounds__(NTD) void k_cholqr_factor(const double* __restrict__ G, const double* __restrict__ cvec, const double* __restrict__ bb, int n1,
                                                        int has_b, const double* __restrict__ T_in, const double* __restrict__ V, const int* __restrict__ zmask,
                                                        double* __restrict__ Rout, int* __restrict__ flags, int round, const int* __restrict__ run_flag,
                                                        double* __restrict__ rho_out)
@@ -563,7 +667,7 @@ __global__ __launch_bounds__(256) void k_cholqr_factor(const double* __restrict_
   __shared__ double s_piv, s_g0[kMaxN1], s_sc[kMaxN1], s_part[kMaxN1], s_gam[kMaxN1];
   __shared__ int s_flag, s_z[kMaxN1], s_skip[kMaxN1];
   const int tid = threadIdx.x, P = n1 - 1;
-  for (int i = tid; i < n1 * n1; i += 256)
+  for (int i = tid; i < n1 * n1; i += NTD)
   {
     const int r = i % n1, c = i / n1;
     double v;
@@ -605,15 +709,15 @@ __global__ __launch_bounds__(256) void k_cholqr_factor(const double* __restrict_
     if (s_skip[k])
     {
       // null direction: its Schur complement is rounding residue -- row k of the factor is zero, nothing is eliminated
-      for (int j = k + tid; j < n1; j += 256) M[j * n1 + k] = 0.0;
+      for (int j = k + tid; j < n1; j += NTD) M[j * n1 + k] = 0.0;
       __syncthreads();
       continue;
     }
     const double inv = 1.0 / s_piv;
-    for (int j = k + 1 + tid; j < n1; j += 256) M[j * n1 + k] *= inv;  // row k of the factor: M(k, j), stored in column j
+    for (int j = k + 1 + tid; j < n1; j += NTD) M[j * n1 + k] *= inv;  // row k of the factor: M(k, j), stored in column j
     __syncthreads();
     const int m = n1 - k - 1;  // trailing update of the upper triangle: M(i, j) -= M(k, i) M(k, j), k < i <= j
-    for (int e = tid; e < m * m; e += 256)
+    for (int e = tid; e < m * m; e += NTD)
     {
       const int i = k + 1 + e % m, j = k + 1 + e / m;
       if (i <= j) M[j * n1 + i] = fma(-M[i * n1 + k], M[j * n1 + k], M[j * n1 + i]);
@@ -621,7 +725,7 @@ __global__ __launch_bounds__(256) void k_cholqr_factor(const double* __restrict_
     __syncthreads();
   }
   // R = R2 T (upper x upper)
-  for (int e = tid; e < n1 * n1; e += 256)
+  for (int e = tid; e < n1 * n1; e += NTD)
   {
     const int i = e % n1, j = e / n1;
     double s = 0.0;
@@ -655,39 +759,28 @@ __global__ __launch_bounds__(256) void k_cholqr_factor(const double* __restrict_
     s_gam[tid] = norm_own > 0.0 ? g / norm_own : 0.0;
   }
   __syncthreads();
-  // the inverse of Re = R2 diag(1 / |Q(:, j)|) over the pivoted columns (skipped rows / columns left out): column c by back substitution
-  if (tid < n1)
+  // the inverse of Re = R2 diag(1 / |Q(:, j)|) over the pivoted columns; a skipped pivot stands in as a 1 on the diagonal of a zero
+  // row and column (its column of the inverse is e_k: left out of the sum below)
+  for (int e = tid; e < n1 * n1; e += NTD)
   {
-    const int c = tid;
-    double fro = 0.0;
-    if (!s_skip[c])
-    {
-      const double xc = s_sc[c] / M[c * n1 + c];  // Re(i, j) = M(i, j) / sqrt(g0(j))
-      T[c * n1 + c] = xc;
-      fro = xc * xc;
-      for (int i = c - 1; i >= 0; --i)
-      {
-        if (s_skip[i]) continue;
-        double s = 0.0;
-        for (int k = i + 1; k <= c; ++k)
-          if (!s_skip[k]) s = fma(M[k * n1 + i] / s_sc[k], T[c * n1 + k], s);
-        const double x = -s * s_sc[i] / M[i * n1 + i];
-        T[c * n1 + i] = x;
-        fro = fma(x, x, fro);
-      }
-    }
-    s_part[c] = fro;
+    const int i = e % n1, j = e / n1;
+    if (i <= j) M[e] = (s_skip[i] || s_skip[j]) ? (i == j ? 1.0 : 0.0) : M[e] / s_sc[j];
   }
+  __syncthreads();
+  if (tid < n1) s_sc[tid] = 1.0 / M[tid * n1 + tid];
+  __syncthreads();
+  tri_inverse_lds(M, s_sc, T, n1, tid, s_part);
   __syncthreads();
   if (tid == 0)
   {
     double fro = 0.0;
     int kept = 0;
     for (int c = 0; c < n1; ++c)
-    {
-      fro += s_part[c];
-      kept += s_skip[c] ? 0 : 1;
-    }
+      if (!s_skip[c])
+      {
+        fro += s_part[c];
+        ++kept;
+      }
     const double rho = kept > 0 ? sqrt(fro / kept) : 1.0;
     double gamma = 0.0;
     for (int c = 0; c < n1; ++c) gamma = fmax(gamma, s_gam[c]);
@@ -705,18 +798,16 @@ __global__ __launch_bounds__(256) void k_cholqr_factor(const double* __restrict_
 // Factor of the reduced chain -> factor of the chain (rdyn_chain.hpp: [A b] = [A_red b] E_aug, E_aug = diag(E, 1)):
 // R = qr([R_prev ; R_red E_aug]) by Householder reflections in LDS, one workgroup.  R_prev (n1 x n1, the caller's running factor)
 // only when accumulating.  The product has nr = 10 n_red + 1 rows and n1 = 10 n_joints + 1 columns; rows beyond the rank stay zero.
-__global__ __launch_bounds__(256) void k_cholqr_expand(const RdynGramExpandArgs a, const double* __restrict__ R_red, const double* __restrict__ R_prev,
+__global__ __launch_bounds__(NTD) void k_cholqr_expand(const RdynGramExpandArgs a, const double* __restrict__ R_red, const double* __restrict__ R_prev,
                                                        double* __restrict__ Rout)
 {
   extern __shared__ __attribute__((aligned(16))) double sh[];
   const int P = 10 * a.n_joints, n1 = P + 1, Pr = 10 * a.n_red, nr = Pr + 1;
   const int m = nr + (R_prev ? n1 : 0);
   double* const B = sh;            // [n1][m] column-major (leading dimension m)
-  double* const v = sh + n1 * m;   // the reflector of the current step
-  __shared__ double s_part[256], s_beta, s_v0;
   const int tid = threadIdx.x;
   // rows 0 .. nr - 1: R_red E_aug; rows nr ..: R_prev
-  for (int e = tid; e < n1 * m; e += 256)
+  for (int e = tid; e < n1 * m; e += NTD)
   {
     const int r = e % m, col = e / m;
     double s = 0.0;
@@ -743,8 +834,8 @@ __global__ __launch_bounds__(256) void k_cholqr_expand(const RdynGramExpandArgs 
     B[e] = s;
   }
   __syncthreads();
-  small_qr_lds(B, m, n1, v, s_part, &s_beta, &s_v0, tid);
-  for (int e = tid; e < n1 * n1; e += 256)
+  small_qr_lds(B, m, n1, tid);
+  for (int e = tid; e < n1 * n1; e += NTD)
   {
     const int r = e % n1, col = e / n1;
     Rout[e] = (r <= col && r < m) ? B[col * m + r] : 0.0;
@@ -753,22 +844,20 @@ __global__ __launch_bounds__(256) void k_cholqr_expand(const RdynGramExpandArgs 
 
 // max_bytes: dynamic LDS the kernel may ask for (kernels with static __shared__ variables must leave room for them inside 160 KB)
 // R <- qr([R ; R_new]): both n1 x n1 upper triangular, column-major (the accumulate step of the preconditioned route: any width)
-__global__ __launch_bounds__(256) void k_cholqr_fold(const double* __restrict__ R_new, double* __restrict__ R, int n1)
+__global__ __launch_bounds__(NTD) void k_cholqr_fold(const double* __restrict__ R_new, double* __restrict__ R, int n1)
 {
   extern __shared__ __attribute__((aligned(16))) double sh[];
   const int m = 2 * n1;
   double* const B = sh;
-  double* const v = sh + n1 * m;
-  __shared__ double s_part[256], s_beta, s_v0;
   const int tid = threadIdx.x;
-  for (int e = tid; e < n1 * m; e += 256)
+  for (int e = tid; e < n1 * m; e += NTD)
   {
     const int r = e % m, col = e / m;
     B[e] = r < n1 ? (r <= col ? R[(int64_t)col * n1 + r] : 0.0) : (r - n1 <= col ? R_new[(int64_t)col * n1 + r - n1] : 0.0);
   }
   __syncthreads();
-  small_qr_lds(B, m, n1, v, s_part, &s_beta, &s_v0, tid);
-  for (int e = tid; e < n1 * n1; e += 256)
+  small_qr_lds(B, m, n1, tid);
+  for (int e = tid; e < n1 * n1; e += NTD)
   {
     const int r = e % n1, col = e / n1;
     R[e] = r <= col ? B[col * m + r] : 0.0;
@@ -865,14 +954,22 @@ hipError_t rdyn_launch_regressor_pgram(int n_joints, const RdynLdsGramArgs& a, c
   }
 }
 
-hipError_t rdyn_launch_cholqr_precond(const double* R1, int n1, int col_shift, double row_scale, double* T, double* W, double* V, int* zmask, int* flags,
-                                      int round, const int* run_flag, double* gamma_out, hipStream_t st)
+hipError_t rdyn_launch_cholqr_identity_w(double* W, int n1, int col_shift, hipStream_t st)
+{
+  hipLaunchKernelGGL(k_cholqr_identity_w, dim3(8), dim3(256), 0, st, W, n1, col_shift);
+  return hipGetLastError();
+}
+
+hipError_t rdyn_launch_cholqr_precond(const double* R1, const double* Gs, const double* cs, const double* bbs, int n1, int col_shift, double row_scale,
+                                      double* T, double* W, double* V, int* zmask, int* flags, int round, const int* run_flag, double* gamma_out,
+                                      hipStream_t st)
 {
   if (n1 < 1 || n1 > kMaxN1) return hipErrorInvalidValue;
   static std::atomic<uint64_t> attr{0};
   hipError_t e = opt_in_lds_once(k_cholqr_precond, attr, 128 * 1024);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(k_cholqr_precond, dim3(1), dim3(256), ((size_t)2 * n1 * n1 + n1) * sizeof(double), st, R1, n1, col_shift, row_scale, T, W, V, zmask, flags, round, run_flag, gamma_out);
+  hipLaunchKernelGGL(k_cholqr_precond, dim3(1), dim3(NTD), ((size_t)2 * n1 * n1 + n1) * sizeof(double), st, R1, Gs, cs, bbs, n1, col_shift, row_scale, T, W, V, zmask, flags, round, run_flag,
+                     gamma_out);
   return hipGetLastError();
 }
 
@@ -883,7 +980,7 @@ hipError_t rdyn_launch_cholqr_factor(const double* G, const double* c, const dou
   static std::atomic<uint64_t> attr{0};
   hipError_t e = opt_in_lds_once(k_cholqr_factor, attr, 128 * 1024);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(k_cholqr_factor, dim3(1), dim3(256), (size_t)2 * n1 * n1 * sizeof(double), st, G, c, bb, n1, has_b, T, V, zmask, R, flags, round, run_flag, rho_out);
+  hipLaunchKernelGGL(k_cholqr_factor, dim3(1), dim3(NTD), (size_t)2 * n1 * n1 * sizeof(double), st, G, c, bb, n1, has_b, T, V, zmask, R, flags, round, run_flag, rho_out);
   return hipGetLastError();
 }
 
@@ -896,7 +993,7 @@ hipError_t rdyn_launch_cholqr_expand(const RdynGramExpandArgs& a, const double* 
   static std::atomic<uint64_t> attr{0};
   hipError_t e = opt_in_lds_once(k_cholqr_expand, attr, 156 * 1024);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(k_cholqr_expand, dim3(1), dim3(256), lds, st, a, R_red, R_prev, R);
+  hipLaunchKernelGGL(k_cholqr_expand, dim3(1), dim3(NTD), lds, st, a, R_red, R_prev, R);
   return hipGetLastError();
 }
 
@@ -906,7 +1003,7 @@ hipError_t rdyn_launch_cholqr_fold(const double* R_new, double* R, int n1, hipSt
   static std::atomic<uint64_t> attr{0};
   hipError_t e = opt_in_lds_once(k_cholqr_fold, attr, 128 * 1024);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(k_cholqr_fold, dim3(1), dim3(256), ((size_t)2 * n1 * n1 + 2 * n1) * sizeof(double), st, R_new, R, n1);
+  hipLaunchKernelGGL(k_cholqr_fold, dim3(1), dim3(NTD), ((size_t)2 * n1 * n1 + 2 * n1) * sizeof(double), st, R_new, R, n1);
   return hipGetLastError();
 }
 

@@ -203,9 +203,12 @@ hipError_t rdyn_launch_regressor_pgram(int n_joints, const RdynLdsGramArgs& a, c
 // flags (device ints): [0] run round 1, [1] run the stand-by Householder factorisation, [2] run round 0.  The preconditioner of a
 // round whose growth factor gamma (Q T reproduces the columns of A with a relative error of about u gamma; *gamma_out, may be null)
 // exceeds 1e4 calls the round off and the stand-by in.
-// V: T^-1 in natural order (n1 x n1, for the factor kernel's own evaluation of gamma)
-hipError_t rdyn_launch_cholqr_precond(const double* R1, int n1, int col_shift, double row_scale, double* T, double* W, double* V, int* zmask, int* flags,
-                                      int round, const int* run_flag, double* gamma_out, hipStream_t st);
+// V: T^-1 in natural order (n1 x n1, for the factor kernel's own evaluation of gamma).
+// Input: the triangular factor R1, or (Gs != null) the Gram matrix [Gs cs; cs' bbs] of the subsample's rows (P x P, P, 1; P = n1 - 1).
+hipError_t rdyn_launch_cholqr_precond(const double* R1, const double* Gs, const double* cs, const double* bbs, int n1, int col_shift, double row_scale,
+                                      double* T, double* W, double* V, int* zmask, int* flags, int round, const int* run_flag, double* gamma_out,
+                                      hipStream_t st);
+hipError_t rdyn_launch_cholqr_identity_w(double* W, int n1, int col_shift, hipStream_t st);  // W = I in the operand order of the pass
 int rdyn_cholqr_col_shift(int n_joints, int xb);
 // G2 = [G c; c' bb] -> R = chol(G2) T (n1 x n1 upper, column-major; zero rows at the confirmed null columns); flags[round] = 1 when the
 // round is not accepted (rho_out, may be null: [0] the conditioning measure of the equilibrated Q, [2] gamma on the norms of all rows);
