@@ -373,10 +373,13 @@ int rdyn_regressor_gram_multi(rdyn_multi_gpu* ctx, const rdyn_chain* chain, cons
  * 2..7 INPUT joints in chain order (else RDYN_ERR_UNSUPPORTED); joints that are not input joints are folded away (the reduced chain
  * of rdyn_chain_reduction is swept and the factor expanded by a small QR: up to RDYN_MAX_JOINTS chain joints).
  * Two routes, chosen by the batch size: Householder folds on the vector units (rdyn_tsqr.hip; ~5x the time of rdyn_regressor_gram),
- * and from 196 608 samples on preconditioned CholeskyQR with the heavy pass on the fp64 matrix cores (rdyn_cholqr.hip: Householder
- * factor R1 of a row subsample, W = R1^-1 without its null columns, G2 = (A W)'(A W) over all rows by MFMA, R = chol(G2) R1 with a
- * pivot check and an automatic second round; ~2.3x the time of rdyn_regressor_gram; rows of R at structurally dependent columns
- * are exactly zero).  Both return R1 with R1'R1 = [A b]'[A b] to rounding and the small singular values to ~cond * eps.
+ * and from 4 096 samples on preconditioned CholeskyQR with the heavy pass on the fp64 matrix cores (rdyn_cholqr.hip: a triangular T
+ * from the Gram matrix of a row subsample, W = T^-1 with nearly dependent pivots deferred, G2 = (A W)'(A W) over all rows by MFMA,
+ * R = chol(G2) T; the device accepts the result only if the measured error growth of A W and the conditioning of the equilibrated
+ * A W are small, runs a second round from R otherwise, and falls back to the Householder folds of all rows if that is not
+ * accepted either -- all inside the one asynchronous call; ~1.7x the time of rdyn_regressor_gram; rows of R at structurally
+ * dependent columns are exactly zero).  Both return R1 with R1'R1 = [A b]'[A b] to rounding and the small singular values to
+ * ~cond * eps.
  * rdyn_identification_tsqr takes the same two routes (the component columns ride in the LDS tile as one more 16-column block).
  * rdyn_identification_tsqr: the same for the identification step's [Y | C | tau_meas] (C = the component columns of
  * rdyn_components_regressor, K = rdyn_components_columns): n1 = 10 joints_number + K + 1, unknowns [inertial ; component]

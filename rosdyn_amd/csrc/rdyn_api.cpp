@@ -1235,10 +1235,11 @@ static int regressor_tsqr_run(const rdyn_chain* c, const rdyn_component* comps, 
   // whose swept form has every joint as an input joint; the Householder folds (rdyn_tsqr.hip) otherwise.
   const char* route_env = probe_env("RDYN_TSQR_ROUTE");  // A/B builds only: "householder" / "cholqr"
   const int pairs = n == nJ ? rdyn_cholqr_pairs(nJ, la.tile_bytes, n_comps > 0 ? 1 : 0) : 0;
-  // ~1.0 ms of fixed cost (subsample leaves + tree + the two small dense kernels) against 0.9 / 1.4 ms per 1e6 samples (6 / 7 joints);
-  // the Householder route: 0.4 ms + 2.8 / 3.8 ms per 1e6 samples -> break-even near 1.6e5 samples (0.8 ms of fixed cost + 0.7 / 1.2 ms
-  // per 1e6 samples on this route)
-  const int64_t kCholqrMinTiles = 12288;  // 196 608 samples
+  // ~0.2 ms of fixed cost (the subsample's Gram matrix, the two small dense kernels, seven launches that leave at once) + 0.78 / 1.2 ms
+  // per 1e6 samples (6 / 7 joints) against 0.3 - 0.4 ms + 2.8 / 3.8 ms per 1e6 samples for the Householder route: faster at every
+  // size measured (2 000 samples: 183 vs 288 us; 200 000: 364 vs 969 us).  Small batches keep the Householder folds -- a few hundred
+  // rows say little about what a preconditioner built on them is worth, and there is nothing to win.
+  const int64_t kCholqrMinTiles = 256;  // 4 096 samples
   bool cholqr = pairs != 0 && tiles >= kCholqrMinTiles;
   if (route_env && pairs != 0) cholqr = !strcmp(route_env, "cholqr");
   // where the factor of the swept chain goes: straight into R when nothing follows

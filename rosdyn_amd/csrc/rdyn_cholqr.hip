@@ -334,6 +334,11 @@ constexpr int kMaxN1 = 81;
 #ifndef RDYN_CHOLQR_DENSE_THREADS
 #define RDYN_CHOLQR_DENSE_THREADS 1024
 #endif
+#ifdef RDYN_CHOLQR_STAMPS  // timing experiments: phase stamps (100 MHz wall clock) behind the diagnostics of the factor kernel
+#define STAMP(i) do { if (threadIdx.x == 0 && rho_out) rho_out[4 + (i)] = (double)wall_clock64(); } while (0)
+#else
+#define STAMP(i) do { } while (0)
+#endif
 constexpr int NTD = RDYN_CHOLQR_DENSE_THREADS;  // threads of the single-workgroup dense kernels (256 / 512 / 1024: 1.45 / 1.41 / 1.40 ms for the whole call at config-2 size; >= 128)
 
 // Householder QR of the m x nc matrix B (column-major, leading dimension m) in LDS, in place, by the NTD threads of the workgroup:
@@ -428,6 +433,62 @@ __device__ __forceinline__ void tri_inverse_lds(const double* U, const double* r
   }
 }
 
+// Cholesky-type factorisation of the symmetric matrix in the upper triangle of M (n x n, column-major, LDS) TOGETHER with the inverse
+// of the factor: an identity rides along in E (n x n, LDS) and receives the same row operations (forward substitution), so the
+// dependent chain of the factorisation pays for both.  One barrier per eliminating pivot: everybody evaluates the (uniform) decision
+// pol(k, d) -> {elim, diag}; the trailing updates work from the UNSCALED row k while the scaled rows are parked where nothing reads
+// them during the loop:
+//   row k of the factor F (F'F = M on the eliminating pivots)  -> column k of the strict LOWER triangle of M, diagonal in fdiag[k]
+//   row k of F^-T = column k of F^-1                           -> column k of the strict UPPER triangle of E, diagonal in xdiag[k]
+// A pivot that does not eliminate (elim = 0) leaves row k of F as diag e_k' (diag = 0: the row is left out altogether, X too).
+// In: E = identity (strict upper triangle zero), strict lower triangle of M zero.  Callers put a barrier in front.
+struct PivotAct
+{
+  int elim;
+  double diag;
+};
+template <class Policy>
+__device__ __forceinline__ void chol_with_inverse_lds(double* M, double* E, int n, int tid, double* fdiag, double* xdiag, Policy pol)
+{
+  const int tx = tid & 31, ty = tid >> 5;
+  for (int k = 0; k < n; ++k)
+  {
+    const double d = M[k * n + k];
+    const PivotAct act = pol(k, d);
+    if (tid == 0)
+    {
+      fdiag[k] = act.diag;
+      xdiag[k] = act.diag > 0.0 ? 1.0 / act.diag : 0.0;
+    }
+    if (!act.elim)
+    {
+      // row k of E has seen the eliminations of the pivots before it and is final: X(k, :) = E(k, :) / diag
+      if (act.diag > 0.0)
+      {
+        const double inv = 1.0 / act.diag;
+        for (int c = tid; c < k; c += NTD) E[k * n + c] = E[c * n + k] * inv;
+      }
+      continue;
+    }
+    const double inv_d = 1.0 / d, inv_p = act.diag * inv_d;  // 1 / sqrt(d) = sqrt(d) / d
+    // 32 x (NTD / 32) threads over (i, j) / (i, c): no integer divisions in the dependent chain
+    for (int j = k + 1 + ty; j < n; j += NTD / 32)  // M(i, j) -= M(k, i) M(k, j) / d, k < i <= j
+    {
+      const double f = M[j * n + k] * inv_d;
+      for (int i = k + 1 + tx; i <= j; i += 32) M[j * n + i] = fma(-M[i * n + k], f, M[j * n + i]);
+    }
+    for (int c = ty; c <= k; c += NTD / 32)  // E(i, c) -= M(k, i) / d E(k, c), i > k, c <= k
+    {
+      const double f = E[c * n + k] * inv_d;
+      for (int i = k + 1 + tx; i < n; i += 32) E[c * n + i] = fma(-M[i * n + k], f, E[c * n + i]);
+    }
+    for (int j = k + 1 + tid; j < n; j += NTD) M[k * n + j] = M[j * n + k] * inv_p;
+    for (int c = tid; c < k; c += NTD) E[k * n + c] = E[c * n + k] * inv_p;
+    __syncthreads();
+  }
+  __syncthreads();
+}
+
 // The preconditioner of a round.  In: an upper-triangular factor R1 (n1 x n1): round 0 the Householder factor of the row subsample,
 // round 1 the factor round 0 produced.  W = T^-1 for a triangular T that makes Q = A W well conditioned -- ANY invertible upper-
 // triangular T gives R = chol((A W)'(A W)) T with R'R = A'A in exact arithmetic.  In floating point Q = A W carries a rounding error
@@ -477,8 +538,8 @@ __global__ __launch_bounds__(NTD) void k_cholqr_precond(const double* __restrict
       if (r < P && c < P) v = Gs[(int64_t)c * P + r];
       else if (r == P && c == P) v = bbs[0];
       else v = cs[r < P ? r : c];
-      B[i] = sc2 * v;
-      A0[i] = 0.0;
+      B[i] = r <= c ? sc2 * v : 0.0;
+      A0[i] = r == c ? 1.0 : 0.0;  // the identity that becomes T^-1
     }
     __syncthreads();
     if (tid < n1) s_norm[tid] = sqrt(fmax(B[tid * n1 + tid], 0.0));
@@ -490,31 +551,31 @@ __global__ __launch_bounds__(NTD) void k_cholqr_precond(const double* __restrict
       s_lift[tid] = mx > 0.0 ? 1e-13 * mx : 1.0;
     }
     __syncthreads();
-    for (int k = 0; k < n1; ++k)
-    {
-      const double d = B[k * n1 + k], rel = d / (s_norm[k] * s_norm[k]);
+    chol_with_inverse_lds(B, A0, n1, tid, s_part, s_g, [&](int k, double d) {
       // the squared sine of the angle to the columns on the left: a Gram matrix resolves it down to ~1e-14; below 1e-10 (sine 1e-5, the
       // own-norm rule of the other branch) or below the residue floor the column is deferred.  The last column eliminates nothing.
-      const bool defer = !(rel >= (k + 1 < n1 ? 1e-10 : 1e-14)) || !(d >= s_lift[k] * s_lift[k]);
-      if (defer)
+      const double g0 = s_norm[k] * s_norm[k];  // d / g0 = the squared sine
+      const bool defer = !(d >= (k + 1 < n1 ? 1e-10 : 1e-14) * g0) || !(g0 > 0.0) || !(d >= s_lift[k] * s_lift[k]);
+      if (tid == 0) s_z[k] = defer ? 1 : 0;
+      return defer ? PivotAct{0, s_lift[k]} : PivotAct{1, sqrt(d)};
+    });
+    // T (rows parked in the lower triangle of B) -> upper triangle of A0; V = T^-1 (parked in the upper triangle of A0) -> B
+    for (int e = tid; e < n1 * n1; e += NTD)
+    {
+      const int i = e % n1, j = e / n1;
+      if (i < j)
       {
-        if (tid == 0)
-        {
-          s_z[k] = 1;
-          A0[k * n1 + k] = s_lift[k];
-        }
-        continue;
+        const double v = A0[e], t = B[i * n1 + j];
+        A0[e] = t;
+        B[e] = v;
+        A0[i * n1 + j] = 0.0;
+        B[i * n1 + j] = 0.0;
       }
-      const double piv = sqrt(d), inv_p = 1.0 / piv, inv_d = 1.0 / d;
-      const int m = n1 - k - 1;
-      for (int e = tid; e < m * m; e += NTD)
+      else if (i == j)
       {
-        const int i = k + 1 + e % m, j = k + 1 + e / m;
-        if (i <= j) B[j * n1 + i] = fma(-B[i * n1 + k] * inv_d, B[j * n1 + k], B[j * n1 + i]);
+        A0[e] = s_part[i];
+        B[e] = s_g[i];
       }
-      for (int j = k + tid; j < n1; j += NTD) A0[j * n1 + k] = j == k ? piv : B[j * n1 + k] * inv_p;
-      if (tid == 0) s_z[k] = 0;
-      __syncthreads();
     }
     __syncthreads();
   }
@@ -577,17 +638,16 @@ __global__ __launch_bounds__(NTD) void k_cholqr_precond(const double* __restrict
   if (tid < n1 && s_z[tid]) A0[tid * n1 + tid] = s_lift[tid];
   __syncthreads();
   }
-  for (int i = tid; i < n1 * n1; i += NTD)
-  {
-    Tout[i] = A0[i];
-    B[i] = 0.0;  // V
-  }
+  for (int i = tid; i < n1 * n1; i += NTD) Tout[i] = A0[i];
   if (tid < n1) zmask[tid] = s_z[tid];
-  __syncthreads();
-  // V = T^-1 (T is nonsingular: full-rank kept block, lifts on the deferred diagonal)
-  if (tid < n1) s_g[tid] = 1.0 / A0[tid * n1 + tid];
-  __syncthreads();
-  tri_inverse_lds(A0, s_g, B, n1, tid, nullptr);
+  if (!Gs)
+  {
+    // V = T^-1 (T is nonsingular: full-rank kept block, lifts on the deferred diagonal)
+    for (int i = tid; i < n1 * n1; i += NTD) B[i] = 0.0;
+    if (tid < n1) s_g[tid] = 1.0 / A0[tid * n1 + tid];
+    __syncthreads();
+    tri_inverse_lds(A0, s_g, B, n1, tid, nullptr);
+  }
   __syncthreads();
   for (int i = tid; i < n1 * n1; i += NTD) Vout[i] = B[i];  // T^-1 in natural order: the factor kernel re-evaluates gamma on the norms of ALL rows
   if (tid < n1)
@@ -663,8 +723,9 @@ __global__ __launch_bounds__(NTD) void k_cholqr_factor(const double* __restrict_
   if (run_flag && *run_flag == 0) return;
   extern __shared__ __attribute__((aligned(16))) double sh[];
   double* const M = sh;             // [n1][n1] column-major, upper triangle = the running Cholesky factor
-  double* const T = sh + n1 * n1;   // T, later the inverse of the equilibrated factor
-  __shared__ double s_piv, s_g0[kMaxN1], s_sc[kMaxN1], s_part[kMaxN1], s_gam[kMaxN1];
+  STAMP(0);
+  double* const T = sh + n1 * n1;   // the identity that becomes the inverse of the Cholesky factor, then T
+  __shared__ double s_g0[kMaxN1], s_sc[kMaxN1], s_xd[kMaxN1], s_part[kMaxN1], s_gam[kMaxN1], s_wave[NTD / 64];
   __shared__ int s_flag, s_z[kMaxN1], s_skip[kMaxN1];
   const int tid = threadIdx.x, P = n1 - 1;
   for (int i = tid; i < n1 * n1; i += NTD)
@@ -674,56 +735,61 @@ __global__ __launch_bounds__(NTD) void k_cholqr_factor(const double* __restrict_
     if (r < P && c < P) v = G[(int64_t)c * P + r];
     else if (r == P && c == P) v = bb[0];
     else v = cvec[r < P ? r : c];
-    M[i] = v;
-    T[i] = T_in[i];
+    M[i] = r <= c ? v : 0.0;
+    T[i] = r == c ? 1.0 : 0.0;
   }
   if (tid < n1) s_z[tid] = zmask[tid] || (!has_b && tid == P);  // no measured torque: the last column is null by construction
   if (tid == 0) s_flag = 0;
   __syncthreads();
   if (tid < n1) s_g0[tid] = M[tid * n1 + tid];  // |Q(:, k)|^2 before anything is eliminated
   __syncthreads();
-  for (int k = 0; k < n1; ++k)
-  {
+  STAMP(1);
+  chol_with_inverse_lds(M, T, n1, tid, s_sc, s_xd, [&](int k, double d) {
+    // d / g0 = the squared sine of the angle between Q(:, k) and the columns to its left; "resolved": >= 1e-12
+    const bool resolved = d >= 1e-12 * s_g0[k] && s_g0[k] > 0.0;
+    const double piv = sqrt(d > 1e-30 ? d : 1e-30);
+    int skip = 0, flag = 0;
+    if (s_z[k])
+    {
+      // residue in all rows (in units of the lift)?  Or nothing left after its own elimination: null as far as this round can tell --
+      // but if the column was large (its elimination's own rounding, u |Q(:, k)|^2, is above the 1/10 mark), that proves nothing
+      skip = !(piv >= 0.1 && resolved);
+      flag = piv >= 0.1 && !resolved;
+    }
+    else if (!resolved)
+      skip = flag = 1;  // a kept column that turns out to be numerically dependent on its left neighbours in the whole batch
     if (tid == 0)
     {
-      const double d = M[k * n1 + k];
-      const double rel = d / s_g0[k];  // squared sine of the angle between Q(:, k) and the columns to its left
-      s_piv = sqrt(d > 1e-30 ? d : 1e-30);
-      int skip = 0;
-      if (s_z[k])
-      {
-        // residue in all rows (in units of the lift)?  Or nothing left after its own elimination: null as far as this round can tell --
-        // but if the column was large (its elimination's own rounding, u |Q(:, k)|^2, is above the 1/10 mark), that proves nothing
-        skip = !(s_piv >= 0.1 && rel >= 1e-12);
-        if (s_piv >= 0.1 && !(rel >= 1e-12)) s_flag = 1;
-      }
-      else if (!(rel >= 1e-12))
-      {
-        skip = 1;  // a kept column that turns out to be numerically dependent on its left neighbours in the whole batch
-        s_flag = 1;
-      }
       s_skip[k] = skip;
-      M[k * n1 + k] = s_piv;
+      if (flag) s_flag = 1;
     }
-    __syncthreads();
-    if (s_skip[k])
+    // a skipped pivot: null direction, its Schur complement is rounding residue -- row k of the factor is zero, nothing is eliminated
+    return skip ? PivotAct{0, 0.0} : PivotAct{1, piv};
+  });
+  STAMP(2);
+  // rho: Re = R2 diag(1 / |Q(:, j)|) over the pivoted columns; Re^-1(i, c) = |Q(:, i)| R2^-1(i, c), R2^-1 parked in the upper triangle of
+  // T (zero in the rows / columns of skipped pivots), its diagonal in s_xd
+  {
+    double part = 0.0;
+    for (int e = tid; e < n1 * n1; e += NTD)
     {
-      // null direction: its Schur complement is rounding residue -- row k of the factor is zero, nothing is eliminated
-      for (int j = k + tid; j < n1; j += NTD) M[j * n1 + k] = 0.0;
-      __syncthreads();
-      continue;
+      const int i = e % n1, c = e / n1;
+      const double x = i < c ? T[e] : (i == c ? s_xd[c] : 0.0);
+      part = fma(s_g0[i] * x, x, part);
     }
-    const double inv = 1.0 / s_piv;
-    for (int j = k + 1 + tid; j < n1; j += NTD) M[j * n1 + k] *= inv;  // row k of the factor: M(k, j), stored in column j
-    __syncthreads();
-    const int m = n1 - k - 1;  // trailing update of the upper triangle: M(i, j) -= M(k, i) M(k, j), k < i <= j
-    for (int e = tid; e < m * m; e += NTD)
-    {
-      const int i = k + 1 + e % m, j = k + 1 + e / m;
-      if (i <= j) M[j * n1 + i] = fma(-M[i * n1 + k], M[j * n1 + k], M[j * n1 + i]);
-    }
-    __syncthreads();
+    for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
+    if ((tid & 63) == 0) s_wave[tid >> 6] = part;
   }
+  __syncthreads();
+  // the factor back into the upper triangle: M(i, j) <- row i parked in column i; T from global memory into its place
+  for (int e = tid; e < n1 * n1; e += NTD)
+  {
+    const int i = e % n1, j = e / n1;
+    if (i < j) M[e] = M[i * n1 + j];
+    else if (i == j) M[e] = s_sc[i];
+    T[e] = T_in[e];
+  }
+  __syncthreads();
   // R = R2 T (upper x upper)
   for (int e = tid; e < n1 * n1; e += NTD)
   {
@@ -733,8 +799,8 @@ __global__ __launch_bounds__(NTD) void k_cholqr_factor(const double* __restrict_
       for (int k = i; k <= j; ++k) s = fma(M[k * n1 + i], T[j * n1 + k], s);
     Rout[e] = s;
   }
-  if (tid < n1) s_sc[tid] = sqrt(s_g0[tid]);
   __syncthreads();
+  STAMP(3);
   // the growth factor of the round on the column norms of ALL rows (|a_j| = |R(:, j)|; the preconditioner's own figure used the norms
   // of its input factor: the subsample's in round 0, which may say little about the batch)
   if (tid < n1)
@@ -759,28 +825,13 @@ __global__ __launch_bounds__(NTD) void k_cholqr_factor(const double* __restrict_
     s_gam[tid] = norm_own > 0.0 ? g / norm_own : 0.0;
   }
   __syncthreads();
-  // the inverse of Re = R2 diag(1 / |Q(:, j)|) over the pivoted columns; a skipped pivot stands in as a 1 on the diagonal of a zero
-  // row and column (its column of the inverse is e_k: left out of the sum below)
-  for (int e = tid; e < n1 * n1; e += NTD)
-  {
-    const int i = e % n1, j = e / n1;
-    if (i <= j) M[e] = (s_skip[i] || s_skip[j]) ? (i == j ? 1.0 : 0.0) : M[e] / s_sc[j];
-  }
-  __syncthreads();
-  if (tid < n1) s_sc[tid] = 1.0 / M[tid * n1 + tid];
-  __syncthreads();
-  tri_inverse_lds(M, s_sc, T, n1, tid, s_part);
-  __syncthreads();
+  STAMP(4);
   if (tid == 0)
   {
     double fro = 0.0;
     int kept = 0;
-    for (int c = 0; c < n1; ++c)
-      if (!s_skip[c])
-      {
-        fro += s_part[c];
-        ++kept;
-      }
+    for (int w = 0; w < NTD / 64; ++w) fro += s_wave[w];
+    for (int c = 0; c < n1; ++c) kept += s_skip[c] ? 0 : 1;
     const double rho = kept > 0 ? sqrt(fro / kept) : 1.0;
     double gamma = 0.0;
     for (int c = 0; c < n1; ++c) gamma = fmax(gamma, s_gam[c]);

@@ -614,7 +614,7 @@ public:
     chk(rdyn_identification_tsqr(m_h, comps.data(), (int)comps.size(), &b, tau_meas, R1, accumulate ? 1 : 0, workspace, workspace_bytes));
   }
   // the R factor of the stacked [regressor | tau_meas] of a batch without the normal equations (include/rdyn.h: rdyn_regressor_tsqr:
-  // Householder folds, from 196 608 samples on preconditioned CholeskyQR on the matrix cores); R1 = (10 joints + 1)^2 doubles, device
+  // Householder folds, from 4 096 samples on preconditioned CholeskyQR on the matrix cores); R1 = (10 joints + 1)^2 doubles, device
   size_t getRegressorTsqrWorkspaceBytes() const { return rdyn_regressor_tsqr_workspace_bytes(m_h); }
   void getRegressorTsqrBatch(const rdyn_batch& b, const double* tau_meas, double* R1, bool accumulate, void* workspace, size_t workspace_bytes) const
   {

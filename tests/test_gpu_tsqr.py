@@ -193,7 +193,7 @@ def test_full_size_factor_reproduces_the_mfma_normal_equations(urdf, base, tool,
     assert torch.equal(torch.tril(R1, -1), torch.zeros_like(R1))
 
 
-# ---- the preconditioned CholeskyQR route (rdyn_cholqr.hip): batches of >= 196 608 samples, the heavy pass on the matrix cores
+# ---- the preconditioned CholeskyQR route (rdyn_cholqr.hip): batches of >= 4 096 samples, the heavy pass on the matrix cores
 CHOLQR_N = 330000
 CHOLQR_CASES = [("ur10_like.urdf", "base_link", "wrist_3_link"),      # 6 joints: W in LDS beside the four tiles
                 ("panda_like.urdf", "link0", "link7"),                # 7 joints: W read from global memory (four tiles fill the LDS)
@@ -208,7 +208,7 @@ def _oracle_rows(ref, q, dq, ddq, tau):
 
 @pytest.mark.parametrize("urdf,base,tool", CHOLQR_CASES, ids=["ur10_6", "panda_7", "ur10_public_tool0", "panda_hand"])
 def test_cholqr_route_against_numpy_qr_of_the_oracle_rows(urdf, base, tool):
-    """N = 330 000 (above the 196 608-sample threshold of the route): upper triangular, R'R = M'M, the singular values of R equal those of numpy's
+    """N = 330 000 (the route of every batch of 4 096 samples or more): upper triangular, R'R = M'M, the singular values of R equal those of numpy's
     Householder factor of the oracle's rows, same minimum-norm least-squares solution; accumulation folds a second factor in."""
     torch = pytest.importorskip("torch")
     from oracle.oracle import OracleChain

@@ -1,0 +1,23 @@
+"""phase stamps of k_cholqr_factor (a -DRDYN_CHOLQR_STAMPS build): 100 MHz wall clock ticks between the phases"""
+import os, sys
+import numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tools"))
+from rosdyn_amd import Chain
+from rosdyn_amd._lib import lib
+from rosdyn_amd.samples import trajectory_batch
+from debug_cholqr3 import layout
+chain = Chain(os.path.join(ROOT, "tests/fixtures/ur10_like.urdf"), "base_link", "wrist_3_link", (0, 0, -9.806))
+n, N = 6, 330000
+L, n1 = layout(6)
+q, dq, ddq = trajectory_batch(1, N, n)
+tau = np.random.default_rng(1).normal(size=(N, n))
+args = [torch.from_numpy(x).cuda() for x in (q, dq, ddq, tau)]
+ws = torch.zeros((lib().rdyn_regressor_tsqr_workspace_bytes(chain._h) // 8,), dtype=torch.float64, device="cuda")
+for _ in range(3):
+    chain.getRegressorTsqr(*args, workspace=ws.view(torch.uint8))
+torch.cuda.synchronize()
+d = ws[L["flag"] + 56:L["flag"] + 63].cpu().numpy()
+names = ["load", "cholesky", "to upper", "R = R2 T", "gamma", "Re", "inverse"]
+for i in range(6):
+    print(f"{names[i + 1] if False else names[i]:10s} {(d[i + 1] - d[i]) / 100.0:8.1f} us")
