@@ -1131,7 +1131,7 @@ int rdyn_tsqr(const double* A, int64_t rows, int64_t lda, int n_cols, const doub
 struct TsqrLayout
 {
   size_t householder_doubles = 0;  // region 1
-  size_t slabs = 0, w = 0, v = 0, r_sub = 0, r1p = 0, g2 = 0, r_swept = 0, flag = 0, total_doubles = 0;  // offsets (doubles) of region 2
+  size_t slabs = 0, w = 0, v = 0, r1p = 0, g2 = 0, r_swept = 0, flag = 0, total_doubles = 0;  // offsets (doubles) of region 2
 };
 static const int kCholqrBlocks = 256;
 // xb = 1: with component columns (one more 16-column block; the factors are sized for the padded width 16 nb)
@@ -1149,7 +1149,6 @@ static TsqrLayout tsqr_layout(int n_joints_swept, int xb = 0)
   };
   L.slabs = take((size_t)kCholqrBlocks * nt * 256);
   L.w = take((size_t)nt * 256);
-  L.r_sub = take((size_t)n1 * n1);
   L.r1p = take((size_t)n1 * n1);
   L.g2 = take((size_t)n1 * n1 + 1);
   L.r_swept = take((size_t)n1 * n1);

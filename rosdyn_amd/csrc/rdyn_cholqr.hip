@@ -3,28 +3,30 @@
 //
 // rdyn_tsqr.hip folds Householder reflections on the vector units: rank-1 updates, a ~1 400-cycle dependent chain per column step,
 // 15.8 ms at config 3 (7 joints, 4e6 samples) with the matrix pipe idle.  The plain Gram route (rdyn_duo_gram.hip + Cholesky) runs
-// at 2.8 ms but squares the condition number.  This file sits between the two -- preconditioned CholeskyQR:
+// at 2.8 ms but squares the condition number.  This file sits between the two -- preconditioned CholeskyQR whose result is accepted
+// by the device only on MEASURED quality:
 //
-//   pass A   R1 = Householder factor (rdyn_tsqr.hip, unchanged) of a ROW SUBSAMPLE: every S-th 16-sample tile, ~1 000 tiles whatever
-//            the batch size (~0.5 ms).  Backward stable; for a batch whose rows are exchangeable (trajectory samples) R1 differs from
-//            the factor of all rows by a well-conditioned factor.
-//   precond  k_cholqr_precond: T = R1 scaled to all rows and re-triangularised without its NULL columns (a regressor is structurally
-//            rank deficient: pivots below 1e-13 x their column's norm; those columns ride through the reflections and get 1e-13 x their
-//            norm on the diagonal), W = T^-1 by back substitution, written in MFMA operand order.
+//   pass A   the Gram matrix of a ROW SUBSAMPLE: every S-th 16-sample tile, ~1 000 tiles whatever the batch size, through the pass-B
+//            kernel with W = I (one tile per wave pair, ~50 us with its slab reduction).
+//   precond  k_cholqr_precond: Cholesky of that matrix scaled to all rows, with nearly dependent pivots DEFERRED (a regressor is
+//            structurally rank deficient; a tiny pivot used for elimination puts 1 / pivot into W, which amplifies the rounding of
+//            A W) -> triangular T, W = T^-1 (carried along by the factorisation), in MFMA operand order; the growth factor gamma.
 //   pass B   k_regressor_pgram: ALL rows.  The wave-pair design of rdyn_duo_gram.hip: the sweeper wave drops every finished link's
 //            regressor rows into the pair's LDS tile; the consumer wave multiplies each 16-row group by W (v_mfma_f64_16x16x4_f64,
 //            W in LDS in operand order) and accumulates the Gram of the PRODUCT straight from the result registers (the D layout of
 //            the first MFMA is the A/B operand layout of the second: no transposition, no LDS round trip).  Q = A W is never stored.
 //            Block-triangular zero band of a row group: preserved by the upper-triangular W, skipped in both stages.
-//   factor   k_cholqr_factor: G2 = Q'Q is well conditioned (cond(Q) ~ 1): R2 = chol(G2), R = R2 T.  R'R = [A b]'[A b] to rounding,
-//            whatever the quality of T; the ACCURACY of R is that of CholeskyQR on Q, u cond(Q)^2 -- so the kernel checks the
-//            pivots of R2: all kept ones within [1/2, 2] (cond(Q) <= 4), and the null set is validated against ALL rows (a null
-//            column's pivot is O(1e-3); a large one is a direction the subsample missed) -- or a SECOND round runs with W = R^-1
-//            (CholeskyQR2 on top of the preconditioner; the round's kernels are always queued and leave at once when the device
-//            flag says "not needed").  Rows of R at confirmed null columns are exactly zero.
+//   factor   k_cholqr_factor: R2 = chol(G2), R = R2 T.  R'R = [A b]'[A b] for ANY invertible triangular T in exact arithmetic; in
+//            floating point the error is u gamma (rounding of A W carried back by T) + u cond^2 of the column-equilibrated Q.  Both
+//            are evaluated on ALL rows here (gamma on the column norms of R, rho = |Re^-1|_F / sqrt(k) of the equilibrated factor),
+//            the deferred columns are decided here (residue -> exactly zero row of R; anything else is a pivot), and a round that
+//            cannot vouch for its result raises a device flag:
+//   round 1  the same four kernels with W from round 0's R (always queued, leave at once when the flag is clear);
+//   stand-by the Householder folds of rdyn_tsqr.hip over all rows (always queued behind round 1, leave at once unless round 1 was not
+//            accepted either, or a preconditioner was called off): the call as a whole is as robust as that route.
 //
 // fp64 throughout.  The multiplication by an explicit inverse (instead of a triangular solve) keeps every step a matrix product;
-// its rounding enters as |A| |W| u per row, which the pivot check of the second factorisation sees like any other loss.
+// its rounding is what gamma measures.  tools/cholqr_emulate.py replays the dense steps in numpy.
 // k_cholqr_expand: factor of the reduced chain -> factor of a chain with fixed joints; k_cholqr_fold: the accumulate step.
 #include <hip/hip_runtime.h>
 #include <atomic>

@@ -1,4 +1,5 @@
-"""Which batches start the second round / the stand-by Householder call of the preconditioned route, and what comes out.
+"""Which batches start the second round / the stand-by Householder call of the preconditioned route, and what comes out
+(flags, deferred columns, gamma / rho of the two rounds read from the diagnostics at the end of the workspace: rdyn_api.cpp, tsqr_layout).
 The subsample's tiles (every S-th) get velocities and accelerations scaled by eps: 0 = static (null columns in the subsample),
 1e-9 .. 1e-4 = the subsample sees the inertia directions, but at a scale that says nothing about the rest of the batch."""
 import os, sys
@@ -14,7 +15,7 @@ def layout(nJ):
     n1 = 10 * nJ + 1; nb = (n1 + 15) // 16; nt = nb * (nb + 1) // 2
     off = ((256 + 128 + 2) * n1 * n1 + 31) & ~31
     L = {}
-    for name, d in (("slabs", 256 * nt * 256), ("w", nt * 256), ("r_sub", n1 * n1), ("r1p", n1 * n1), ("g2", n1 * n1 + 1), ("r_swept", n1 * n1), ("v", n1 * n1), ("flag", 64)):
+    for name, d in (("slabs", 256 * nt * 256), ("w", nt * 256), ("r1p", n1 * n1), ("g2", n1 * n1 + 1), ("r_swept", n1 * n1), ("v", n1 * n1), ("flag", 64)):
         L[name] = off; off = (off + d + 31) & ~31
     return L, n1
 
