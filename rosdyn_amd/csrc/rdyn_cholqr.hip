@@ -444,6 +444,8 @@ __device__ __forceinline__ void tri_inverse_lds(const double* U, const double* r
 //   row k of F^-T = column k of F^-1                           -> column k of the strict UPPER triangle of E, diagonal in xdiag[k]
 // A pivot that does not eliminate (elim = 0) leaves row k of F as diag e_k' (diag = 0: the row is left out altogether, X too).
 // In: E = identity (strict upper triangle zero), strict lower triangle of M zero.  Callers put a barrier in front.
+// (Two pivots per barrier -- a rank-2 update with the second pivot's row formed on the fly -- was measured: 51 us instead of 43 us per
+// 61 pivots.  A step is a chain of three or four LDS round trips, a square root and a division; the barrier is the small part.)
 struct PivotAct
 {
   int elim;
