@@ -227,7 +227,17 @@ __global__ __launch_bounds__(512) void k_regressor_gram_duo(const RdynLdsGramArg
 #pragma unroll
           for (int rb = 0; rb <= cb; ++rb)
           {
+#ifdef RDYN_DUO_4X4_TIMING  // timing experiment only (wrong numbers): the issue cost of four (three on the diagonal) 4x4x4_4b MFMAs per tile k-step
+            if (DESC ? cb <= band : rb >= band)
+            {
+              acc[ti][0] = __builtin_amdgcn_mfma_f64_4x4x4f64(op[rb][t], op[cb][t], acc[ti][0], 0, 0, 0);
+              acc[ti][1] = __builtin_amdgcn_mfma_f64_4x4x4f64(op[rb][t], op[cb][t], acc[ti][1], 0, 0, 0);
+              acc[ti][2] = __builtin_amdgcn_mfma_f64_4x4x4f64(op[rb][t], op[cb][t], acc[ti][2], 0, 0, 0);
+              if (rb != cb) acc[ti][3] = __builtin_amdgcn_mfma_f64_4x4x4f64(op[rb][t], op[cb][t], acc[ti][3], 0, 0, 0);
+            }
+#else
             if (DESC ? cb <= band : rb >= band) acc[ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(op[rb][t], op[cb][t], acc[ti], 0, 0, 0);
+#endif
             ++ti;
           }
       }
