@@ -347,6 +347,47 @@ def test_cholqr_route_with_a_slow_subsample(eps, joints):
     assert np.all(s_gpu[~keep] <= 1e-8 * s_ref[0])
 
 
+@pytest.mark.parametrize("urdf,base,tool", [CHOLQR_CASES[0], CHOLQR_CASES[1], CHOLQR_CASES[2]], ids=["ur10_6", "panda_7", "ur10_public_tool0"])
+@pytest.mark.parametrize("N", [4096, 4097, 5555, 20000, 40000])
+def test_cholqr_route_from_its_threshold_on(urdf, base, tool, N):
+    """The route's smallest batches (4 096 samples = 256 tiles: the "subsample" is the whole batch up to 2 047 tiles, every second or
+    third tile after that), element-major inputs, with and without a measured torque, the layouts of the batch, accumulation into a
+    factor that came from the other route (N = 1 000: Householder folds)."""
+    torch = pytest.importorskip("torch")
+    from oracle.oracle import OracleChain
+    from rosdyn_amd import Chain
+    from rosdyn_amd.samples import trajectory_batch
+    path = os.path.join(FIXTURES, urdf)
+    chain, ref = Chain(path, base, tool, GRAV), OracleChain(path, base, tool, GRAV)
+    n, P = ref.n, ref.P
+    q, dq, ddq = trajectory_batch(N, N, n)
+    tau = ref.joint_torque(q, dq, ddq) + 1e-2 * np.random.default_rng(N).normal(size=(N, n))
+    M = _oracle_rows(ref, q, dq, ddq, tau)
+    G = M.T @ M
+    s_ref = np.linalg.svd(np.linalg.qr(M, mode="r"), compute_uv=False)
+    keep = s_ref > 1e-9 * s_ref[0]
+    dev = [torch.from_numpy(x).cuda() for x in (q, dq, ddq, tau)]
+    elem = [x.t().contiguous() for x in dev]
+    for args, layout in ((dev, "sample"), (elem, "element")):
+        R1 = chain.getRegressorTsqr(*args, layout=layout).cpu().numpy()
+        assert np.allclose(np.tril(R1, -1), 0.0)
+        assert np.abs(R1.T @ R1 - G).max() <= 1e-12 * np.abs(G).max()
+        s_gpu = np.linalg.svd(R1, compute_uv=False)
+        assert np.abs(s_gpu[keep] / s_ref[keep] - 1.0).max() <= 1e-9
+        assert np.all(s_gpu[~keep] <= 1e-8 * s_ref[0])
+    # no measured torque: the last column (and row) of the factor is zero
+    R0 = chain.getRegressorTsqr(*dev[:3]).cpu().numpy()
+    assert np.all(R0[:, P] == 0.0) and np.abs(R0[:P, :P].T @ R0[:P, :P] - G[:P, :P]).max() <= 1e-12 * np.abs(G).max()
+    # a factor of 1 000 other samples (Householder route) accumulated into
+    q2, dq2, ddq2 = trajectory_batch(N + 1, 1000, n)
+    tau2 = ref.joint_torque(q2, dq2, ddq2)
+    M2 = _oracle_rows(ref, q2, dq2, ddq2, tau2)
+    Rs = chain.getRegressorTsqr(*(torch.from_numpy(x).cuda() for x in (q2, dq2, ddq2, tau2)))
+    Ra = chain.getRegressorTsqr(*dev, out=Rs.contiguous(), accumulate=True).cpu().numpy()
+    G2 = G + M2.T @ M2
+    assert np.allclose(np.tril(Ra, -1), 0.0) and np.abs(Ra.T @ Ra - G2).max() <= 1e-12 * np.abs(G2).max()
+
+
 def test_cholqr_route_with_component_columns():
     """rdyn_identification_tsqr above the route's threshold: [Y | friction / spring columns | tau_meas] through the preconditioned
     CholeskyQR route (the component columns ride in the LDS tile as one more 16-column block): R'R = M'M, the singular values of
