@@ -388,7 +388,8 @@ def test_cholqr_route_from_its_threshold_on(urdf, base, tool, N):
     assert np.allclose(np.tril(Ra, -1), 0.0) and np.abs(Ra.T @ Ra - G2).max() <= 1e-12 * np.abs(G2).max()
 
 
-def test_cholqr_route_with_component_columns():
+@pytest.mark.parametrize("N", [6000, CHOLQR_N])
+def test_cholqr_route_with_component_columns(N):
     """rdyn_identification_tsqr above the route's threshold: [Y | friction / spring columns | tau_meas] through the preconditioned
     CholeskyQR route (the component columns ride in the LDS tile as one more 16-column block): R'R = M'M, the singular values of
     numpy's Householder factor of the oracle's rows, the friction coefficients come back from the factor, accumulation."""
@@ -400,7 +401,7 @@ def test_cholqr_route_with_component_columns():
     from rosdyn_amd.samples import trajectory_batch
     path = os.path.join(FIXTURES, "ur10_like.urdf")
     chain, ref = Chain(path, "base_link", "wrist_3_link", GRAV), OracleChain(path, "base_link", "wrist_3_link", GRAV)
-    n, P, N = 6, 60, CHOLQR_N
+    n, P = 6, 60
     q, dq, ddq = trajectory_batch(808, N, n)
     kinds = [FRICTION1, FRICTION2, SPRING]
     specs, dicts = [], []
