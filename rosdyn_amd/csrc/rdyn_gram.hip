@@ -134,22 +134,27 @@ __global__ __launch_bounds__(256) void k_gram(const RdynGramArgs a)
 }
 
 // sums the per-block slabs (fixed order) and scatters the tiles into G (P x P, both triangles), c = A^T b, bb.
-// One workgroup per 32 tile elements: 8 slab groups x 32 elements, slab groups reduced through LDS in fixed order.
-__global__ __launch_bounds__(256) void k_gram_finish(const RdynGramArgs a, int nb, int n_slabs)
+// One workgroup per 32 tile elements: FG slab groups x 32 elements, slab groups reduced through LDS in fixed order
+// (FG = 32: 1 024 threads, 8 slabs each at 256 slabs -- 7.8 MB of slabs at 6 joints in ~5 us; 8 groups: 13 us).
+#ifndef RDYN_GRAM_FINISH_GROUPS
+#define RDYN_GRAM_FINISH_GROUPS 32
+#endif
+constexpr int FG = RDYN_GRAM_FINISH_GROUPS;
+__global__ __launch_bounds__(32 * FG) void k_gram_finish(const RdynGramArgs a, int nb, int n_slabs)
 {
   if (a.run_flag && *a.run_flag == 0) return;
   const int nt = nb * (nb + 1) / 2;
   const int e_loc = threadIdx.x & 31, grp = threadIdx.x >> 5;
   const int i = blockIdx.x * 32 + e_loc;
-  __shared__ double part[8][32];
+  __shared__ double part[FG][32];
   double s = 0.0;
   if (i < nt * 256)
-    for (int b = grp; b < n_slabs; b += 8) s += a.slabs[(int64_t)b * nt * 256 + i];
+    for (int b = grp; b < n_slabs; b += FG) s += a.slabs[(int64_t)b * nt * 256 + i];
   part[grp][e_loc] = s;
   __syncthreads();
   if (grp != 0 || i >= nt * 256) return;
   s = 0.0;
-  for (int k = 0; k < 8; ++k) s += part[k][e_loc];
+  for (int k = 0; k < FG; ++k) s += part[k][e_loc];
   const int t = i >> 8, e = i & 255;
   // tile t -> (rb, cb): t = cb (cb + 1) / 2 + rb
   int cb = 0;
@@ -271,7 +276,7 @@ hipError_t rdyn_launch_gram_finish(const RdynGramArgs& a, int blocks, hipStream_
 {
   const int nb = a.slab_nb > 0 ? a.slab_nb : rdyn_gram_blocks_for(a.P);
   const int nt = nb * (nb + 1) / 2;
-  hipLaunchKernelGGL(k_gram_finish, dim3((nt * 256 + 31) / 32), dim3(256), 0, st, a, nb, blocks);
+  hipLaunchKernelGGL(k_gram_finish, dim3((nt * 256 + 31) / 32), dim3(32 * FG), 0, st, a, nb, blocks);
   return hipGetLastError();
 }
 
