@@ -1245,8 +1245,8 @@ static int regressor_tsqr_run(const rdyn_chain* c, const rdyn_component* comps, 
   double* const R_swept = (expand || (cholqr && accumulate)) ? ws + L.r_swept : R;
   if (cholqr)
   {
-    // pass A: the Gram matrix of every S-th tile (about 1 024 tiles whatever the batch size: one tile per wave pair of the pass-B kernel
-    // run with W = I; 16 384 samples = 115 000 rows for <= 81 columns put the pivots of the second factorisation within a few % of 1).
+    // pass A: the Gram matrix of every S-th tile (about 1 024 tiles whatever the batch size: one tile per wave pair of the regressor ->
+    // Gram kernel; 16 384 samples = 115 000 rows for <= 81 columns put the pivots of the second factorisation within a few % of 1).
     // A preconditioner does not have to be a backward-stable factor -- what it is worth is measured on all rows afterwards.
     RdynLdsGramArgs sub = la;
     const int64_t kSubTiles = probe_env("RDYN_CHOLQR_SUBTILES") ? atoll(probe_env("RDYN_CHOLQR_SUBTILES")) : 1024;
@@ -1257,7 +1257,6 @@ static int regressor_tsqr_run(const rdyn_chain* c, const rdyn_component* comps, 
     sub.slabs = la.slabs;
     const int np = pairs < 0 ? -pairs : pairs;
     const int blocks = (int)((tiles + np - 1) / np < kCholqrBlocks ? (tiles + np - 1) / np : kCholqrBlocks);
-    const int sub_blocks = (int)((sub_tiles + np - 1) / np < kCholqrBlocks ? (sub_tiles + np - 1) / np : kCholqrBlocks);
     int* const flag = (int*)(ws + L.flag);
     const int col_shift = rdyn_cholqr_col_shift(nJ, n_comps > 0 ? 1 : 0);
     RdynGramArgs ga;
@@ -1269,9 +1268,21 @@ static int regressor_tsqr_run(const rdyn_chain* c, const rdyn_component* comps, 
     ga.bb = ga.c + (n1s - 1);
     ga.col_shift = col_shift;
     ga.slab_nb = n_comps > 0 ? (10 * nJ + 1 + 15) / 16 + 1 : 0;
-    RDYN_HIP_TRY(rdyn_launch_cholqr_identity_w(ws + L.w, n1s, col_shift, stream));
-    RDYN_HIP_TRY(rdyn_launch_regressor_pgram(nJ, sub, ws + L.w, nullptr, sub_blocks, pairs, stream));
-    RDYN_HIP_TRY(rdyn_launch_gram_finish(ga, sub_blocks, stream));
+    {
+      // the plain regressor -> Gram kernel (rdyn_duo_gram.hip) on the subsample: its slab layout (descending link order without
+      // component columns), its workgroups of four pairs
+      const int sub4 = (int)((sub_tiles + 3) / 4 < kCholqrBlocks ? (sub_tiles + 3) / 4 : kCholqrBlocks);
+      const int nbt = (10 * nJ + 1 + 15) / 16 + (n_comps > 0 ? 1 : 0);
+      size_t lds_bytes = 4 * (size_t)la.tile_bytes;
+      const size_t red_bytes = (size_t)(nbt * (nbt + 1) / 2) * 256 * sizeof(double);
+      if (lds_bytes < red_bytes) lds_bytes = red_bytes;
+      RDYN_HIP_TRY(rdyn_launch_regressor_gram_duo(10 * nJ, sub, sub4, lds_bytes, stream));
+      RdynGramArgs gs = ga;
+      gs.col_shift = 0;
+      gs.desc_nj = n_comps > 0 ? 0 : nJ;
+      gs.slab_nb = n_comps > 0 ? nbt : 0;
+      RDYN_HIP_TRY(rdyn_launch_gram_finish(gs, sub4, stream));
+    }
     const int n_rounds = probe_env("RDYN_CHOLQR_ROUNDS") ? atoi(probe_env("RDYN_CHOLQR_ROUNDS")) : 2;  // A/B builds only
     for (int round = 0; round < n_rounds; ++round)
     {

@@ -6,8 +6,8 @@
 // at 2.8 ms but squares the condition number.  This file sits between the two -- preconditioned CholeskyQR whose result is accepted
 // by the device only on MEASURED quality:
 //
-//   pass A   the Gram matrix of a ROW SUBSAMPLE: every S-th 16-sample tile, ~1 000 tiles whatever the batch size, through the pass-B
-//            kernel with W = I (one tile per wave pair, ~50 us with its slab reduction).
+//   pass A   the Gram matrix of a ROW SUBSAMPLE: every S-th 16-sample tile, ~1 000 tiles whatever the batch size, through the
+//            regressor -> Gram kernel of rdyn_duo_gram.hip (one tile per wave pair, ~30 us with its slab reduction).
 //   precond  k_cholqr_precond: Cholesky of that matrix scaled to all rows, with nearly dependent pivots DEFERRED (a regressor is
 //            structurally rank deficient; a tiny pivot used for elimination puts 1 / pivot into W, which amplifies the rounding of
 //            A W) -> triangular T, W = T^-1 (carried along by the factorisation), in MFMA operand order; the growth factor gamma.
@@ -694,21 +694,6 @@ __global__ __launch_bounds__(NTD) void k_cholqr_precond(const double* __restrict
   }
 }
 
-// W = identity in the operand order of k_regressor_pgram (the subsample pass: the Gram matrix of the rows themselves)
-__global__ __launch_bounds__(256) void k_cholqr_identity_w(double* __restrict__ W, int n1, int col_shift)
-{
-  const int nb = (n1 + col_shift + 15) / 16, nt = nb * (nb + 1) / 2;
-  for (int i = blockIdx.x * 256 + threadIdx.x; i < nt * 256; i += gridDim.x * 256)
-  {
-    const int blk = i >> 8, kk = (i >> 6) & 3, ln = i & 63;
-    int cb2 = 0;
-    while ((cb2 + 1) * (cb2 + 2) / 2 <= blk) ++cb2;
-    const int cb1 = blk - cb2 * (cb2 + 1) / 2;
-    const int r = 16 * cb1 + 4 * kk + (ln >> 4) - col_shift, c = 16 * cb2 + (ln & 15) - col_shift;
-    W[i] = (r == c && r >= 0 && r < n1) ? 1.0 : 0.0;
-  }
-}
-
 // G2 = [G c; c' bb] (the Gram of Q = [A b] W over ALL rows) -> R = chol(G2) T.
 //   Columns the preconditioner deferred (zmask): whether they hold anything is decided HERE, on all rows.  Rounding residue of a dependent
 //   column reads O(1e-3) in units of its lift (1e-13 x the largest column to its left) and has nothing left after its own elimination
@@ -1007,12 +992,6 @@ hipError_t rdyn_launch_regressor_pgram(int n_joints, const RdynLdsGramArgs& a, c
   case 7: return launch_pgram<7>(a, W, run_flag, blocks, pairs, st);
   default: return hipErrorInvalidValue;
   }
-}
-
-hipError_t rdyn_launch_cholqr_identity_w(double* W, int n1, int col_shift, hipStream_t st)
-{
-  hipLaunchKernelGGL(k_cholqr_identity_w, dim3(8), dim3(256), 0, st, W, n1, col_shift);
-  return hipGetLastError();
 }
 
 hipError_t rdyn_launch_cholqr_precond(const double* R1, const double* Gs, const double* cs, const double* bbs, int n1, int col_shift, double row_scale,

@@ -66,7 +66,9 @@ __global__ __launch_bounds__(512) void k_regressor_gram_duo(const RdynLdsGramArg
   const bool sweeper = wave < 4;
   char* const tile = lds_raw + (size_t)pair * fa.tile_bytes;  // shared by the pair
   const int n = fa.n_active;
-  const int64_t n_tiles = (fa.n_samples + 15) / 16;
+  // tile_stride > 1: only every tile_stride-th 16-sample tile (the subsample pass of the robust factor, rdyn_cholqr.hip)
+  const int64_t t_mul = fa.tile_stride > 1 ? fa.tile_stride : 1;
+  const int64_t n_tiles = ((fa.n_samples + 15) / 16 + t_mul - 1) / t_mul;
   const int64_t t_step = (int64_t)gridDim.x * 4;
   const int64_t t_first = (int64_t)blockIdx.x * 4 + pair;
   // same trip count for every wave of the workgroup (the barriers are workgroup-wide): pairs without a tile sweep masked samples
@@ -92,7 +94,7 @@ __global__ __launch_bounds__(512) void k_regressor_gram_duo(const RdynLdsGramArg
         if (fa.lds_m[f] >= 5) fB = f;
     double nqa = 0.0, ndqa = 0.0, nddqa = 0.0, nqb = 0.0, ndqb = 0.0, nddqb = 0.0, nb0 = 0.0, nb1 = 0.0;
     auto fetch = [&](int64_t tile_index) {
-      int64_t sx = tile_index * 16 + s_loc;
+      int64_t sx = tile_index * t_mul * 16 + s_loc;
       if (sx >= fa.n_samples) sx = fa.n_samples - 1;
       const int64_t o = sx * fa.in_ss;
       if (fa.bcol)
@@ -117,7 +119,7 @@ __global__ __launch_bounds__(512) void k_regressor_gram_duo(const RdynLdsGramArg
     for (int64_t it = 0; it < trips; ++it)
     {
       const int64_t tl = t_first + it * t_step;
-      const bool valid = tl < n_tiles && tl * 16 + s_loc < fa.n_samples;
+      const bool valid = tl < n_tiles && tl * t_mul * 16 + s_loc < fa.n_samples;
       // a masked sample keeps zero joint twists for both rows (its rows never "start"), so every regressor entry is 0
       const int m0idx = valid ? r0 : -2, m1idx = valid ? r1 : -2;
       const double qa = nqa, dqa = ndqa, ddqa = nddqa, qb = nqb, dqb = ndqb, ddqb = nddqb;

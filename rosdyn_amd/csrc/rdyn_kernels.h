@@ -170,7 +170,7 @@ struct RdynLdsGramArgs
   int tile_bytes;                      // one wave's tile
   double* slabs;
   int debug;                           // timing experiments only (RDYN_FUSED_DEBUG): bit 0 sweep only the first tile, bit 1 no Gram phase
-  int tile_stride;                     // k_regressor_tsqr only: sweep every tile_stride-th 16-sample tile (0 / 1 = all): the subsample pass of the preconditioned route
+  int tile_stride;                     // wave-pair kernels: sweep every tile_stride-th 16-sample tile only (0 / 1 = all): the subsample pass of the preconditioned route
   const int* run_flag;                 // k_regressor_tsqr and its tree only: null, or a device word -- 0 = leave at once
   // wave-pair kernel only (rdyn_duo_gram.hip): the per-joint component columns [Y | C | tau_meas] of rdyn_identification_gram.
   // Column P + k of the tile belongs to component comp_col_comp[k] and is non-zero only in the rows of that component's joint:
@@ -208,7 +208,6 @@ hipError_t rdyn_launch_regressor_pgram(int n_joints, const RdynLdsGramArgs& a, c
 hipError_t rdyn_launch_cholqr_precond(const double* R1, const double* Gs, const double* cs, const double* bbs, int n1, int col_shift, double row_scale,
                                       double* T, double* W, double* V, int* zmask, int* flags, int round, const int* run_flag, double* gamma_out,
                                       hipStream_t st);
-hipError_t rdyn_launch_cholqr_identity_w(double* W, int n1, int col_shift, hipStream_t st);  // W = I in the operand order of the pass
 int rdyn_cholqr_col_shift(int n_joints, int xb);
 // G2 = [G c; c' bb] -> R = chol(G2) T (n1 x n1 upper, column-major; zero rows at the confirmed null columns); flags[round] = 1 when the
 // round is not accepted (rho_out, may be null: [0] the conditioning measure of the equilibrated Q, [2] gamma on the norms of all rows);
