@@ -388,6 +388,61 @@ def test_cholqr_route_from_its_threshold_on(urdf, base, tool, N):
     assert np.allclose(np.tril(Ra, -1), 0.0) and np.abs(Ra.T @ Ra - G2).max() <= 1e-12 * np.abs(G2).max()
 
 
+def _doctor(rng, q, dq, ddq, N, n):
+    """a random subset of joints moves eps x slower (or not at all, or is frozen) in a random set of 16-sample tiles: the tiles the
+    preconditioner is built from, a random third of all tiles, one contiguous stretch, or a mixture"""
+    tiles = (N + 15) // 16
+    stride = max(1, tiles // 1024)
+    stride += 1 if (stride > 1 and stride % 2 == 0) else 0
+    tile_of = np.arange(N) // 16
+    kind = rng.integers(0, 4)
+    if kind == 0:
+        sel = tile_of % stride == 0
+    elif kind == 1:
+        sel = rng.random(tiles)[tile_of] < 0.33
+    elif kind == 2:
+        a = rng.integers(0, tiles)
+        sel = (tile_of >= a) & (tile_of < a + rng.integers(1, tiles // 2))
+    else:
+        sel = (tile_of % stride == 0) | (rng.random(tiles)[tile_of] < 0.1)
+    joints = np.where(rng.random(n) < 0.6)[0]
+    if len(joints) == 0:
+        joints = np.array([rng.integers(0, n)])
+    eps = 0.0 if rng.random() < 0.15 else 10.0 ** rng.uniform(-12, 0)
+    idx = np.where(sel)[0]
+    dq[idx[:, None], joints[None, :]] *= eps
+    ddq[idx[:, None], joints[None, :]] *= eps
+    if rng.random() < 0.3:
+        q[idx[:, None], joints[None, :]] = q[idx[0], joints][None, :]
+
+
+@pytest.mark.parametrize("case", range(16))
+def test_cholqr_route_on_randomly_doctored_batches(case):
+    """Whatever path the device takes (tools/cholqr_fuzz.py prints it: of these 16 cases eleven end in round 0, three in round 1, two in
+    the stand-by call), the factor is numpy's Householder factor: R'R = M'M to 1e-13, singular values to 1e-10."""
+    torch = pytest.importorskip("torch")
+    from oracle.oracle import OracleChain
+    from rosdyn_amd import Chain
+    from rosdyn_amd.samples import trajectory_batch
+    urdf, base, tool = CHOLQR_CASES[case % 2]
+    path = os.path.join(FIXTURES, urdf)
+    chain, ref = Chain(path, base, tool, GRAV), OracleChain(path, base, tool, GRAV)
+    n, P, N = ref.n, ref.P, 66000
+    rng = np.random.default_rng(case)
+    q, dq, ddq = trajectory_batch(case, N, n)
+    _doctor(rng, q, dq, ddq, N, n)
+    tau = ref.joint_torque(q, dq, ddq) + 1e-3 * rng.normal(size=(N, n))
+    M = _oracle_rows(ref, q, dq, ddq, tau)
+    R1 = chain.getRegressorTsqr(*(torch.from_numpy(x).cuda() for x in (q, dq, ddq, tau))).cpu().numpy()
+    G = M.T @ M
+    assert np.allclose(np.tril(R1, -1), 0.0)
+    assert np.abs(R1.T @ R1 - G).max() <= 1e-13 * np.abs(G).max()
+    s_ref, s_gpu = np.linalg.svd(np.linalg.qr(M, mode="r"), compute_uv=False), np.linalg.svd(R1, compute_uv=False)
+    keep = s_ref > 1e-9 * s_ref[0]
+    assert np.abs(s_gpu[keep] / s_ref[keep] - 1.0).max() <= 1e-10
+    assert np.all(s_gpu[~keep] <= 1e-8 * s_ref[0])
+
+
 @pytest.mark.parametrize("N", [6000, CHOLQR_N])
 def test_cholqr_route_with_component_columns(N):
     """rdyn_identification_tsqr above the route's threshold: [Y | friction / spring columns | tau_meas] through the preconditioned
