@@ -509,8 +509,9 @@ __device__ __forceinline__ void chol_with_inverse_lds(double* M, double* E, int 
 //                    the kept directions to its LEFT go into T(:, k), its diagonal is its own pivot (or the 1e-13 floor).  Row k of T
 //                    holds the diagonal only, so W has no large rows; the large column W(:, k) touches nothing but column k itself.
 //                    What the later columns keep of direction k is left to the Cholesky factorisation of Q'Q over ALL rows.
-//   gamma            max_j gamma_j is evaluated on the finished T, W.  Above 1e4 the round is not run: flags say so and the
-//                    Householder factorisation of all rows (the stand-by call of rdyn_api.cpp) takes over.
+//   gamma            max_j gamma_j is evaluated on the finished T, W.  Above 1e4 (round 1; round 0, which may still serve as the
+//                    preconditioner of round 1: 1e10) the round is not run: flags say so and the Householder factorisation of all
+//                    rows (the stand-by call of rdyn_api.cpp) takes over.
 // flags: [0] run round 1, [1] run the stand-by, [2] run round 0 (written here in round 0).  zmask <- Z (for the factor kernel).
 // W is written in the MFMA operand order of k_regressor_pgram.
 constexpr double kCholqrGammaMax = 1e4;
@@ -672,7 +673,9 @@ __global__ __launch_bounds__(NTD) void k_cholqr_precond(const double* __restrict
   {
     double gamma = 0.0;
     for (int j = 0; j < n1; ++j) gamma = fmax(gamma, s_part[j]);
-    const bool safe = gamma <= kCholqrGammaMax;  // (false for NaN)
+    // round 1 cannot be accepted above the limit: called off.  Round 0 only has to be worth running as a PRECONDITIONER for round 1 (the
+    // factor kernel rejects it as a result by the same figure on all rows): called off when even that is hopeless
+    const bool safe = gamma <= (round == 0 ? 1e10 : kCholqrGammaMax);  // (false for NaN)
     if (gamma_out) *gamma_out = gamma;
     if (round == 0) flags[2] = safe ? 1 : 0;
     if (!safe)

@@ -418,7 +418,7 @@ def _doctor(rng, q, dq, ddq, N, n):
 
 @pytest.mark.parametrize("case", range(16))
 def test_cholqr_route_on_randomly_doctored_batches(case):
-    """Whatever path the device takes (tools/cholqr_fuzz.py prints it: of these 16 cases eleven end in round 0, three in round 1, two in
+    """Whatever path the device takes (tools/cholqr_fuzz.py prints it: of these 16 cases eleven end in round 0, four in round 1, one in
     the stand-by call), the factor is numpy's Householder factor: R'R = M'M to 1e-13, singular values to 1e-10."""
     torch = pytest.importorskip("torch")
     from oracle.oracle import OracleChain
