@@ -244,7 +244,10 @@ __global__ __launch_bounds__(512) void k_regressor_gram_duo(const RdynLdsGramArg
           }
       }
     };
-    d4 opa[NB], opb[NB];
+    // 7 joints + component columns: 21 accumulator tiles (168 registers) + two operand sets (96) do not fit 256 registers (468 B of
+    // scratch in the hot loop): ONE operand set there -- the next group's loads are issued behind this group's MFMAs instead of in front
+    constexpr bool ONEBUF = NJ >= 7 && XB > 0;
+    d4 opa[NB], opb[ONEBUF ? 1 : NB];
     for (int64_t it = 0; it <= trips; ++it)
     {
       // it > 0: the tile in LDS is complete (nothing to consume while the first tile is being swept): group 0
@@ -253,14 +256,22 @@ __global__ __launch_bounds__(512) void k_regressor_gram_duo(const RdynLdsGramArg
 #pragma unroll
       for (int f = 0; f < NJ; ++f)
       {
-        d4* const cur = (f & 1) ? opb : opa;
-        d4* const nxt = (f & 1) ? opa : opb;
+        d4* const cur = (ONEBUF || !(f & 1)) ? opa : opb;
+        d4* const nxt = (ONEBUF || (f & 1)) ? opa : opb;
         if (it < trips) DUO_BARRIER_LDS();  // my reads of group f have returned -> the sweeper may overwrite link f's columns
         else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (have)
         {
-          if (f + 1 < NJ) lds_group(f + 1, DESC ? (10 * (NJ - f - 1)) >> 4 : (10 * (f + 1)) >> 4, nxt);
-          mfma_band(cur, DESC ? (10 * (NJ - f)) >> 4 : (10 * f) >> 4);
+          if constexpr (ONEBUF)
+          {
+            mfma_band(cur, DESC ? (10 * (NJ - f)) >> 4 : (10 * f) >> 4);
+            if (f + 1 < NJ) lds_group(f + 1, DESC ? (10 * (NJ - f - 1)) >> 4 : (10 * (f + 1)) >> 4, nxt);
+          }
+          else
+          {
+            if (f + 1 < NJ) lds_group(f + 1, DESC ? (10 * (NJ - f - 1)) >> 4 : (10 * (f + 1)) >> 4, nxt);
+            mfma_band(cur, DESC ? (10 * (NJ - f)) >> 4 : (10 * f) >> 4);
+          }
         }
       }
       if (it < trips) DUO_BARRIER_LDS();  // end of the sweeper's tile
