@@ -1279,7 +1279,8 @@ static int regressor_tsqr_run(const rdyn_chain* c, const rdyn_component* comps, 
       RDYN_HIP_TRY(rdyn_launch_regressor_gram_duo(10 * nJ, sub, sub4, lds_bytes, stream));
       RdynGramArgs gs = ga;
       gs.col_shift = 0;
-      gs.desc_nj = n_comps > 0 ? 0 : nJ;
+      gs.desc_nj = nJ;
+      gs.desc_k = n_comps > 0 ? K : 0;
       gs.slab_nb = n_comps > 0 ? nbt : 0;
       RDYN_HIP_TRY(rdyn_launch_gram_finish(gs, sub4, stream));
     }
@@ -1461,7 +1462,8 @@ int rdyn_identification_gram(const rdyn_chain* c, const rdyn_component* comps, i
       RDYN_HIP_TRY(rdyn_launch_regressor_gram_duo(P, la, blocks, lds_bytes, stream));
       RdynGramArgs ga;
       memset(&ga, 0, sizeof ga);
-      ga.desc_nj = K == 0 ? c->n_joints() : 0;  // without component columns the kernel accumulates in descending link order
+      ga.desc_nj = c->n_joints();  // the kernel accumulates in the order [component columns | tau_meas | links descending]
+      ga.desc_k = K;
       ga.slab_nb = nbt;
       ga.P = cols;
       ga.add_to_output = accumulate ? 1 : 0;

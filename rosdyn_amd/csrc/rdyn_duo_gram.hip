@@ -172,17 +172,19 @@ __global__ __launch_bounds__(512) void k_regressor_gram_duo(const RdynLdsGramArg
 #endif
     const int cl = lane & 15, g = lane >> 4;
     // per column block: LDS offset of MY column (for row group 0) and the row groups [collo, colm) it stores
-    constexpr bool DESC = XB == 0;
     int colbase[NB], colm[NB], collo[NB];
-    const int K = XB > 0 || fa.n_comp_cols > 0 ? fa.n_comp_cols : 0;
+    const int K = XB > 0 ? fa.n_comp_cols : 0;  // component columns: in FRONT of the accumulation order (a constant 0 without them)
+    const int KF = K;
 #pragma unroll
     for (int cb = 0; cb < NB; ++cb)
     {
-      // XB == 0: the Gram is accumulated in the column order [tau_meas | link NJ-1 | ... | link 0]: row group j is non-zero in
-      // the FIRST 10 (NJ - j) + 1 columns, so its zero band ends at a 16-column boundary more often than in natural order
-      // (48 instead of 62 tile k-steps per tile at 7 joints, 33 instead of 36 at 6); k_gram_finish undoes the permutation
+      // The Gram is accumulated in the column order [component columns | tau_meas | link NJ-1 | ... | link 0]: row group j is non-zero
+      // in the FIRST KF + 10 (NJ - j) + 1 columns (its own joint's component columns among the first KF), so its zero band ends at a
+      // 16-column boundary more often than in natural order (without components: 48 instead of 62 tile k-steps per tile at 7 joints,
+      // 33 instead of 36 at 6; with 14 / 12 of them: 76 instead of 94, 50 instead of 59); k_gram_finish undoes the permutation
       const int pp = 16 * cb + cl;
-      const int p = !DESC ? pp : (pp == 0 ? P : (pp > P ? P + 1 : 10 * (NJ - 1 - (pp - 1) / 10) + (pp - 1) % 10));
+      const int pl = pp - KF - 1;  // position among the link columns
+      const int p = pp < KF ? P + pp : (pp == KF ? P + K : (pl >= P ? P + K + 1 : 10 * (NJ - 1 - pl / 10) + pl % 10));
       int base = 0, hi = 0, lo = 0;
       if (p < P)
       {
@@ -208,14 +210,14 @@ __global__ __launch_bounds__(512) void k_regressor_gram_duo(const RdynLdsGramArg
     d4 acc[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) acc[t] = (d4){0.0, 0.0, 0.0, 0.0};
-    // operands of row group j: column blocks >= (10 j) >> 4 (input joints in chain order: joint j sits at chain index >= j)
-    // band of row group j: natural order -> column blocks >= (10 j) >> 4; descending order -> column blocks <= (10 (NJ - j)) >> 4
+    // operands of row group j: column blocks <= band = (KF + 10 (NJ - j)) >> 4 (input joints in chain order: joint j sits at chain
+    // index >= j; a run-time figure with component columns, folded per unrolled group without)
     auto lds_group = [&](int j, int band, d4* op) {
 #pragma unroll
       for (int cb = 0; cb < NB; ++cb)
       {
         d4 x = (d4){0.0, 0.0, 0.0, 0.0};
-        if ((DESC ? cb <= band : cb >= band) && j < colm[cb] && j >= collo[cb]) x = *(const d4h*)(tile + colbase[cb] + j * 128);
+        if (cb <= band && j < colm[cb] && j >= collo[cb]) x = *(const d4h*)(tile + colbase[cb] + j * 128);
         op[cb] = x;
       }
     };
@@ -230,7 +232,7 @@ __global__ __launch_bounds__(512) void k_regressor_gram_duo(const RdynLdsGramArg
           for (int rb = 0; rb <= cb; ++rb)
           {
 #ifdef RDYN_DUO_4X4_TIMING  // timing experiment only (wrong numbers): the issue cost of four (three on the diagonal) 4x4x4_4b MFMAs per tile k-step
-            if (DESC ? cb <= band : rb >= band)
+            if (cb <= band)
             {
               acc[ti][0] = __builtin_amdgcn_mfma_f64_4x4x4f64(op[rb][t], op[cb][t], acc[ti][0], 0, 0, 0);
               acc[ti][1] = __builtin_amdgcn_mfma_f64_4x4x4f64(op[rb][t], op[cb][t], acc[ti][1], 0, 0, 0);
@@ -238,7 +240,7 @@ __global__ __launch_bounds__(512) void k_regressor_gram_duo(const RdynLdsGramArg
               if (rb != cb) acc[ti][3] = __builtin_amdgcn_mfma_f64_4x4x4f64(op[rb][t], op[cb][t], acc[ti][3], 0, 0, 0);
             }
 #else
-            if (DESC ? cb <= band : rb >= band) acc[ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(op[rb][t], op[cb][t], acc[ti], 0, 0, 0);
+            if (cb <= band) acc[ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(op[rb][t], op[cb][t], acc[ti], 0, 0, 0);
 #endif
             ++ti;
           }
@@ -252,7 +254,7 @@ __global__ __launch_bounds__(512) void k_regressor_gram_duo(const RdynLdsGramArg
     {
       // it > 0: the tile in LDS is complete (nothing to consume while the first tile is being swept): group 0
       const bool have = it > 0;
-      if (have) lds_group(0, DESC ? (10 * NJ) >> 4 : 0, opa);
+      if (have) lds_group(0, (KF + 10 * NJ) >> 4, opa);
 #pragma unroll
       for (int f = 0; f < NJ; ++f)
       {
@@ -264,13 +266,13 @@ __global__ __launch_bounds__(512) void k_regressor_gram_duo(const RdynLdsGramArg
         {
           if constexpr (ONEBUF)
           {
-            mfma_band(cur, DESC ? (10 * (NJ - f)) >> 4 : (10 * f) >> 4);
-            if (f + 1 < NJ) lds_group(f + 1, DESC ? (10 * (NJ - f - 1)) >> 4 : (10 * (f + 1)) >> 4, nxt);
+            mfma_band(cur, (KF + 10 * (NJ - f)) >> 4);
+            if (f + 1 < NJ) lds_group(f + 1, (KF + 10 * (NJ - f - 1)) >> 4, nxt);
           }
           else
           {
-            if (f + 1 < NJ) lds_group(f + 1, DESC ? (10 * (NJ - f - 1)) >> 4 : (10 * (f + 1)) >> 4, nxt);
-            mfma_band(cur, DESC ? (10 * (NJ - f)) >> 4 : (10 * f) >> 4);
+            if (f + 1 < NJ) lds_group(f + 1, (KF + 10 * (NJ - f - 1)) >> 4, nxt);
+            mfma_band(cur, (KF + 10 * (NJ - f)) >> 4);
           }
         }
       }
@@ -337,7 +339,7 @@ hipError_t launch_duo_nj(const RdynLdsGramArgs& a, int blocks, size_t lds_bytes,
   // direct = every chain joint is an input joint, in chain order (the tile layout tables then follow from NJ alone)
   bool direct = a.n_active == NJ;
   for (int f = 0; direct && f < NJ; ++f) direct = a.lds_m[f] == f + 1 && a.first_col[f] == 10 * f && a.lds_stride[f] == (16 * (f + 1) + 4) * 8;
-  // component columns always take the XB = 1 instantiation (natural column order); without them XB = 0 (descending link order)
+  // component columns always take the XB = 1 instantiation (one more column block, the component columns in front of the order)
   const int xb = a.n_comp_cols > 0 ? 1 : 0;
   if (xb == 0 && direct && a.all_revolute) return launch_duo_nj2<NJ, true, 0, true>(a, blocks, lds_bytes, st);
   if (xb == 0) return direct ? launch_duo_nj2<NJ, true, 0>(a, blocks, lds_bytes, st) : launch_duo_nj2<NJ, false, 0>(a, blocks, lds_bytes, st);

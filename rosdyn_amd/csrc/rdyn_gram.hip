@@ -166,9 +166,12 @@ __global__ __launch_bounds__(32 * FG) void k_gram_finish(const RdynGramArgs a, i
   auto col_of = [&](int pp) -> int {
     if (a.col_shift > 0) return pp < a.col_shift ? P + 1 : pp - a.col_shift;  // padding in front of the natural order
     if (a.desc_nj <= 0) return pp;
-    if (pp == 0) return P;
-    if (pp > P) return P + 1;
-    return 10 * (a.desc_nj - 1 - (pp - 1) / 10) + (pp - 1) % 10;
+    // [desc_k component columns | tau_meas | link desc_nj - 1 | ... | link 0 | padding]; in G the links come first, then the components
+    if (pp < a.desc_k) return P - a.desc_k + pp;
+    if (pp == a.desc_k) return P;
+    const int pl = pp - a.desc_k - 1;
+    if (pl >= 10 * a.desc_nj) return P + 1;
+    return 10 * (a.desc_nj - 1 - pl / 10) + pl % 10;
   };
   const int p1 = col_of(pp1), p2 = col_of(pp2);
   const double prev_scale = a.add_to_output ? 1.0 : 0.0;

@@ -117,6 +117,7 @@ struct RdynGramArgs
   // finish only: > 0 = the slabs hold the columns in the wave-pair kernel's order [tau_meas | link desc_nj - 1 | ... | link 0]
   // (rdyn_duo_gram.hip: the zero band of every row group then ends at a 16-column boundary more often); 0 = natural order
   int desc_nj;
+  int desc_k;   // finish only, with desc_nj > 0: component columns in front of that order ([C | tau_meas | links descending]; P counts them)
   int slab_nb;  // finish only: 16-column blocks of the slabs' tile layout if it is wider than P + 1 columns need (0 = derive from P)
   const int* run_flag;  // finish only, may be null: device word; 0 = leave at once (conditional second round of rdyn_cholqr.hip)
   int col_shift;        // finish only: the slabs' column space is the natural order shifted right by col_shift (rdyn_cholqr.hip)
