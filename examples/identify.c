@@ -97,6 +97,17 @@ int main(int argc, char** argv)
   hipMalloc((void**)&d_R1, sizeof(double) * (size_t)n1 * n1);
   CHECK(rdyn_regressor_tsqr(chain, &b, d_tau, d_R1, 0, ws_r, nb_r));
   hipDeviceSynchronize();
+  {
+    /* which stage of the factorisation vouched for the result (decided on the device, read back here) */
+    rdyn_tsqr_report rep;
+    CHECK(rdyn_tsqr_last_report(chain, NULL, 0, N, ws_r, -1, NULL, &rep));
+    if (rep.route == 0)
+      printf("R factor: Householder folds\n");
+    else
+      printf("R factor: preconditioned CholeskyQR, %s; %d columns deferred, growth factor %.3g, conditioning %.3g\n",
+             rep.stage == 0 ? "accepted after the first round" : (rep.stage == 1 ? "accepted after the second round" : "stand-by Householder factorisation"),
+             (int)rep.n_deferred, rep.gamma[rep.stage == 1 ? 1 : 0], rep.rho[rep.stage == 1 ? 1 : 0]);
+  }
   G = (double*)malloc(sizeof(double) * ((size_t)P * P + P + 1));
   c = G + (size_t)P * P;
   R1 = (double*)malloc(sizeof(double) * (size_t)n1 * n1);

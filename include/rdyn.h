@@ -393,6 +393,21 @@ int rdyn_regressor_tsqr(const rdyn_chain* chain, const rdyn_batch* batch, const 
 size_t rdyn_identification_tsqr_workspace_bytes(const rdyn_chain* chain, const rdyn_component* comps, int n_comps);
 int rdyn_identification_tsqr(const rdyn_chain* chain, const rdyn_component* comps, int n_comps, const rdyn_batch* batch, const double* tau_meas,
                              double* R1, int accumulate, void* workspace, size_t workspace_bytes);
+/* What the LAST rdyn_regressor_tsqr / rdyn_identification_tsqr call that used `workspace` did (the preconditioned route decides on the
+ * device which of its stages vouches for the result; this reads the decision back).  Same chain, components and n_samples as that
+ * call; waits for `stream`.  No reference counterpart. */
+typedef struct rdyn_tsqr_report
+{
+  int32_t route;      /* 0: Householder folds (batches below 4 096 samples): nothing else is filled in; 1: preconditioned CholeskyQR */
+  int32_t stage;      /* route 1: 0 = accepted after round 0, 1 = after round 1, 2 = the stand-by Householder factorisation ran */
+  int32_t n_deferred; /* columns the last preconditioner did not use for elimination (structurally dependent or nearly so) */
+  int32_t reserved;
+  double gamma[2];    /* growth factor of the rounding of A W on the column norms of all rows, round 0 / 1 (0 = round not run);
+                         accepted up to 1e4 */
+  double rho[2];      /* |Re^-1|_F / sqrt(k) of the column-equilibrated A W (1 = orthogonal columns), round 0 / 1; accepted up to 4 */
+} rdyn_tsqr_report;
+int rdyn_tsqr_last_report(const rdyn_chain* chain, const rdyn_component* comps, int n_comps, int64_t n_samples, const void* workspace,
+                          int device, void* stream, rdyn_tsqr_report* out);
 /* HOST: folds n_factors upper-triangular n x n factors (stacked, each column-major n x n) into one (Householder). */
 int rdyn_tsqr_combine_host(const double* R_stack, int n_factors, int n, double* R_out);
 

@@ -113,11 +113,17 @@ SYMBOLS = {
     "rdyn_regressor_tsqr": (_I, [_VP, _BP, _VP, _VP, _I, _VP, C.c_size_t]),
     "rdyn_identification_tsqr_workspace_bytes": (C.c_size_t, [_VP, _VP, _I]),
     "rdyn_identification_tsqr": (_I, [_VP, _VP, _I, _BP, _VP, _VP, _I, _VP, C.c_size_t]),
+    "rdyn_tsqr_last_report": (_I, [_VP, _VP, _I, C.c_int64, _VP, _I, _VP, _VP]),
     "rdyn_tsqr_combine_host": (_I, [_DP, _I, _I, _DP]),
     "rdyn_solve_normal_equations": (_I, [_DP, _DP, _I, C.c_double, _DP, C.POINTER(C.c_int)]),
     "rdyn_gram_r_factor": (_I, [_DP, _I, C.c_double, _DP, C.POINTER(C.c_int32), C.POINTER(C.c_int)]),
     "rdyn_solve_r_factor": (_I, [_DP, C.c_int64, _I, _I, _DP, C.c_double, _DP, C.POINTER(C.c_int)]),
 }
+
+class RdynTsqrReport(C.Structure):
+    _fields_ = [("route", C.c_int32), ("stage", C.c_int32), ("n_deferred", C.c_int32), ("reserved", C.c_int32),
+                ("gamma", C.c_double * 2), ("rho", C.c_double * 2)]
+
 
 _lib = None
 

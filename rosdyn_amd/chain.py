@@ -473,5 +473,19 @@ class Chain(object):
         return R1
 
 
+    def lastTsqrReport(self, n_samples, workspace, components=None):
+        """What the last getRegressorTsqr / getIdentificationTsqr call that used `workspace` did (include/rdyn.h:
+        rdyn_tsqr_last_report): dict(route = 0 Householder folds / 1 preconditioned CholeskyQR; stage = 0 accepted after round 0,
+        1 after round 1, 2 the stand-by Householder factorisation ran; n_deferred; gamma, rho of the two rounds).  Synchronises."""
+        from ._lib import RdynTsqrReport
+        torch = _torch()
+        arr, n_comps = (C.cast(components._arr, C.c_void_p), components.n_comps) if components is not None else (None, 0)
+        rep = RdynTsqrReport()
+        stream = torch.cuda.current_stream(workspace.device).cuda_stream
+        check(lib().rdyn_tsqr_last_report(self._h, arr, n_comps, int(n_samples), workspace.data_ptr(), workspace.device.index or 0, stream,
+                                          C.byref(rep)))
+        return dict(route=rep.route, stage=rep.stage, n_deferred=rep.n_deferred, gamma=tuple(rep.gamma), rho=tuple(rep.rho))
+
+
 def createChain(urdf_xml, base_frame, tool_frame, gravity=(0.0, 0.0, 0.0)):
     return Chain(urdf_xml, base_frame, tool_frame, gravity)

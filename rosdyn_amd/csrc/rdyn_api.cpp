@@ -1134,6 +1134,11 @@ struct TsqrLayout
   size_t slabs = 0, w = 0, v = 0, r1p = 0, g2 = 0, r_swept = 0, flag = 0, total_doubles = 0;  // offsets (doubles) of region 2
 };
 static const int kCholqrBlocks = 256;
+// ~0.2 ms of fixed cost (the subsample's Gram matrix, the two small dense kernels, seven launches that leave at once) + 0.78 / 1.2 ms
+// per 1e6 samples (6 / 7 joints) against 0.3 - 0.4 ms + 2.8 / 3.8 ms per 1e6 samples for the Householder route: faster at every
+// size measured (2 000 samples: 183 vs 288 us; 200 000: 364 vs 969 us).  Small batches keep the Householder folds -- a few hundred
+// rows say little about what a preconditioner built on them is worth, and there is nothing to win.
+static const int64_t kCholqrMinTiles = 256;  // 4 096 samples
 // xb = 1: with component columns (one more 16-column block; the factors are sized for the padded width 16 nb)
 static TsqrLayout tsqr_layout(int n_joints_swept, int xb = 0)
 {
@@ -1234,11 +1239,6 @@ static int regressor_tsqr_run(const rdyn_chain* c, const rdyn_component* comps, 
   // whose swept form has every joint as an input joint; the Householder folds (rdyn_tsqr.hip) otherwise.
   const char* route_env = probe_env("RDYN_TSQR_ROUTE");  // A/B builds only: "householder" / "cholqr"
   const int pairs = n == nJ ? rdyn_cholqr_pairs(nJ, la.tile_bytes, n_comps > 0 ? 1 : 0) : 0;
-  // ~0.2 ms of fixed cost (the subsample's Gram matrix, the two small dense kernels, seven launches that leave at once) + 0.78 / 1.2 ms
-  // per 1e6 samples (6 / 7 joints) against 0.3 - 0.4 ms + 2.8 / 3.8 ms per 1e6 samples for the Householder route: faster at every
-  // size measured (2 000 samples: 183 vs 288 us; 200 000: 364 vs 969 us).  Small batches keep the Householder folds -- a few hundred
-  // rows say little about what a preconditioner built on them is worth, and there is nothing to win.
-  const int64_t kCholqrMinTiles = 256;  // 4 096 samples
   bool cholqr = pairs != 0 && tiles >= kCholqrMinTiles;
   if (route_env && pairs != 0) cholqr = !strcmp(route_env, "cholqr");
   // where the factor of the swept chain goes: straight into R when nothing follows
@@ -1362,6 +1362,54 @@ int rdyn_identification_tsqr(const rdyn_chain* c, const rdyn_component* comps, i
                              int accumulate, void* workspace, size_t workspace_bytes)
 {
   return regressor_tsqr_run(c, comps, n_comps, b, tau_meas, R, accumulate, workspace, workspace_bytes, "rdyn_identification_tsqr");
+}
+
+int rdyn_tsqr_last_report(const rdyn_chain* c, const rdyn_component* comps, int n_comps, int64_t n_samples, const void* workspace, int device,
+                          void* stream, rdyn_tsqr_report* out)
+{
+  if (!c || !workspace || !out || n_comps < 0 || (n_comps > 0 && !comps) || n_samples < 0)
+  {
+    rdyn_set_error("rdyn_tsqr_last_report: invalid argument");
+    return RDYN_ERR_INVALID_ARGUMENT;
+  }
+  memset(out, 0, sizeof *out);
+  const rdyn_chain* cs = swept_chain(c, n_comps);
+  const int n = cs->n_active(), nJ = cs->n_joints();
+  const int K = n_comps > 0 ? rdyn_components_columns(comps, n_comps) : 0;
+  RdynLdsGramArgs la;
+  memset(&la, 0, sizeof la);
+  if (K < 0 || nJ < 2 || nJ > 7 || !build_lds_tile(cs, K > 0 ? K : 0, false, &la))
+  {
+    rdyn_set_error("rdyn_tsqr_last_report: the factor entry points do not serve this chain");
+    return RDYN_ERR_UNSUPPORTED;
+  }
+  const int pairs = n == nJ ? rdyn_cholqr_pairs(nJ, la.tile_bytes, n_comps > 0 ? 1 : 0) : 0;
+  if (pairs == 0 || (n_samples + 15) / 16 < kCholqrMinTiles) return RDYN_OK;  // route 0: the Householder folds, nothing to report
+  DeviceGuard g;
+  int st = g.enter(device);
+  if (st != RDYN_OK) return st;
+  const TsqrLayout L = tsqr_layout(nJ, n_comps > 0 ? 1 : 0);
+  double raw[64];
+  RDYN_HIP_TRY(hipMemcpyAsync(raw, (const double*)workspace + L.flag, sizeof raw, hipMemcpyDeviceToHost, (hipStream_t)stream));
+  RDYN_HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+  int flags[128];
+  memcpy(flags, raw, sizeof flags);
+  out->route = 1;
+  const bool round0 = flags[2] != 0, round1 = round0 && flags[0] != 0;
+  out->stage = flags[1] ? 2 : (round1 ? 1 : 0);
+  const int n1s = 10 * nJ + (K > 0 ? K : 0) + 1;
+  for (int k = 0; k < n1s && 16 + k < 128; ++k) out->n_deferred += flags[16 + k] ? 1 : 0;
+  if (round0)
+  {
+    out->gamma[0] = raw[54];
+    out->rho[0] = raw[52];
+  }
+  if (round1)
+  {
+    out->gamma[1] = raw[55];
+    out->rho[1] = raw[53];
+  }
+  return RDYN_OK;
 }
 
 // ---- identification step: normal equations of [Y | C | tau_meas] (rigid-body regressor + component columns) -------------

@@ -620,6 +620,15 @@ public:
   {
     chk(rdyn_regressor_tsqr(m_h, &b, tau_meas, R1, accumulate ? 1 : 0, workspace, workspace_bytes));
   }
+  // what the last factor call on `workspace` did (include/rdyn.h: rdyn_tsqr_last_report): route, the stage of the preconditioned route that
+  // vouched for the result (0 / 1: first / second round, 2: the stand-by Householder factorisation), growth factor and conditioning
+  rdyn_tsqr_report getTsqrReport(int64_t n_samples, const void* workspace, int device = -1, void* stream = nullptr,
+                                 const std::vector<rdyn_component>& comps = std::vector<rdyn_component>()) const
+  {
+    rdyn_tsqr_report rep;
+    chk(rdyn_tsqr_last_report(m_h, comps.empty() ? nullptr : comps.data(), (int)comps.size(), n_samples, workspace, device, stream, &rep));
+    return rep;
+  }
   // rigid-body reduction of a chain whose input joints are a subset of its joints (include/rdyn.h: rdyn_chain_reduction): returns the
   // number of bodies (0: no reduction); body_joint[f] = chain index of the input joint link f + 1 rides on (-1: on the base),
   // X = [joints][10][10] row-major with Y(:, 10 f + p) = sum_a Y(:, 10 body_joint[f] + a) X[f][a][p], pi_body = merged parameters

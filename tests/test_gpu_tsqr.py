@@ -201,6 +201,13 @@ CHOLQR_CASES = [("ur10_like.urdf", "base_link", "wrist_3_link"),      # 6 joints
                 ("panda_like.urdf", "link0", "hand")]
 
 
+
+def _workspace(chain):
+    import torch
+    from rosdyn_amd._lib import lib
+    return torch.empty((lib().rdyn_regressor_tsqr_workspace_bytes(chain._h),), dtype=torch.uint8, device="cuda")
+
+
 def _oracle_rows(ref, q, dq, ddq, tau):
     Y = ref.regressor(q, dq, ddq)
     return np.column_stack([Y.reshape(-1, ref.P), tau.reshape(-1)])
@@ -223,7 +230,10 @@ def test_cholqr_route_against_numpy_qr_of_the_oracle_rows(urdf, base, tool):
     tau = ref.joint_torque(q, dq, ddq) + 1e-3 * rng.normal(size=(N, n))
     M = _oracle_rows(ref, q, dq, ddq, tau)
     args = [torch.from_numpy(x).cuda() for x in (q, dq, ddq, tau)]
-    R1 = chain.getRegressorTsqr(*args).cpu().numpy()
+    ws = _workspace(chain)
+    R1 = chain.getRegressorTsqr(*args, workspace=ws).cpu().numpy()
+    rep = chain.lastTsqrReport(N, ws)          # a trajectory batch: the first round is accepted (what the device measured: gamma, rho)
+    assert rep["route"] == 1 and rep["stage"] == 0 and 0 < rep["gamma"][0] <= 1e4 and 0.99 <= rep["rho"][0] <= 1.5, rep
     assert R1.shape == (P + 1, P + 1) and np.allclose(np.tril(R1, -1), 0.0)
     G = M.T @ M
     assert np.abs(R1.T @ R1 - G).max() <= 1e-11 * np.abs(G).max()
@@ -298,7 +308,10 @@ def test_cholqr_route_survives_an_unrepresentative_subsample():
     ddq[sub] = 0.0
     tau = ref.joint_torque(q, dq, ddq) + 1e-3 * np.random.default_rng(3).normal(size=(N, n))   # a residual: the last column counts too
     M = _oracle_rows(ref, q, dq, ddq, tau)
-    R1 = chain.getRegressorTsqr(*(torch.from_numpy(x).cuda() for x in (q, dq, ddq, tau))).cpu().numpy()
+    ws = _workspace(chain)
+    R1 = chain.getRegressorTsqr(*(torch.from_numpy(x).cuda() for x in (q, dq, ddq, tau)), workspace=ws).cpu().numpy()
+    rep = chain.lastTsqrReport(N, ws)
+    assert rep["route"] == 1 and rep["stage"] == 1 and rep["gamma"][0] > 1e4 and rep["gamma"][1] <= 1e4 and rep["rho"][1] <= 4.0, rep
     assert np.allclose(np.tril(R1, -1), 0.0)
     G = M.T @ M
     assert np.abs(R1.T @ R1 - G).max() <= 1e-11 * np.abs(G).max()
@@ -311,9 +324,9 @@ def test_cholqr_route_survives_an_unrepresentative_subsample():
     assert np.linalg.matrix_rank(M[np.repeat(sub, n), :P], tol=1e-9 * s_ref[0]) < np.linalg.matrix_rank(M[:, :P], tol=1e-9 * s_ref[0])
 
 
-@pytest.mark.parametrize("eps,joints", [(1e-3, slice(None)), (1e-7, slice(None)), (1e-9, slice(None)), (1e-8, slice(3, 6))],
+@pytest.mark.parametrize("eps,joints,stage", [(1e-3, slice(None), 1), (1e-7, slice(None), 1), (1e-9, slice(None), 2), (1e-8, slice(3, 6), 0)],
                          ids=["1e-3", "1e-7", "1e-9_standby", "joints456_1e-8"])
-def test_cholqr_route_with_a_slow_subsample(eps, joints):
+def test_cholqr_route_with_a_slow_subsample(eps, joints, stage):
     """The tiles the preconditioner is built from move 1e-3 .. 1e-9 times slower than the rest of the batch: the subsample sees every
     direction, but at scales that say nothing about the batch -- its inverse factor has entries that are harmless on the subsample's own
     rows and amplify the rounding of Q = A W by up to 1e9 on the others (round 2 was fine with itself and R'R - G was 1e-6 before the
@@ -336,7 +349,10 @@ def test_cholqr_route_with_a_slow_subsample(eps, joints):
     ddq[idx[:, None], cols[None, :]] *= eps
     tau = ref.joint_torque(q, dq, ddq) + 1e-3 * np.random.default_rng(3).normal(size=(N, n))
     M = _oracle_rows(ref, q, dq, ddq, tau)
-    R1 = chain.getRegressorTsqr(*(torch.from_numpy(x).cuda() for x in (q, dq, ddq, tau))).cpu().numpy()
+    ws = _workspace(chain)
+    R1 = chain.getRegressorTsqr(*(torch.from_numpy(x).cuda() for x in (q, dq, ddq, tau)), workspace=ws).cpu().numpy()
+    rep = chain.lastTsqrReport(N, ws)
+    assert rep["route"] == 1 and rep["stage"] == stage, rep      # second round / stand-by / first round: decided on the device
     assert np.allclose(np.tril(R1, -1), 0.0)
     G = M.T @ M
     assert np.abs(R1.T @ R1 - G).max() <= 1e-13 * np.abs(G).max()
@@ -382,7 +398,9 @@ def test_cholqr_route_from_its_threshold_on(urdf, base, tool, N):
     q2, dq2, ddq2 = trajectory_batch(N + 1, 1000, n)
     tau2 = ref.joint_torque(q2, dq2, ddq2)
     M2 = _oracle_rows(ref, q2, dq2, ddq2, tau2)
-    Rs = chain.getRegressorTsqr(*(torch.from_numpy(x).cuda() for x in (q2, dq2, ddq2, tau2)))
+    ws = _workspace(chain)
+    Rs = chain.getRegressorTsqr(*(torch.from_numpy(x).cuda() for x in (q2, dq2, ddq2, tau2)), workspace=ws)
+    assert chain.lastTsqrReport(1000, ws)["route"] == 0
     Ra = chain.getRegressorTsqr(*dev, out=Rs.contiguous(), accumulate=True).cpu().numpy()
     G2 = G + M2.T @ M2
     assert np.allclose(np.tril(Ra, -1), 0.0) and np.abs(Ra.T @ Ra - G2).max() <= 1e-12 * np.abs(G2).max()
