@@ -289,14 +289,17 @@ def extras_config3(dev, steps=5):
     torch.cuda.synchronize()
     ms = ev0.elapsed_time(ev1) / steps
     # the same batch through the tall-skinny QR (the R factor of [A | tau] without forming A'A): the robust route, not the default
-    chain.getRegressorTsqr(q, dq, ddq, tau)
+    from rosdyn_amd._lib import lib
+    ws_qr = torch.empty((lib().rdyn_regressor_tsqr_workspace_bytes(chain._h),), dtype=torch.uint8, device=dev)
+    chain.getRegressorTsqr(q, dq, ddq, tau, workspace=ws_qr)
     torch.cuda.synchronize()
     ev0.record()
-    for _ in range(2):
-        chain.getRegressorTsqr(q, dq, ddq, tau)
+    for _ in range(4):
+        chain.getRegressorTsqr(q, dq, ddq, tau, workspace=ws_qr)
     ev1.record()
     torch.cuda.synchronize()
-    tsqr_ms = ev0.elapsed_time(ev1) / 2
+    tsqr_ms = ev0.elapsed_time(ev1) / 4
+    report = chain.lastTsqrReport(N, ws_qr)   # which stage of the factorisation vouched for the result (decided on the device)
     f_eval = gram_flop_per_eval(n, P)
     tf = f_eval * N / (ms * 1e-3) / 1e12
     # dense Householder convention for the factor of the (n N) x (P + 1) matrix [A | tau]: 2 rows cols^2
@@ -308,7 +311,8 @@ def extras_config3(dev, steps=5):
                          "frac": tf / FP64_MATRIX_PEAK_TFLOPS, "flop_per_eval_dense_syrk": f_eval, "kernel_ms": ms},
             "tsqr_roofline": {"bound": "fp64-matrix", "achieved": qr_tf, "peak": FP64_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
                               "frac": qr_tf / FP64_MATRIX_PEAK_TFLOPS, "flop_dense_householder": qr_flop, "ms": tsqr_ms,
-                              "route": "rdyn_regressor_tsqr (R factor of [A | tau] without the normal equations)"}}
+                              "route": "rdyn_regressor_tsqr (R factor of [A | tau] without the normal equations)",
+                              "report": report}}
 
 
 def extras_real_chains(dev, steps=5, N=1000000):
