@@ -131,6 +131,12 @@ int main()
       for (int p = 0; p < 10; ++p) bad += X[(size_t)2 * 100 + a * 10 + p] != (a == p ? 1.0 : 0.0);
     for (int k = 0; k < 10 && !bad; ++k) bad += std::fabs(pib(20 + k) - pc(20 + k)) > 1e-15;   // tool has no inertia: body 3 = link l3
   }
+  {
+    // the factor's report for a batch below the preconditioned route's threshold: route 0 (Householder folds), decided on the host
+    double dummy = 0.0;
+    const rdyn_tsqr_report rep = c->getTsqrReport(1000, &dummy);
+    bad += rep.route != 0 || rep.stage != 0 || rep.n_deferred != 0;
+  }
   std::printf("facade typed surface: %s (%u links, %u joints, %u active, %d parameters)\n", bad ? "MISMATCH" : "ok", a->getLinksNumber(),
               a->getJointsNumber(), a->getActiveJointsNumber(), (int)pa.rows());
   return bad ? 1 : 0;

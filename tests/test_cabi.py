@@ -263,3 +263,20 @@ def test_joint_constants_and_link_parameters_rebuild_the_chain(name):
         assert p[0] == m.value and np.allclose(np.array(p)[1:4], m.value * np.array(cg), atol=1e-15)
     assert lib().rdyn_chain_link_parameters(chain._h, nJ + 1, None, None, None) != 0      # out of range
     assert lib().rdyn_chain_joint_constants(chain._h, -1, None, None, None, None) != 0
+
+
+def test_tsqr_report_answers_without_a_device_where_it_can():
+    """Host-only: a batch below the preconditioned route's threshold is reported as route 0 (Householder folds) without touching
+    the workspace or the GPU; invalid arguments are refused."""
+    import ctypes as C
+    from rosdyn_amd import Chain
+    from rosdyn_amd._lib import RdynTsqrReport, lib
+    ur6 = Chain(os.path.join(FIXTURES, "ur10_like.urdf"), "base_link", "wrist_3_link")
+    L = lib()
+    rep = RdynTsqrReport()
+    dummy = C.c_double(0.0)
+    assert L.rdyn_tsqr_last_report(ur6._h, None, 0, 1000, C.byref(dummy), -1, None, C.byref(rep)) == 0
+    assert (rep.route, rep.stage, rep.n_deferred) == (0, 0, 0)
+    assert L.rdyn_tsqr_last_report(ur6._h, None, 0, 1000, None, -1, None, C.byref(rep)) != 0          # null workspace
+    assert L.rdyn_tsqr_last_report(ur6._h, None, 0, -1, C.byref(dummy), -1, None, C.byref(rep)) != 0  # negative batch size
+    assert L.rdyn_tsqr_last_report(None, None, 0, 1000, C.byref(dummy), -1, None, C.byref(rep)) != 0  # null chain
