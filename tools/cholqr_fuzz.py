@@ -47,12 +47,12 @@ def main(n_cases=24, N=66000, seed0=0, only=None):
         path = os.path.join(ROOT, "tests/fixtures", urdf)
         chain, ref = Chain(path, base, tool, GRAV), OracleChain(path, base, tool, GRAV)
         n, P = ref.n, ref.P
-        L, n1 = layout(n)
         q, dq, ddq = trajectory_batch(seed0 + case, N, n)
         what = doctor(rng, q, dq, ddq, N, n)
         tau = ref.joint_torque(q, dq, ddq) + 1e-3 * rng.normal(size=(N, n))
         M = np.column_stack([ref.regressor(q, dq, ddq).reshape(-1, P), tau.reshape(-1)])
         ws = torch.zeros((lib().rdyn_regressor_tsqr_workspace_bytes(chain._h) // 8,), dtype=torch.float64, device="cuda")
+        L, n1 = layout(n, ws.numel() * 8)
         R = chain.getRegressorTsqr(*(torch.from_numpy(x).cuda() for x in (q, dq, ddq, tau)), workspace=ws.view(torch.uint8)).cpu().numpy()
         ints = ws[L["flag"]:L["flag"] + 64].cpu().numpy().view(np.int32)
         G = M.T @ M

@@ -11,12 +11,15 @@ from rosdyn_amd._lib import lib
 from rosdyn_amd.samples import trajectory_batch
 from oracle.oracle import OracleChain
 
-def layout(nJ):
+def layout(nJ, workspace_bytes=None):
+    """offsets (doubles) of the preconditioned route's regions in the factor workspace: a copy of tsqr_layout() in rdyn_api.cpp for chains
+    without component columns (the supported way to read the outcome is rdyn_tsqr_last_report); checked against the library's size"""
     n1 = 10 * nJ + 1; nb = (n1 + 15) // 16; nt = nb * (nb + 1) // 2
     off = ((256 + 128 + 2) * n1 * n1 + 31) & ~31
     L = {}
     for name, d in (("slabs", 256 * nt * 256), ("w", nt * 256), ("r1p", n1 * n1), ("g2", n1 * n1 + 1), ("r_swept", n1 * n1), ("v", n1 * n1), ("flag", 64)):
         L[name] = off; off = (off + d + 31) & ~31
+    assert workspace_bytes is None or workspace_bytes == off * 8, "tools/debug_cholqr3.py: layout() is out of step with rdyn_api.cpp"
     return L, n1
 
 def main():
@@ -24,8 +27,8 @@ def main():
     path = os.path.join(ROOT, "tests/fixtures/ur10_like.urdf")
     chain, ref = Chain(path, "base_link", "wrist_3_link", GRAV), OracleChain(path, "base_link", "wrist_3_link", GRAV)
     n, P, N = 6, 60, 330000
-    L, n1 = layout(6)
     ws = torch.zeros((lib().rdyn_regressor_tsqr_workspace_bytes(chain._h) // 8,), dtype=torch.float64, device="cuda")
+    L, n1 = layout(6, ws.numel() * 8)
     tiles = (N + 15) // 16
     stride = max(1, tiles // 1024); stride += 1 if (stride > 1 and stride % 2 == 0) else 0
     sub = (np.arange(N) // 16) % stride == 0
