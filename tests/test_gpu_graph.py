@@ -76,3 +76,52 @@ def test_pipelined_gram_ik_and_wrench_replay_from_a_graph():
     sol2, st2, it2 = chain.computeLocalIk(T, seeds, toll=1e-8, max_iterations=25, layout="element")
     assert torch.equal(sol, sol2) and torch.equal(holder["ik"][1], st2) and torch.equal(holder["ik"][2], it2)
     assert torch.equal(w, chain.getWrench(q, dq, ddq, layout="element"))
+
+
+def test_robust_factor_decides_on_the_device_inside_a_replayed_graph():
+    """rdyn_regressor_tsqr above 4 096 samples (preconditioned CholeskyQR): the second round and the stand-by are launches that are
+    always queued and leave at once unless a device flag says otherwise -- so ONE captured graph serves a batch the first round
+    is accepted for and, replayed on new data in the same buffers, a batch that needs the second round (the tiles the preconditioner
+    is built from are static poses).  Both factors must be numpy's."""
+    torch = pytest.importorskip("torch")
+    from oracle.oracle import OracleChain
+    from rosdyn_amd import Chain
+    from rosdyn_amd._lib import lib
+    from rosdyn_amd.samples import trajectory_batch
+    path = os.path.join(FIXTURES, "ur10_like.urdf")
+    grav = (0.0, 0.0, -9.806)
+    chain, ref = Chain(path, "base_link", "wrist_3_link", grav), OracleChain(path, "base_link", "wrist_3_link", grav)
+    n, P, N = 6, 60, 66000
+    qa, dqa, ddqa = trajectory_batch(1, N, n)
+    taua = ref.joint_torque(qa, dqa, ddqa) + 1e-3 * np.random.default_rng(1).normal(size=(N, n))
+    qb, dqb, ddqb = trajectory_batch(2, N, n)
+    tiles = (N + 15) // 16
+    stride = max(1, tiles // 1024)
+    stride += 1 if (stride > 1 and stride % 2 == 0) else 0
+    sub = (np.arange(N) // 16) % stride == 0
+    dqb[sub] = 0.0
+    ddqb[sub] = 0.0
+    taub = ref.joint_torque(qb, dqb, ddqb) + 1e-3 * np.random.default_rng(2).normal(size=(N, n))
+    bufs = [torch.from_numpy(x).cuda() for x in (qa, dqa, ddqa, taua)]
+    ws = torch.empty((lib().rdyn_regressor_tsqr_workspace_bytes(chain._h),), dtype=torch.uint8, device="cuda")
+    chain.getRegressorTsqr(*bufs, workspace=ws)      # first use: chain constants, LDS opt-in attributes
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    s = torch.cuda.Stream()
+    holder = {}
+    with torch.cuda.stream(s):
+        with torch.cuda.graph(g, stream=s):
+            holder["R"] = chain.getRegressorTsqr(*bufs, workspace=ws)
+    for (q, dq, ddq, tau), stage in (((qa, dqa, ddqa, taua), 0), ((qb, dqb, ddqb, taub), 1), ((qa, dqa, ddqa, taua), 0)):
+        for dst, src in zip(bufs, (q, dq, ddq, tau)):
+            dst.copy_(torch.from_numpy(src))
+        g.replay()
+        torch.cuda.synchronize()
+        R = holder["R"].cpu().numpy()
+        assert chain.lastTsqrReport(N, ws)["stage"] == stage
+        M = np.column_stack([ref.regressor(q, dq, ddq).reshape(-1, P), tau.reshape(-1)])
+        G = M.T @ M
+        assert np.allclose(np.tril(R, -1), 0.0) and np.abs(R.T @ R - G).max() <= 1e-13 * np.abs(G).max()
+        s_ref, s_gpu = np.linalg.svd(np.linalg.qr(M, mode="r"), compute_uv=False), np.linalg.svd(R, compute_uv=False)
+        keep = s_ref > 1e-9 * s_ref[0]
+        assert np.abs(s_gpu[keep] / s_ref[keep] - 1.0).max() <= 1e-10
