@@ -368,22 +368,28 @@ int rdyn_regressor_gram_multi(rdyn_multi_gpu* ctx, const rdyn_chain* chain, cons
  *   R1 = [R d; 0 rho],  A = Q R,  d = Q'b,  rho = |A x_ls - b|   (diagonal signs are not normalised)
  * accumulate != 0: R1 <- factor of [previous R1 ; new rows] (chunked batches).  Multi-GPU: every rank all-gathers its R1 and folds
  * the stack with rdyn_tsqr_combine_host.  Solve with rdyn_solve_r_factor(R1, n1, n_cols, n_cols, d = R1 + n_cols * n1, ...).
- * rdyn_tsqr: any column-major rows x n_cols device matrix (n1 <= 64).  rdyn_regressor_tsqr: the stacked regressor of the batch and
+ * rdyn_tsqr: any column-major rows x n_cols device matrix, n1 <= 112 (what rdyn_gram takes: a materialised [Y | C | tau_meas] of a
+ * chain with fixed frames and friction columns has 90 - 110 columns).  rdyn_regressor_tsqr: the stacked regressor of the batch and
  * tau_meas (layout of batch->q), rows generated in LDS by the regressor sweep, never stored: n1 = 10 joints_number + 1; chains of
- * 2..7 INPUT joints in chain order (else RDYN_ERR_UNSUPPORTED); joints that are not input joints are folded away (the reduced chain
+ * 1..8 INPUT joints in chain order (else RDYN_ERR_UNSUPPORTED); joints that are not input joints are folded away (the reduced chain
  * of rdyn_chain_reduction is swept and the factor expanded by a small QR: up to RDYN_MAX_JOINTS chain joints).
- * Two routes, chosen by the batch size: Householder folds on the vector units (rdyn_tsqr.hip; ~5x the time of rdyn_regressor_gram),
- * and from 4 096 samples on preconditioned CholeskyQR with the heavy pass on the fp64 matrix cores (rdyn_cholqr.hip: a triangular T
- * from the Gram matrix of a row subsample, W = T^-1 with nearly dependent pivots deferred, G2 = (A W)'(A W) over all rows by MFMA,
- * R = chol(G2) T; the device accepts the result only if the measured error growth of A W and the conditioning of the equilibrated
- * A W are small, runs a second round from R otherwise, and falls back to the Householder folds of all rows if that is not
- * accepted either -- all inside the one asynchronous call; ~1.7x the time of rdyn_regressor_gram; rows of R at structurally
- * dependent columns are exactly zero).  Both return R1 with R1'R1 = [A b]'[A b] to rounding and the small singular values to
- * ~cond * eps.
- * rdyn_identification_tsqr takes the same two routes (the component columns ride in the LDS tile as one more 16-column block).
  * rdyn_identification_tsqr: the same for the identification step's [Y | C | tau_meas] (C = the component columns of
- * rdyn_components_regressor, K = rdyn_components_columns): n1 = 10 joints_number + K + 1, unknowns [inertial ; component]
- * parameters; chains of 2..6 joints, 10 joints_number + 1 + K <= 16 (ceil((10 joints_number + 1) / 16) + 1). */
+ * rdyn_components_regressor -- friction_polynomial1.h:126, ideal_spring.h:64 -- K = rdyn_components_columns):
+ * n1 = 10 joints_number + K + 1 <= 112 after the reduction, unknowns [inertial ; component] parameters.  The component columns
+ * belong to input joints and pass through the reduction unchanged, so the reference's own chains (ur10 base_link -> tool0,
+ * test.cpp:47-48; a Panda with its fixed flange and hand frames) are served with friction columns stacked beside getRegressor.
+ * Routes, chosen by the shape and the batch size:
+ *   Householder folds on the vector units -- in the registers of one wave where the factor fits them (rdyn_tsqr.hip: <= 64 columns of a
+ *     matrix; swept chains of 2..7 joints, 2..6 with component columns; ~5x the time of rdyn_regressor_gram), with the factor packed in
+ *     LDS beyond (rdyn_tsqr_wide.hip: up to 112 columns; a 7-joint arm with friction columns; slower, a dependent chain per column);
+ *   from 4 096 samples (32 768 rows of a matrix) on, factors of <= 96 columns: preconditioned CholeskyQR with the heavy pass on the
+ *     fp64 matrix cores (rdyn_cholqr.hip: a triangular T from the Gram matrix of a row subsample, W = T^-1 with nearly dependent
+ *     pivots deferred, G2 = (A W)'(A W) over all rows by MFMA, R = chol(G2) T; the device accepts the result only if the measured
+ *     error growth of A W and the conditioning of the equilibrated A W are small, runs a second round from R otherwise, and falls
+ *     back to the Householder folds of all rows if that is not accepted either -- all inside the one asynchronous call; ~1.7x the
+ *     time of rdyn_regressor_gram; rows of R at structurally dependent columns are exactly zero).
+ * Every route returns R1 with R1'R1 = [A b]'[A b] to rounding and the small singular values to ~cond * eps.
+ * The first call per (chain, device) uploads the chain's constants (a blocking copy): make it outside a stream capture. */
 size_t rdyn_tsqr_workspace_bytes(int n_cols_with_rhs);
 int rdyn_tsqr(const double* A, int64_t rows, int64_t lda, int n_cols, const double* b, double* R1, int accumulate, void* workspace,
               size_t workspace_bytes, int device, void* stream);
@@ -398,7 +404,8 @@ int rdyn_identification_tsqr(const rdyn_chain* chain, const rdyn_component* comp
  * call; waits for `stream`.  No reference counterpart. */
 typedef struct rdyn_tsqr_report
 {
-  int32_t route;      /* 0: Householder folds (batches below 4 096 samples): nothing else is filled in; 1: preconditioned CholeskyQR */
+  int32_t route;      /* 0: Householder folds (batches below 4 096 samples, shapes the other route does not serve): nothing else is
+                         filled in; 1: preconditioned CholeskyQR */
   int32_t stage;      /* route 1: 0 = accepted after round 0, 1 = after round 1, 2 = the stand-by Householder factorisation ran */
   int32_t n_deferred; /* columns the last preconditioner did not use for elimination (structurally dependent or nearly so) */
   int32_t reserved;
@@ -408,6 +415,8 @@ typedef struct rdyn_tsqr_report
 } rdyn_tsqr_report;
 int rdyn_tsqr_last_report(const rdyn_chain* chain, const rdyn_component* comps, int n_comps, int64_t n_samples, const void* workspace,
                           int device, void* stream, rdyn_tsqr_report* out);
+/* the same for the last rdyn_tsqr call (n_cols_with_rhs = n_cols + (b != NULL), rows as in that call) */
+int rdyn_tsqr_rows_last_report(int n_cols_with_rhs, int64_t rows, const void* workspace, int device, void* stream, rdyn_tsqr_report* out);
 /* HOST: folds n_factors upper-triangular n x n factors (stacked, each column-major n x n) into one (Householder). */
 int rdyn_tsqr_combine_host(const double* R_stack, int n_factors, int n, double* R_out);
 

@@ -114,6 +114,7 @@ SYMBOLS = {
     "rdyn_identification_tsqr_workspace_bytes": (C.c_size_t, [_VP, _VP, _I]),
     "rdyn_identification_tsqr": (_I, [_VP, _VP, _I, _BP, _VP, _VP, _I, _VP, C.c_size_t]),
     "rdyn_tsqr_last_report": (_I, [_VP, _VP, _I, C.c_int64, _VP, _I, _VP, _VP]),
+    "rdyn_tsqr_rows_last_report": (_I, [_I, C.c_int64, _VP, _I, _VP, _VP]),
     "rdyn_tsqr_combine_host": (_I, [_DP, _I, _I, _DP]),
     "rdyn_solve_normal_equations": (_I, [_DP, _DP, _I, C.c_double, _DP, C.POINTER(C.c_int)]),
     "rdyn_gram_r_factor": (_I, [_DP, _I, C.c_double, _DP, C.POINTER(C.c_int32), C.POINTER(C.c_int)]),

@@ -412,7 +412,7 @@ class Chain(object):
         buf = torch.zeros((P1, P1), dtype=torch.float64, device=q.device) if out is None else out.t().contiguous()
         nbytes = lib().rdyn_regressor_tsqr_workspace_bytes(self._h)
         if nbytes == 0:
-            raise ValueError("rdyn_regressor_tsqr: chains of 2..7 joints")
+            raise ValueError("rdyn_regressor_tsqr: chains of 1..8 input joints in chain order, at most 112 columns after the reduction")
         if workspace is None:
             workspace = torch.empty((nbytes,), dtype=torch.uint8, device=q.device)
         check(lib().rdyn_regressor_tsqr(self._h, C.byref(b), tau_meas.data_ptr() if tau_meas is not None else None, buf.data_ptr(),
@@ -461,7 +461,7 @@ class Chain(object):
         buf = torch.zeros((n1, n1), dtype=torch.float64, device=q.device) if out is None else out.t().contiguous()
         nbytes = lib().rdyn_identification_tsqr_workspace_bytes(self._h, arr, n_comps)
         if nbytes == 0:
-            raise ValueError("rdyn_identification_tsqr: chains of 2..6 joints, component columns within one 16-column slot")
+            raise ValueError("rdyn_identification_tsqr: chains of 1..8 input joints in chain order, at most 112 columns after the reduction")
         if workspace is None:
             workspace = torch.empty((nbytes,), dtype=torch.uint8, device=q.device)
         check(lib().rdyn_identification_tsqr(self._h, arr, n_comps, C.byref(b), tau_meas.data_ptr(), buf.data_ptr(), 1 if accumulate else 0,

@@ -15,6 +15,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstring>
+#include <functional>
 #include <map>
 #include <memory>
 #include <vector>
@@ -1083,17 +1084,140 @@ int rdyn_regressor_gram(const rdyn_chain* c, const rdyn_batch* b, const double* 
   return RDYN_OK;
 }
 
-// ---- tall-skinny QR: the R factor without forming A'A (rdyn_tsqr.hip) ---------------------------------------------------------
-static const int kTsqrBlocks = 256;  // persistent workgroups (one per CU), four waves = four running factors each
+// ---- tall-skinny QR: the R factor without forming A'A (rdyn_tsqr.hip, rdyn_tsqr_wide.hip, rdyn_cholqr.hip) ---------------------
+static const int kTsqrBlocks = 256;    // persistent workgroups (one per CU), four waves = four running factors each
+static const int kCholqrBlocks = 256;
+// ~0.2 ms of fixed cost (the subsample's Gram matrix, the two small dense kernels, seven launches that leave at once) + 0.78 / 1.2 ms
+// per 1e6 samples (6 / 7 joints) against 0.3 - 0.4 ms + 2.8 / 3.8 ms per 1e6 samples for the Householder route: faster at every
+// size measured (2 000 samples: 183 vs 288 us; 200 000: 364 vs 969 us).  Small batches keep the Householder folds -- a few hundred
+// rows say little about what a preconditioner built on them is worth, and there is nothing to win.
+static const int64_t kCholqrMinTiles = 256;        // fused routes: 4 096 samples
+static const int64_t kCholqrMinGroups = 2048;      // rdyn_tsqr: 32 768 rows
+
+// offsets (doubles) of the regions every factor call carves out of its workspace.  Region 1: the Householder route's leaves + tree
+// levels (rdyn_tsqr.hip or rdyn_tsqr_wide.hip).  Region 2: the preconditioned route's slabs, W, the intermediate factors and the flags.
+struct TsqrLayout
+{
+  size_t householder_doubles = 0;
+  size_t slabs = 0, w = 0, v = 0, r1p = 0, g2 = 0, r_swept = 0, r_full = 0, flag = 0, total_doubles = 0;
+};
+// n1: width of the factor that is computed (padded width where the kernels pad); nb: 16-column blocks of the preconditioned route's
+// column space (0: that route does not serve the shape); n1_full: width of the expanded factor (0: nothing is expanded)
+static TsqrLayout tsqr_layout(size_t householder_doubles, int n1, int nb, int n1_full)
+{
+  TsqrLayout L;
+  L.householder_doubles = householder_doubles;
+  size_t off = (L.householder_doubles + 31) & ~(size_t)31;
+  auto take = [&](size_t doubles) {
+    const size_t at = off;
+    off = (off + doubles + 31) & ~(size_t)31;
+    return at;
+  };
+  const int nt = nb * (nb + 1) / 2;
+  L.slabs = take((size_t)kCholqrBlocks * nt * 256);
+  L.w = take((size_t)nt * 256);
+  L.r1p = take((size_t)n1 * n1);
+  L.g2 = take((size_t)n1 * n1 + 1);
+  L.r_swept = take((size_t)n1 * n1);
+  L.v = take((size_t)n1 * n1);
+  L.r_full = take((size_t)n1_full * n1_full);  // the expanded factor of a call that accumulates (folded into the caller's afterwards)
+  L.flag = take(64);  // ints: [0] run round 1, [1] run the stand-by (Householder) call, [2] run round 0, [16 ..] the deferred columns;
+                      // doubles [50 .. 55]: gamma (preconditioner), rho, gamma (factor kernel) of the two rounds (diagnostics)
+  L.total_doubles = off;
+  return L;
+}
+
+// The preconditioned CholeskyQR rounds on a Gram matrix of a row subsample that already sits in ws + L.g2 ([G (P x P) | c (P) | bb]):
+// two rounds of  precond -> pass B (run_pass_b(W, run_flag, slabs)) -> slab reduction -> factor kernel, the second one and the
+// stand-by started by the device only (flags).  R_out <- the accepted factor (n1 x n1).  Shared by the fused routes and rdyn_tsqr.
+typedef std::function<int(const double* W, const int* run_flag, double* slabs)> PassB;
+static int cholqr_rounds(double* ws, const TsqrLayout& L, int n1, int col_shift, int nb, int slab_nb, int has_b, double row_scale, int blocks,
+                         double* R_out, hipStream_t stream, const PassB& run_pass_b)
+{
+  int* const flag = (int*)(ws + L.flag);
+  RdynGramArgs ga;
+  memset(&ga, 0, sizeof ga);
+  ga.P = n1 - 1;
+  ga.slabs = ws + L.slabs;
+  ga.G = ws + L.g2;
+  ga.c = ws + L.g2 + (size_t)(n1 - 1) * (n1 - 1);
+  ga.bb = ga.c + (n1 - 1);
+  ga.col_shift = col_shift;
+  ga.slab_nb = slab_nb;
+  const int n_rounds = probe_env("RDYN_CHOLQR_ROUNDS") ? atoi(probe_env("RDYN_CHOLQR_ROUNDS")) : 2;  // A/B builds only
+  for (int round = 0; round < n_rounds; ++round)
+  {
+    // round 0: W from the subsample's Gram matrix.  Round 1 (CholeskyQR2 on top): W from round 0's factor; its kernels leave at once
+    // unless round 0's factor kernel asked for it (flag[0]).  Round 0 itself runs when its preconditioner is fit for it (flag[2]).
+    const int* const run = round == 0 ? flag + 2 : flag;
+    if (round == 0)
+      RDYN_HIP_TRY(rdyn_launch_cholqr_precond(nullptr, ga.G, ga.c, ga.bb, n1, col_shift, nb, row_scale, ws + L.r1p, ws + L.w, ws + L.v, flag + 16, flag, 0,
+                                              nullptr, ws + L.flag + 50, stream));
+    else
+      RDYN_HIP_TRY(rdyn_launch_cholqr_precond(R_out, nullptr, nullptr, nullptr, n1, col_shift, nb, 1.0, ws + L.r1p, ws + L.w, ws + L.v, flag + 16, flag, 1,
+                                              flag, ws + L.flag + 51, stream));
+    int st = run_pass_b(ws + L.w, run, ws + L.slabs);
+    if (st != RDYN_OK) return st;
+    ga.run_flag = run;
+    RDYN_HIP_TRY(rdyn_launch_gram_finish(ga, blocks, stream));
+    RDYN_HIP_TRY(rdyn_launch_cholqr_factor(ga.G, ga.c, ga.bb, n1, has_b, ws + L.r1p, ws + L.v, flag + 16, R_out, flag, round, run, ws + L.flag + 52 + round,
+                                           stream));
+  }
+  return RDYN_OK;
+}
+
+static void read_report(const double* raw, int n1, rdyn_tsqr_report* out)
+{
+  int flags[128];
+  memcpy(flags, raw, sizeof flags);
+  out->route = 1;
+  const bool round0 = flags[2] != 0, round1 = round0 && flags[0] != 0;
+  out->stage = flags[1] ? 2 : (round1 ? 1 : 0);
+  for (int k = 0; k < n1 && 16 + k < 128; ++k) out->n_deferred += flags[16 + k] ? 1 : 0;
+  if (round0)
+  {
+    out->gamma[0] = raw[54];
+    out->rho[0] = raw[52];
+  }
+  if (round1)
+  {
+    out->gamma[1] = raw[55];
+    out->rho[1] = raw[53];
+  }
+}
+
+// ---- rdyn_tsqr: a materialised matrix
+struct TsqrRowsPlan
+{
+  int n1 = 0, nc_reg = 0, nb = 0;  // nc_reg: padded width of the register-resident folds (0: wider than 64 -> LDS-resident folds)
+  bool cholqr_ok = false;          // the dense steps of the preconditioned route hold the factor
+  TsqrLayout L;
+};
+static bool tsqr_rows_plan(int n1, TsqrRowsPlan* p)
+{
+  if (n1 < 1 || n1 > rdyn_tsqr_wide_max_cols()) return false;
+  p->n1 = n1;
+  p->nc_reg = rdyn_tsqr_padded_cols(n1);
+  p->cholqr_ok = n1 >= 2 && n1 <= rdyn_cholqr_max_cols();
+  p->nb = p->cholqr_ok ? (n1 + 15) / 16 : 0;
+  size_t hh = rdyn_tsqr_wide_workspace_doubles(n1, kTsqrBlocks);
+  if (p->nc_reg)
+  {
+    const size_t reg = rdyn_tsqr_workspace_doubles(p->nc_reg, kTsqrBlocks);
+    if (reg > hh) hh = reg;
+  }
+  p->L = tsqr_layout(hh, n1, p->nb, 0);
+  return true;
+}
 
 size_t rdyn_tsqr_workspace_bytes(int n_cols_with_rhs)
 {
-  const int nc = rdyn_tsqr_padded_cols(n_cols_with_rhs);
-  return nc ? rdyn_tsqr_workspace_doubles(nc, kTsqrBlocks) * sizeof(double) : 0;
+  TsqrRowsPlan p;
+  return tsqr_rows_plan(n_cols_with_rhs, &p) ? p.L.total_doubles * sizeof(double) : 0;
 }
 
 int rdyn_tsqr(const double* A, int64_t rows, int64_t lda, int n_cols, const double* bvec, double* R, int accumulate, void* workspace,
-              size_t workspace_bytes, int device, void* stream)
+              size_t workspace_bytes, int device, void* stream_v)
 {
   if (!A || !R || rows < 0 || lda < rows || n_cols < 1 || !workspace)
   {
@@ -1101,12 +1225,13 @@ int rdyn_tsqr(const double* A, int64_t rows, int64_t lda, int n_cols, const doub
     return RDYN_ERR_INVALID_ARGUMENT;
   }
   const int n1 = n_cols + (bvec ? 1 : 0);
-  if (!rdyn_tsqr_padded_cols(n1))
+  TsqrRowsPlan p;
+  if (!tsqr_rows_plan(n1, &p))
   {
-    rdyn_set_error("rdyn_tsqr: at most 64 columns (right-hand side included) are supported");
+    rdyn_set_error("rdyn_tsqr: at most %d columns (right-hand side included) are supported", rdyn_tsqr_wide_max_cols());
     return RDYN_ERR_UNSUPPORTED;
   }
-  if (workspace_bytes < rdyn_tsqr_workspace_bytes(n1))
+  if (workspace_bytes < p.L.total_doubles * sizeof(double))
   {
     rdyn_set_error("rdyn_tsqr: workspace too small");
     return RDYN_ERR_INVALID_ARGUMENT;
@@ -1114,57 +1239,208 @@ int rdyn_tsqr(const double* A, int64_t rows, int64_t lda, int n_cols, const doub
   DeviceGuard g;
   int st = g.enter(device);
   if (st != RDYN_OK) return st;
+  hipStream_t stream = (hipStream_t)stream_v;
   if (rows == 0)
   {
-    if (!accumulate) RDYN_HIP_TRY(hipMemsetAsync(R, 0, sizeof(double) * n1 * n1, (hipStream_t)stream));
+    if (!accumulate) RDYN_HIP_TRY(hipMemsetAsync(R, 0, sizeof(double) * n1 * n1, stream));
     return RDYN_OK;
   }
-  const int64_t blocks64 = (rows + 63) / 64;  // one wave folds 64 rows at a time
-  const int blocks = (int)((blocks64 + 3) / 4 < kTsqrBlocks ? (blocks64 + 3) / 4 : kTsqrBlocks);
-  RDYN_HIP_TRY(rdyn_launch_tsqr_rows(A, bvec, rows, lda, n_cols, blocks, (double*)workspace, R, accumulate ? 1 : 0, (hipStream_t)stream));
+  double* const ws = (double*)workspace;
+  const TsqrLayout& L = p.L;
+  // the Householder folds of all rows: in registers up to 64 columns, with the factor in LDS beyond
+  auto householder = [&](double* R_to, int acc, const int* run_flag, int fan) -> int {
+    if (p.nc_reg)
+    {
+      const int64_t blocks64 = (rows + 63) / 64;  // one wave folds 64 rows at a time
+      const int blocks = (int)((blocks64 + 3) / 4 < kTsqrBlocks ? (blocks64 + 3) / 4 : kTsqrBlocks);
+      RDYN_HIP_TRY(rdyn_launch_tsqr_rows(A, bvec, rows, lda, n_cols, blocks, ws, R_to, acc, stream, run_flag, fan));
+    }
+    else
+      RDYN_HIP_TRY(rdyn_launch_tsqr_wide_rows(A, bvec, rows, lda, n_cols, kTsqrBlocks, ws, R_to, acc, run_flag, stream));
+    return RDYN_OK;
+  };
+  const int64_t groups = (rows + 15) / 16;
+  const char* route_env = probe_env("RDYN_TSQR_ROUTE");  // A/B builds only: "householder" / "cholqr"
+  bool cholqr = p.cholqr_ok && groups >= kCholqrMinGroups;
+  if (route_env && p.cholqr_ok) cholqr = !strcmp(route_env, "cholqr");
+  if (!cholqr) return householder(R, accumulate ? 1 : 0, nullptr, 2);
+  // ---- preconditioned CholeskyQR on the matrix cores (rdyn_cholqr.hip), as the fused routes below: the Gram matrix of every S-th
+  // 16-row group (about 8 192 groups), the rounds, the stand-by
+  const int64_t kSubGroups = probe_env("RDYN_CHOLQR_SUBTILES") ? atoll(probe_env("RDYN_CHOLQR_SUBTILES")) * 8 : 8192;
+  int64_t gs = groups / kSubGroups > 1 ? groups / kSubGroups : 1;
+  if (gs > 1 && gs % 2 == 0) ++gs;  // odd: does not lock onto power-of-two periods of the rows
+  const int64_t sub_groups = (groups + gs - 1) / gs;
+  int* const flag = (int*)(ws + L.flag);
+  {
+    RdynGramArgs sa;
+    memset(&sa, 0, sizeof sa);
+    // [A | b] as ONE matrix of n1 columns whose last column is split off as the right-hand side of the dense steps
+    sa.A = A;
+    sa.b = bvec ? bvec : A + (int64_t)(n1 - 1) * lda;
+    sa.rows = rows;
+    sa.lda = lda;
+    sa.P = n1 - 1;
+    sa.slabs = ws + L.slabs;
+    sa.G = ws + L.g2;
+    sa.c = ws + L.g2 + (size_t)(n1 - 1) * (n1 - 1);
+    sa.bb = sa.c + (n1 - 1);
+    sa.group_stride = (int)gs;
+    const int sub4 = (int)((sub_groups + 3) / 4 < kCholqrBlocks ? (sub_groups + 3) / 4 : kCholqrBlocks);
+    RDYN_HIP_TRY(rdyn_launch_gram(sa, sub4, stream));
+    RDYN_HIP_TRY(rdyn_launch_gram_finish(sa, sub4, stream));
+  }
+  double* const R_new = accumulate ? ws + L.r_swept : R;
+  const int blocks = (int)((groups + 3) / 4 < kCholqrBlocks ? (groups + 3) / 4 : kCholqrBlocks);
+  st = cholqr_rounds(ws, L, n1, 0, p.nb, p.nb, 1, sqrt((double)groups / (double)sub_groups), blocks, R_new, stream,
+                     [&](const double* W, const int* run, double* slabs) -> int {
+                       RDYN_HIP_TRY(rdyn_launch_pgram_rows(A, bvec, rows, lda, n_cols, W, slabs, run, blocks, stream));
+                       return RDYN_OK;
+                     });
+  if (st != RDYN_OK) return st;
+  st = householder(R_new, 0, flag + 1, 16);  // stand-by: started by the device only when neither round was accepted
+  if (st != RDYN_OK) return st;
+  if (accumulate) RDYN_HIP_TRY(rdyn_launch_cholqr_fold(R_new, R, n1, stream));
   return RDYN_OK;
 }
 
-// ---- layout of the factor workspaces.  Region 1: the Householder route's leaves + tree levels (rdyn_tsqr.hip) for the chain that is
-// swept (the reduced companion when the chain has one).  Region 2 (regressor factor only): the preconditioned route's slabs, W, the
-// intermediate factors and the second-round flag (rdyn_cholqr.hip).
-struct TsqrLayout
+int rdyn_tsqr_rows_last_report(int n_cols_with_rhs, int64_t rows, const void* workspace, int device, void* stream, rdyn_tsqr_report* out)
 {
-  size_t householder_doubles = 0;  // region 1
-  size_t slabs = 0, w = 0, v = 0, r1p = 0, g2 = 0, r_swept = 0, flag = 0, total_doubles = 0;  // offsets (doubles) of region 2
-};
-static const int kCholqrBlocks = 256;
-// ~0.2 ms of fixed cost (the subsample's Gram matrix, the two small dense kernels, seven launches that leave at once) + 0.78 / 1.2 ms
-// per 1e6 samples (6 / 7 joints) against 0.3 - 0.4 ms + 2.8 / 3.8 ms per 1e6 samples for the Householder route: faster at every
-// size measured (2 000 samples: 183 vs 288 us; 200 000: 364 vs 969 us).  Small batches keep the Householder folds -- a few hundred
-// rows say little about what a preconditioner built on them is worth, and there is nothing to win.
-static const int64_t kCholqrMinTiles = 256;  // 4 096 samples
-// xb = 1: with component columns (one more 16-column block; the factors are sized for the padded width 16 nb)
-static TsqrLayout tsqr_layout(int n_joints_swept, int xb = 0)
-{
-  TsqrLayout L;
-  const int nb = (10 * n_joints_swept + 1 + 15) / 16 + xb, nt = nb * (nb + 1) / 2;
-  const int n1 = xb ? 16 * nb : 10 * n_joints_swept + 1;
-  L.householder_doubles = rdyn_tsqr_workspace_doubles(n1, kTsqrBlocks);
-  size_t off = (L.householder_doubles + 31) & ~(size_t)31;
-  auto take = [&](size_t doubles) {
-    const size_t at = off;
-    off = (off + doubles + 31) & ~(size_t)31;
-    return at;
-  };
-  L.slabs = take((size_t)kCholqrBlocks * nt * 256);
-  L.w = take((size_t)nt * 256);
-  L.r1p = take((size_t)n1 * n1);
-  L.g2 = take((size_t)n1 * n1 + 1);
-  L.r_swept = take((size_t)n1 * n1);
-  L.v = take((size_t)n1 * n1);
-  L.flag = take(64);  // ints: [0] run round 1, [1] run the stand-by (Householder) call, [2] run round 0, [16 ..] the deferred columns;
-                      // doubles [50 .. 55]: gamma (preconditioner), rho, gamma (factor kernel) of the two rounds (diagnostics)
-  L.total_doubles = off;
-  return L;
+  TsqrRowsPlan p;
+  if (!workspace || !out || rows < 0 || !tsqr_rows_plan(n_cols_with_rhs, &p))
+  {
+    rdyn_set_error("rdyn_tsqr_rows_last_report: invalid argument");
+    return RDYN_ERR_INVALID_ARGUMENT;
+  }
+  memset(out, 0, sizeof *out);
+  if (!p.cholqr_ok || (rows + 15) / 16 < kCholqrMinGroups) return RDYN_OK;  // route 0: the Householder folds, nothing to report
+  DeviceGuard g;
+  int st = g.enter(device);
+  if (st != RDYN_OK) return st;
+  double raw[64];
+  RDYN_HIP_TRY(hipMemcpyAsync(raw, (const double*)workspace + p.L.flag, sizeof raw, hipMemcpyDeviceToHost, (hipStream_t)stream));
+  RDYN_HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+  read_report(raw, p.n1, out);
+  return RDYN_OK;
 }
-// the chain whose rows are swept: the reduced companion when the chain has non-input joints (no component columns in that case)
-static const rdyn_chain* swept_chain(const rdyn_chain* c, int n_comps) { return (c->reduced && n_comps == 0) ? c->reduced.get() : c; }
+
+// ---- rdyn_regressor_tsqr / rdyn_identification_tsqr: rows generated by the sweep, never stored
+// the chain whose rows are swept: the reduced companion when the chain has non-input joints (component columns belong to input
+// joints, which the companion keeps in the same order: they ride along unchanged).  A companion of ONE joint is below what the
+// sweeping kernels are built for: such a chain is swept as it is.
+static const rdyn_chain* swept_chain(const rdyn_chain* c) { return (c->reduced && c->reduced->n_joints() >= 2) ? c->reduced.get() : c; }
+
+// rectangular 16-sample tile of rdyn_tsqr_wide.hip: every column 16 n rows + 4 doubles, structural zeros stored
+static bool build_rect_tile(const rdyn_chain* c, int n_comp_cols, RdynLdsGramArgs* la)
+{
+  const int n = c->n_active(), nJ = c->n_joints();
+  const int cs = (16 * n + 4) * 8;
+  bool monotonic = true;
+  for (int j = 1; j < n; ++j) monotonic = monotonic && c->active[j] > c->active[j - 1];
+  la->all_revolute = 0;
+  for (int f = 0; f < nJ; ++f)
+  {
+    int m = 0;
+    for (int j = 0; j < n; ++j) m += (c->active[j] <= f) ? 1 : 0;
+    la->lds_m[f] = m;
+    la->lds_stride[f] = cs;
+    la->lds_off[f] = 10 * f * cs;
+  }
+  la->lds_off_c = 10 * nJ * cs;
+  la->comp_stride = cs;
+  la->comp_row_step = 128;
+  la->lds_off_b = (10 * nJ + n_comp_cols) * cs;
+  la->lds_dummy_off = 0;
+  la->tile_bytes = (10 * nJ + n_comp_cols + 1) * cs;
+  la->n_active = n;
+  for (int j = 0; j < n; ++j) la->first_col[j] = 10 * c->active[j];
+  return monotonic;
+}
+
+// everything a factor call decides from (chain, components) alone: which chain is swept, which kernels serve it, the workspace
+struct TsqrPlan
+{
+  const rdyn_chain* cs = nullptr;
+  bool expand = false;
+  int n = 0, nJ = 0, K = 0, xb = 0;
+  int n1s = 0, n1 = 0;        // factor widths: swept chain, chain
+  int nc_reg = 0;             // padded factor width of the register-resident folds of rdyn_tsqr.hip (0: they do not serve the shape)
+  bool wide = false;          // the LDS-resident folds of rdyn_tsqr_wide.hip serve the shape
+  int pairs = 0, nb = 0;      // preconditioned route: pass-B configuration (0: not served), 16-column blocks of its column space
+  bool sub_compact = false;   // the subsample pass (four tiles per workgroup) needs the compact tile
+  RdynLdsGramArgs la, la_sub, la_wide;
+  TsqrLayout L;
+  const char* why = nullptr;  // when nothing serves the shape
+};
+
+static bool tsqr_plan(const rdyn_chain* c, const rdyn_component* comps, int n_comps, TsqrPlan* p)
+{
+  p->cs = swept_chain(c);
+  p->expand = p->cs != c;
+  const rdyn_chain* cs = p->cs;
+  p->n = cs->n_active();
+  p->nJ = cs->n_joints();
+  const int K = n_comps > 0 ? rdyn_components_columns(comps, n_comps) : 0;
+  if (K < 0 || K > 96)
+  {
+    p->why = "invalid components";
+    return false;
+  }
+  p->K = K;
+  p->xb = K > 0 ? 1 : 0;
+  p->n1s = 10 * p->nJ + K + 1;
+  p->n1 = 10 * c->n_joints() + K + 1;
+  memset(&p->la, 0, sizeof p->la);
+  memset(&p->la_sub, 0, sizeof p->la_sub);
+  memset(&p->la_wide, 0, sizeof p->la_wide);
+  if (p->n < 1 || p->n > 8 || p->nJ < 1 || !build_rect_tile(cs, K, &p->la_wide))
+  {
+    p->why = "chains of 1..8 input joints in chain order are supported";
+    return false;
+  }
+  const bool tile_ok = build_lds_tile(cs, K, false, &p->la) && 4 * (size_t)p->la.tile_bytes <= 160 * 1024;
+  // register-resident Householder folds: 2..7 joints, 2..6 with component columns (which must fit one 16-column slot)
+  p->nc_reg = (tile_ok && p->nJ >= 2 && p->nJ <= 7) ? rdyn_regressor_tsqr_cols(p->nJ, K) : 0;
+  // LDS-resident folds: the rectangular tile beside the packed factor
+  p->wide = rdyn_regressor_tsqr_wide_lds_bytes(p->n1s, p->n) != 0;
+  // preconditioned route: every joint of the swept chain an input joint, the factor within the dense kernels' LDS, the component
+  // columns within the one extra column block, and a subsample kernel for the shape
+  p->nb = (10 * p->nJ + 1 + 15) / 16 + p->xb;
+  if (p->n == p->nJ && p->nJ >= 2 && p->nJ <= 7 && p->n1s <= rdyn_cholqr_max_cols() && p->n1s <= 16 * p->nb &&
+      (K == 0 || rdyn_regressor_gram_duo_supports_components(10 * p->nJ, K)) && build_lds_tile(cs, K, false, &p->la))
+  {
+    p->pairs = rdyn_cholqr_pairs(p->nJ, p->la.tile_bytes, p->xb);
+    if (p->pairs != 0)
+    {
+      build_lds_tile(cs, K, false, &p->la_sub);
+      if (4 * (size_t)p->la_sub.tile_bytes > 160 * 1024)
+      {
+        build_lds_tile(cs, K, false, &p->la_sub, true);
+        p->sub_compact = true;
+        if (4 * (size_t)p->la_sub.tile_bytes > 160 * 1024) p->pairs = 0;
+      }
+    }
+  }
+  if (!p->nc_reg && !p->wide)
+  {
+    p->why = "the factor does not fit the LDS-resident folds (at most 112 columns)";
+    return false;
+  }
+  if (p->expand && rdyn_cholqr_expand_lds_bytes(c->n_joints(), p->nJ, K) > 156 * 1024)
+  {
+    p->why = "the expansion of the reduced chain's factor exceeds the LDS of one workgroup";
+    return false;
+  }
+  size_t hh = p->wide ? rdyn_tsqr_wide_workspace_doubles(p->n1s, kTsqrBlocks) : 0;
+  int n1w = p->n1s;
+  if (p->nc_reg)
+  {
+    const size_t reg = rdyn_tsqr_workspace_doubles(p->nc_reg, kTsqrBlocks);
+    if (reg > hh) hh = reg;
+    if (p->nc_reg > n1w) n1w = p->nc_reg;
+  }
+  p->L = tsqr_layout(hh, n1w, p->pairs != 0 ? p->nb : 0, p->expand ? p->n1 : 0);
+  return true;
+}
 
 static int regressor_tsqr_run(const rdyn_chain* c, const rdyn_component* comps, int n_comps, const rdyn_batch* b, const double* tau_meas, double* R,
                               int accumulate, void* workspace, size_t workspace_bytes, const char* who)
@@ -1176,24 +1452,17 @@ static int regressor_tsqr_run(const rdyn_chain* c, const rdyn_component* comps, 
     rdyn_set_error("%s: null output / workspace, or more than %d components", who, RDYN_MAX_COMPONENTS);
     return RDYN_ERR_INVALID_ARGUMENT;
   }
-  const rdyn_chain* cs = swept_chain(c, n_comps);  // chains with fixed joints: the reduced companion is swept, the factor expanded
-  const bool expand = cs != c;
-  const int n = cs->n_active(), nJ = cs->n_joints();
-  const int K = n_comps > 0 ? rdyn_components_columns(comps, n_comps) : 0;
-  const int n1s = 10 * nJ + (K > 0 ? K : 0) + 1, n1 = 10 * c->n_joints() + (K > 0 ? K : 0) + 1;
-  const int nc = K < 0 ? 0 : rdyn_regressor_tsqr_cols(nJ, K);
-  RdynLdsGramArgs la;
-  memset(&la, 0, sizeof la);
-  const bool monotonic = nc > 0 && nJ >= 2 && nJ <= 7 && n >= 1 && n <= 8 && build_lds_tile(cs, K > 0 ? K : 0, false, &la);
-  if (!monotonic || 4 * (size_t)la.tile_bytes > 160 * 1024)
+  TsqrPlan p;
+  if (!tsqr_plan(c, comps, n_comps, &p))
   {
-    rdyn_set_error("%s: chains of 2..7 input joints in chain order (2..6 chain joints with component columns, which must fit one 16-column slot) "
-                   "are supported", who);
+    rdyn_set_error("%s: %s", who, p.why);
     return RDYN_ERR_UNSUPPORTED;
   }
-  const TsqrLayout L = tsqr_layout(nJ, n_comps > 0 ? 1 : 0);
-  const size_t need = L.total_doubles * sizeof(double);
-  if (workspace_bytes < need)
+  const rdyn_chain* cs = p.cs;  // chains with fixed joints: the reduced companion is swept, the factor expanded
+  const bool expand = p.expand;
+  const int n = p.n, nJ = p.nJ, K = p.K, n1s = p.n1s, n1 = p.n1;
+  const TsqrLayout& L = p.L;
+  if (workspace_bytes < L.total_doubles * sizeof(double))
   {
     rdyn_set_error("%s: workspace too small", who);
     return RDYN_ERR_INVALID_ARGUMENT;
@@ -1217,28 +1486,51 @@ static int regressor_tsqr_run(const rdyn_chain* c, const rdyn_component* comps, 
     if (!accumulate) RDYN_HIP_TRY(hipMemsetAsync(R, 0, sizeof(double) * n1 * n1, stream));
     return RDYN_OK;
   }
-  la.chain = dc;
-  la.q = b->q;
-  la.dq = b->dq;
-  la.ddq = b->ddq;
-  la.bcol = tau_meas;
-  la.n_samples = b->n_samples;
-  rec_strides(b, n, &la.in_ss, &la.in_sj);
-  la.n_comps = n_comps;
-  la.n_comp_cols = K;
-  int col = 0;
-  for (int i = 0; i < n_comps; ++i)
-  {
-    la.comps[i] = ca.comps[i];
-    const int w = ca.comps[i].type == RDYN_COMP_FRICTION2 ? 3 : 2;
-    for (int k = 0; k < w; ++k) la.comp_col_row[col++] = (signed char)ca.comps[i].joint;
-  }
+  auto bind = [&](RdynLdsGramArgs& la) {
+    la.chain = dc;
+    la.q = b->q;
+    la.dq = b->dq;
+    la.ddq = b->ddq;
+    la.bcol = tau_meas;
+    la.n_samples = b->n_samples;
+    rec_strides(b, n, &la.in_ss, &la.in_sj);
+    la.n_comps = n_comps;
+    la.n_comp_cols = K;
+    int col = 0;
+    for (int i = 0; i < n_comps; ++i)
+    {
+      la.comps[i] = ca.comps[i];
+      const int w = ca.comps[i].type == RDYN_COMP_FRICTION2 ? 3 : 2;
+      for (int k = 0; k < w; ++k) la.comp_col_row[col++] = (signed char)ca.comps[i].joint;
+    }
+  };
+  bind(p.la);
+  bind(p.la_sub);
+  bind(p.la_wide);
   double* const ws = (double*)workspace;
   const int64_t tiles = (b->n_samples + 15) / 16;
+  // the Householder folds of all rows: rdyn_tsqr.hip where the factor fits a wave's registers, rdyn_tsqr_wide.hip otherwise
+  auto householder = [&](double* R_to, int acc, const int* run_flag, int fan) -> int {
+    if (p.nc_reg)
+    {
+      RdynLdsGramArgs all = p.la;
+      all.run_flag = run_flag;
+      const int hblocks = (int)((tiles + 3) / 4 < kTsqrBlocks ? (tiles + 3) / 4 : kTsqrBlocks);
+      RDYN_HIP_TRY(rdyn_launch_regressor_tsqr(nJ, all, hblocks, 4 * (size_t)p.la.tile_bytes, ws, R_to, acc, stream, fan));
+    }
+    else
+    {
+      RdynLdsGramArgs all = p.la_wide;
+      all.run_flag = run_flag;
+      const int hblocks = (int)(tiles < kTsqrBlocks ? tiles : kTsqrBlocks);
+      RDYN_HIP_TRY(rdyn_launch_regressor_tsqr_wide(nJ, all, hblocks, ws, R_to, acc, stream));
+    }
+    return RDYN_OK;
+  };
   // ---- which route.  Preconditioned CholeskyQR (rdyn_cholqr.hip: the heavy pass on the matrix cores) for large batches of chains
-  // whose swept form has every joint as an input joint; the Householder folds (rdyn_tsqr.hip) otherwise.
+  // whose swept form has every joint as an input joint; the Householder folds otherwise.
   const char* route_env = probe_env("RDYN_TSQR_ROUTE");  // A/B builds only: "householder" / "cholqr"
-  const int pairs = n == nJ ? rdyn_cholqr_pairs(nJ, la.tile_bytes, n_comps > 0 ? 1 : 0) : 0;
+  const int pairs = p.pairs;
   bool cholqr = pairs != 0 && tiles >= kCholqrMinTiles;
   if (route_env && pairs != 0) cholqr = !strcmp(route_env, "cholqr");
   // where the factor of the swept chain goes: straight into R when nothing follows
@@ -1246,9 +1538,10 @@ static int regressor_tsqr_run(const rdyn_chain* c, const rdyn_component* comps, 
   if (cholqr)
   {
     // pass A: the Gram matrix of every S-th tile (about 1 024 tiles whatever the batch size: one tile per wave pair of the regressor ->
-    // Gram kernel; 16 384 samples = 115 000 rows for <= 81 columns put the pivots of the second factorisation within a few % of 1).
+    // Gram kernel; 16 384 samples = 115 000 rows for <= 96 columns put the pivots of the second factorisation within a few % of 1).
     // A preconditioner does not have to be a backward-stable factor -- what it is worth is measured on all rows afterwards.
-    RdynLdsGramArgs sub = la;
+    RdynLdsGramArgs& la = p.la;
+    RdynLdsGramArgs sub = p.la_sub;
     const int64_t kSubTiles = probe_env("RDYN_CHOLQR_SUBTILES") ? atoll(probe_env("RDYN_CHOLQR_SUBTILES")) : 1024;
     sub.tile_stride = (int)(tiles / kSubTiles > 1 ? tiles / kSubTiles : 1);
     if (sub.tile_stride > 1 && sub.tile_stride % 2 == 0) ++sub.tile_stride;  // odd: does not lock onto power-of-two periods of a trajectory
@@ -1258,70 +1551,49 @@ static int regressor_tsqr_run(const rdyn_chain* c, const rdyn_component* comps, 
     const int np = pairs < 0 ? -pairs : pairs;
     const int blocks = (int)((tiles + np - 1) / np < kCholqrBlocks ? (tiles + np - 1) / np : kCholqrBlocks);
     int* const flag = (int*)(ws + L.flag);
-    const int col_shift = rdyn_cholqr_col_shift(nJ, n_comps > 0 ? 1 : 0);
-    RdynGramArgs ga;
-    memset(&ga, 0, sizeof ga);
-    ga.P = n1s - 1;
-    ga.slabs = la.slabs;
-    ga.G = ws + L.g2;
-    ga.c = ws + L.g2 + (size_t)(n1s - 1) * (n1s - 1);
-    ga.bb = ga.c + (n1s - 1);
-    ga.col_shift = col_shift;
-    ga.slab_nb = n_comps > 0 ? (10 * nJ + 1 + 15) / 16 + 1 : 0;
+    const int col_shift = rdyn_cholqr_col_shift(nJ, p.xb);
     {
-      // the plain regressor -> Gram kernel (rdyn_duo_gram.hip) on the subsample: its slab layout (descending link order without
-      // component columns), its workgroups of four pairs
+      // the plain regressor -> Gram kernel (rdyn_duo_gram.hip) on the subsample: its slab layout (descending link order, component
+      // columns in front), its workgroups of four pairs
       const int sub4 = (int)((sub_tiles + 3) / 4 < kCholqrBlocks ? (sub_tiles + 3) / 4 : kCholqrBlocks);
-      const int nbt = (10 * nJ + 1 + 15) / 16 + (n_comps > 0 ? 1 : 0);
-      size_t lds_bytes = 4 * (size_t)la.tile_bytes;
+      const int nbt = p.nb;
+      size_t lds_bytes = 4 * (size_t)sub.tile_bytes;
       const size_t red_bytes = (size_t)(nbt * (nbt + 1) / 2) * 256 * sizeof(double);
       if (lds_bytes < red_bytes) lds_bytes = red_bytes;
       RDYN_HIP_TRY(rdyn_launch_regressor_gram_duo(10 * nJ, sub, sub4, lds_bytes, stream));
-      RdynGramArgs gs = ga;
-      gs.col_shift = 0;
+      RdynGramArgs gs;
+      memset(&gs, 0, sizeof gs);
+      gs.P = n1s - 1;
+      gs.slabs = la.slabs;
+      gs.G = ws + L.g2;
+      gs.c = ws + L.g2 + (size_t)(n1s - 1) * (n1s - 1);
+      gs.bb = gs.c + (n1s - 1);
       gs.desc_nj = nJ;
-      gs.desc_k = n_comps > 0 ? K : 0;
-      gs.slab_nb = n_comps > 0 ? nbt : 0;
+      gs.desc_k = K;
+      gs.slab_nb = K > 0 ? nbt : 0;
       RDYN_HIP_TRY(rdyn_launch_gram_finish(gs, sub4, stream));
     }
-    const int n_rounds = probe_env("RDYN_CHOLQR_ROUNDS") ? atoi(probe_env("RDYN_CHOLQR_ROUNDS")) : 2;  // A/B builds only
-    for (int round = 0; round < n_rounds; ++round)
-    {
-      // round 0: W from the subsample's Gram matrix.  Round 1 (CholeskyQR2 on top): W from round 0's factor; its kernels leave at once
-      // unless round 0's factor kernel asked for it (flag[0]).  Round 0 itself runs when its preconditioner is fit for it (flag[2]).
-      const int* const run = round == 0 ? flag + 2 : flag;
-      if (round == 0)
-        RDYN_HIP_TRY(rdyn_launch_cholqr_precond(nullptr, ga.G, ga.c, ga.bb, n1s, col_shift, sqrt((double)tiles / (double)sub_tiles), ws + L.r1p, ws + L.w,
-                                                ws + L.v, flag + 16, flag, 0, nullptr, ws + L.flag + 50, stream));
-      else
-        RDYN_HIP_TRY(rdyn_launch_cholqr_precond(R_swept, nullptr, nullptr, nullptr, n1s, col_shift, 1.0, ws + L.r1p, ws + L.w, ws + L.v, flag + 16, flag, 1,
-                                                flag, ws + L.flag + 51, stream));
-      RDYN_HIP_TRY(rdyn_launch_regressor_pgram(nJ, la, ws + L.w, run, blocks, pairs, stream));
-      ga.run_flag = run;
-      RDYN_HIP_TRY(rdyn_launch_gram_finish(ga, blocks, stream));
-      RDYN_HIP_TRY(rdyn_launch_cholqr_factor(ga.G, ga.c, ga.bb, n1s, tau_meas ? 1 : 0, ws + L.r1p, ws + L.v, flag + 16, R_swept, flag, round, run,
-                                             ws + L.flag + 52 + round, stream));
-    }
-    {
-      // stand-by: the Householder factorisation of ALL rows, queued behind the two rounds and started by the device only when a
-      // preconditioner was unfit (growth factor) or round 1 was not accepted either (flag[1]; three launches that leave at once
-      // otherwise).  It asks nothing of the batch, so the call as a whole is as robust as the Householder route whatever the
-      // subsample looked like.
-      RdynLdsGramArgs all = la;
-      all.run_flag = flag + 1;
-      const int hblocks = (int)((tiles + 3) / 4 < kTsqrBlocks ? (tiles + 3) / 4 : kTsqrBlocks);
-      RDYN_HIP_TRY(rdyn_launch_regressor_tsqr(nJ, all, hblocks, 4 * (size_t)la.tile_bytes, ws, R_swept, 0, stream, 16));
-    }
+    st = cholqr_rounds(ws, L, n1s, col_shift, p.nb, K > 0 ? p.nb : 0, tau_meas ? 1 : 0, sqrt((double)tiles / (double)sub_tiles), blocks, R_swept, stream,
+                       [&](const double* W, const int* run, double*) -> int {
+                         RDYN_HIP_TRY(rdyn_launch_regressor_pgram(nJ, la, W, run, blocks, pairs, stream));
+                         return RDYN_OK;
+                       });
+    if (st != RDYN_OK) return st;
+    // stand-by: the Householder factorisation of ALL rows, queued behind the two rounds and started by the device only when a
+    // preconditioner was unfit (growth factor) or round 1 was not accepted either (flag[1]; launches that leave at once otherwise).
+    // It asks nothing of the batch, so the call as a whole is as robust as the Householder route whatever the subsample looked like.
+    st = householder(R_swept, 0, flag + 1, 16);
+    if (st != RDYN_OK) return st;
     if (!expand && accumulate) RDYN_HIP_TRY(rdyn_launch_cholqr_fold(R_swept, R, n1s, stream));
   }
   else
   {
-    const int blocks = (int)((tiles + 3) / 4 < kTsqrBlocks ? (tiles + 3) / 4 : kTsqrBlocks);
-    RDYN_HIP_TRY(rdyn_launch_regressor_tsqr(nJ, la, blocks, 4 * (size_t)la.tile_bytes, ws, R_swept, (accumulate && !expand) ? 1 : 0, stream));
+    st = householder(R_swept, (accumulate && !expand) ? 1 : 0, nullptr, 2);
+    if (st != RDYN_OK) return st;
   }
   if (expand)
   {
-    // [A b] = [A_red b] diag(E, 1): R = qr([R_prev ; R_red diag(E, 1)])
+    // [A C b] = [A_red C b] diag(E, I_K, 1): R = qr(R_red diag(E, I_K, 1)), folded into the caller's factor when accumulating
     RdynGramExpandArgs ea;
     memset(&ea, 0, sizeof ea);
     st = device_expand(c, &ea.X);
@@ -1329,7 +1601,10 @@ static int regressor_tsqr_run(const rdyn_chain* c, const rdyn_component* comps, 
     for (int f = 0; f < c->n_joints(); ++f) ea.red_of[f] = c->red_of[f];
     ea.n_joints = c->n_joints();
     ea.n_red = nJ;
-    RDYN_HIP_TRY(rdyn_launch_cholqr_expand(ea, R_swept, accumulate ? R : nullptr, R, stream));
+    ea.n_comp_cols = K;
+    double* const R_exp = accumulate ? ws + L.r_full : R;
+    RDYN_HIP_TRY(rdyn_launch_cholqr_expand(ea, R_swept, R_exp, stream));
+    if (accumulate) RDYN_HIP_TRY(rdyn_launch_cholqr_fold(R_exp, R, n1, stream));
   }
   return RDYN_OK;
 }
@@ -1337,9 +1612,8 @@ static int regressor_tsqr_run(const rdyn_chain* c, const rdyn_component* comps, 
 size_t rdyn_regressor_tsqr_workspace_bytes(const rdyn_chain* c)
 {
   if (!c) return 0;
-  const rdyn_chain* cs = swept_chain(c, 0);
-  if (cs->n_joints() < 2 || cs->n_joints() > 7) return 0;
-  return tsqr_layout(cs->n_joints()).total_doubles * sizeof(double);
+  TsqrPlan p;
+  return tsqr_plan(c, nullptr, 0, &p) ? p.L.total_doubles * sizeof(double) : 0;
 }
 
 int rdyn_regressor_tsqr(const rdyn_chain* c, const rdyn_batch* b, const double* tau_meas, double* R, int accumulate, void* workspace,
@@ -1350,12 +1624,9 @@ int rdyn_regressor_tsqr(const rdyn_chain* c, const rdyn_batch* b, const double* 
 
 size_t rdyn_identification_tsqr_workspace_bytes(const rdyn_chain* c, const rdyn_component* comps, int n_comps)
 {
-  if (!c || n_comps < 0 || (n_comps > 0 && !comps)) return 0;
-  if (n_comps == 0) return rdyn_regressor_tsqr_workspace_bytes(c);  // without components it is the regressor factor (and its routes)
-  const int K = n_comps > 0 ? rdyn_components_columns(comps, n_comps) : 0;
-  const int nc = K < 0 ? 0 : rdyn_regressor_tsqr_cols(c->n_joints(), K);
-  if (nc == 0 || c->n_joints() < 2 || c->n_joints() > 7) return 0;
-  return tsqr_layout(c->n_joints(), 1).total_doubles * sizeof(double);
+  if (!c || n_comps < 0 || n_comps > RDYN_MAX_COMPONENTS || (n_comps > 0 && !comps)) return 0;
+  TsqrPlan p;
+  return tsqr_plan(c, comps, n_comps, &p) ? p.L.total_doubles * sizeof(double) : 0;
 }
 
 int rdyn_identification_tsqr(const rdyn_chain* c, const rdyn_component* comps, int n_comps, const rdyn_batch* b, const double* tau_meas, double* R,
@@ -1367,48 +1638,26 @@ int rdyn_identification_tsqr(const rdyn_chain* c, const rdyn_component* comps, i
 int rdyn_tsqr_last_report(const rdyn_chain* c, const rdyn_component* comps, int n_comps, int64_t n_samples, const void* workspace, int device,
                           void* stream, rdyn_tsqr_report* out)
 {
-  if (!c || !workspace || !out || n_comps < 0 || (n_comps > 0 && !comps) || n_samples < 0)
+  if (!c || !workspace || !out || n_comps < 0 || n_comps > RDYN_MAX_COMPONENTS || (n_comps > 0 && !comps) || n_samples < 0)
   {
     rdyn_set_error("rdyn_tsqr_last_report: invalid argument");
     return RDYN_ERR_INVALID_ARGUMENT;
   }
   memset(out, 0, sizeof *out);
-  const rdyn_chain* cs = swept_chain(c, n_comps);
-  const int n = cs->n_active(), nJ = cs->n_joints();
-  const int K = n_comps > 0 ? rdyn_components_columns(comps, n_comps) : 0;
-  RdynLdsGramArgs la;
-  memset(&la, 0, sizeof la);
-  if (K < 0 || nJ < 2 || nJ > 7 || !build_lds_tile(cs, K > 0 ? K : 0, false, &la))
+  TsqrPlan p;
+  if (!tsqr_plan(c, comps, n_comps, &p))
   {
     rdyn_set_error("rdyn_tsqr_last_report: the factor entry points do not serve this chain");
     return RDYN_ERR_UNSUPPORTED;
   }
-  const int pairs = n == nJ ? rdyn_cholqr_pairs(nJ, la.tile_bytes, n_comps > 0 ? 1 : 0) : 0;
-  if (pairs == 0 || (n_samples + 15) / 16 < kCholqrMinTiles) return RDYN_OK;  // route 0: the Householder folds, nothing to report
+  if (p.pairs == 0 || (n_samples + 15) / 16 < kCholqrMinTiles) return RDYN_OK;  // route 0: the Householder folds, nothing to report
   DeviceGuard g;
   int st = g.enter(device);
   if (st != RDYN_OK) return st;
-  const TsqrLayout L = tsqr_layout(nJ, n_comps > 0 ? 1 : 0);
   double raw[64];
-  RDYN_HIP_TRY(hipMemcpyAsync(raw, (const double*)workspace + L.flag, sizeof raw, hipMemcpyDeviceToHost, (hipStream_t)stream));
+  RDYN_HIP_TRY(hipMemcpyAsync(raw, (const double*)workspace + p.L.flag, sizeof raw, hipMemcpyDeviceToHost, (hipStream_t)stream));
   RDYN_HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
-  int flags[128];
-  memcpy(flags, raw, sizeof flags);
-  out->route = 1;
-  const bool round0 = flags[2] != 0, round1 = round0 && flags[0] != 0;
-  out->stage = flags[1] ? 2 : (round1 ? 1 : 0);
-  const int n1s = 10 * nJ + (K > 0 ? K : 0) + 1;
-  for (int k = 0; k < n1s && 16 + k < 128; ++k) out->n_deferred += flags[16 + k] ? 1 : 0;
-  if (round0)
-  {
-    out->gamma[0] = raw[54];
-    out->rho[0] = raw[52];
-  }
-  if (round1)
-  {
-    out->gamma[1] = raw[55];
-    out->rho[1] = raw[53];
-  }
+  read_report(raw, p.n1s, out);
   return RDYN_OK;
 }
 

@@ -48,6 +48,10 @@ namespace
 
 // pass B.  NPAIR wave pairs per workgroup (4, or 3 when four LDS tiles do not fit beside W: 7 joints).  Waves are dealt to the four
 // SIMDs cyclically: with 8 waves pair p = (wave p, wave p + 4) shares SIMD p; with 6 waves the pairs are (0, 4), (1, 5) and (2, 3).
+// NPAIR = 2 (7 joints + component columns: 21 accumulator tiles + 6 product tiles do not fit the 256 registers of a wave that shares
+// its SIMD): four waves, every wave alone on its SIMD with up to 512 registers, pairs (0, 2) and (1, 3); fp64 MFMA and fp64 VALU
+// exclude each other on a SIMD anyway, so two pairs on four SIMDs have the issue capacity of four pairs that
+// share -- what is lost is the latency hiding of the second wave.
 // Every chain joint is an input joint, in chain order (the reduced companion of a chain with fixed joints qualifies).
 // WGLOBAL: W stays in global memory (30 KB at 7 joints: L1 / L2 resident) and the consumer loads its operands from there -- the LDS
 // then holds four tiles again where W + four tiles exceed 160 KB (7 joints).
@@ -70,8 +74,8 @@ __global__ __launch_bounds__(128 * NPAIR) void k_regressor_pgram(const RdynLdsGr
   extern __shared__ __attribute__((aligned(32))) char lds_raw[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const bool sweeper = wave < (NPAIR == 4 ? 4 : 3);
-  const int pair = NPAIR == 4 ? (wave & 3) : (wave < 3 ? wave : (wave == 3 ? 2 : wave - 4));
+  const bool sweeper = wave < NPAIR;
+  const int pair = NPAIR == 4 ? (wave & 3) : NPAIR == 2 ? (wave & 1) : (wave < 3 ? wave : (wave == 3 ? 2 : wave - 4));
   if constexpr (!WGLOBAL)
   {
     double* const wl = (double*)lds_raw;
@@ -331,8 +335,114 @@ __global__ __launch_bounds__(128 * NPAIR) void k_regressor_pgram(const RdynLdsGr
   }
 }
 
+// pass B for a MATERIALISED matrix (rdyn_tsqr): 16-row groups of the column-major rows x n_cols device matrix [A | b] (b may be null:
+// n1 = n_cols + (b != null) columns, n1 <= 16 NB) times W, then the Gram of the product -- the consumer of k_regressor_pgram fed from
+// memory instead of a sweeper's LDS tile.  Operand A of the first MFMA: lane (cl, g) supplies X[row r0 + cl][column 16 cb1 + 4 kk + g]:
+// per (cb1, kk) the wave reads 16 consecutive rows (128 contiguous bytes) of four columns; the next group's 4 NB operands are
+// requested behind this group's MFMAs.  No zero band (nothing is known about the matrix), natural column order.  Four waves per
+// workgroup, one per SIMD (NB (NB + 1) / 2 accumulator tiles + NB product tiles: up to 432 registers at NB = 6), W in LDS.
+template <int NB>
+__global__ __launch_bounds__(256) void k_pgram_rows(const double* __restrict__ A, const double* __restrict__ bvec, int64_t rows, int64_t lda, int n_cols,
+                                                    const double* __restrict__ Wg, double* __restrict__ slabs, const int* __restrict__ run_flag)
+{
+  constexpr int NT = NB * (NB + 1) / 2;
+  if (run_flag && *run_flag == 0) return;
+  extern __shared__ __attribute__((aligned(32))) char lds_raw[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int cl = lane & 15, g = lane >> 4;
+  {
+    double* const wl = (double*)lds_raw;
+    for (int i = threadIdx.x; i < NT * 256; i += 256) wl[i] = Wg[i];
+    __syncthreads();
+  }
+  d4 acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) acc[t] = (d4){0.0, 0.0, 0.0, 0.0};
+  const char* const wl = lds_raw + lane * 8;
+  const int64_t gstride = (int64_t)gridDim.x * 4 * 16;
+  int64_t r0 = ((int64_t)blockIdx.x * 4 + wave) * 16;
+  double cur[4 * NB], nxt[4 * NB];
+  // operand id (= 4 cb1 + kk) of lane (cl, g): column 4 id + g -- one per-lane base (column g) + a wave-uniform column step, so that
+  // the 4 NB addresses cost no registers; the right-hand side (column n_cols) sits in one operand id only
+  const double* const base = A + (int64_t)g * lda;
+  const int id_b = bvec ? n_cols >> 2 : -1, g_b = n_cols & 3;
+  auto load = [&](int64_t rbase, double (&v)[4 * NB]) {
+    const int64_t r = rbase + cl;
+    const bool in = r < rows;
+    const double* pcol = base + r;  // walks the columns g, g + 4, ... (one address register pair for the 4 NB loads)
+#pragma unroll
+    for (int id = 0; id < 4 * NB; ++id)
+    {
+      double x = 0.0;
+      if (in && 4 * id + g < n_cols) x = *pcol;
+      if (id == id_b && in && g == g_b) x = bvec[r];
+      v[id] = x;
+      pcol += 4 * lda;
+      asm volatile("" : "+v"(pcol));
+    }
+  };
+  if (r0 < rows) load(r0, cur);
+  while (r0 < rows)
+  {
+    const int64_t rn = r0 + gstride;
+    if (rn < rows) load(rn, nxt);
+    d4 D[NB];
+#pragma unroll
+    for (int cb = 0; cb < NB; ++cb) D[cb] = (d4){0.0, 0.0, 0.0, 0.0};
+    {
+      // rows (cb1, kk) of W from LDS, two rows ahead of their MFMAs and no further (compiler barrier): left alone the scheduler hoists
+      // every operand of the group and spills the accumulators at six column blocks
+      constexpr int AH = 2;
+      double ring[AH + 1][NB];
+      auto load_row = [&](int r, double (&dst)[NB]) {
+        const int c1 = r >> 2, k4 = r & 3;
+#pragma unroll
+        for (int cb2 = 0; cb2 < NB; ++cb2)
+        {
+          dst[cb2] = 0.0;
+          if (c1 < NB && cb2 >= c1) dst[cb2] = *(const double*)(wl + ((cb2 * (cb2 + 1) / 2 + c1) * 4 + k4) * 512);
+        }
+      };
+#pragma unroll
+      for (int r = 0; r < AH; ++r) load_row(r, ring[r]);
+#pragma unroll
+      for (int cb1 = 0; cb1 < NB; ++cb1)
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+        {
+          const int r = cb1 * 4 + kk;
+          load_row(r + AH, ring[(r + AH) % (AH + 1)]);
+          asm volatile("" ::: "memory");
+          const double a = cur[r];
+#pragma unroll
+          for (int cb2 = cb1; cb2 < NB; ++cb2) D[cb2] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, ring[r % (AH + 1)][cb2], D[cb2], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+    {
+      int ti = 0;
+#pragma unroll
+      for (int cb = 0; cb < NB; ++cb)
+#pragma unroll
+        for (int rb = 0; rb <= cb; ++rb)
+        {
+          acc[ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(D[rb][t], D[cb][t], acc[ti], 0, 0, 0);
+          ++ti;
+        }
+    }
+#pragma unroll
+    for (int id = 0; id < 4 * NB; ++id) cur[id] = nxt[id];
+    r0 = rn;
+  }
+  __syncthreads();  // everybody is done with W: the reduction area overlays it
+  gram_block_reduce_to_slab<NT>(acc, (double*)lds_raw, wave, cl, g, slabs + (int64_t)blockIdx.x * (NT * 256), false);
+}
+
 // ---------------------------------------------------------------- the small dense steps (one workgroup each, n1 <= 81)
-constexpr int kMaxN1 = 81;
+constexpr int kMaxN1 = 96;  // 2 n1^2 doubles of LDS per dense kernel: 147 KB
+constexpr int kMaxFoldN1 = 136;  // k_cholqr_fold: two packed triangles in LDS (136 * 137 * 8 = 149 KB)
 #ifndef RDYN_CHOLQR_DENSE_THREADS
 #define RDYN_CHOLQR_DENSE_THREADS 1024
 #endif
@@ -516,7 +626,7 @@ __device__ __forceinline__ void chol_with_inverse_lds(double* M, double* E, int 
 // W is written in the MFMA operand order of k_regressor_pgram.
 constexpr double kCholqrGammaMax = 1e4;
 __global__ __launch_bounds__(NTD) void k_cholqr_precond(const double* __restrict__ R1, const double* __restrict__ Gs, const double* __restrict__ cs,
-                                                        const double* __restrict__ bbs, int n1, int col_shift, double row_scale,
+                                                        const double* __restrict__ bbs, int n1, int col_shift, int nb_w, double row_scale,
                                                         double* __restrict__ Tout, double* __restrict__ W, double* __restrict__ Vout, int* __restrict__ zmask,
                                                         int* __restrict__ flags, int round, const int* __restrict__ run_flag,
                                                         double* __restrict__ gamma_out)
@@ -685,7 +795,8 @@ __global__ __launch_bounds__(NTD) void k_cholqr_precond(const double* __restrict
     }
   }
   // operand order of k_regressor_pgram, in its column space (natural order shifted right by col_shift)
-  const int nb = (n1 + col_shift + 15) / 16, nt = nb * (nb + 1) / 2;
+  // (every operand block the consumer loads is written: what lies beyond n1 + col_shift columns is zero, not stale workspace)
+  const int nb = nb_w, nt = nb * (nb + 1) / 2;
   for (int i = tid; i < nt * 256; i += NTD)
   {
     const int blk = i >> 8, kk = (i >> 6) & 3, ln = i & 63;
@@ -838,41 +949,35 @@ __global__ __launch_bounds__(NTD) void k_cholqr_factor(const double* __restrict_
   }
 }
 
-// Factor of the reduced chain -> factor of the chain (rdyn_chain.hpp: [A b] = [A_red b] E_aug, E_aug = diag(E, 1)):
-// R = qr([R_prev ; R_red E_aug]) by Householder reflections in LDS, one workgroup.  R_prev (n1 x n1, the caller's running factor)
-// only when accumulating.  The product has nr = 10 n_red + 1 rows and n1 = 10 n_joints + 1 columns; rows beyond the rank stay zero.
-__global__ __launch_bounds__(NTD) void k_cholqr_expand(const RdynGramExpandArgs a, const double* __restrict__ R_red, const double* __restrict__ R_prev,
-                                                       double* __restrict__ Rout)
+// Factor of the reduced chain -> factor of the chain (rdyn_chain.hpp: [A C b] = [A_red C b] E_aug, E_aug = diag(E, I_K, 1)):
+// R = qr(R_red E_aug) by Householder reflections in LDS, one workgroup.  The product has nr = 10 n_red + K + 1 rows and
+// n1 = 10 n_joints + K + 1 columns; rows beyond the rank stay zero.  The K component columns (friction_polynomial1.h:126,
+// ideal_spring.h:64) belong to INPUT joints, which the reduced chain keeps: they pass through unchanged, like the measured torque.
+__global__ __launch_bounds__(NTD) void k_cholqr_expand(const RdynGramExpandArgs a, const double* __restrict__ R_red, double* __restrict__ Rout)
 {
   extern __shared__ __attribute__((aligned(16))) double sh[];
-  const int P = 10 * a.n_joints, n1 = P + 1, Pr = 10 * a.n_red, nr = Pr + 1;
-  const int m = nr + (R_prev ? n1 : 0);
+  const int K = a.n_comp_cols, P = 10 * a.n_joints, n1 = P + K + 1, Pr = 10 * a.n_red, nr = Pr + K + 1;
+  const int m = nr;
   double* const B = sh;            // [n1][m] column-major (leading dimension m)
   const int tid = threadIdx.x;
-  // rows 0 .. nr - 1: R_red E_aug; rows nr ..: R_prev
   for (int e = tid; e < n1 * m; e += NTD)
   {
     const int r = e % m, col = e / m;
     double s = 0.0;
-    if (r < nr)
+    if (col >= P)
     {
-      if (col == P)
-        s = R_red[(int64_t)Pr * nr + r];
-      else
-      {
-        const int f = col / 10, p = col - 10 * f, rb = a.red_of[f];
-        if (rb >= 0)
-          for (int x = 0; x < 10; ++x)
-          {
-            const int cr = 10 * rb + x;
-            if (r <= cr) s = fma(R_red[(int64_t)cr * nr + r], a.X[f * 100 + x * 10 + p], s);
-          }
-      }
+      const int cr = Pr + (col - P);  // component column / measured torque: the same column of the reduced factor
+      s = r <= cr ? R_red[(int64_t)cr * nr + r] : 0.0;
     }
     else
     {
-      const int rp = r - nr;
-      s = rp <= col ? R_prev[(int64_t)col * n1 + rp] : 0.0;
+      const int f = col / 10, p = col - 10 * f, rb = a.red_of[f];
+      if (rb >= 0)
+        for (int x = 0; x < 10; ++x)
+        {
+          const int cr = 10 * rb + x;
+          if (r <= cr) s = fma(R_red[(int64_t)cr * nr + r], a.X[f * 100 + x * 10 + p], s);
+        }
     }
     B[e] = s;
   }
@@ -885,25 +990,69 @@ __global__ __launch_bounds__(NTD) void k_cholqr_expand(const RdynGramExpandArgs 
   }
 }
 
-// max_bytes: dynamic LDS the kernel may ask for (kernels with static __shared__ variables must leave room for them inside 160 KB)
-// R <- qr([R ; R_new]): both n1 x n1 upper triangular, column-major (the accumulate step of the preconditioned route: any width)
+// R <- qr([R ; R_new]): both n1 x n1 upper triangular, column-major (the accumulate step of the preconditioned route and of the
+// expansion above).  Both triangles PACKED in LDS (column j holds its j + 1 entries: n1 (n1 + 1) doubles in all, 101 KB at 112
+// columns).  Step k: the reflector is [R(k, k); R_new(0 .. k, k)] -- what lies below row k of R is zero and stays zero, and a column
+// j > k is touched in R(k, j) and R_new(0 .. k, j) only: no fill-in outside the two triangles.  One barrier per step (every wave forms
+// the column norm by itself, the same sum in the same order), four threads per column.
 __global__ __launch_bounds__(NTD) void k_cholqr_fold(const double* __restrict__ R_new, double* __restrict__ R, int n1)
 {
   extern __shared__ __attribute__((aligned(16))) double sh[];
-  const int m = 2 * n1;
-  double* const B = sh;
-  const int tid = threadIdx.x;
-  for (int e = tid; e < n1 * m; e += NTD)
-  {
-    const int r = e % m, col = e / m;
-    B[e] = r < n1 ? (r <= col ? R[(int64_t)col * n1 + r] : 0.0) : (r - n1 <= col ? R_new[(int64_t)col * n1 + r - n1] : 0.0);
-  }
-  __syncthreads();
-  small_qr_lds(B, m, n1, tid);
+  const int tri = n1 * (n1 + 1) / 2;
+  double* const A = sh;        // R:     A[j (j + 1) / 2 + i], i <= j
+  double* const B = sh + tri;  // R_new: same packing
+  const int tid = threadIdx.x, lane = tid & 63;
   for (int e = tid; e < n1 * n1; e += NTD)
   {
-    const int r = e % n1, col = e / n1;
-    R[e] = r <= col ? B[col * m + r] : 0.0;
+    const int i = e % n1, j = e / n1;
+    if (i <= j)
+    {
+      A[j * (j + 1) / 2 + i] = R[e];
+      B[j * (j + 1) / 2 + i] = R_new[e];
+    }
+  }
+  __syncthreads();
+  for (int k = 0; k < n1; ++k)
+  {
+    const double* const bk = B + k * (k + 1) / 2;
+    double sigma = 0.0;
+    for (int i = lane; i <= k; i += 64) sigma = fma(bk[i], bk[i], sigma);
+    for (int o = 32; o > 0; o >>= 1) sigma += __shfl_xor(sigma, o);
+    const double alpha = A[k * (k + 1) / 2 + k];
+    double beta = alpha;
+    if (sigma > 1e-280)
+    {
+      const double norm = sqrt(fma(alpha, alpha, sigma));
+      beta = alpha > 0.0 ? -norm : norm;
+      const double v0 = alpha - beta, scale = 2.0 / fma(v0, v0, sigma);
+      const int ncol = n1 - k - 1;
+      for (int e = tid; e < (ncol * 4 + NTD - 1) / NTD * NTD; e += NTD)
+      {
+        const bool on = e < ncol * 4;
+        const int j = on ? k + 1 + (e >> 2) : k, q = e & 3;
+        double* const aj = A + j * (j + 1) / 2;
+        double* const bj = B + j * (j + 1) / 2;
+        double d = (on && q == 0) ? v0 * aj[k] : 0.0;
+        if (on)
+          for (int i = q; i <= k; i += 4) d = fma(bk[i], bj[i], d);
+        d += __shfl_xor(d, 1);
+        d += __shfl_xor(d, 2);
+        const double f = scale * d;
+        if (on)
+        {
+          if (q == 0) aj[k] = fma(-f, v0, aj[k]);
+          for (int i = q; i <= k; i += 4) bj[i] = fma(-f, bk[i], bj[i]);
+        }
+      }
+    }
+    __syncthreads();
+    if (tid == 0) A[k * (k + 1) / 2 + k] = beta;
+  }
+  __syncthreads();
+  for (int e = tid; e < n1 * n1; e += NTD)
+  {
+    const int i = e % n1, j = e / n1;
+    R[e] = i <= j ? A[j * (j + 1) / 2 + i] : 0.0;
   }
 }
 
@@ -941,7 +1090,12 @@ hipError_t launch_pgram(const RdynLdsGramArgs& a, const double* W, const int* ru
 {
   if (a.n_comp_cols > 0)
   {
-    // [Y | C | tau_meas]: chains of up to 6 joints (as the Householder route), W beside the four tiles or in global memory
+    // [Y | C | tau_meas]: chains of up to 6 joints: W beside the four tiles or in global memory; 7 joints: two pairs on four SIMDs
+    if constexpr (NJ == 7)
+    {
+      if (pairs == 2)
+        return a.all_revolute ? launch_pgram3<NJ, true, 2, false, 1>(a, W, run_flag, blocks, st) : launch_pgram3<NJ, false, 2, false, 1>(a, W, run_flag, blocks, st);
+    }
     if constexpr (NJ <= 6)
     {
       if (pairs == 4)
@@ -962,6 +1116,16 @@ hipError_t launch_pgram(const RdynLdsGramArgs& a, const double* W, const int* ru
   }
   return hipErrorInvalidValue;
 }
+template <int NB>
+hipError_t launch_pgram_rows(const double* A, const double* b, int64_t rows, int64_t lda, int n_cols, const double* W, double* slabs, const int* run_flag,
+                             int blocks, hipStream_t st)
+{
+  static std::atomic<uint64_t> attr{0};
+  hipError_t e = opt_in_lds_once(k_pgram_rows<NB>, attr);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL((k_pgram_rows<NB>), dim3(blocks), dim3(256), (size_t)(NB * (NB + 1) / 2) * 2048, st, A, b, rows, lda, n_cols, W, slabs, run_flag);
+  return hipGetLastError();
+}
 }  // namespace
 
 size_t rdyn_cholqr_w_doubles(int n_joints, int xb)
@@ -972,8 +1136,9 @@ size_t rdyn_cholqr_w_doubles(int n_joints, int xb)
 
 int rdyn_cholqr_pairs(int n_joints, int tile_bytes, int xb)
 {
-  if (n_joints < 2 || n_joints > (xb ? 6 : 7)) return 0;
+  if (n_joints < 2 || n_joints > 7) return 0;
   const size_t wb = rdyn_cholqr_w_doubles(n_joints, xb) * 8;
+  if (n_joints == 7 && xb) return wb + 2 * (size_t)tile_bytes <= 160 * 1024 ? 2 : 0;
   if (wb + 4 * (size_t)tile_bytes <= 160 * 1024) return 4;
 #ifdef RDYN_CHOLQR_W_LDS3
   if (wb + 3 * (size_t)tile_bytes <= 160 * 1024) return 3;
@@ -981,6 +1146,22 @@ int rdyn_cholqr_pairs(int n_joints, int tile_bytes, int xb)
   if (4 * (size_t)tile_bytes <= 160 * 1024) return -4;  // W from global memory (7 joints)
 #endif
   return 0;
+}
+
+// nb = ceil(n1 / 16) <= 6 column blocks (n1 = n_cols + (b != null)); slabs: [blocks][nb (nb + 1) / 2 * 256]
+hipError_t rdyn_launch_pgram_rows(const double* A, const double* b, int64_t rows, int64_t lda, int n_cols, const double* W, double* slabs,
+                                  const int* run_flag, int blocks, hipStream_t st)
+{
+  switch ((n_cols + (b ? 1 : 0) + 15) / 16)
+  {
+  case 1: return launch_pgram_rows<1>(A, b, rows, lda, n_cols, W, slabs, run_flag, blocks, st);
+  case 2: return launch_pgram_rows<2>(A, b, rows, lda, n_cols, W, slabs, run_flag, blocks, st);
+  case 3: return launch_pgram_rows<3>(A, b, rows, lda, n_cols, W, slabs, run_flag, blocks, st);
+  case 4: return launch_pgram_rows<4>(A, b, rows, lda, n_cols, W, slabs, run_flag, blocks, st);
+  case 5: return launch_pgram_rows<5>(A, b, rows, lda, n_cols, W, slabs, run_flag, blocks, st);
+  case 6: return launch_pgram_rows<6>(A, b, rows, lda, n_cols, W, slabs, run_flag, blocks, st);
+  default: return hipErrorInvalidValue;
+  }
 }
 
 hipError_t rdyn_launch_regressor_pgram(int n_joints, const RdynLdsGramArgs& a, const double* W, const int* run_flag, int blocks, int pairs, hipStream_t st)
@@ -997,15 +1178,17 @@ hipError_t rdyn_launch_regressor_pgram(int n_joints, const RdynLdsGramArgs& a, c
   }
 }
 
-hipError_t rdyn_launch_cholqr_precond(const double* R1, const double* Gs, const double* cs, const double* bbs, int n1, int col_shift, double row_scale,
-                                      double* T, double* W, double* V, int* zmask, int* flags, int round, const int* run_flag, double* gamma_out,
-                                      hipStream_t st)
+int rdyn_cholqr_max_cols() { return kMaxN1; }
+
+hipError_t rdyn_launch_cholqr_precond(const double* R1, const double* Gs, const double* cs, const double* bbs, int n1, int col_shift, int nb_w,
+                                      double row_scale, double* T, double* W, double* V, int* zmask, int* flags, int round, const int* run_flag,
+                                      double* gamma_out, hipStream_t st)
 {
-  if (n1 < 1 || n1 > kMaxN1) return hipErrorInvalidValue;
+  if (n1 < 1 || n1 > kMaxN1 || 16 * nb_w < n1 + col_shift) return hipErrorInvalidValue;
   static std::atomic<uint64_t> attr{0};
-  hipError_t e = opt_in_lds_once(k_cholqr_precond, attr, 128 * 1024);
+  hipError_t e = opt_in_lds_once(k_cholqr_precond, attr, 154 * 1024);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(k_cholqr_precond, dim3(1), dim3(NTD), ((size_t)2 * n1 * n1 + n1) * sizeof(double), st, R1, Gs, cs, bbs, n1, col_shift, row_scale, T, W, V, zmask, flags, round, run_flag,
+  hipLaunchKernelGGL(k_cholqr_precond, dim3(1), dim3(NTD), ((size_t)2 * n1 * n1 + n1) * sizeof(double), st, R1, Gs, cs, bbs, n1, col_shift, nb_w, row_scale, T, W, V, zmask, flags, round, run_flag,
                      gamma_out);
   return hipGetLastError();
 }
@@ -1015,32 +1198,37 @@ hipError_t rdyn_launch_cholqr_factor(const double* G, const double* c, const dou
 {
   if (n1 < 2 || n1 > kMaxN1 || round < 0 || round > 1) return hipErrorInvalidValue;
   static std::atomic<uint64_t> attr{0};
-  hipError_t e = opt_in_lds_once(k_cholqr_factor, attr, 128 * 1024);
+  hipError_t e = opt_in_lds_once(k_cholqr_factor, attr, 154 * 1024);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(k_cholqr_factor, dim3(1), dim3(NTD), (size_t)2 * n1 * n1 * sizeof(double), st, G, c, bb, n1, has_b, T, V, zmask, R, flags, round, run_flag, rho_out);
   return hipGetLastError();
 }
 
-// a.G_red / c_red / bb_red / G / c / bb are unused here: the factors travel as separate arguments (R_prev null = not accumulating)
-hipError_t rdyn_launch_cholqr_expand(const RdynGramExpandArgs& a, const double* R_red, const double* R_prev, double* R, hipStream_t st)
+// a.G_red / c_red / bb_red / G / c / bb are unused here: the factors travel as separate arguments.  R must not alias R_red.
+hipError_t rdyn_launch_cholqr_expand(const RdynGramExpandArgs& a, const double* R_red, double* R, hipStream_t st)
 {
-  const int n1 = 10 * a.n_joints + 1, nr = 10 * a.n_red + 1, m = nr + (R_prev ? n1 : 0);
-  const size_t lds = ((size_t)n1 * m + m) * sizeof(double);
+  const int n1 = 10 * a.n_joints + a.n_comp_cols + 1, nr = 10 * a.n_red + a.n_comp_cols + 1;
+  const size_t lds = ((size_t)n1 * nr + nr) * sizeof(double);
   if (lds > 156 * 1024) return hipErrorInvalidValue;
   static std::atomic<uint64_t> attr{0};
   hipError_t e = opt_in_lds_once(k_cholqr_expand, attr, 156 * 1024);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(k_cholqr_expand, dim3(1), dim3(NTD), lds, st, a, R_red, R_prev, R);
+  hipLaunchKernelGGL(k_cholqr_expand, dim3(1), dim3(NTD), lds, st, a, R_red, R);
   return hipGetLastError();
+}
+
+size_t rdyn_cholqr_expand_lds_bytes(int n_joints, int n_red, int n_comp_cols)
+{
+  return ((size_t)(10 * n_joints + n_comp_cols + 1) * (10 * n_red + n_comp_cols + 1) + (10 * n_red + n_comp_cols + 1)) * sizeof(double);
 }
 
 hipError_t rdyn_launch_cholqr_fold(const double* R_new, double* R, int n1, hipStream_t st)
 {
-  if (n1 < 1 || n1 > kMaxN1) return hipErrorInvalidValue;
+  if (n1 < 1 || n1 > kMaxFoldN1) return hipErrorInvalidValue;
   static std::atomic<uint64_t> attr{0};
-  hipError_t e = opt_in_lds_once(k_cholqr_fold, attr, 128 * 1024);
+  hipError_t e = opt_in_lds_once(k_cholqr_fold, attr, 156 * 1024);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(k_cholqr_fold, dim3(1), dim3(NTD), ((size_t)2 * n1 * n1 + 2 * n1) * sizeof(double), st, R_new, R, n1);
+  hipLaunchKernelGGL(k_cholqr_fold, dim3(1), dim3(NTD), (size_t)n1 * (n1 + 1) * sizeof(double), st, R_new, R, n1);
   return hipGetLastError();
 }
 

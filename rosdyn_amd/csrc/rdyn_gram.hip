@@ -52,8 +52,9 @@ __global__ __launch_bounds__(256) void k_gram(const RdynGramArgs a)
 #pragma unroll
   for (int t = 0; t < NT; ++t) acc[t] = (d4){0.0, 0.0, 0.0, 0.0};
 
-  const int64_t wstride = (int64_t)gridDim.x * 4 * 16;
-  int64_t r0 = ((int64_t)blockIdx.x * 4 + wave) * 16;
+  const int64_t gmul = a.group_stride > 1 ? a.group_stride : 1;  // subsample: every gmul-th 16-row group
+  const int64_t wstride = (int64_t)gridDim.x * 4 * 16 * gmul;
+  int64_t r0 = ((int64_t)blockIdx.x * 4 + wave) * 16 * gmul;
 
   // first column block that can be non-zero for the 16-row group starting at r (wave-uniform)
   // (rows only grow, so the row-block index is tracked incrementally: no 64-bit division per group)

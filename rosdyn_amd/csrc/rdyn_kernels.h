@@ -118,6 +118,7 @@ struct RdynGramArgs
   // (rdyn_duo_gram.hip: the zero band of every row group then ends at a 16-column boundary more often); 0 = natural order
   int desc_nj;
   int desc_k;   // finish only, with desc_nj > 0: component columns in front of that order ([C | tau_meas | links descending]; P counts them)
+  int group_stride;  // k_gram only: every group_stride-th 16-row group (0 / 1 = all): the subsample pass of the preconditioned route
   int slab_nb;  // finish only: 16-column blocks of the slabs' tile layout if it is wider than P + 1 columns need (0 = derive from P)
   const int* run_flag;  // finish only, may be null: device word; 0 = leave at once (conditional second round of rdyn_cholqr.hip)
   int col_shift;        // finish only: the slabs' column space is the natural order shifted right by col_shift (rdyn_cholqr.hip)
@@ -178,6 +179,7 @@ struct RdynLdsGramArgs
   // it is stored as ONE 16-row group (stride 160 bytes) at lds_off_c + 160 k; the measured torque moves to column P + n_comp_cols.
   int n_comps, n_comp_cols;
   int lds_off_c, comp_stride;          // component column k at lds_off_c + comp_stride * k (160, or 144 in the compact layout)
+  int comp_row_step;                   // 0: a component column stores its own joint's 16-row group only; 128: all row groups (rectangular tile of rdyn_tsqr_wide.hip)
   signed char comp_col_row[96];        // per component column: the input joint (row group) it belongs to
   RdynComponent comps[RDYN_MAX_COMPONENTS];
 };
@@ -194,10 +196,13 @@ hipError_t rdyn_launch_regressor_gram_duo(int n_cols, const RdynLdsGramArgs& a, 
 //   W = R1^-1 of a Householder factor R1 of a row SUBSAMPLE (rdyn_tsqr.hip);  G2 = (A W)'(A W) over ALL rows: sweep -> LDS tile -> the
 //   consumer wave multiplies every 16-row group by W (MFMA) and accumulates the Gram of the product (MFMA);  R = chol(G2) R1.
 // xb = 1: one more 16-column block for the component columns of rdyn_identification_tsqr (chains of <= 6 joints)
-int rdyn_cholqr_pairs(int n_joints, int tile_bytes, int xb);  // 4: W in LDS beside four tiles; -4: four tiles, W in global memory; 0: unsupported
+int rdyn_cholqr_pairs(int n_joints, int tile_bytes, int xb);  // 4: W in LDS beside four tiles; -4: four tiles, W in global memory; 2: two pairs on four SIMDs (7 joints + components); 0: unsupported
 size_t rdyn_cholqr_w_doubles(int n_joints, int xb);           // W in MFMA operand order
-hipError_t rdyn_launch_cholqr_fold(const double* R_new, double* R, int n1, hipStream_t st);  // R <- qr([R ; R_new]), n1 <= 81
+hipError_t rdyn_launch_cholqr_fold(const double* R_new, double* R, int n1, hipStream_t st);  // R <- qr([R ; R_new]), n1 <= 136
 hipError_t rdyn_launch_regressor_pgram(int n_joints, const RdynLdsGramArgs& a, const double* W, const int* run_flag, int blocks, int pairs, hipStream_t st);
+// the same pass over a materialised column-major matrix [A | b] (rdyn_tsqr): n_cols + (b != null) <= 96 columns, natural column order
+hipError_t rdyn_launch_pgram_rows(const double* A, const double* b, int64_t rows, int64_t lda, int n_cols, const double* W, double* slabs,
+                                  const int* run_flag, int blocks, hipStream_t st);
 // R1 (n1 x n1 upper, column-major) -> T = R1 re-triangularised without its deferred columns (zmask <- that set), W = T^-1 in MFMA
 // operand order.  row_scale: R1 is the factor of one row in row_scale^2 (the subsample), T is scaled to all rows.
 // col_shift: columns of padding in FRONT of the natural order in the consumer's column space (rdyn_cholqr_col_shift).
@@ -206,17 +211,20 @@ hipError_t rdyn_launch_regressor_pgram(int n_joints, const RdynLdsGramArgs& a, c
 // exceeds 1e4 calls the round off and the stand-by in.
 // V: T^-1 in natural order (n1 x n1, for the factor kernel's own evaluation of gamma).
 // Input: the triangular factor R1, or (Gs != null) the Gram matrix [Gs cs; cs' bbs] of the subsample's rows (P x P, P, 1; P = n1 - 1).
-hipError_t rdyn_launch_cholqr_precond(const double* R1, const double* Gs, const double* cs, const double* bbs, int n1, int col_shift, double row_scale,
-                                      double* T, double* W, double* V, int* zmask, int* flags, int round, const int* run_flag, double* gamma_out,
-                                      hipStream_t st);
+// nb_w: 16-column blocks of the consumer's column space (W is written, zero-padded, for all nb_w (nb_w + 1) / 2 operand blocks)
+hipError_t rdyn_launch_cholqr_precond(const double* R1, const double* Gs, const double* cs, const double* bbs, int n1, int col_shift, int nb_w,
+                                      double row_scale, double* T, double* W, double* V, int* zmask, int* flags, int round, const int* run_flag,
+                                      double* gamma_out, hipStream_t st);
+int rdyn_cholqr_max_cols();  // widest factor (right-hand side included) the dense steps of the preconditioned route hold in LDS
 int rdyn_cholqr_col_shift(int n_joints, int xb);
 // G2 = [G c; c' bb] -> R = chol(G2) T (n1 x n1 upper, column-major; zero rows at the confirmed null columns); flags[round] = 1 when the
 // round is not accepted (rho_out, may be null: [0] the conditioning measure of the equilibrated Q, [2] gamma on the norms of all rows);
 // round 0 clears flags[1]
 hipError_t rdyn_launch_cholqr_factor(const double* G, const double* c, const double* bb, int n1, int has_b, const double* T, const double* V, const int* zmask,
                                      double* R, int* flags, int round, const int* run_flag, double* rho_out, hipStream_t st);
-// factor of the reduced chain -> factor of the chain: R = qr([R_prev ; R_red diag(E, 1)]) (a.X, a.red_of, a.n_joints, a.n_red used)
-hipError_t rdyn_launch_cholqr_expand(const RdynGramExpandArgs& a, const double* R_red, const double* R_prev, double* R, hipStream_t st);
+// factor of the reduced chain -> factor of the chain: R = qr(R_red diag(E, I_K, 1)) (a.X, a.red_of, a.n_joints, a.n_red, a.n_comp_cols used)
+hipError_t rdyn_launch_cholqr_expand(const RdynGramExpandArgs& a, const double* R_red, double* R, hipStream_t st);
+size_t rdyn_cholqr_expand_lds_bytes(int n_joints, int n_red, int n_comp_cols);  // dynamic LDS of that launch (limit: 156 KB)
 // tall-skinny QR (rdyn_tsqr.hip): R factor of [A | b] without forming A'A
 int rdyn_tsqr_padded_cols(int n_cols_with_rhs);              // 16 / 32 / 48 / 64, 0 = unsupported
 size_t rdyn_tsqr_workspace_doubles(int nc, int blocks);
@@ -226,7 +234,15 @@ int rdyn_regressor_tsqr_cols(int n_joints, int n_comp_cols);  // factor width of
 hipError_t rdyn_launch_regressor_tsqr(int n_joints, const RdynLdsGramArgs& a, int blocks, size_t lds_bytes, double* workspace, double* R, int accumulate,
                                       hipStream_t st, int tree_fan = 2);
 hipError_t rdyn_launch_tsqr_rows(const double* A, const double* b, int64_t rows, int64_t lda, int n_cols, int blocks, double* workspace, double* R,
-                                 int accumulate, hipStream_t st);
+                                 int accumulate, hipStream_t st, const int* run_flag = nullptr, int tree_fan = 2);
+// the shapes beyond the register-resident folds (rdyn_tsqr_wide.hip): factor packed in LDS, up to 112 columns
+int rdyn_tsqr_wide_max_cols();
+size_t rdyn_regressor_tsqr_wide_lds_bytes(int n1, int n_active);  // 0: the 16-sample tile does not fit beside the factor
+size_t rdyn_tsqr_wide_workspace_doubles(int n1, int blocks);
+// a: the rectangular tile layout (comp_row_step = 128); factor width 10 n_joints + a.n_comp_cols + 1; blocks <= 256; a.run_flag as above
+hipError_t rdyn_launch_regressor_tsqr_wide(int n_joints, const RdynLdsGramArgs& a, int blocks, double* workspace, double* R, int accumulate, hipStream_t st);
+hipError_t rdyn_launch_tsqr_wide_rows(const double* A, const double* b, int64_t rows, int64_t lda, int n_cols, int blocks, double* workspace, double* R,
+                                      int accumulate, const int* run_flag, hipStream_t st);
 int rdyn_gram_blocks_for(int P);
 hipError_t rdyn_launch_gram(const RdynGramArgs& a, int blocks, hipStream_t st);
 hipError_t rdyn_launch_gram_finish(const RdynGramArgs& a, int blocks, hipStream_t st);

@@ -409,8 +409,9 @@ struct ConstRowSlots
 
 template <int NC>
 __global__ __launch_bounds__(256) void k_tsqr_rows(const double* __restrict__ A, const double* __restrict__ b, int64_t rows, int64_t lda, int n_cols,
-                                                   double* __restrict__ factors)
+                                                   double* __restrict__ factors, const int* __restrict__ run_flag)
 {
+  if (run_flag && *run_flag == 0) return;  // stand-by call, not needed
   constexpr int TR = 64, SB = (TR + 2) * 8;  // block: NC columns of TR rows (+ pad), column-major
   constexpr int NCI = (NC + 15) / 16, NK = (NC + 3) / 4, RM = TR / 16;
   extern __shared__ __attribute__((aligned(32))) char lds_raw[];
@@ -544,15 +545,15 @@ hipError_t launch_regressor_tsqr(const RdynLdsGramArgs& a, int blocks, size_t ld
 
 template <int NC>
 hipError_t launch_tsqr_rows(const double* A, const double* b, int64_t rows, int64_t lda, int n_cols, int blocks, double* slab, double* scratch, double* R,
-                            const double* extra, hipStream_t st)
+                            const double* extra, hipStream_t st, const int* run_flag, int fan)
 {
   static std::atomic<uint64_t> attr{0};
   hipError_t e = opt_in_lds(k_tsqr_rows<NC>, attr);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL((k_tsqr_rows<NC>), dim3(blocks), dim3(256), (size_t)4 * NC * ((64 + 2) * 8), st, A, b, rows, lda, n_cols, slab);
+  hipLaunchKernelGGL((k_tsqr_rows<NC>), dim3(blocks), dim3(256), (size_t)4 * NC * ((64 + 2) * 8), st, A, b, rows, lda, n_cols, slab, run_flag);
   e = hipGetLastError();
   if (e != hipSuccess) return e;
-  return combine_tree<NC>(slab, blocks, scratch, R, n_cols + (b ? 1 : 0), extra, st);
+  return combine_tree<NC>(slab, blocks, scratch, R, n_cols + (b ? 1 : 0), extra, st, fan, run_flag);
 }
 }  // namespace
 
@@ -600,7 +601,7 @@ hipError_t rdyn_launch_regressor_tsqr(int n_joints, const RdynLdsGramArgs& a, in
 }
 
 hipError_t rdyn_launch_tsqr_rows(const double* A, const double* b, int64_t rows, int64_t lda, int n_cols, int blocks, double* workspace, double* R,
-                                 int accumulate, hipStream_t st)
+                                 int accumulate, hipStream_t st, const int* run_flag, int tree_fan)
 {
   const int nc = rdyn_tsqr_padded_cols(n_cols + (b ? 1 : 0));
   double* slab = workspace;
@@ -608,10 +609,10 @@ hipError_t rdyn_launch_tsqr_rows(const double* A, const double* b, int64_t rows,
   const double* extra = accumulate ? R : nullptr;
   switch (nc)
   {
-  case 16: return launch_tsqr_rows<16>(A, b, rows, lda, n_cols, blocks, slab, scratch, R, extra, st);
-  case 32: return launch_tsqr_rows<32>(A, b, rows, lda, n_cols, blocks, slab, scratch, R, extra, st);
-  case 48: return launch_tsqr_rows<48>(A, b, rows, lda, n_cols, blocks, slab, scratch, R, extra, st);
-  case 64: return launch_tsqr_rows<64>(A, b, rows, lda, n_cols, blocks, slab, scratch, R, extra, st);
+  case 16: return launch_tsqr_rows<16>(A, b, rows, lda, n_cols, blocks, slab, scratch, R, extra, st, run_flag, tree_fan);
+  case 32: return launch_tsqr_rows<32>(A, b, rows, lda, n_cols, blocks, slab, scratch, R, extra, st, run_flag, tree_fan);
+  case 48: return launch_tsqr_rows<48>(A, b, rows, lda, n_cols, blocks, slab, scratch, R, extra, st, run_flag, tree_fan);
+  case 64: return launch_tsqr_rows<64>(A, b, rows, lda, n_cols, blocks, slab, scratch, R, extra, st, run_flag, tree_fan);
   default: return hipErrorInvalidValue;
   }
 }

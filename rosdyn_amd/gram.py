@@ -166,7 +166,7 @@ def tsqr(A, b=None, out=None, accumulate=False, workspace=None):
     buf = torch.zeros((n1, n1), dtype=torch.float64, device=A.device) if out is None else out.t().contiguous()
     nbytes = lib().rdyn_tsqr_workspace_bytes(n1)
     if nbytes == 0:
-        raise ValueError("rdyn_tsqr: at most 64 columns (right-hand side included)")
+        raise ValueError("rdyn_tsqr: at most 112 columns (right-hand side included)")
     if workspace is None:
         workspace = torch.empty((nbytes,), dtype=torch.uint8, device=A.device)
     check(lib().rdyn_tsqr(A.data_ptr(), rows, rows, P, b.data_ptr() if b is not None else None, buf.data_ptr(), 1 if accumulate else 0,
@@ -176,6 +176,16 @@ def tsqr(A, b=None, out=None, accumulate=False, workspace=None):
         out.copy_(buf.t())
         return out
     return buf.t()
+
+
+def tsqr_last_report(n1, rows, workspace):
+    """rdyn_tsqr_rows_last_report: what the last tsqr() call that used `workspace` did (route / stage / gamma / rho); synchronises."""
+    import torch
+    from ._lib import RdynTsqrReport
+    rep = RdynTsqrReport()
+    check(lib().rdyn_tsqr_rows_last_report(int(n1), int(rows), workspace.data_ptr(), workspace.device.index or 0,
+                                           torch.cuda.current_stream(workspace.device).cuda_stream, C.byref(rep)))
+    return dict(route=rep.route, stage=rep.stage, n_deferred=rep.n_deferred, gamma=tuple(rep.gamma), rho=tuple(rep.rho))
 
 
 def tsqr_combine_host(factors):

@@ -206,16 +206,23 @@ def test_workspace_queries_reflect_what_the_tsqr_entry_points_support():
     # round 3: joints that are not input joints are folded away (the reduced chain is swept, the factor expanded): 8 chain joints with
     # 5 input joints are served; the limit is 7 INPUT joints
     assert L.rdyn_regressor_tsqr_workspace_bytes(mix8._h) > 0
-    assert L.rdyn_regressor_tsqr_workspace_bytes(ur7._h) == L.rdyn_regressor_tsqr_workspace_bytes(ur6._h)   # same reduced chain width
+    # same reduced chain; the chain with the fixed flange also carries the buffer of the expanded 71 x 71 factor
+    assert L.rdyn_regressor_tsqr_workspace_bytes(ur7._h) >= L.rdyn_regressor_tsqr_workspace_bytes(ur6._h) + 71 * 71 * 8
     six = ComponentSet([dict(type=FRICTION1, joint=j, min_velocity=1e-3, max_velocity=5.0, parameters=[1.0, 1.0]) for j in range(6)], 6)
     arr = C.cast(six._arr, C.c_void_p)
     w6 = L.rdyn_identification_tsqr_workspace_bytes(ur6._h, arr, six.n_comps)
     assert w6 > 0                                                                        # one more 16-column slot: 80 x 80 factors
-    assert L.rdyn_identification_tsqr_workspace_bytes(ur7._h, arr, six.n_comps) == 0     # components: chains of at most 6 joints
+    # round 4: component columns ride through the reduction (they belong to input joints): fixed frames no longer exclude them
+    assert L.rdyn_identification_tsqr_workspace_bytes(ur7._h, arr, six.n_comps) >= w6
     assert L.rdyn_identification_tsqr_workspace_bytes(ur6._h, None, 0) == L.rdyn_regressor_tsqr_workspace_bytes(ur6._h)
     many = ComponentSet([dict(type=FRICTION2, joint=j % 6, min_velocity=1e-3, max_velocity=5.0, parameters=[1.0, 1.0, 0.1]) for j in range(7)], 6)
-    assert many.columns == 21                                                            # 61 + 21 > 80: does not fit the extra slot
-    assert L.rdyn_identification_tsqr_workspace_bytes(ur6._h, C.cast(many._arr, C.c_void_p), many.n_comps) == 0
+    assert many.columns == 21                                                            # 61 + 21 > 80: beyond the extra 16-column slot ...
+    assert L.rdyn_identification_tsqr_workspace_bytes(ur6._h, C.cast(many._arr, C.c_void_p), many.n_comps) > 0   # ... the LDS-resident folds take it
+    toomany = ComponentSet([dict(type=FRICTION1, joint=j % 6, min_velocity=1e-3, max_velocity=5.0, parameters=[1.0, 1.0]) for j in range(26)], 6)
+    assert toomany.columns == 52                                                         # 61 + 52 = 113 columns: nothing holds that factor
+    assert L.rdyn_identification_tsqr_workspace_bytes(ur6._h, C.cast(toomany._arr, C.c_void_p), toomany.n_comps) == 0
+    # a materialised matrix: up to 112 columns (right-hand side included)
+    assert L.rdyn_tsqr_workspace_bytes(64) > 0 and L.rdyn_tsqr_workspace_bytes(112) > 0 and L.rdyn_tsqr_workspace_bytes(113) == 0
 
 
 @pytest.mark.parametrize("name", ["ur10_tool0", "mixed"])

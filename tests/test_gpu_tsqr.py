@@ -115,7 +115,8 @@ def test_accumulate_and_host_combine_equal_one_shot():
     assert np.array_equal(full, again)
 
 
-@pytest.mark.parametrize("urdf,base,tool", [("ur10_like.urdf", "base_link", "wrist_3_link"), ("mixed_joints.urdf", "world", "slider"), ("panda_like.urdf", "link0", "link5")], ids=["ur10_6", "mixed", "panda5"])
+@pytest.mark.parametrize("urdf,base,tool", [("ur10_like.urdf", "base_link", "wrist_3_link"), ("mixed_joints.urdf", "world", "slider"), ("panda_like.urdf", "link0", "link5"),
+                                            ("panda_like.urdf", "link0", "link7")], ids=["ur10_6", "mixed", "panda5", "panda7"])
 @pytest.mark.parametrize("N", [1, 33, 2000])
 def test_identification_tsqr_against_the_oracle_rows(urdf, base, tool, N):
     """[Y | C | tau_meas] with friction / spring columns folded straight into the R factor (rdyn_identification_tsqr): the factor
@@ -130,8 +131,6 @@ def test_identification_tsqr_against_the_oracle_rows(urdf, base, tool, N):
     path = os.path.join(FIXTURES, urdf)
     chain, ref = Chain(path, base, tool, GRAV), OracleChain(path, base, tool, GRAV)
     n, P = chain.getActiveJointsNumber(), 10 * chain.getJointsNumber()
-    if chain.getJointsNumber() > 6:
-        pytest.skip("identification TSQR: chains of at most 6 joints")
     q, dq, ddq = trajectory_batch(70 + N, N, n)
     # one component per joint, the three kinds mixed (K = 2, 3, 2, 2, 3, ... columns)
     kinds = [FRICTION1, FRICTION2, SPRING]
