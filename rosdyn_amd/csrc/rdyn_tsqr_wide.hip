@@ -6,14 +6,17 @@
 //   * [Y | C | tau_meas] of a 7-joint arm (friction_polynomial1.h:126, ideal_spring.h:64 columns beside getRegressor): 86 columns,
 //   * a caller's materialised matrix of up to 111 columns + right-hand side (what rdyn_gram already takes)
 // -- run here, with the factor in LDS: one workgroup keeps its running R PACKED in LDS (column j holds its j + 1 entries, 51 KB at
-// 112 columns) beside ONE row block and folds block after block into it, R <- qr([R ; block]), one barrier per column step, four
-// threads per column.  A block is
+// 112 columns) and folds row block after row block into it, R <- qr([R ; block]).  The BLOCK lives in registers, spread over the
+// workgroup: four threads per column, each holding a quarter of the column's rows (<= 32 doubles); a column step publishes column k
+// (1 KB) through LDS, every thread reads its quarter of it, forms its partial dot, the four quarters meet by two DPP shuffles and the
+// reflection is applied in registers: one barrier per step.  (The first version kept the block in LDS: 2.5 x rows x columns x 8 bytes
+// of LDS traffic per step = 3 us per step at 128 rows x 86 columns -- the LDS pipe of the CU, not the dependent chain, was the
+// bound; 26 ms for 1e6 rows x 112 columns.)  A block is
 //   k_regressor_tsqr_wide   the 16-sample tile the workgroup's first wave has just swept (the row-pair sweeper of rdyn_duo_gram.hip /
 //                           rdyn_tsqr.hip writing a RECTANGULAR tile: every column 16 n rows, the structural zeros stored), or
 //   k_tsqr_wide_rows        up to 128 rows of a column-major device matrix -- also the tree: the per-workgroup factors are folded
-//                           sixteen at a time as the rows of a stacked matrix, in a fixed order (bitwise reproducible).
-// A step is a dependent chain of ~900 cycles whatever the block holds (LDS round trips, one square root, one division): 86 steps per
-// 16-sample tile = 35 us, 40 ms for 4e6 samples of a 7-joint arm with 14 component columns.  This is the slow, unconditionally
+//                           four at a time as the rows of a stacked matrix, in a fixed order (bitwise reproducible).
+// A step is a dependent chain (LDS round trip, one square root, one division, 2 x 32 fmas) whatever the block holds.  This is the slow, unconditionally
 // robust route: small batches, and the STAND-BY of the preconditioned route of rdyn_cholqr.hip for the shapes rdyn_tsqr.hip does not
 // serve (the device starts it only when that route cannot vouch for its result).  fp64 VALU + LDS only.
 #include <hip/hip_runtime.h>
@@ -32,47 +35,97 @@ constexpr int NTW = 512;  // threads per workgroup: two waves per SIMD leave the
 
 __device__ __forceinline__ int tri_off(int j) { return j * (j + 1) / 2; }
 
-// R <- qr([R ; B]): R packed in LDS (Rp[tri_off(j) + i], i <= j), B = nrows x n1 column-major in LDS (leading dimension ldb doubles,
-// ldb = 4 mod 8: the four lanes of a column and the sixteen columns of a wave read disjoint banks).  B is destroyed.
-// Ends with a barrier.  Columns that are exactly zero (or rounding residue below 1e-140) in the block are passed.
-__device__ __forceinline__ void wide_fold(double* Rp, double* B, int ldb, int nrows, int n1, int tid)
+constexpr int RPT_MAX = 32;       // rows of a block per thread: blocks of at most 128 rows
+constexpr int PUB = 4 * RPT_MAX + 8;  // doubles of one publish buffer: the column + its sum of squares
+
+// sum over the four lanes of a quad, in every lane: two DPP quad_perm moves per step (no LDS crossbar)
+__device__ __forceinline__ double quad_sum(double x)
 {
-  const int lane = tid & 63;
+  {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), 0xB1, 0xF, 0xF, false);  // quad_perm [1, 0, 3, 2]
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), 0xB1, 0xF, 0xF, false);
+    x += __hiloint2double(hi, lo);
+  }
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), 0x4E, 0xF, 0xF, false);    // quad_perm [2, 3, 0, 1]
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), 0x4E, 0xF, 0xF, false);
+  return x + __hiloint2double(hi, lo);
+}
+
+// the four owner lanes of a column write it, and its sum of squares, into a publish buffer
+__device__ __forceinline__ void publish_column(double* pn, const double (&y)[RPT_MAX], int rpt, int q)
+{
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+#pragma unroll
+  for (int i = 0; i < RPT_MAX; i += 4)
+  {
+    if (i < rpt)  // rpt is a multiple of 4
+    {
+      pn[q * rpt + i] = y[i];
+      pn[q * rpt + i + 1] = y[i + 1];
+      pn[q * rpt + i + 2] = y[i + 2];
+      pn[q * rpt + i + 3] = y[i + 3];
+      s0 = fma(y[i], y[i], s0);
+      s1 = fma(y[i + 1], y[i + 1], s1);
+      s2 = fma(y[i + 2], y[i + 2], s2);
+      s3 = fma(y[i + 3], y[i + 3], s3);
+    }
+  }
+  const double sigma = quad_sum((s0 + s1) + (s2 + s3));
+  if (q == 0) pn[4 * RPT_MAX] = sigma;
+}
+
+// R <- qr([R ; block]).  R packed in LDS (Rp[tri_off(j) + i], i <= j).  The block: thread (j = tid >> 2, q = tid & 3) holds rows
+// q * rpt .. (q + 1) * rpt - 1 of column j in y[0 .. rpt) (rpt a multiple of 4; threads with j >= n1 hold nothing and only take part
+// in the barriers); which rows those are is irrelevant as long as every column uses the same partition.  pub: 2 * PUB doubles of LDS.
+// Column step k: the owners of column k have published it together with |y_k|^2 (no wave-wide reduction in the chain); every thread
+// reads its quarter, forms its partial dot in four independent chains, the quarters meet by DPP, the reflection is applied in
+// registers, the owners of column k + 1 publish: one barrier per step.
+// The block is destroyed.  Ends with a barrier.  A column that is exactly zero (or rounding residue below 1e-140) in the block is passed.
+__device__ __forceinline__ void wide_fold(double* Rp, double* pub, double (&y)[RPT_MAX], int rpt, int n1, int tid)
+{
+  const int j = tid >> 2, q = tid & 3;
+  if (j == 0) publish_column(pub, y, rpt, q);
+  __syncthreads();
   for (int k = 0; k < n1; ++k)
   {
-    const double* const bk = B + (size_t)k * ldb;
-    double sigma = 0.0;
-    for (int r = lane; r < nrows; r += 64) sigma = fma(bk[r], bk[r], sigma);
-    for (int o = 32; o > 0; o >>= 1) sigma += __shfl_xor(sigma, o);  // every wave: the same sum in the same order
+    const double* const pk = pub + (k & 1) * PUB;
+    const bool on = j > k && j < n1;
+    double* const rjk = Rp + tri_off(on ? j : k) + k;
+    const double rkj = *rjk;                      // R(k, j) (R(k, k) for the lanes that hold no column to the right)
+    const double sigma = pk[4 * RPT_MAX];
     const double alpha = Rp[tri_off(k) + k];
     double beta = alpha;
-    if (sigma > 1e-280)
+    if (sigma > 1e-280)  // workgroup-uniform
     {
       const double norm = sqrt(fma(alpha, alpha, sigma));
       beta = alpha > 0.0 ? -norm : norm;
       const double v0 = alpha - beta, scale = 2.0 / fma(v0, v0, sigma);
-      const int ncol = n1 - k - 1;
-      for (int e = tid; e < (ncol * 4 + NTW - 1) / NTW * NTW; e += NTW)
-      {
-        const bool on = e < ncol * 4;
-        const int j = on ? k + 1 + (e >> 2) : k, q = e & 3;
-        double* const bj = B + (size_t)j * ldb;
-        double* const rj = Rp + tri_off(j);
-        double d = (on && q == 0) ? v0 * rj[k] : 0.0;
-        if (on)
-          for (int r = q; r < nrows; r += 4) d = fma(bk[r], bj[r], d);
-        d += __shfl_xor(d, 1);
-        d += __shfl_xor(d, 2);
-        const double f = scale * d;
-        if (on)
+      double yk[RPT_MAX];
+      double d0 = (on && q == 0) ? v0 * rkj : 0.0, d1 = 0.0, d2 = 0.0, d3 = 0.0;
+#pragma unroll
+      for (int i = 0; i < RPT_MAX; i += 4)
+        if (i < rpt)
         {
-          if (q == 0) rj[k] = fma(-f, v0, rj[k]);
-          for (int r = q; r < nrows; r += 4) bj[r] = fma(-f, bk[r], bj[r]);
+          yk[i] = pk[q * rpt + i];
+          yk[i + 1] = pk[q * rpt + i + 1];
+          yk[i + 2] = pk[q * rpt + i + 2];
+          yk[i + 3] = pk[q * rpt + i + 3];
+          d0 = fma(yk[i], y[i], d0);
+          d1 = fma(yk[i + 1], y[i + 1], d1);
+          d2 = fma(yk[i + 2], y[i + 2], d2);
+          d3 = fma(yk[i + 3], y[i + 3], d3);
         }
-      }
+      const double d = quad_sum((d0 + d1) + (d2 + d3));
+      const double f = on ? scale * d : 0.0;
+      if (on && q == 0) *rjk = fma(-f, v0, rkj);
+#pragma unroll
+      for (int i = 0; i < RPT_MAX; ++i)
+        if (i < rpt) y[i] = fma(-f, yk[i], y[i]);
     }
+    // the next column goes out (into the buffer nobody has read since the barrier before last)
+    if (j == k + 1 && j < n1) publish_column(pub + ((k + 1) & 1) * PUB, y, rpt, q);
     __syncthreads();
-    if (tid == 0) Rp[tri_off(k) + k] = beta;
+    if (tid == 0) Rp[tri_off(k) + k] = beta;  // (behind the barrier: everybody has read alpha)
   }
   __syncthreads();
 }
@@ -100,8 +153,9 @@ __global__ __launch_bounds__(NTW) void k_regressor_tsqr_wide(const RdynLdsGramAr
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int tri = tri_off(n1);
   double* const Rp = (double*)lds_raw;
-  char* const tile = lds_raw + (((size_t)tri * 8 + 255) & ~(size_t)255);
-  const int n = fa.n_active, nrows = 16 * n, ldb = fa.lds_stride[0] / 8;
+  double* const pub = (double*)(lds_raw + (((size_t)tri * 8 + 255) & ~(size_t)255));
+  char* const tile = (char*)(pub + 2 * PUB);
+  const int n = fa.n_active, rpt = 4 * n, ldb = fa.lds_stride[0] / 8;  // 16 n rows: 4 n per thread
   for (int i = tid; i < tri; i += NTW) Rp[i] = 0.0;
   const int s_loc = lane >> 2, k = lane & 3;
   const int r0 = k, r1 = k + 4;
@@ -110,11 +164,12 @@ __global__ __launch_bounds__(NTW) void k_regressor_tsqr_wide(const RdynLdsGramAr
     if (fa.lds_m[f] >= 5) fB = f;
   const int64_t t_mul = fa.tile_stride > 1 ? fa.tile_stride : 1;
   const int64_t n_tiles = ((fa.n_samples + 15) / 16 + t_mul - 1) / t_mul;
+  // the structural zeros of the rectangular tile are written once: the sweep stores the same positions for every tile, and the fold
+  // works on a register copy
+  for (int i = tid; i < n1 * ldb; i += NTW) ((double*)tile)[i] = 0.0;
+  __syncthreads();
   for (int64_t tl = blockIdx.x; tl < n_tiles; tl += gridDim.x)
   {
-    // the fold fills the structural zeros of the previous tile: every tile starts from a zero block
-    for (int i = tid; i < n1 * ldb; i += NTW) ((double*)tile)[i] = 0.0;
-    __syncthreads();
     if (wave == 0)
     {
       int64_t sx = tl * t_mul * 16 + s_loc;
@@ -164,7 +219,14 @@ __global__ __launch_bounds__(NTW) void k_regressor_tsqr_wide(const RdynLdsGramAr
       }
     }
     __syncthreads();
-    wide_fold(Rp, (double*)tile, ldb, nrows, n1, tid);
+    double y[RPT_MAX];
+    {
+      const int j = tid >> 2, q = tid & 3;
+      const double* const col = (const double*)tile + (size_t)(j < n1 ? j : 0) * ldb + q * rpt;
+#pragma unroll
+      for (int i = 0; i < RPT_MAX; ++i) y[i] = (i < rpt && j < n1) ? col[i] : 0.0;
+    }
+    wide_fold(Rp, pub, y, rpt, n1, tid);
   }
   __syncthreads();
   store_packed_factor(Rp, factors + (int64_t)blockIdx.x * ((int64_t)n1 * n1), n1, tid);
@@ -176,55 +238,58 @@ __global__ __launch_bounds__(NTW) void k_regressor_tsqr_wide(const RdynLdsGramAr
 // [w * rows_per_wg, (w + 1) * rows_per_wg) in blocks of rb rows and writes its factor to out + w * n1 * n1; workgroup 0 also folds
 // `extra` (an n1 x n1 upper-triangular factor, column-major: the caller's running factor when accumulating), last.
 __global__ __launch_bounds__(NTW) void k_tsqr_wide_rows(const double* __restrict__ A, const double* __restrict__ b, int64_t rows, int64_t lda, int n_cols,
-                                                        int seg_rows, int64_t seg_stride, int rb, int64_t rows_per_wg, double* __restrict__ out,
+                                                        int seg_rows, int64_t seg_stride, int64_t rows_per_wg, double* __restrict__ out,
                                                         const double* __restrict__ extra, const int* __restrict__ run_flag)
 {
+  constexpr int RB = 4 * RPT_MAX;  // rows per block
   if (run_flag && *run_flag == 0) return;
   extern __shared__ __attribute__((aligned(32))) char lds_raw[];
-  const int tid = threadIdx.x;
-  const int n1 = n_cols + (b ? 1 : 0), tri = tri_off(n1), ldb = rb + 4;
+  const int tid = threadIdx.x, j = tid >> 2, q = tid & 3;
+  const int n1 = n_cols + (b ? 1 : 0), tri = tri_off(n1);
   double* const Rp = (double*)lds_raw;
-  double* const B = (double*)(lds_raw + (((size_t)tri * 8 + 255) & ~(size_t)255));
+  double* const pub = (double*)(lds_raw + (((size_t)tri * 8 + 255) & ~(size_t)255));
   for (int i = tid; i < tri; i += NTW) Rp[i] = 0.0;
   const int64_t row_lo = (int64_t)blockIdx.x * rows_per_wg;
   const int64_t row_hi = row_lo + rows_per_wg < rows ? row_lo + rows_per_wg : rows;
   __syncthreads();
-  for (int64_t r0 = row_lo; r0 < row_hi; r0 += rb)
+  for (int64_t r0 = row_lo; r0 < row_hi; r0 += RB)
   {
-    const int cnt = (int)(row_hi - r0 < rb ? row_hi - r0 : rb);
-    for (int e = tid; e < n1 * rb; e += NTW)
+    // my quarter of column j: rows r0 + q * 32 .. + 31 (256 contiguous bytes of a column-major matrix)
+    double y[RPT_MAX];
+    const int64_t g0 = r0 + q * RPT_MAX;
+#pragma unroll
+    for (int i = 0; i < RPT_MAX; ++i)
     {
-      const int col = e / rb, r = e - col * rb;
+      const int64_t gr = g0 + i;
       double v = 0.0;
-      if (r < cnt)
+      if (j < n1 && gr < row_hi)
       {
-        const int64_t gr = r0 + r;
-        if (col >= n_cols)
+        if (j >= n_cols)
           v = b[gr];
         else if (seg_rows > 0)
         {
           const int64_t g = gr / seg_rows;
-          v = A[g * seg_stride + (int64_t)col * lda + (gr - g * seg_rows)];
+          v = A[g * seg_stride + (int64_t)j * lda + (gr - g * seg_rows)];
         }
         else
-          v = A[(int64_t)col * lda + gr];
+          v = A[(int64_t)j * lda + gr];
       }
-      B[(size_t)col * ldb + r] = v;
+      y[i] = v;
     }
-    __syncthreads();
-    wide_fold(Rp, B, ldb, rb, n1, tid);
+    wide_fold(Rp, pub, y, RPT_MAX, n1, tid);
   }
   if (extra && blockIdx.x == 0)
   {
-    for (int r0 = 0; r0 < n1; r0 += rb)
+    for (int r0 = 0; r0 < n1; r0 += RB)
     {
-      for (int e = tid; e < n1 * rb; e += NTW)
+      double y[RPT_MAX];
+#pragma unroll
+      for (int i = 0; i < RPT_MAX; ++i)
       {
-        const int col = e / rb, r = e - col * rb, gr = r0 + r;
-        B[(size_t)col * ldb + r] = (gr < n1 && gr <= col) ? extra[(int64_t)col * n1 + gr] : 0.0;
+        const int gr = r0 + q * RPT_MAX + i;
+        y[i] = (j < n1 && gr < n1 && gr <= j) ? extra[(int64_t)j * n1 + gr] : 0.0;
       }
-      __syncthreads();
-      wide_fold(Rp, B, ldb, rb, n1, tid);
+      wide_fold(Rp, pub, y, RPT_MAX, n1, tid);
     }
   }
   __syncthreads();
@@ -248,38 +313,28 @@ hipError_t opt_in(const void* kernel, std::atomic<uint64_t>& done)
 
 constexpr size_t kWideLdsBudget = 158 * 1024;
 size_t tri_bytes(int n1) { return (((size_t)n1 * (n1 + 1) / 2) * 8 + 255) & ~(size_t)255; }
+constexpr size_t kPubBytes = 2 * PUB * 8;
+constexpr int kRowsPerBlock = 4 * RPT_MAX;
 
-// rows per block of k_tsqr_wide_rows: what fits beside the packed factor, a multiple of 4, at most 128 (0: does not fit)
-int wide_rows_per_block(int n1)
-{
-  const size_t left = kWideLdsBudget - tri_bytes(n1);
-  int rb = (int)(left / ((size_t)n1 * 8)) - 4;
-  rb &= ~3;
-  if (rb > 128) rb = 128;
-  return rb >= 16 ? rb : 0;
-}
-
-// count factors (n1 x n1, column-major, contiguous) at `in` -> R, sixteen per workgroup and level; scratch: room for 16 factors
+// count factors (n1 x n1, column-major, contiguous) at `in` -> R, four per workgroup and level; scratch: room for 64 + 16 + 4 factors
 hipError_t wide_tree(const double* in, int count, double* scratch, double* R, int n1, const double* extra, const int* run_flag, hipStream_t st)
 {
   static std::atomic<uint64_t> attr{0};
   hipError_t e = opt_in((const void*)k_tsqr_wide_rows, attr);
   if (e != hipSuccess) return e;
-  const int rb = wide_rows_per_block(n1);
-  if (rb == 0) return hipErrorInvalidValue;
-  const size_t lds = tri_bytes(n1) + (size_t)n1 * (rb + 4) * 8;
-  const int fan = 16;
+  const size_t lds = tri_bytes(n1) + kPubBytes;
+  const int fan = 4;  // 256 leaves: four levels of at most 448 rows (3.5 blocks) each; a 16 : 1 tree folds 2 x 14 blocks
   while (true)
   {
     const int nout = (count + fan - 1) / fan;
     const bool last = nout <= 1;
     hipLaunchKernelGGL(k_tsqr_wide_rows, dim3(last ? 1 : nout), dim3(NTW), lds, st, in, (const double*)nullptr, (int64_t)count * n1, (int64_t)n1, n1, n1,
-                       (int64_t)n1 * n1, rb, (int64_t)fan * n1, last ? R : scratch, last ? extra : (const double*)nullptr, run_flag);
+                       (int64_t)n1 * n1, (int64_t)fan * n1, last ? R : scratch, last ? extra : (const double*)nullptr, run_flag);
     e = hipGetLastError();
     if (e != hipSuccess || last) return e;
     in = scratch;
     count = nout;
-    scratch = scratch + (size_t)nout * n1 * n1;  // (256 leaves -> 16 -> 1: the second level reads what the first wrote, writes R)
+    scratch = scratch + (size_t)nout * n1 * n1;  // (256 leaves -> 64 -> 16 -> 4 -> R)
   }
 }
 }  // namespace
@@ -291,12 +346,12 @@ int rdyn_tsqr_wide_max_cols() { return 112; }
 size_t rdyn_regressor_tsqr_wide_lds_bytes(int n1, int n_active)
 {
   if (n1 < 1 || n1 > rdyn_tsqr_wide_max_cols() || n_active < 1 || n_active > 8) return 0;
-  const size_t bytes = tri_bytes(n1) + (size_t)n1 * (16 * n_active + 4) * 8;
+  const size_t bytes = tri_bytes(n1) + kPubBytes + (size_t)n1 * (16 * n_active + 4) * 8;
   return bytes <= kWideLdsBudget ? bytes : 0;
 }
 
 // doubles of workspace: the leaves' factors + the tree's intermediate level
-size_t rdyn_tsqr_wide_workspace_doubles(int n1, int blocks) { return (size_t)(blocks + 17) * n1 * n1; }
+size_t rdyn_tsqr_wide_workspace_doubles(int n1, int blocks) { return (size_t)(blocks + (blocks + 3) / 4 + (blocks + 15) / 16 + (blocks + 63) / 64 + 4) * n1 * n1; }
 
 hipError_t rdyn_launch_regressor_tsqr_wide(int n_joints, const RdynLdsGramArgs& a, int blocks, double* workspace, double* R, int accumulate, hipStream_t st)
 {
@@ -316,8 +371,8 @@ hipError_t rdyn_launch_tsqr_wide_rows(const double* A, const double* b, int64_t 
                                       int accumulate, const int* run_flag, hipStream_t st)
 {
   const int n1 = n_cols + (b ? 1 : 0);
-  const int rb = wide_rows_per_block(n1);
-  if (n1 < 1 || n1 > rdyn_tsqr_wide_max_cols() || rb == 0 || blocks < 1) return hipErrorInvalidValue;
+  const int rb = kRowsPerBlock;
+  if (n1 < 1 || n1 > rdyn_tsqr_wide_max_cols() || blocks < 1) return hipErrorInvalidValue;
   static std::atomic<uint64_t> attr{0};
   hipError_t e = opt_in((const void*)k_tsqr_wide_rows, attr);
   if (e != hipSuccess) return e;
@@ -325,7 +380,7 @@ hipError_t rdyn_launch_tsqr_wide_rows(const double* A, const double* b, int64_t 
   const int64_t n_blk = (rows + rb - 1) / rb;
   const int64_t per = (n_blk + blocks - 1) / blocks;
   const int used = (int)((n_blk + per - 1) / per);
-  hipLaunchKernelGGL(k_tsqr_wide_rows, dim3(used), dim3(NTW), tri_bytes(n1) + (size_t)n1 * (rb + 4) * 8, st, A, b, rows, lda, n_cols, 0, (int64_t)0, rb, per * rb,
+  hipLaunchKernelGGL(k_tsqr_wide_rows, dim3(used), dim3(NTW), tri_bytes(n1) + kPubBytes, st, A, b, rows, lda, n_cols, 0, (int64_t)0, per * rb,
                      workspace, (const double*)nullptr, run_flag);
   e = hipGetLastError();
   if (e != hipSuccess) return e;

@@ -60,6 +60,33 @@ row("ur10_public base_link->tool0: getRegressor + tau (images)", lambda: pub.get
 row("ur10_public base_link->tool0: regressor -> Gram (P = 90)", lambda: pub.getRegressorGram(q, dq, ddq, tau, layout=E), 192)
 row("ur10_public base_link->tool0: R factor of [A | tau]", lambda: pub.getRegressorTsqr(q, dq, ddq, tau, layout=E), 192, reps=5)
 
+# round 4: the identification step's R factor on the reference's own chains (friction columns beside getRegressor), and rdyn_tsqr on
+# materialised matrices beyond 64 columns
+from rosdyn_amd.gram import tsqr            # noqa: E402
+comps_pub = ComponentSet([dict(type=j % 3, joint=j, min_velocity=1e-3, max_velocity=10.0, parameters=[0.1, 0.2, 0.01][:3 if j % 3 == 1 else 2]) for j in range(6)], 6)
+row("ur10_public base_link->tool0: identification R factor, 6 mixed comps", lambda: pub.getIdentificationTsqr(comps_pub, q, dq, ddq, tau, layout=E), 192, reps=5)
+row("ur10_public base_link->tool0: identification Gram, 6 mixed comps", lambda: pub.getIdentificationGram(comps_pub, q, dq, ddq, tau, layout=E), 192, reps=5)
+n7 = 7
+q7, dq7, ddq7 = (torch.rand((n7, N), dtype=torch.float64, device="cuda") * 2 - 1 for _ in range(3))
+comps7 = ComponentSet([dict(type=0, joint=j, min_velocity=1e-3, max_velocity=10.0, parameters=[0.1, 0.2]) for j in range(n7)], n7)
+for tool in ("link7", "hand"):
+    pa = Chain(os.path.join(ROOT, "tests/fixtures/panda_like.urdf"), "link0", tool, (0, 0, -9.806))
+    tau7 = pa.getJointTorque(q7, dq7, ddq7, layout=E)
+    row("panda link0->%s: regressor -> Gram" % tool, lambda: pa.getRegressorGram(q7, dq7, ddq7, tau7, layout=E), 224, reps=5)
+    row("panda link0->%s: R factor of [A | tau]" % tool, lambda: pa.getRegressorTsqr(q7, dq7, ddq7, tau7, layout=E), 224, reps=5)
+    row("panda link0->%s: identification Gram, 7 friction comps" % tool, lambda: pa.getIdentificationGram(comps7, q7, dq7, ddq7, tau7, layout=E), 224, reps=5)
+    row("panda link0->%s: identification R factor, 7 friction comps" % tool, lambda: pa.getIdentificationTsqr(comps7, q7, dq7, ddq7, tau7, layout=E), 224, reps=5)
+    if tool == "link7":
+        small = [t[:, :2000].contiguous() for t in (q7, dq7, ddq7, tau7)]
+        t = timeit(lambda: pa.getIdentificationTsqr(comps7, *small, layout=E), reps=5, warm=2)
+        rows.append(("panda link0->link7: identification R factor, N = 2 000 (LDS-resident folds)", t * 1e6, 2000 / t, 224, 224 * 2000 / t / 1e9))
+for rws, cols in ((6000000, 60), (6000000, 85), (1000000, 111)):
+    Am = torch.rand((cols, rws), dtype=torch.float64, device="cuda")
+    bm = torch.rand((rws,), dtype=torch.float64, device="cuda")
+    t = timeit(lambda: tsqr(Am, bm), reps=3, warm=1)
+    rows.append(("rdyn_tsqr: %d rows x (%d + 1) columns from memory" % (rws, cols), t * 1e6, rws / t, 8 * (cols + 1), 8 * (cols + 1) * rws / t / 1e9))
+    del Am, bm
+
 print("%-60s %10s %14s %10s %10s" % ("entry point (N = 1e6 per call)", "us / call", "evals/s", "B / eval", "GB/s"))
 for r in rows:
     print("%-60s %10.1f %14.3e %10d %10.0f" % r)
