@@ -24,6 +24,9 @@ Beside `value` the line carries
   * "config4_library": the same exchange through the library's own multi-device path (rdyn_regressor_gram_multi: one process,
     ncclCommInitAll over the N devices, one stream per device, one grouped ncclAllReduce) -- measured by a child process
     `bench.py --single-process --gpus N` that rank 0 starts after the torch.distributed legs are done and torn down;
+  * "config3_sharded" / "config5_sharded" (N > 1 only): configs[2]'s robust R factor with every rank's 4e6-sample shard factored on
+    its GPU, ONE all-gather of the (P + 1)^2 factors and the fold of the stack on every rank (SURVEY 8(e), the TSQR alternative);
+    configs[4]'s 256 chains split 256 / N per rank (no collective) -- both timed like the headline (barrier, max over ranks);
   * "extras" (rank 0's GPU, outside every timed region of the headline): configs[2] (7-DOF, N = 4e6, Gram) and configs[4]
     (256 distinct chains x 4 096 samples) once each with their own roofline blocks;
   * "cpu_baseline": the C oracle on rank 0's host cores (every line, also for N > 1).
@@ -34,7 +37,8 @@ Beside `value` the line carries
       (before anything touches the GPU), relays rank 0's JSON line and exits with the child's return code.
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...      (what the driver runs)
   python bench.py --gpus 2 --backend gloo --dry     launcher / process-group / all-reduce plumbing only, no GPU (CPU tests)
-  python bench.py --single-process --gpus N         configs[3] through the library's in-process RCCL path only (one JSON line)
+  python bench.py --single-process --gpus N         configs[3], configs[2]'s R factor and configs[4] through the library's in-process
+                                                    multi-device paths only (one process, one JSON line)
 
 Prints ONE JSON line on rank 0.
 """
@@ -250,10 +254,22 @@ def config4_library(n_dev, N, steps, warmup):
                          "frac": tf / (FP64_MATRIX_PEAK_TFLOPS * n_dev), "flop_per_eval_dense_syrk": f_eval}}
 
 
-def config4_library_child(n_dev, N, steps, timeout_s=240):
+def wait_for_exit(pids, timeout_s):
+    """True once none of the processes `pids` exists any more (they are siblings, not children: /proc is polled)."""
+    t_end = time.time() + timeout_s
+    while time.time() < t_end:
+        if not any(os.path.exists("/proc/%d" % p) for p in pids):
+            return True
+        time.sleep(0.05)
+    return not any(os.path.exists("/proc/%d" % p) for p in pids)
+
+
+def config4_library_child(n_dev, N, steps, timeout_s=400, no_extras=False):
     """Runs config4_library in a CHILD process (`bench.py --single-process`): a fresh process owns all n_dev devices and its own RCCL
     communicator, and a failure or hang there cannot take the bench line with it."""
     cmd = [sys.executable, os.path.abspath(__file__), "--single-process", "--gpus", str(n_dev), "--samples", str(N), "--steps", str(steps)]
+    if no_extras:
+        cmd.append("--no-extras")
     env = dict(os.environ)
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "GROUP_RANK", "LOCAL_WORLD_SIZE", "ROLE_RANK", "TORCHELASTIC_RUN_ID"):
         env.pop(k, None)
@@ -266,6 +282,153 @@ def config4_library_child(n_dev, N, steps, timeout_s=240):
     if p.returncode != 0 or not lines:
         return {"error": "child rc %d: %s" % (p.returncode, p.stderr[-400:])}
     return json.loads(lines[-1])
+
+
+def config3_sharded(world, rank, dist, dev, N=4000000, steps=4):
+    """BASELINE.json configs[2] over the ranks (weak: N per rank): every rank the robust R factor of [A | tau] of ITS shard
+    (rdyn_regressor_tsqr: preconditioned CholeskyQR on the matrix cores), ONE all-gather of the (P + 1)^2 factors and the fold of the
+    stack on every rank -- the R-factor counterpart of config4's all-reduce."""
+    import torch
+    from rosdyn_amd import Chain
+    from rosdyn_amd._lib import lib
+    from rosdyn_amd.gram import allgather_fold_r_factors
+    chain = Chain(os.path.join(ROOT, "tests", "fixtures", "panda_like.urdf"), "link0", "link7", GRAVITY)
+    n, P = chain.getActiveJointsNumber(), 10 * chain.getJointsNumber()
+    gen = torch.Generator(device=dev).manual_seed(0x5EED0003 + rank)
+    q, dq, ddq, tau = (torch.rand((N, n), dtype=torch.float64, device=dev, generator=gen) * 2 - 1 for _ in range(4))
+    ws = torch.empty((lib().rdyn_regressor_tsqr_workspace_bytes(chain._h),), dtype=torch.uint8, device=dev)
+    d = dist if world > 1 else None
+    state = {}
+
+    def factor_only():
+        state["R"] = chain.getRegressorTsqr(q, dq, ddq, tau, workspace=ws)
+
+    def step():
+        factor_only()
+        state["Rall"] = allgather_fold_r_factors(state["R"], d, device_fold=True)
+
+    def exchange_only():
+        allgather_fold_r_factors(state["R"], d, device_fold=True)
+
+    wall, _ = time_region(step, steps, 1, world, dist, dev)
+    _, f_ms = time_region(factor_only, steps, 1, world, dist, dev)
+    x_wall, _ = time_region(exchange_only, 10, 2, world, dist, dev)
+    Rall = state["Rall"]
+    # every rank must hold the same factor: the max over ranks of |R - R of rank 0|
+    ref = Rall.clone()
+    if world > 1:
+        dist.broadcast(ref, src=0)
+    agree = max_over_ranks(float((Rall - ref).abs().max().item()), d, dev) == 0.0
+    qr_flop = 2.0 * n * N * (P + 1) ** 2
+    tf = qr_flop / (f_ms / steps * 1e-3) / 1e12
+    return {"workload": "configs[2] sharded: 7-DOF panda_like link0->link7 (n=7, P=70), %d samples per GPU x %d GPUs, R factor of [A | tau] per rank "
+                        "+ one all-gather of %d doubles per rank + the fold of the stack on every rank" % (N, world, (P + 1) ** 2),
+            "value": N * world * steps / wall, "unit": "evals/s", "ms_per_step": wall / steps * 1e3, "factor_ms_per_rank": f_ms / steps,
+            "gather_and_fold_us": x_wall / 10 * 1e6, "all_ranks_agree_bitwise": agree, "scaling": "weak",
+            "backend": "torch.distributed nccl(RCCL)" if world > 1 else "none (1 rank)",
+            "roofline": {"bound": "fp64-matrix", "achieved": tf, "peak": FP64_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP64_MATRIX_PEAK_TFLOPS,
+                         "flop_dense_householder_per_rank": qr_flop, "kernel_ms": f_ms / steps}}
+
+
+def config5_sharded(world, rank, dist, dev, steps=10, n_chains=256, S=4096):
+    """BASELINE.json configs[4] split over the ranks as SURVEY.md section 8(e) says (256 / N chains per GPU, strong scaling: the 256
+    chains are the job): every rank one plan over ITS chains, no collective."""
+    import torch
+    from rosdyn_amd import Chain
+    from rosdyn_amd.multi import MultiChainRegressor
+    from rosdyn_amd.urdf_gen import mixed_chain_set
+    sizes = shard_sizes(n_chains, world)
+    lo = sum(sizes[:rank])
+    mine = mixed_chain_set(os.path.join(ROOT, "tests", "fixtures"), n_chains)[lo:lo + sizes[rank]]
+    items, nbytes = [], 0
+    gen = torch.Generator(device=dev).manual_seed(0x5EED0005 + rank)
+    for xml, base, tool in mine:
+        c = Chain(xml, base, tool, GRAVITY)
+        n, P = c.getActiveJointsNumber(), 10 * c.getJointsNumber()
+        q, dq, ddq = (torch.rand((n, S), dtype=torch.float64, device=dev, generator=gen) * 2 - 1 for _ in range(3))
+        items.append((c, q, dq, ddq))
+        nbytes += S * algorithmic_bytes_per_eval(n, P)
+    plan = MultiChainRegressor(items, y_layout="stacked")
+    wall, dev_ms = time_region(plan.run, steps, 2, world, dist, dev)
+    total_bytes = nbytes
+    if world > 1:
+        t = torch.tensor([float(nbytes)], dtype=torch.float64, device=dev)
+        dist.all_reduce(t)
+        total_bytes = float(t.item())
+    gbps = total_bytes / (wall / steps) / 1e9
+    return {"workload": "configs[4] sharded: %d distinct 6-/7-DOF chains x %d samples split %s chains per rank over %d GPUs, stacked matrices, no collective"
+                        % (n_chains, S, "/".join(str(x) for x in sorted(set(sizes), reverse=True)), world),
+            "value": n_chains * S * steps / wall, "unit": "evals/s", "ms_per_step": wall / steps * 1e3, "kernel_ms_slowest_rank": dev_ms / steps,
+            "scaling": "strong", "chains_per_rank": sizes,
+            "roofline": {"bound": "hbm", "achieved": gbps, "peak": HBM_PEAK_GBPS * world, "unit": "GB/s", "frac": gbps / (HBM_PEAK_GBPS * world),
+                         "algorithmic_bytes_per_step": total_bytes}}
+
+
+def library_multi_legs(n_dev, steps=4, N3=4000000, n_chains=256, S=4096):
+    """--single-process: the other two multi-device legs through the library alone -- configs[2]'s R factor with
+    rdyn_regressor_tsqr_multi (factor per device, ONE grouped ncclAllGather, the fold on every device) and configs[4] with one plan per
+    device launched from the one process (no collective)."""
+    import torch
+    from rosdyn_amd import Chain
+    from rosdyn_amd.gram import MultiGpuGram
+    from rosdyn_amd.multi import MultiChainRegressor
+    from rosdyn_amd.urdf_gen import mixed_chain_set
+    out = {}
+    chain = Chain(os.path.join(ROOT, "tests", "fixtures", "panda_like.urdf"), "link0", "link7", GRAVITY)
+    n, P = chain.getActiveJointsNumber(), 10 * chain.getJointsNumber()
+    shards = []
+    for d in range(n_dev):
+        dev = torch.device("cuda", d)
+        gen = torch.Generator(device=dev).manual_seed(0x5EED0003 + d)
+        shards.append(tuple(torch.rand((N3, n), dtype=torch.float64, device=dev, generator=gen) * 2 - 1 for _ in range(4)))
+    ctx = MultiGpuGram(list(range(n_dev)))
+    R = ctx.identification_tsqr(chain, shards)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        R = ctx.identification_tsqr(chain, shards, sync=False)
+    ctx.synchronize()
+    wall = time.perf_counter() - t0
+    same = all(bool(torch.equal(R[0].cpu(), r.cpu())) for r in R[1:])
+    out["config3_library"] = {"workload": "configs[2] in the library: %d samples per GPU x %d GPUs in ONE process, rdyn_regressor_tsqr_multi (R factor per device + one "
+                                          "grouped ncclAllGather of %d doubles + the fold on every device)" % (N3, n_dev, (P + 1) ** 2),
+                              "value": N3 * n_dev * steps / wall, "unit": "evals/s", "ms_per_step": wall / steps * 1e3, "all_devices_agree_bitwise": same}
+    del shards, R, ctx
+    torch.cuda.empty_cache()
+    sizes = shard_sizes(n_chains, n_dev)
+    all_items = mixed_chain_set(os.path.join(ROOT, "tests", "fixtures"), n_chains)
+    plans, lo = [], 0
+    for d in range(n_dev):
+        dev = torch.device("cuda", d)
+        gen = torch.Generator(device=dev).manual_seed(0x5EED0005 + d)
+        items = []
+        for xml, base, tool in all_items[lo:lo + sizes[d]]:
+            c = Chain(xml, base, tool, GRAVITY)
+            nn = c.getActiveJointsNumber()
+            items.append((c,) + tuple(torch.rand((nn, S), dtype=torch.float64, device=dev, generator=gen) * 2 - 1 for _ in range(3)))
+        lo += sizes[d]
+        with torch.cuda.device(dev):
+            plans.append(MultiChainRegressor(items, y_layout="stacked"))
+
+    def run_all():
+        for d, pl in enumerate(plans):
+            with torch.cuda.device(d):
+                pl.run()
+
+    def sync_all():
+        for d in range(n_dev):
+            torch.cuda.synchronize(d)
+
+    run_all()
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(steps * 3):
+        run_all()
+    sync_all()
+    wall = time.perf_counter() - t0
+    out["config5_library"] = {"workload": "configs[4] in ONE process: %d chains x %d samples, one plan per device (%s chains each), no collective"
+                                          % (n_chains, S, "/".join(str(x) for x in sorted(set(sizes), reverse=True))),
+                              "value": n_chains * S * steps * 3 / wall, "unit": "evals/s", "ms_per_step": wall / (steps * 3) * 1e3}
+    return out
 
 
 def extras_config3(dev, steps=5):
@@ -473,13 +636,36 @@ def dry_run(args, world, rank):
     b = torch.rand((64,), dtype=torch.float64, generator=g)
     G, c, bb, count = allreduce_normal_equations(A.T @ A, A.T @ b, (b @ b).reshape(1), N, dist if world > 1 else None)
     seen = ranks_seen(dist if world > 1 else None, dev)
+    # the R-factor exchange of config3_sharded: every rank the factor of ITS rows, one all-gather, the fold of the stack (host fold here)
+    import numpy as np
+    from rosdyn_amd.gram import allgather_fold_r_factors
+    M = torch.cat([A, b[:, None]], dim=1).numpy()
+    Rr = torch.from_numpy(np.linalg.qr(M, mode="r"))
+    Rall = allgather_fold_r_factors(Rr, dist if world > 1 else None)
+    gram_all = torch.from_numpy(M.T @ M)
+    if world > 1:
+        dist.all_reduce(gram_all)
+    fold_err = float((Rall.T @ Rall - gram_all).abs().max() / gram_all.abs().max())
+    # config5_sharded's split of the 256 chains, and the process ids rank 0 waits on before it starts the library child
+    chains = shard_sizes(256, world)
+    mine = torch.tensor([float(chains[rank])], dtype=torch.float64)
+    pids = [os.getpid()]
+    if world > 1:
+        dist.all_reduce(mine)
+        pids = [None] * world
+        dist.all_gather_object(pids, os.getpid())
     out = {"metric": "RNEA+regressor evals/s (6-DOF, batch 1e6)", "value": None, "unit": "evals/s", "n_gpus": world, "dry": True,
            "backend": args.backend, "n_ranks_seen": seen, "samples_reduced": count, "gram_trace": float(torch.trace(G).item()),
-           "steps": args.steps, "warmup": args.warmup}
-    if rank == 0:
-        print(json.dumps(out))
+           "steps": args.steps, "warmup": args.warmup,
+           "legs": ["config4"] + (["config3_sharded", "config5_sharded"] if world > 1 and not args.no_extras else []),
+           "r_factor_gather_fold_rel_err": fold_err, "config5_chains_per_rank": chains, "config5_chains_total": int(mine.item()),
+           "distinct_pids": len(set(pids))}
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        out["other_ranks_exited"] = wait_for_exit([p for p in pids if p != os.getpid()], 30.0) if world > 1 else True
+        print(json.dumps(out))
     return 0
 
 
@@ -497,15 +683,20 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip the configs[2] / configs[4] legs after the timed region")
     ap.add_argument("--no-config4", action="store_true", help="skip the regressor -> Gram -> all-reduce block (configs[3])")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="process-group backend (gloo: --dry only)")
+    ap.add_argument("--sharded-legs", action="store_true", help="run config3_sharded / config5_sharded also with one rank (they run by themselves for N > 1)")
     ap.add_argument("--dry", action="store_true", help="no GPU work: launcher + process group + all-reduce plumbing (CPU tests)")
     args = ap.parse_args()
 
     if args.single_process:
         # one process, every device: the library's own communicator (nothing of torch.distributed is initialised)
         if args.dry:
-            print(json.dumps({"metric": "config4_library", "dry": True, "n_gpus": args.gpus, "steps": args.steps, "samples_per_gpu": args.samples}))
+            print(json.dumps({"metric": "config4_library", "dry": True, "n_gpus": args.gpus, "steps": args.steps, "samples_per_gpu": args.samples,
+                              "legs": ["config4_library"] + ([] if args.no_extras else ["config3_library", "config5_library"])}))
             sys.exit(0)
-        print(json.dumps(config4_library(args.gpus, args.samples, max(1, args.steps), 3)))
+        line = config4_library(args.gpus, args.samples, max(1, args.steps), 3)
+        if not args.no_extras:
+            line.update(guarded(library_multi_legs, args.gpus))
+        print(json.dumps(line))
         sys.exit(0)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args, sys.argv[1:]))   # before anything touches the GPU
@@ -590,14 +781,38 @@ def main():
                                          "frac": b_eval * N / (t_kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "probe_ms": placement["probe_ms"],
                                          "candidates": placement["candidates"], "chosen": placement["chosen"],
                                          "note": "same launch, same device, best of the probed output allocations; NOT the headline"}
+    def collective_leg(name, fn, *a):
+        """A secondary leg that holds collectives: not guarded per rank when world > 1 (a rank that swallowed an exception would leave
+        the others waiting inside the collective) -- but the headline measured above is not lost with it: rank 0 prints the line as
+        it stands, marked, before the error takes the job down."""
+        if world == 1:
+            out[name] = guarded(fn, *a)
+            return
+        try:
+            out[name] = fn(*a)
+        except Exception as e:   # noqa: BLE001
+            if rank == 0:
+                out[name] = {"error": repr(e)}
+                out["incomplete"] = "leg %s raised; the legs behind it were not run" % name
+                print(json.dumps(out))
+                sys.stdout.flush()
+            raise
+
     if not args.no_config4:
-        # measured torques of this rank's shard: tau of the evaluation just timed (noise-free: exact normal equations).
-        # NOT guarded per rank when world > 1: this leg holds collectives -- a rank that swallowed an exception here would leave
-        # the others waiting inside the all-reduce; an error must take the whole job down instead.
-        c4 = (config4_block, chain, q, dq, ddq, tau, in_layout, N, n, P, world, dist, dev, max(50, args.steps), 3)
-        out["config4"] = guarded(*c4) if world == 1 else c4[0](*c4[1:])
+        # measured torques of this rank's shard: tau of the evaluation just timed (noise-free: exact normal equations)
+        collective_leg("config4", config4_block, chain, q, dq, ddq, tau, in_layout, N, n, P, world, dist, dev, max(50, args.steps), 3)
     del Y
+    pids = [os.getpid()]
+    if (world > 1 or args.sharded_legs) and not args.no_extras:
+        del q, dq, ddq
+        torch.cuda.empty_cache()
+        collective_leg("config3_sharded", config3_sharded, world, rank, dist, dev)
+        torch.cuda.empty_cache()
+        collective_leg("config5_sharded", config5_sharded, world, rank, dist, dev)
+        q = dq = ddq = None
     if world > 1:
+        pids = [None] * world
+        dist.all_gather_object(pids, os.getpid())
         dist.barrier()
         dist.destroy_process_group()   # everything collective is done: the other ranks leave, rank 0 goes on alone
     if rank != 0:
@@ -609,7 +824,12 @@ def main():
                          "real_chains": guarded(extras_real_chains, dev)}
         torch.cuda.empty_cache()
     if not args.no_config4 and not args.no_library_config4:
-        out["config4_library"] = config4_library_child(world, N, max(50, args.steps))
+        # the child owns ALL devices with its own communicator: it starts only once the other ranks' processes are gone (a process that
+        # has exited has torn its GPU context down -- nothing of theirs is still being dismantled on the devices the child opens)
+        gone = wait_for_exit([p for p in pids if p != os.getpid()], 60.0)
+        out["config4_library"] = config4_library_child(world, N, max(50, args.steps), no_extras=args.no_extras)
+        if isinstance(out["config4_library"], dict):
+            out["config4_library"]["other_ranks_exited_before_start"] = gone
     if args.cpu_seconds > 0:
         out["cpu_baseline"] = guarded(cpu_baseline, urdf, base, tool, n, args.cpu_seconds)
     print(json.dumps(out))

@@ -360,6 +360,18 @@ int rdyn_multi_gpu_device_count(const rdyn_multi_gpu* ctx);
 int rdyn_multi_gpu_synchronize(rdyn_multi_gpu* ctx);
 int rdyn_regressor_gram_multi(rdyn_multi_gpu* ctx, const rdyn_chain* chain, const rdyn_batch* batches, const double* const* tau_meas,
                               double* const* acc);
+/* The R factor WITHOUT the normal equations over the devices of the context (the TSQR alternative):
+ * device i computes the robust factor of its shard (rdyn_identification_tsqr with all its routes; comps may be NULL / n_comps 0:
+ * rdyn_regressor_tsqr), ONE ncclAllGather moves the n1 x n1 factors (the payload of the Gram all-reduce), and every device folds
+ * the same stack in the same fixed order: on completion EVERY R1[i] (device i, n1 x n1 column-major, n1 = 10 joints_number + K + 1)
+ * holds the factor of all shards, bitwise identical on all devices.  accumulate != 0: R1[i] <- factor of [previous R1[i] ; all shards].
+ * Asynchronous like rdyn_regressor_gram_multi.  Both calls end by making batches[i].stream WAIT (on the device, by an event) for the
+ * collective: work queued on the caller's stream afterwards sees the results; a host-side read still needs a synchronisation
+ * (rdyn_multi_gpu_synchronize, or of that stream). */
+int rdyn_identification_tsqr_multi(rdyn_multi_gpu* ctx, const rdyn_chain* chain, const rdyn_component* comps, int n_comps,
+                                   const rdyn_batch* batches, const double* const* tau_meas, double* const* R1, int accumulate);
+int rdyn_regressor_tsqr_multi(rdyn_multi_gpu* ctx, const rdyn_chain* chain, const rdyn_batch* batches, const double* const* tau_meas,
+                              double* const* R1, int accumulate);
 
 /* ---- tall-skinny QR (rdyn_tsqr.hip): the R factor of [A | b] WITHOUT forming A'A -- BASELINE.json configs[2] "regressor + TSQR".
  * The Gram route squares the condition number; this one does not.  Every wave folds row blocks into a running upper-triangular

@@ -243,6 +243,7 @@ size_t rdyn_tsqr_wide_workspace_doubles(int n1, int blocks);
 hipError_t rdyn_launch_regressor_tsqr_wide(int n_joints, const RdynLdsGramArgs& a, int blocks, double* workspace, double* R, int accumulate, hipStream_t st);
 hipError_t rdyn_launch_tsqr_wide_rows(const double* A, const double* b, int64_t rows, int64_t lda, int n_cols, int blocks, double* workspace, double* R,
                                       int accumulate, const int* run_flag, hipStream_t st);
+hipError_t rdyn_launch_tsqr_fold_factors(const double* factors, int count, int64_t stride, int n1, double* scratch, double* R, int accumulate, hipStream_t st);
 int rdyn_gram_blocks_for(int P);
 hipError_t rdyn_launch_gram(const RdynGramArgs& a, int blocks, hipStream_t st);
 hipError_t rdyn_launch_gram_finish(const RdynGramArgs& a, int blocks, hipStream_t st);

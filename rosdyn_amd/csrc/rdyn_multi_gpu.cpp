@@ -7,6 +7,14 @@
 // RCCL is resolved at run time (dlopen of librccl.so.1) the first time a context is created: the library has no link-time
 // dependency on it, and a process that already carries an RCCL (PyTorch bundles one under the same SONAME) shares that copy.
 // Every ncclResult_t and hipError_t is checked.  No reference counterpart (rosdyn_core has no multi-device code).
+//
+// rdyn_identification_tsqr_multi / rdyn_regressor_tsqr_multi: the same sharding for the R factor without the normal equations
+// ("alternative for TSQR"): every device the robust factor of its shard (rdyn_identification_tsqr: the
+// preconditioned CholeskyQR route with its stand-by), ONE ncclAllGather of the n1 x n1 factors, and every device folds the stack of
+// factors in the same fixed order (rdyn_tsqr_wide.hip) -- the result is bitwise identical on all devices.
+//
+// Both calls end by ordering the CALLER's stream (batches[i].stream) behind the collective with an event: work queued there
+// afterwards sees the results, without a host synchronisation.
 #include <dlfcn.h>
 #include <cstring>
 #include <memory>
@@ -31,6 +39,7 @@ struct Rccl
   ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
   ncclResult_t (*AllReduce)(const void*, void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*AllGather)(const void*, void*, size_t, int, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*GroupStart)() = nullptr;
   ncclResult_t (*GroupEnd)() = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
@@ -55,10 +64,11 @@ int load_rccl()
   r.CommInitAll = (decltype(r.CommInitAll))dlsym(h, "ncclCommInitAll");
   r.CommDestroy = (decltype(r.CommDestroy))dlsym(h, "ncclCommDestroy");
   r.AllReduce = (decltype(r.AllReduce))dlsym(h, "ncclAllReduce");
+  r.AllGather = (decltype(r.AllGather))dlsym(h, "ncclAllGather");
   r.GroupStart = (decltype(r.GroupStart))dlsym(h, "ncclGroupStart");
   r.GroupEnd = (decltype(r.GroupEnd))dlsym(h, "ncclGroupEnd");
   r.GetErrorString = (decltype(r.GetErrorString))dlsym(h, "ncclGetErrorString");
-  if (!r.CommInitAll || !r.CommDestroy || !r.AllReduce || !r.GroupStart || !r.GroupEnd || !r.GetErrorString)
+  if (!r.CommInitAll || !r.CommDestroy || !r.AllReduce || !r.AllGather || !r.GroupStart || !r.GroupEnd || !r.GetErrorString)
   {
     rdyn_set_error("RCCL is missing an entry point (ncclCommInitAll / ncclAllReduce / ncclGroup*)");
     return RDYN_ERR_UNSUPPORTED;
@@ -98,6 +108,7 @@ struct rdyn_multi_gpu
   std::vector<void*> workspaces;
   std::vector<size_t> workspace_bytes;
   std::vector<hipEvent_t> events;  // per device: orders the context's stream behind the caller's stream (batches[i].stream)
+  std::vector<hipEvent_t> done;    // per device: orders the caller's stream behind the collective
   ~rdyn_multi_gpu()
   {
     int prev = 0;
@@ -110,10 +121,23 @@ struct rdyn_multi_gpu
       if (i < workspaces.size() && workspaces[i]) (void)hipFree(workspaces[i]);
       if (i < streams.size() && streams[i]) (void)hipStreamDestroy(streams[i]);
       if (i < events.size() && events[i]) (void)hipEventDestroy(events[i]);
+      if (i < done.size() && done[i]) (void)hipEventDestroy(done[i]);
     }
     (void)hipSetDevice(prev);
   }
 };
+
+// the results live on the context's (non-blocking) streams: every caller stream waits for its device's -- on the device, not the host
+static int order_callers_behind(rdyn_multi_gpu* ctx, const rdyn_batch* batches)
+{
+  for (size_t i = 0; i < ctx->devices.size(); ++i)
+  {
+    RDYN_HIP_TRY2(hipSetDevice(ctx->devices[i]));
+    RDYN_HIP_TRY2(hipEventRecord(ctx->done[i], ctx->streams[i]));
+    RDYN_HIP_TRY2(hipStreamWaitEvent((hipStream_t)batches[i].stream, ctx->done[i], 0));
+  }
+  return RDYN_OK;
+}
 
 extern "C"
 {
@@ -160,6 +184,7 @@ int rdyn_multi_gpu_create(const int* devices, int n_devices, rdyn_multi_gpu** ou
   std::unique_ptr<rdyn_multi_gpu> ctx(new rdyn_multi_gpu());
   ctx->devices.assign(devices, devices + n_devices);
   ctx->events.assign(n_devices, nullptr);
+  ctx->done.assign(n_devices, nullptr);
   ctx->comms.assign(n_devices, nullptr);
   ctx->streams.assign(n_devices, nullptr);
   ctx->workspaces.assign(n_devices, nullptr);
@@ -170,6 +195,7 @@ int rdyn_multi_gpu_create(const int* devices, int n_devices, rdyn_multi_gpu** ou
     RDYN_HIP_TRY2(hipSetDevice(devices[i]));
     RDYN_HIP_TRY2(hipStreamCreateWithFlags(&ctx->streams[i], hipStreamNonBlocking));
     RDYN_HIP_TRY2(hipEventCreateWithFlags(&ctx->events[i], hipEventDisableTiming));
+    RDYN_HIP_TRY2(hipEventCreateWithFlags(&ctx->done[i], hipEventDisableTiming));
   }
   *out = ctx.release();
   return RDYN_OK;
@@ -268,7 +294,101 @@ int rdyn_regressor_gram_multi(rdyn_multi_gpu* ctx, const rdyn_chain* chain, cons
     }
   }
   RDYN_NCCL_TRY(g_rccl.GroupEnd());
-  return RDYN_OK;
+  return order_callers_behind(ctx, batches);
+}
+
+int rdyn_identification_tsqr_multi(rdyn_multi_gpu* ctx, const rdyn_chain* chain, const rdyn_component* comps, int n_comps, const rdyn_batch* batches,
+                                   const double* const* tau_meas, double* const* R1, int accumulate)
+{
+  if (!ctx || !chain || !batches || !R1 || n_comps < 0 || (n_comps > 0 && !comps))
+  {
+    rdyn_set_error("rdyn_identification_tsqr_multi: null argument");
+    return RDYN_ERR_INVALID_ARGUMENT;
+  }
+  const int n_dev = (int)ctx->devices.size();
+  const int K = n_comps > 0 ? rdyn_components_columns(comps, n_comps) : 0;
+  const size_t ws_factor = rdyn_identification_tsqr_workspace_bytes(chain, comps, n_comps);
+  if (K < 0 || ws_factor == 0)
+  {
+    rdyn_set_error("rdyn_identification_tsqr_multi: the factor entry points do not serve this chain / these components");
+    return RDYN_ERR_UNSUPPORTED;
+  }
+  const int n1 = 10 * chain->n_joints() + K + 1;
+  if (n1 > rdyn_tsqr_wide_max_cols())
+  {
+    rdyn_set_error("rdyn_identification_tsqr_multi: at most %d columns (the fold of the gathered factors)", rdyn_tsqr_wide_max_cols());
+    return RDYN_ERR_UNSUPPORTED;
+  }
+  for (int i = 0; i < n_dev; ++i)
+  {
+    if (!R1[i] || (batches[i].device >= 0 && batches[i].device != ctx->devices[i]))
+    {
+      rdyn_set_error("rdyn_identification_tsqr_multi: shard %d: null factor, or batch.device differs from the context's device %d", i, ctx->devices[i]);
+      return RDYN_ERR_INVALID_ARGUMENT;
+    }
+  }
+  int prev = 0;
+  RDYN_HIP_TRY2(hipGetDevice(&prev));
+  struct Restore
+  {
+    int d;
+    ~Restore() { (void)hipSetDevice(d); }
+  } restore{prev};
+  // workspace of a device: [the factor call's | own factor n1^2 | gathered factors n_dev n1^2 | the fold's tree levels]
+  const size_t f_bytes = (((size_t)n1 * n1 * sizeof(double)) + 255) & ~(size_t)255;
+  const size_t off_own = (ws_factor + 255) & ~(size_t)255, off_gather = off_own + f_bytes, off_tree = off_gather + (size_t)n_dev * f_bytes;
+  const size_t need = off_tree + rdyn_tsqr_wide_workspace_doubles(n1, n_dev) * sizeof(double);
+  for (int i = 0; i < n_dev; ++i)
+  {
+    RDYN_HIP_TRY2(hipSetDevice(ctx->devices[i]));
+    if (ctx->workspace_bytes[i] < need)
+    {
+      // (a larger workspace replaces the old one only after what is queued on the context's stream has finished with it)
+      RDYN_HIP_TRY2(hipStreamSynchronize(ctx->streams[i]));
+      if (ctx->workspaces[i]) RDYN_HIP_TRY2(hipFree(ctx->workspaces[i]));
+      ctx->workspaces[i] = nullptr;
+      ctx->workspace_bytes[i] = 0;
+      RDYN_HIP_TRY2(hipMalloc(&ctx->workspaces[i], need));
+      ctx->workspace_bytes[i] = need;
+    }
+    RDYN_HIP_TRY2(hipEventRecord(ctx->events[i], (hipStream_t)batches[i].stream));
+    RDYN_HIP_TRY2(hipStreamWaitEvent(ctx->streams[i], ctx->events[i], 0));
+    rdyn_batch b = batches[i];
+    b.device = ctx->devices[i];
+    b.stream = ctx->streams[i];
+    char* const ws = (char*)ctx->workspaces[i];
+    int st = rdyn_identification_tsqr(chain, comps, n_comps, &b, tau_meas ? tau_meas[i] : nullptr, (double*)(ws + off_own), 0, ws, ws_factor);
+    if (st != RDYN_OK) return st;
+  }
+  // ---- ONE all-gather of the factors (n1 x n1 doubles each: the payload of the Gram all-reduce), all devices inside one group
+  RDYN_NCCL_TRY(g_rccl.GroupStart());
+  for (int i = 0; i < n_dev; ++i)
+  {
+    char* const ws = (char*)ctx->workspaces[i];
+    ncclResult_t r = g_rccl.AllGather(ws + off_own, ws + off_gather, f_bytes / sizeof(double), kNcclDouble, ctx->comms[i], ctx->streams[i]);
+    if (r != kNcclSuccess)
+    {
+      (void)g_rccl.GroupEnd();
+      rdyn_set_error("RCCL error: %s (ncclAllGather on device %d)", g_rccl.GetErrorString(r), ctx->devices[i]);
+      return RDYN_ERR_HIP;
+    }
+  }
+  RDYN_NCCL_TRY(g_rccl.GroupEnd());
+  // ---- every device folds the same stack in the same order: identical bits everywhere
+  for (int i = 0; i < n_dev; ++i)
+  {
+    RDYN_HIP_TRY2(hipSetDevice(ctx->devices[i]));
+    char* const ws = (char*)ctx->workspaces[i];
+    RDYN_HIP_TRY2(rdyn_launch_tsqr_fold_factors((const double*)(ws + off_gather), n_dev, (int64_t)(f_bytes / sizeof(double)), n1, (double*)(ws + off_tree), R1[i],
+                                                accumulate ? 1 : 0, ctx->streams[i]));
+  }
+  return order_callers_behind(ctx, batches);
+}
+
+int rdyn_regressor_tsqr_multi(rdyn_multi_gpu* ctx, const rdyn_chain* chain, const rdyn_batch* batches, const double* const* tau_meas, double* const* R1,
+                              int accumulate)
+{
+  return rdyn_identification_tsqr_multi(ctx, chain, nullptr, 0, batches, tau_meas, R1, accumulate);
 }
 
 }  // extern "C"

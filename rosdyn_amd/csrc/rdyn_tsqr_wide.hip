@@ -317,8 +317,10 @@ constexpr size_t kPubBytes = 2 * PUB * 8;
 constexpr int kRowsPerBlock = 4 * RPT_MAX;
 
 // count factors (n1 x n1, column-major, contiguous) at `in` -> R, four per workgroup and level; scratch: room for 64 + 16 + 4 factors
-hipError_t wide_tree(const double* in, int count, double* scratch, double* R, int n1, const double* extra, const int* run_flag, hipStream_t st)
+hipError_t wide_tree(const double* in, int count, double* scratch, double* R, int n1, const double* extra, const int* run_flag, hipStream_t st,
+                     int64_t in_stride = 0)
 {
+  int64_t stride = in_stride > 0 ? in_stride : (int64_t)n1 * n1;  // doubles between the factors of the first level
   static std::atomic<uint64_t> attr{0};
   hipError_t e = opt_in((const void*)k_tsqr_wide_rows, attr);
   if (e != hipSuccess) return e;
@@ -329,10 +331,11 @@ hipError_t wide_tree(const double* in, int count, double* scratch, double* R, in
     const int nout = (count + fan - 1) / fan;
     const bool last = nout <= 1;
     hipLaunchKernelGGL(k_tsqr_wide_rows, dim3(last ? 1 : nout), dim3(NTW), lds, st, in, (const double*)nullptr, (int64_t)count * n1, (int64_t)n1, n1, n1,
-                       (int64_t)n1 * n1, (int64_t)fan * n1, last ? R : scratch, last ? extra : (const double*)nullptr, run_flag);
+                       stride, (int64_t)fan * n1, last ? R : scratch, last ? extra : (const double*)nullptr, run_flag);
     e = hipGetLastError();
     if (e != hipSuccess || last) return e;
     in = scratch;
+    stride = (int64_t)n1 * n1;
     count = nout;
     scratch = scratch + (size_t)nout * n1 * n1;  // (256 leaves -> 64 -> 16 -> 4 -> R)
   }
@@ -365,6 +368,14 @@ hipError_t rdyn_launch_regressor_tsqr_wide(int n_joints, const RdynLdsGramArgs& 
   e = hipGetLastError();
   if (e != hipSuccess) return e;
   return wide_tree(workspace, blocks, workspace + (size_t)blocks * n1 * n1, R, n1, accumulate ? R : nullptr, a.run_flag, st);
+}
+
+// R <- the fold of `count` upper-triangular n1 x n1 factors (column-major, `stride` doubles apart), plus R itself when accumulating;
+// fixed order.  scratch: rdyn_tsqr_wide_workspace_doubles(n1, count) doubles.
+hipError_t rdyn_launch_tsqr_fold_factors(const double* factors, int count, int64_t stride, int n1, double* scratch, double* R, int accumulate, hipStream_t st)
+{
+  if (n1 < 1 || n1 > rdyn_tsqr_wide_max_cols() || count < 1 || stride < (int64_t)n1 * n1) return hipErrorInvalidValue;
+  return wide_tree(factors, count, scratch, R, n1, accumulate ? R : nullptr, nullptr, st, stride);
 }
 
 hipError_t rdyn_launch_tsqr_wide_rows(const double* A, const double* b, int64_t rows, int64_t lda, int n_cols, int blocks, double* workspace, double* R,

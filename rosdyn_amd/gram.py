@@ -77,6 +77,26 @@ def allreduce_normal_equations(G, c, bb, count, dist=None):
     return unpack_normal_equations(buf, G.shape[0])
 
 
+def allgather_fold_r_factors(R1, dist=None, device_fold=False):
+    """The R-factor exchange of SURVEY.md section 8(e) under torch.distributed: ONE all-gather of every rank's (n1, n1) factor (math
+    layout; RCCL over xGMI on GPUs, gloo in the CPU tests) and the fold of the stack in rank order -- every rank folds the same stack in
+    the same order, so all ranks hold the same bits.  device_fold=True folds on the GPU (rdyn_tsqr over the stacked factors as one
+    (world n1) x n1 matrix); default: rdyn_tsqr_combine_host on the host."""
+    import torch
+    world = dist.get_world_size() if (dist is not None and dist.is_initialized()) else 1
+    if world == 1:
+        return R1
+    R1 = R1.contiguous()
+    parts = [torch.empty_like(R1) for _ in range(world)]
+    dist.all_gather(parts, R1)
+    if device_fold and R1.is_cuda:
+        n1 = R1.shape[0]
+        stack = torch.cat(parts, dim=0)                     # (world n1, n1) math layout = rows of the stacked factors
+        return tsqr(stack.t().contiguous())                 # column-major (world n1) x n1 as the (n1, world n1) tensor tsqr() takes
+    out = tsqr_combine_host([p.cpu().numpy() for p in parts])
+    return torch.from_numpy(out).to(R1.device)
+
+
 def r_factor(G, rtol=1e-10):
     """Rank-revealing R factor of the stacked regressor A from its Gram G = A'A (what a tall-skinny QR of A returns, up to
     the signs of the rows): pivoted Cholesky on the host, R'R = G[perm][:, perm] restricted to the numerical rank.
@@ -260,6 +280,42 @@ class MultiGpuGram(object):
         if sync:
             self.synchronize()
         return out
+
+    def identification_tsqr(self, chain, shards, components=None, layout="sample", out=None, accumulate=False, sync=True):
+        """include/rdyn.h: rdyn_identification_tsqr_multi (components=None: rdyn_regressor_tsqr_multi) -- every device the robust R
+        factor of its shard, ONE ncclAllGather of the factors, every device folds the stack in the same order.  Returns the list of
+        per-device factors in MATH layout ((n1, n1) upper triangular, n1 = P + K + 1), bitwise identical on all devices.  The call
+        leaves torch's current stream of every device waiting (on the device) for the collective, so torch work queued afterwards
+        sees the results; sync=True additionally waits on the host."""
+        import torch
+        from ._lib import Batch, LAYOUT_ELEMENT_MAJOR, LAYOUT_SAMPLE_MAJOR
+        assert len(shards) == len(self.devices)
+        n = chain.getActiveJointsNumber()
+        n1 = 10 * chain.getJointsNumber() + (components.columns if components is not None else 0) + 1
+        arr, n_comps = (C.cast(components._arr, C.c_void_p), components.n_comps) if components is not None else (None, 0)
+        batches = (Batch * len(shards))()
+        taus = (C.c_void_p * len(shards))()
+        ptrs = (C.c_void_p * len(shards))()
+        bufs = []
+        for i, (q, dq, ddq, tau) in enumerate(shards):
+            for t in (q, dq, ddq, tau):
+                assert t.is_cuda and t.device.index == self.devices[i] and t.dtype == torch.float64 and t.is_contiguous()
+            b = batches[i]
+            b.n_samples = q.shape[1] if layout == "element" else q.shape[0]
+            assert (q.shape[0] if layout == "element" else q.shape[1]) == n
+            b.q, b.dq, b.ddq = q.data_ptr(), dq.data_ptr(), ddq.data_ptr()
+            b.layout = LAYOUT_ELEMENT_MAJOR if layout == "element" else LAYOUT_SAMPLE_MAJOR
+            b.device = self.devices[i]
+            b.stream = torch.cuda.current_stream(q.device).cuda_stream
+            taus[i] = tau.data_ptr()
+            with torch.cuda.device(q.device):
+                buf = torch.zeros((n1, n1), dtype=torch.float64, device=q.device) if out is None else out[i].t().contiguous()   # column-major for the library
+            ptrs[i] = buf.data_ptr()
+            bufs.append(buf)
+        check(lib().rdyn_identification_tsqr_multi(self._h, chain._h, arr, n_comps, batches, taus, ptrs, 1 if accumulate else 0))
+        if sync:
+            self.synchronize()
+        return [b.t() for b in bufs]
 
     def synchronize(self):
         check(lib().rdyn_multi_gpu_synchronize(self._h))

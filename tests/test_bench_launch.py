@@ -27,6 +27,12 @@ def test_self_launch_two_ranks_gloo_dry():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["n_ranks_seen"] == 2 and d["dry"] is True
     assert d["samples_reduced"] == 2000.0     # the count travels inside the one all-reduce payload
+    # round 4: the legs a multi-GPU run adds, through their CPU plumbing -- configs[2]'s R-factor all-gather + fold, configs[4]'s split
+    # of the 256 chains, and rank 0 waiting for the other ranks' processes to be gone before it would start the library child
+    assert d["legs"] == ["config4", "config3_sharded", "config5_sharded"]
+    assert d["r_factor_gather_fold_rel_err"] <= 1e-12
+    assert d["config5_chains_per_rank"] == [128, 128] and d["config5_chains_total"] == 256
+    assert d["distinct_pids"] == 2 and d["other_ranks_exited"] is True
 
 
 def test_single_rank_dry_needs_no_launcher():
@@ -53,4 +59,5 @@ def test_single_process_argument_path_dry():
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, timeout=120)
     assert p.returncode == 0, p.stderr[-2000:]
     d = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][0])
-    assert d == {"metric": "config4_library", "dry": True, "n_gpus": 8, "steps": 20, "samples_per_gpu": 1000}
+    assert d == {"metric": "config4_library", "dry": True, "n_gpus": 8, "steps": 20, "samples_per_gpu": 1000,
+                 "legs": ["config4_library", "config3_library", "config5_library"]}

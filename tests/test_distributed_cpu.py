@@ -52,6 +52,17 @@ def _worker(rank, world, port, q):
         assert allreduce_packed(buf, dist, count=rows) is buf
         G2, c2, bb2, cnt2 = unpack_normal_equations(buf, P)
         ok = ok and torch.equal(G2, G) and torch.equal(c2, c) and cnt2 == world * rows
+    # the R-factor exchange (the TSQR alternative): every rank the factor of ITS rows, one all-gather, the fold of the stack
+    # in rank order -- against the factor of all rows, and the same bits on both ranks
+    from rosdyn_amd.gram import allgather_fold_r_factors
+    Mr = np.column_stack([Ar, br])
+    Rr = np.linalg.qr(Mr, mode="r")
+    Rall = allgather_fold_r_factors(torch.from_numpy(Rr), dist).numpy()
+    Mall = np.column_stack([A, b])
+    ok = ok and np.allclose(np.tril(Rall, -1), 0.0) and np.abs(Rall.T @ Rall - Mall.T @ Mall).max() <= 1e-12 * np.abs(Mall.T @ Mall).max()
+    both = [torch.empty_like(torch.from_numpy(Rall)) for _ in range(world)]
+    dist.all_gather(both, torch.from_numpy(Rall))
+    ok = ok and all(torch.equal(both[0], x) for x in both)
     q.put((rank, ok))
     dist.destroy_process_group()
 

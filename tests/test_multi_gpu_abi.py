@@ -20,6 +20,8 @@ def test_symbols_and_argument_checks_without_a_gpu():
     assert l.rdyn_multi_gpu_device_count(None) == 0
     assert l.rdyn_multi_gpu_synchronize(None) == 1
     assert l.rdyn_regressor_gram_multi(None, None, None, None, None) == 1
+    assert l.rdyn_regressor_tsqr_multi(None, None, None, None, None, 0) == 1
+    assert l.rdyn_identification_tsqr_multi(None, None, None, 0, None, None, None, 0) == 1
     l.rdyn_multi_gpu_destroy(None)      # harmless
 
 
@@ -69,3 +71,47 @@ def test_back_to_back_calls_with_different_shard_sizes_and_no_sync():
         a = acc.cpu().numpy()
         assert a[P * P + P + 1] == N
         assert np.array_equal(a[:P * P].reshape(P, P), G.cpu().numpy()) and np.array_equal(a[P * P:P * P + P], c.cpu().numpy())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("urdf,base,tool,with_comps,N", [("ur10_like.urdf", "base_link", "wrist_3_link", False, 30000), ("ur10_public.urdf", "base_link", "tool0", True, 5000),
+                                                        ("panda_like.urdf", "link0", "link7", True, 700)], ids=["ur10_6", "ur10_public_comps", "panda7_comps_small"])
+def test_world_one_r_factor_gather_and_fold(urdf, base, tool, with_comps, N):
+    """rdyn_identification_tsqr_multi / rdyn_regressor_tsqr_multi on ONE device: the robust factor of the shard, the all-gather of one
+    rank, the fold of the stack -- R'R = M'M against the oracle's rows, accumulation, and the result is visible to work queued on the
+    caller's stream WITHOUT a host synchronisation of the context (an event orders the caller's stream)."""
+    torch = pytest.importorskip("torch")
+    from oracle.oracle import OracleChain, components_regressor
+    from rosdyn_amd import Chain
+    from rosdyn_amd.components import ComponentSet
+    from rosdyn_amd.gram import MultiGpuGram
+    from rosdyn_amd.samples import trajectory_batch
+    path = os.path.join(FIXTURES, urdf)
+    g = (0.0, 0.0, -9.806)
+    chain, ref = Chain(path, base, tool, g), OracleChain(path, base, tool, g)
+    n, P = ref.n, ref.P
+    q, dq, ddq = trajectory_batch(77, N, n)
+    comps, K, Cm, tau_c = None, 0, np.zeros((N, n, 0)), 0.0
+    if with_comps:
+        specs = [(0, j, 1e-3, 5.0, [0.4 + 0.1 * j, 1.0]) for j in range(n)]
+        comps = ComponentSet([dict(type=0, joint=j, min_velocity=1e-3, max_velocity=5.0, parameters=sp[4]) for j, sp in enumerate(specs)], n)
+        K = comps.columns
+        Cm, tau_c = components_regressor(specs, n, q, dq)
+    tau = ref.joint_torque(q, dq, ddq) + tau_c + 1e-3 * np.random.default_rng(1).normal(size=(N, n))
+    M = np.column_stack([ref.regressor(q, dq, ddq).reshape(-1, P), Cm.reshape(-1, K), tau.reshape(-1)])
+    G = M.T @ M
+    shard = tuple(torch.from_numpy(x).cuda() for x in (q, dq, ddq, tau))
+    ctx = MultiGpuGram([0])
+    R = ctx.identification_tsqr(chain, [shard], components=comps, sync=False)[0]
+    seen = (R.t() @ R).clone()                      # queued on torch's stream right behind the call: no ctx.synchronize() in between
+    torch.cuda.current_stream().synchronize()
+    R1 = R.cpu().numpy()
+    assert np.allclose(np.tril(R1, -1), 0.0)
+    assert np.abs(R1.T @ R1 - G).max() <= 1e-11 * np.abs(G).max()
+    assert np.abs(seen.cpu().numpy() - G).max() <= 1e-11 * np.abs(G).max()
+    # the same rows again, accumulated: twice the Gram matrix
+    R2 = ctx.identification_tsqr(chain, [shard], components=comps, out=[torch.from_numpy(R1).cuda()], accumulate=True)[0].cpu().numpy()
+    assert np.allclose(np.tril(R2, -1), 0.0) and np.abs(R2.T @ R2 - 2 * G).max() <= 1e-11 * np.abs(G).max()
+    # reproducible
+    again = ctx.identification_tsqr(chain, [shard], components=comps)[0].cpu().numpy()
+    assert np.array_equal(R1, again)
