@@ -98,7 +98,7 @@ def test_world_one_r_factor_gather_and_fold(urdf, base, tool, with_comps, N):
         K = comps.columns
         Cm, tau_c = components_regressor(specs, n, q, dq)
     tau = ref.joint_torque(q, dq, ddq) + tau_c + 1e-3 * np.random.default_rng(1).normal(size=(N, n))
-    M = np.column_stack([ref.regressor(q, dq, ddq).reshape(-1, P), Cm.reshape(-1, K), tau.reshape(-1)])
+    M = np.column_stack([ref.regressor(q, dq, ddq).reshape(-1, P), Cm.reshape(N * n, K), tau.reshape(-1)])
     G = M.T @ M
     shard = tuple(torch.from_numpy(x).cuda() for x in (q, dq, ddq, tau))
     ctx = MultiGpuGram([0])
