@@ -132,8 +132,8 @@ __global__ __launch_bounds__(128 * NPAIR) void k_regressor_pgram(const RdynLdsGr
       const double tb0 = valid ? nb0 : 0.0, tb1 = valid ? nb1 : 0.0;
       if (tl + t_step < n_tiles) fetch(tl + t_step);
       double sna, csa, snb, csb;
-      sincos(qa, &sna, &csa);
-      sincos(qb, &snb, &csb);
+      rdyn_sincos(qa, &sna, &csa);
+      rdyn_sincos(qb, &snb, &csb);
       const double oca = 1.0 - csa, ocb = 1.0 - csb;
       V3 w = mk(0, 0, 0), vl = mk(0, 0, 0), al = mk(0, 0, 0);
       V3 lin = mk(-c->g[0], -c->g[1], -c->g[2]);

@@ -58,6 +58,40 @@ __device__ __forceinline__ V3 symv(Ptr I, V3 v)
             fma(I[2], v.x, fma(I[4], v.y, I[5] * v.z)));
 }
 
+// sin and cos of a joint angle (Joint::computedTpc, primitives_impl.h:38-47: the one transcendental of the path).  ocml's sincos
+// carries a Payne-Hanek reduction for arbitrary arguments behind a branch: ~150 instructions where a 750-instruction sample
+// spends six of them (profiles/r3/perf_sheet.txt: getTransformation / getJointTorque are ALU-bound).  Joint angles are small:
+// for |x| <= 2^20 a two-constant Cody-Waite reduction is exact to ~5e-21 (n = rint(x 2/pi) has <= 20 bits, pio2_1 has 33:
+// n pio2_1 is exact, and so is x - n pio2_1 in one fma; the tail constant carries the next 53 bits), followed by the fdlibm kernel
+// polynomials on [-pi/4, pi/4] (< 1 ulp) and a quadrant select -- 40 instructions, branch-free.  Beyond 2^20 (or NaN / Inf): ocml.
+__device__ __forceinline__ void rdyn_sincos(double x, double* sn, double* cs)
+{
+  if (__builtin_expect(!(fabs(x) <= 1048576.0), 0))
+  {
+    sincos(x, sn, cs);
+    return;
+  }
+  const double fn = __builtin_rint(x * 6.36619772367581382433e-01);
+  const double r = fma(-fn, 1.57079632673412561417e+00, x);  // exact
+  const double w = fn * 6.07710050650619224932e-11;
+  const double y0 = r - w, y1 = (r - y0) - w;                // reduced argument y0 + y1
+  const double z = y0 * y0, v = z * y0;
+  // __kernel_sin(y0, y1)
+  const double rs = fma(z, fma(z, fma(z, fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08), 2.75573137070700676789e-06), -1.98412698298579493134e-04),
+                        8.33333333332248946124e-03);
+  const double S = y0 - ((z * (0.5 * y1 - v * rs) - y1) - v * -1.66666666666666324348e-01);
+  // __kernel_cos(y0, y1)
+  const double w2 = z * z;
+  const double rc = z * fma(z, fma(z, 2.48015872894767294178e-05, -1.38888888888741095749e-03), 4.16666666666666019037e-02) +
+                    (w2 * w2) * fma(z, fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09), -2.75573143513906633035e-07);
+  const double hz = 0.5 * z, wc = 1.0 - hz;
+  const double C = wc + (((1.0 - wc) - hz) + (z * rc - y0 * y1));
+  const int n = (int)fn;
+  const double s1 = (n & 1) ? C : S, c1 = (n & 1) ? S : C;
+  *sn = (n & 2) ? -s1 : s1;
+  *cs = ((n + 1) & 2) ? -c1 : c1;
+}
+
 }  // namespace
 
 #endif

@@ -128,8 +128,8 @@ __global__ __launch_bounds__(512) void k_regressor_gram_duo(const RdynLdsGramArg
       // sin / 1 - cos of MY two input joints, once per tile (the two evaluations interleave); the link loop gets its joint's
       // pair by a quad shuffle instead of every lane of the quad repeating the same sincos per link
       double sna, csa, snb, csb;
-      sincos(qa, &sna, &csa);
-      sincos(qb, &snb, &csb);
+      rdyn_sincos(qa, &sna, &csa);
+      rdyn_sincos(qb, &snb, &csb);
       const double oca = 1.0 - csa, ocb = 1.0 - csb;
 
       V3 w = mk(0, 0, 0), vl = mk(0, 0, 0), al = mk(0, 0, 0);

@@ -138,7 +138,7 @@ __global__ __launch_bounds__(WRENCH ? 64 : 256, RDYN_KIN_EXT_WAVES) void k_base_
     if (type == RDYN_REVOLUTE)
     {
       double sn, cs;
-      sincos(qf, &sn, &cs);
+      rdyn_sincos(qf, &sn, &cs);
       const double oc = 1.0 - cs;
 #pragma unroll
       for (int i = 0; i < 9; ++i) Rpc[i] = fma(sn, J.B[i], fma(oc, J.C[i], J.A[i]));

@@ -11,7 +11,7 @@
 //   * __builtin_amdgcn_sched_group_barrier interleaves the group's MFMAs with the VALU stream of the link, one
 //     v_mfma_f64_16x16x4_f64 per RDYN_PIPE_VALU_PER_MFMA VALU instructions, so each fills the other's dependency stalls;
 //   * to give the scheduler one large straight-line region per link the sweep is written branch-free after the sincos:
-//     joint kinds are handled by selects / zero factors (a non-revolute joint takes sincos(0): R = A exactly), rows that
+//     joint kinds are handled by selects / zero factors (a non-revolute joint takes rdyn_sincos(0): R = A exactly), rows that
 //     are not stored for a link are written to a per-lane dummy slot instead of being branched around;
 //   * the chain pointer is laundered once per tile: hoisted out of the tile loop the unrolled links' constants need ~450
 //     SGPRs and come back as v_readlane traffic.

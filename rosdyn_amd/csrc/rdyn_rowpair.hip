@@ -96,7 +96,7 @@ __global__ __launch_bounds__(256) void k_rowpair_sweep(const RdynSweepArgs a, co
     if (type == RDYN_REVOLUTE)
     {
       double sn, cs;
-      sincos(qf, &sn, &cs);
+      rdyn_sincos(qf, &sn, &cs);
       const double oc = 1.0 - cs;
 #pragma unroll
       for (int i = 0; i < 9; ++i) R[i] = fma(sn, J.B[i], fma(oc, J.C[i], J.A[i]));

@@ -352,8 +352,8 @@ __global__ __launch_bounds__(256) void k_regressor_tsqr(const RdynLdsGramArgs fa
     if (!valid) tb0 = tb1 = 0.0;
     const int m0idx = valid ? r0 : -2, m1idx = valid ? r1 : -2;
     double sna, csa, snb, csb;
-    sincos(qa, &sna, &csa);
-    sincos(qb, &snb, &csb);
+    rdyn_sincos(qa, &sna, &csa);
+    rdyn_sincos(qb, &snb, &csb);
     const double oca = 1.0 - csa, ocb = 1.0 - csb;
     V3 w = mk(0, 0, 0), vl = mk(0, 0, 0), al = mk(0, 0, 0);
     V3 lin = mk(-c->g[0], -c->g[1], -c->g[2]);
