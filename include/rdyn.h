@@ -39,10 +39,18 @@ extern "C" {
 #endif
 
 #define RDYN_VERSION 100
-/* Chain joints INCLUDING fixed ones (reference: m_joints_number, primitives_impl.h:638).  Kernels are
- * instantiated for 1..RDYN_MAX_JOINTS; the reference's own compile-time bound is MAX_NUM_AXES
- * (rosdyn_core/CMakeLists.txt:12-25). */
-#define RDYN_MAX_JOINTS 10
+/* Chain joints INCLUDING fixed ones (reference: m_joints_number, primitives_impl.h:638).  The reference's default build is
+ * unbounded (rosdyn_core/CMakeLists.txt:12-16: MAX_NUM_AXES = -1); here a chain may have up to RDYN_MAX_JOINTS joints, of which the
+ * kernels sweep at most RDYN_MAX_SWEPT_JOINTS (they are instantiated for 1..RDYN_MAX_SWEPT_JOINTS with every per-link quantity in
+ * registers).  A chain with more joints than that is long because of FIXED frames (a tool changer, a camera mount, the flange /
+ * tool0 frames of the public UR and Panda models): its input joints (at most RDYN_MAX_SWEPT_JOINTS, in chain order) define a reduced
+ * companion chain -- the fixed frames folded into the neighbouring bodies, rdyn_chain_reduction -- which the kernels sweep, and the
+ * columns of every folded link are restored exactly (Y_f = Y_body X_f).  Served that way: rdyn_regressor, rdyn_joint_torque,
+ * rdyn_joint_torque_nonlinear, rdyn_joint_inertia, rdyn_nominal_parameters, the normal equations and the R factors
+ * (rdyn_regressor_gram, rdyn_identification_gram, rdyn_regressor_tsqr, rdyn_identification_tsqr and their multi-GPU forms).
+ * The by-link kinematic outputs (transformations, twists, wrenches of every link, the IK) answer RDYN_ERR_UNSUPPORTED for such a chain. */
+#define RDYN_MAX_JOINTS 32
+#define RDYN_MAX_SWEPT_JOINTS 10
 
 typedef enum rdyn_status
 {
@@ -51,7 +59,7 @@ typedef enum rdyn_status
   RDYN_ERR_BASE_NOT_FOUND = 2,   /* "Base link not found"   primitives_impl.h:603                        */
   RDYN_ERR_TOOL_NOT_FOUND = 3,   /* "Tool link not found"   primitives_impl.h:610                        */
   RDYN_ERR_URDF = 4,             /* malformed URDF XML                                                   */
-  RDYN_ERR_UNSUPPORTED = 5,      /* more than RDYN_MAX_JOINTS chain joints                               */
+  RDYN_ERR_UNSUPPORTED = 5,      /* more than RDYN_MAX_JOINTS chain joints, or a shape an entry point does not serve */
   RDYN_ERR_JOINT_NOT_FOUND = 6,  /* setInputJointsName: "Joint named '%s' not found" primitives_impl.h:734 */
   RDYN_ERR_NO_DEVICE = 7,        /* no HIP device / HIP runtime failure at start-up                      */
   RDYN_ERR_HIP = 8               /* a HIP call failed (message carries hipGetErrorString)                */

@@ -7,7 +7,8 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("RDYN_LIB_PATH", os.path.join(_HERE, "librdyn_hip.so"))  # override: A/B builds only
 
-RDYN_MAX_JOINTS = 10
+RDYN_MAX_JOINTS = 32
+RDYN_MAX_SWEPT_JOINTS = 10
 LAYOUT_SAMPLE_MAJOR = 0
 LAYOUT_ELEMENT_MAJOR = 1
 OK = 0

@@ -75,6 +75,11 @@ struct DeviceGuard
 
 int device_const(const rdyn_chain* c, const RdynChainConst** out)
 {
+  if (c->long_chain())
+  {
+    rdyn_set_error("chains of more than %d joints are served through their reduced companion only", RDYN_MAX_SWEPT_JOINTS);
+    return RDYN_ERR_UNSUPPORTED;
+  }
   int dev = 0;
   RDYN_HIP_TRY(hipGetDevice(&dev));
   std::lock_guard<std::mutex> lk(c->mu);
@@ -124,12 +129,22 @@ int device_expand(const rdyn_chain* c, const double** out)
 // temporary normal equations of the reduced chain at the end of a Gram workspace: G_red | c_red | bb_red
 size_t reduce_tmp_bytes(int cols_red) { return (((size_t)cols_red * cols_red + cols_red + 1) * sizeof(double) + 255) & ~(size_t)255; }
 
-int check_batch(const rdyn_chain* c, const rdyn_batch* b, bool need_dq, bool need_ddq, const char* fn)
+// long_ok: the entry point serves chains of more than RDYN_MAX_SWEPT_JOINTS joints (through the reduced companion)
+int check_batch(const rdyn_chain* c, const rdyn_batch* b, bool need_dq, bool need_ddq, const char* fn, bool long_ok = false)
 {
   if (!c || !b)
   {
     rdyn_set_error("%s: null chain or batch", fn);
     return RDYN_ERR_INVALID_ARGUMENT;
+  }
+  if (c->long_chain() && !(long_ok && c->reduced))
+  {
+    if (!long_ok)
+      rdyn_set_error("%s: chains of more than %d joints are not served by this entry point (regressor, torque, inertia, normal equations and R "
+                     "factors are)", fn, RDYN_MAX_SWEPT_JOINTS);
+    else
+      rdyn_set_error("%s: a chain of %d joints needs at most %d input joints, in chain order", fn, c->n_joints(), RDYN_MAX_SWEPT_JOINTS);
+    return RDYN_ERR_UNSUPPORTED;
   }
   if (b->n_samples < 0 || (b->layout != RDYN_LAYOUT_SAMPLE_MAJOR && b->layout != RDYN_LAYOUT_ELEMENT_MAJOR))
   {
@@ -198,6 +213,21 @@ int run_local(const rdyn_chain* c, const rdyn_batch* b, int mode, double* tau, d
   if (st != RDYN_OK) return st;
   RdynSweepArgs a;
   memset(&a, 0, sizeof a);
+  // a chain longer than the kernels sweep: its reduced companion has the same input joints, torques and joint-space inertia; the
+  // dense regressor is the companion's with every body's ten-vector multiplied by the blocks of the links that ride on it
+  const rdyn_chain* const full = c;
+  if (c->long_chain())
+  {
+    if (mode == RDYN_MODE_REGRESSOR)
+    {
+      mode = RDYN_MODE_REGRESSOR_EXPAND;
+      st = device_expand(full, &a.expand_X);
+      if (st != RDYN_OK) return st;
+      a.expand_n = full->n_joints();
+      for (int f = 0; f < full->n_joints(); ++f) a.expand_red_of[f] = (signed char)full->red_of[f];
+    }
+    c = full->reduced.get();
+  }
   st = device_const(c, &a.chain);
   if (st != RDYN_OK) return st;
   const int n = c->n_active();
@@ -216,7 +246,7 @@ int run_local(const rdyn_chain* c, const rdyn_batch* b, int mode, double* tau, d
     a.y_sr = yl->stride_row;
     a.y_sc = yl->stride_col;
   }
-  if (yl && mode == RDYN_MODE_REGRESSOR)
+  if (yl && (mode == RDYN_MODE_REGRESSOR || mode == RDYN_MODE_REGRESSOR_EXPAND))
   {
     // the one-thread-per-sample kernel addresses a workgroup's 256 samples with 32-bit lane offsets: free strides must be
     // positive and keep 255 * stride_sample * 8 inside 32 bits (the presets of rdyn.h are far below that)
@@ -269,7 +299,7 @@ extern "C"
 
 int rdyn_joint_torque(const rdyn_chain* c, const rdyn_batch* b, double* tau)
 {
-  int st = check_batch(c, b, true, true, "rdyn_joint_torque");
+  int st = check_batch(c, b, true, true, "rdyn_joint_torque", true);
   if (st != RDYN_OK) return st;
   if (!tau && b->n_samples > 0)
   {
@@ -281,7 +311,7 @@ int rdyn_joint_torque(const rdyn_chain* c, const rdyn_batch* b, double* tau)
 
 int rdyn_joint_torque_nonlinear(const rdyn_chain* c, const rdyn_batch* b, double* tau)
 {
-  int st = check_batch(c, b, true, false, "rdyn_joint_torque_nonlinear");
+  int st = check_batch(c, b, true, false, "rdyn_joint_torque_nonlinear", true);
   if (st != RDYN_OK) return st;
   if (!tau && b->n_samples > 0)
   {
@@ -293,7 +323,7 @@ int rdyn_joint_torque_nonlinear(const rdyn_chain* c, const rdyn_batch* b, double
 
 int rdyn_regressor(const rdyn_chain* c, const rdyn_batch* b, double* tau, double* Y, const rdyn_regressor_layout* yl)
 {
-  int st = check_batch(c, b, true, true, "rdyn_regressor");
+  int st = check_batch(c, b, true, true, "rdyn_regressor", true);
   if (st != RDYN_OK) return st;
   if (b->n_samples > 0 && (!Y || !yl))
   {
@@ -305,7 +335,7 @@ int rdyn_regressor(const rdyn_chain* c, const rdyn_batch* b, double* tau, double
 
 int rdyn_joint_inertia(const rdyn_chain* c, const rdyn_batch* b, double* M)
 {
-  int st = check_batch(c, b, false, false, "rdyn_joint_inertia");
+  int st = check_batch(c, b, false, false, "rdyn_joint_inertia", true);
   if (st != RDYN_OK) return st;
   if (!M && b->n_samples > 0)
   {
@@ -785,7 +815,7 @@ static int gram_launch(const double* A, int64_t rows, int64_t lda, int n_cols, c
   RdynGramArgs a;
   memset(&a, 0, sizeof a);
   a.row_block = first_col ? row_block : 0;
-  for (int j = 0; first_col && j < n_row_blocks && j < RDYN_MAX_JOINTS; ++j) a.first_col[j] = first_col[j];
+  for (int j = 0; first_col && j < n_row_blocks && j < RDYN_MAX_SWEPT_JOINTS; ++j) a.first_col[j] = first_col[j];
   a.A = A;
   a.b = bvec;
   a.rows = rows;
@@ -837,6 +867,12 @@ extern "C" int rdyn_identification_gram(const rdyn_chain* c, const rdyn_componen
 size_t rdyn_regressor_gram_workspace_bytes(const rdyn_chain* c, int64_t chunk_samples)
 {
   if (!c) return 0;
+  if (c->long_chain())
+  {
+    // only the reduced companion is swept: its workspace + its normal equations behind it
+    const size_t w = c->reduced ? rdyn_regressor_gram_workspace_bytes(c->reduced.get(), 0) : 0;
+    return w ? w + reduce_tmp_bytes(10 * c->reduced->n_joints()) : 0;
+  }
   const int P = 10 * c->n_joints();
   if (rdyn_gram_blocks_for(P) > 7) return 0;
   const int64_t chunk = default_chunk(chunk_samples);
@@ -892,7 +928,7 @@ static bool build_lds_tile(const rdyn_chain* c, int n_comp_cols, bool dummy_slot
   for (int j = 1; j < n; ++j) monotonic = monotonic && c->active[j] > c->active[j - 1];
   la->all_revolute = probe_env("RDYN_DUO_NO_ALLREV") ? 0 : 1;
   for (int f = 0; f < nJ; ++f)
-    if (c->host_const.j[f].type != RDYN_REVOLUTE) la->all_revolute = 0;
+    if (c->host_joints[f].type != RDYN_REVOLUTE) la->all_revolute = 0;
   int off = 0;
   for (int f = 0; f < nJ; ++f)
   {
@@ -919,7 +955,7 @@ static bool build_lds_tile(const rdyn_chain* c, int n_comp_cols, bool dummy_slot
 int rdyn_regressor_gram(const rdyn_chain* c, const rdyn_batch* b, const double* tau_meas, double* G, double* cvec, double* bb,
                         int accumulate, int64_t chunk_samples, void* workspace, size_t workspace_bytes)
 {
-  int st = check_batch(c, b, true, true, "rdyn_regressor_gram");
+  int st = check_batch(c, b, true, true, "rdyn_regressor_gram", true);
   if (st != RDYN_OK) return st;
   if (!G || !workspace)
   {
@@ -927,6 +963,29 @@ int rdyn_regressor_gram(const rdyn_chain* c, const rdyn_batch* b, const double* 
     return RDYN_ERR_INVALID_ARGUMENT;
   }
   const int n = c->n_active(), P = 10 * c->n_joints();
+  if (c->long_chain())
+  {
+    const size_t need = rdyn_regressor_gram_workspace_bytes(c, 0);
+    if (need == 0 || workspace_bytes < need)
+    {
+      rdyn_set_error("rdyn_regressor_gram: %s", need == 0 ? "at most 111 columns of the reduced chain are supported" : "workspace too small");
+      return need == 0 ? RDYN_ERR_UNSUPPORTED : RDYN_ERR_INVALID_ARGUMENT;
+    }
+    DeviceGuard g;
+    st = g.enter(b->device);
+    if (st != RDYN_OK) return st;
+    if (b->n_samples == 0)
+    {
+      if (!accumulate)
+      {
+        RDYN_HIP_TRY(hipMemsetAsync(G, 0, sizeof(double) * P * P, (hipStream_t)b->stream));
+        if (cvec) RDYN_HIP_TRY(hipMemsetAsync(cvec, 0, sizeof(double) * P, (hipStream_t)b->stream));
+        if (bb) RDYN_HIP_TRY(hipMemsetAsync(bb, 0, sizeof(double), (hipStream_t)b->stream));
+      }
+      return RDYN_OK;
+    }
+    return gram_through_reduced(c, nullptr, 0, 0, b, tau_meas, G, cvec, bb, accumulate, workspace, need);
+  }
   if (rdyn_gram_blocks_for(P) > 7)
   {
     rdyn_set_error("rdyn_regressor_gram: at most 111 regressor columns are supported");
@@ -962,7 +1021,7 @@ int rdyn_regressor_gram(const rdyn_chain* c, const rdyn_batch* b, const double* 
   if (c->reduced && chunk_samples <= 0 && !probe_env("RDYN_GRAM_NO_REDUCE"))
     return gram_through_reduced(c, nullptr, 0, 0, b, tau_meas, G, cvec, bb, accumulate, workspace, rdyn_regressor_gram_workspace_bytes(c, chunk));
   // structural zero band of every row block (input joint j): columns < 10 * chain index of joint j
-  int first_col[RDYN_MAX_JOINTS];
+  int first_col[RDYN_MAX_SWEPT_JOINTS];
   for (int j = 0; j < n; ++j) first_col[j] = 10 * c->active[j];
   const char* path_env = probe_env("RDYN_GRAM_PATH");  // A/B only: "lds" (default when eligible), "image", "two"
   const bool want_lds = !path_env || !strcmp(path_env, "lds") || !strcmp(path_env, "lds0") || !strcmp(path_env, "pipe") || !strcmp(path_env, "duo");
@@ -1376,6 +1435,11 @@ static bool tsqr_plan(const rdyn_chain* c, const rdyn_component* comps, int n_co
 {
   p->cs = swept_chain(c);
   p->expand = p->cs != c;
+  if (c->long_chain() && !p->expand)
+  {
+    p->why = "a chain of more than 10 joints needs at most 10 input joints, in chain order";
+    return false;
+  }
   const rdyn_chain* cs = p->cs;
   p->n = cs->n_active();
   p->nJ = cs->n_joints();
@@ -1445,7 +1509,7 @@ static bool tsqr_plan(const rdyn_chain* c, const rdyn_component* comps, int n_co
 static int regressor_tsqr_run(const rdyn_chain* c, const rdyn_component* comps, int n_comps, const rdyn_batch* b, const double* tau_meas, double* R,
                               int accumulate, void* workspace, size_t workspace_bytes, const char* who)
 {
-  int st = check_batch(c, b, true, true, who);
+  int st = check_batch(c, b, true, true, who, true);
   if (st != RDYN_OK) return st;
   if (!R || !workspace || n_comps < 0 || n_comps > RDYN_MAX_COMPONENTS || (n_comps > 0 && !comps))
   {
@@ -1604,7 +1668,7 @@ static int regressor_tsqr_run(const rdyn_chain* c, const rdyn_component* comps, 
     ea.n_comp_cols = K;
     double* const R_exp = accumulate ? ws + L.r_full : R;
     RDYN_HIP_TRY(rdyn_launch_cholqr_expand(ea, R_swept, R_exp, stream));
-    if (accumulate) RDYN_HIP_TRY(rdyn_launch_cholqr_fold(R_exp, R, n1, stream));
+    if (accumulate) RDYN_HIP_TRY(rdyn_launch_cholqr_fold(R_exp, R, n1, stream, n1s));
   }
   return RDYN_OK;
 }
@@ -1668,6 +1732,11 @@ size_t rdyn_identification_gram_workspace_bytes(const rdyn_chain* c, const rdyn_
 {
   if (!c) return 0;
   const int K = n_comps > 0 ? rdyn_components_columns(comps, n_comps) : 0;
+  if (c->long_chain())
+  {
+    const size_t w = (c->reduced && K >= 0) ? rdyn_identification_gram_workspace_bytes(c->reduced.get(), comps, n_comps) : 0;
+    return w ? w + reduce_tmp_bytes(10 * c->reduced->n_joints() + K) : 0;
+  }
   const int cols = 10 * c->n_joints() + (K > 0 ? K : 0);
   if (K < 0 || rdyn_gram_blocks_for(cols) > 7) return 0;
   const size_t base = (gram_slab_bytes(cols) + (size_t)kIdentChunk * c->n_active() * (cols + 1) * sizeof(double) + 255) & ~(size_t)255;
@@ -1677,7 +1746,7 @@ size_t rdyn_identification_gram_workspace_bytes(const rdyn_chain* c, const rdyn_
 int rdyn_identification_gram(const rdyn_chain* c, const rdyn_component* comps, int n_comps, const rdyn_batch* b, const double* tau_meas,
                              double* G, double* cvec, double* bb, int accumulate, void* workspace, size_t workspace_bytes)
 {
-  int st = check_batch(c, b, true, true, "rdyn_identification_gram");
+  int st = check_batch(c, b, true, true, "rdyn_identification_gram", true);
   if (st != RDYN_OK) return st;
   if (!G || !workspace || n_comps < 0 || n_comps > RDYN_MAX_COMPONENTS || (n_comps > 0 && !comps))
   {
@@ -1687,6 +1756,29 @@ int rdyn_identification_gram(const rdyn_chain* c, const rdyn_component* comps, i
   const int n = c->n_active(), P = 10 * c->n_joints();
   const int K = n_comps > 0 ? rdyn_components_columns(comps, n_comps) : 0;
   const int cols = P + K;
+  if (c->long_chain())
+  {
+    const size_t need = rdyn_identification_gram_workspace_bytes(c, comps, n_comps);
+    if (need == 0 || workspace_bytes < need)
+    {
+      rdyn_set_error("rdyn_identification_gram: %s", need == 0 ? "at most 111 columns (reduced chain + components) are supported" : "workspace too small");
+      return need == 0 ? RDYN_ERR_UNSUPPORTED : RDYN_ERR_INVALID_ARGUMENT;
+    }
+    DeviceGuard g;
+    st = g.enter(b->device);
+    if (st != RDYN_OK) return st;
+    if (b->n_samples == 0)
+    {
+      if (!accumulate)
+      {
+        RDYN_HIP_TRY(hipMemsetAsync(G, 0, sizeof(double) * cols * cols, (hipStream_t)b->stream));
+        if (cvec) RDYN_HIP_TRY(hipMemsetAsync(cvec, 0, sizeof(double) * cols, (hipStream_t)b->stream));
+        if (bb) RDYN_HIP_TRY(hipMemsetAsync(bb, 0, sizeof(double), (hipStream_t)b->stream));
+      }
+      return RDYN_OK;
+    }
+    return gram_through_reduced(c, comps, n_comps, K, b, tau_meas, G, cvec, bb, accumulate, workspace, need);
+  }
   if (rdyn_gram_blocks_for(cols) > 7)
   {
     rdyn_set_error("rdyn_identification_gram: at most 111 columns (regressor + components) are supported");
@@ -1773,7 +1865,7 @@ int rdyn_identification_gram(const rdyn_chain* c, const rdyn_component* comps, i
     }
   }
   const int64_t in_step = (b->layout == RDYN_LAYOUT_SAMPLE_MAJOR) ? n : 1;
-  int first_col[RDYN_MAX_JOINTS];
+  int first_col[RDYN_MAX_SWEPT_JOINTS];
   for (int j = 0; j < n; ++j) first_col[j] = 10 * c->active[j];  // the component columns lie to the right: always loaded
   int64_t prev_cnt = -1;
   for (int64_t s0 = 0; s0 < N; s0 += kIdentChunk)

@@ -170,7 +170,8 @@ void build_reduced(rdyn_chain* c)
   if (n < 1 || n == nj) return;
   for (int k = 1; k < n; ++k)
     if (c->active[k] <= c->active[k - 1]) return;  // input joints not in chain order: no companion
-  const RdynChainConst& H = c->host_const;
+  if (n > RDYN_MAX_SWEPT_JOINTS) return;  // the companion itself would be longer than what the kernels sweep
+  const std::vector<RdynJointConst>& HJ = c->host_joints;
   std::unique_ptr<rdyn_chain> r(new rdyn_chain());
   r->joints.resize(n);
   r->links.resize(n + 1);
@@ -180,7 +181,7 @@ void build_reduced(rdyn_chain* c)
   RdynChainConst& K = r->host_const;
   memset(&K, 0, sizeof K);
   K.n_joints = K.n_active = n;
-  for (int i = 0; i < 3; ++i) K.g[i] = H.g[i];
+  for (int i = 0; i < 3; ++i) K.g[i] = c->gravity[i];
   c->red_of.assign(nj, -1);
   c->expand_X.assign((size_t)nj * 100, 0.0);
   // frame of the current rigid body -> frame of the link being visited: x_body = Rc x_link + pc
@@ -188,7 +189,7 @@ void build_reduced(rdyn_chain* c)
   int red = -1;  // reduced link the current body is (index of its joint in the reduced chain)
   for (int f = 0; f < nj; ++f)
   {
-    const RdynJointConst& J = H.j[f];
+    const RdynJointConst& J = HJ[f];
     // compose the parent -> joint transform of chain joint f (R_pj, t_pj) onto the running transform
     double Rn[9], pn[3];
     mat3_mul(Rc, J.A, Rn);
@@ -243,6 +244,7 @@ void build_reduced(rdyn_chain* c)
       for (int a = 0; a < 10; ++a) K.j[red].pi[a] += img[a];
     }
   }
+  r->host_joints.assign(K.j, K.j + n);
   r->q_max.assign(n, 1e10);
   r->q_min.assign(n, -1e10);
   r->dq_max.assign(n, 1e10);
@@ -257,9 +259,8 @@ void rdyn_chain_finalize(rdyn_chain* c)
   const int nj = c->n_joints();
   RdynChainConst& H = c->host_const;
   memset(&H, 0, sizeof H);
-  H.n_joints = nj;
-  H.n_active = c->n_active();
-  for (int i = 0; i < 3; ++i) H.g[i] = c->gravity[i];
+  c->host_joints.assign(nj, RdynJointConst());
+  std::vector<RdynJointConst>& HJ = c->host_joints;
   c->q_max.assign(nj, 0.0);
   c->q_min.assign(nj, 0.0);
   c->dq_max.assign(nj, 0.0);
@@ -268,7 +269,8 @@ void rdyn_chain_finalize(rdyn_chain* c)
   for (int j = 0; j < nj; ++j)
   {
     const rdyn_joint_desc& d = c->joints[j];
-    RdynJointConst& K = H.j[j];
+    RdynJointConst& K = HJ[j];
+    memset(&K, 0, sizeof K);
     double R[9], Ks[9], K2[9];
     quat_to_R(d.origin_quat, R);
     double u[3] = {d.axis[0], d.axis[1], d.axis[2]};
@@ -324,7 +326,15 @@ void rdyn_chain_finalize(rdyn_chain* c)
     c->ddq_max[j] = 10.0 * dqmax;
     c->tau_max[j] = taumax;
   }
-  for (int k = 0; k < c->n_active(); ++k) H.j[c->active[k]].in_idx = k;
+  for (int k = 0; k < c->n_active(); ++k) HJ[c->active[k]].in_idx = k;
+  if (!c->long_chain())
+  {
+    // the flat copy the kernels read (a chain longer than what they sweep is served through its reduced companion only)
+    H.n_joints = nj;
+    H.n_active = c->n_active();
+    for (int i = 0; i < 3; ++i) H.g[i] = c->gravity[i];
+    for (int j = 0; j < nj; ++j) H.j[j] = HJ[j];
+  }
   build_reduced(c);
 }
 
@@ -332,7 +342,8 @@ static int build_chain(std::vector<rdyn_joint_desc>& joints, std::vector<rdyn_li
 {
   if ((int)joints.size() > RDYN_MAX_JOINTS)
   {
-    rdyn_set_error("chain has %d joints (fixed included); this build supports at most %d", (int)joints.size(), RDYN_MAX_JOINTS);
+    rdyn_set_error("chain has %d joints (fixed included); this build supports at most %d (of which at most %d input joints)", (int)joints.size(),
+                   RDYN_MAX_JOINTS, RDYN_MAX_SWEPT_JOINTS);
     return RDYN_ERR_UNSUPPORTED;
   }
   rdyn_chain* c = new rdyn_chain();
@@ -422,7 +433,7 @@ const char* rdyn_chain_active_joint_name(const rdyn_chain* c, int i)
 {
   return (c && i >= 0 && i < c->n_active()) ? c->joints[c->active[i]].name : nullptr;
 }
-int rdyn_chain_joint_type(const rdyn_chain* c, int i) { return (c && i >= 0 && i < c->n_joints()) ? c->host_const.j[i].type : -1; }
+int rdyn_chain_joint_type(const rdyn_chain* c, int i) { return (c && i >= 0 && i < c->n_joints()) ? c->host_joints[i].type : -1; }
 int rdyn_chain_gravity(const rdyn_chain* c, double g[3])
 {
   if (!c || !g) return RDYN_ERR_INVALID_ARGUMENT;
@@ -470,7 +481,7 @@ int rdyn_chain_joint_constants(const rdyn_chain* c, int i, double R_pj[9], doubl
     rdyn_set_error("rdyn_chain_joint_constants: invalid argument");
     return RDYN_ERR_INVALID_ARGUMENT;
   }
-  const RdynJointConst& K = c->host_const.j[i];
+  const RdynJointConst& K = c->host_joints[i];
   if (R_pj) memcpy(R_pj, K.A, sizeof K.A);
   if (t_pj) memcpy(t_pj, K.t, sizeof K.t);
   if (axis) memcpy(axis, K.u, sizeof K.u);
@@ -523,7 +534,7 @@ int rdyn_chain_reduction(const rdyn_chain* c, int32_t* body_joint, double* X, do
     if (X) memcpy(X + (size_t)f * 100, c->expand_X.data() + (size_t)f * 100, sizeof(double) * 100);
   }
   for (int r = 0; pi_body && r < nb; ++r)
-    for (int p = 0; p < 10; ++p) pi_body[10 * r + p] = c->reduced->host_const.j[r].pi[p];
+    for (int p = 0; p < 10; ++p) pi_body[10 * r + p] = c->reduced->host_joints[r].pi[p];
   return nb;
 }
 
@@ -531,7 +542,7 @@ int rdyn_nominal_parameters(const rdyn_chain* c, double* pi)
 {
   if (!c || !pi) return RDYN_ERR_INVALID_ARGUMENT;
   for (int j = 0; j < c->n_joints(); ++j)  // primitives_impl.h:1382-1391
-    for (int p = 0; p < 10; ++p) pi[10 * j + p] = c->host_const.j[j].pi[p];
+    for (int p = 0; p < 10; ++p) pi[10 * j + p] = c->host_joints[j].pi[p];
   return RDYN_OK;
 }
 

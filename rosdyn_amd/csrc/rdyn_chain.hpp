@@ -21,7 +21,11 @@ struct rdyn_chain
   // per chain joint limits (Joint::fromUrdf, primitives_impl.h:85-143)
   std::vector<double> q_max, q_min, dq_max, ddq_max, tau_max;
 
-  RdynChainConst host_const;                // flat constants for the kernels
+  std::vector<RdynJointConst> host_joints;  // per chain joint (any number up to RDYN_MAX_JOINTS): constants + child-link parameters
+  RdynChainConst host_const;                // flat constants for the kernels: valid for chains of <= RDYN_MAX_SWEPT_JOINTS joints only
+  // a chain with more joints than the kernels sweep: served through its reduced companion (regressor, torque, inertia, normal
+  // equations, R factors); the by-link kinematic outputs are not available for it
+  bool long_chain() const { return (int)joints.size() > RDYN_MAX_SWEPT_JOINTS; }
 
   // lazily created device copies, one per HIP device ordinal; invalidated by set_input_joints
   mutable std::mutex mu;

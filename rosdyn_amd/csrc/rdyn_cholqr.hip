@@ -991,34 +991,40 @@ __global__ __launch_bounds__(NTD) void k_cholqr_expand(const RdynGramExpandArgs 
 }
 
 // R <- qr([R ; R_new]): both n1 x n1 upper triangular, column-major (the accumulate step of the preconditioned route and of the
-// expansion above).  Both triangles PACKED in LDS (column j holds its j + 1 entries: n1 (n1 + 1) doubles in all, 101 KB at 112
-// columns).  Step k: the reflector is [R(k, k); R_new(0 .. k, k)] -- what lies below row k of R is zero and stays zero, and a column
+// expansion above); R_new is zero below its first rows_new rows (the expanded factor of a reduced chain has the reduced chain's row
+// count).  Step k: the reflector is [R(k, k); R_new(0 .. k, k)] -- what lies below row k of R is zero and stays zero, and a column
 // j > k is touched in R(k, j) and R_new(0 .. k, j) only: no fill-in outside the two triangles.  One barrier per step (every wave forms
 // the column norm by itself, the same sum in the same order), four threads per column.
-__global__ __launch_bounds__(NTD) void k_cholqr_fold(const double* __restrict__ R_new, double* __restrict__ R, int n1)
+// R_new is PACKED in LDS (column j holds its min(j + 1, rows_new) entries).  R: packed in LDS too (A_GLOBAL = false, n1 <= 136), or
+// left where it is and updated in place (A_GLOBAL = true, long chains: every entry of R is read once and written once, by the same
+// thread, so nothing travels between threads through it).
+template <bool A_GLOBAL>
+__global__ __launch_bounds__(NTD) void k_cholqr_fold(const double* __restrict__ R_new, double* R, int n1, int rows_new)
 {
   extern __shared__ __attribute__((aligned(16))) double sh[];
+  const int rn = rows_new < n1 ? rows_new : n1;
   const int tri = n1 * (n1 + 1) / 2;
-  double* const A = sh;        // R:     A[j (j + 1) / 2 + i], i <= j
-  double* const B = sh + tri;  // R_new: same packing
+  auto boff = [&](int j) { return j < rn ? j * (j + 1) / 2 : rn * (rn + 1) / 2 + (j - rn) * rn; };
+  auto bcnt = [&](int j) { return j < rn ? j + 1 : rn; };
+  double* const A = A_GLOBAL ? R : sh;                 // R: packed A[j (j + 1) / 2 + i] in LDS, or the caller's column-major matrix
+  double* const B = A_GLOBAL ? sh : sh + tri;          // R_new, packed
+  auto aidx = [&](int i, int j) { return A_GLOBAL ? j * n1 + i : j * (j + 1) / 2 + i; };
   const int tid = threadIdx.x, lane = tid & 63;
   for (int e = tid; e < n1 * n1; e += NTD)
   {
     const int i = e % n1, j = e / n1;
-    if (i <= j)
-    {
-      A[j * (j + 1) / 2 + i] = R[e];
-      B[j * (j + 1) / 2 + i] = R_new[e];
-    }
+    if (!A_GLOBAL && i <= j) A[j * (j + 1) / 2 + i] = R[e];
+    if (i < bcnt(j)) B[boff(j) + i] = R_new[e];
   }
   __syncthreads();
   for (int k = 0; k < n1; ++k)
   {
-    const double* const bk = B + k * (k + 1) / 2;
+    const double* const bk = B + boff(k);
+    const int cnt = bcnt(k);
     double sigma = 0.0;
-    for (int i = lane; i <= k; i += 64) sigma = fma(bk[i], bk[i], sigma);
+    for (int i = lane; i < cnt; i += 64) sigma = fma(bk[i], bk[i], sigma);
     for (int o = 32; o > 0; o >>= 1) sigma += __shfl_xor(sigma, o);
-    const double alpha = A[k * (k + 1) / 2 + k];
+    const double alpha = A[aidx(k, k)];
     double beta = alpha;
     if (sigma > 1e-280)
     {
@@ -1030,30 +1036,32 @@ __global__ __launch_bounds__(NTD) void k_cholqr_fold(const double* __restrict__ 
       {
         const bool on = e < ncol * 4;
         const int j = on ? k + 1 + (e >> 2) : k, q = e & 3;
-        double* const aj = A + j * (j + 1) / 2;
-        double* const bj = B + j * (j + 1) / 2;
-        double d = (on && q == 0) ? v0 * aj[k] : 0.0;
+        double* const akj = A + aidx(k, j);
+        double* const bj = B + boff(j);
+        const double a_old = (on && q == 0) ? *akj : 0.0;
+        double d = v0 * a_old;
         if (on)
-          for (int i = q; i <= k; i += 4) d = fma(bk[i], bj[i], d);
+          for (int i = q; i < cnt; i += 4) d = fma(bk[i], bj[i], d);
         d += __shfl_xor(d, 1);
         d += __shfl_xor(d, 2);
         const double f = scale * d;
         if (on)
         {
-          if (q == 0) aj[k] = fma(-f, v0, aj[k]);
-          for (int i = q; i <= k; i += 4) bj[i] = fma(-f, bk[i], bj[i]);
+          if (q == 0) *akj = fma(-f, v0, a_old);
+          for (int i = q; i < cnt; i += 4) bj[i] = fma(-f, bk[i], bj[i]);
         }
       }
     }
     __syncthreads();
-    if (tid == 0) A[k * (k + 1) / 2 + k] = beta;
+    if (tid == 0) A[aidx(k, k)] = beta;
   }
   __syncthreads();
-  for (int e = tid; e < n1 * n1; e += NTD)
-  {
-    const int i = e % n1, j = e / n1;
-    R[e] = i <= j ? A[j * (j + 1) / 2 + i] : 0.0;
-  }
+  if (!A_GLOBAL)
+    for (int e = tid; e < n1 * n1; e += NTD)
+    {
+      const int i = e % n1, j = e / n1;
+      R[e] = i <= j ? A[j * (j + 1) / 2 + i] : 0.0;
+    }
 }
 
 template <class K>
@@ -1222,13 +1230,25 @@ size_t rdyn_cholqr_expand_lds_bytes(int n_joints, int n_red, int n_comp_cols)
   return ((size_t)(10 * n_joints + n_comp_cols + 1) * (10 * n_red + n_comp_cols + 1) + (10 * n_red + n_comp_cols + 1)) * sizeof(double);
 }
 
-hipError_t rdyn_launch_cholqr_fold(const double* R_new, double* R, int n1, hipStream_t st)
+hipError_t rdyn_launch_cholqr_fold(const double* R_new, double* R, int n1, hipStream_t st, int rows_new)
 {
-  if (n1 < 1 || n1 > kMaxFoldN1) return hipErrorInvalidValue;
-  static std::atomic<uint64_t> attr{0};
-  hipError_t e = opt_in_lds_once(k_cholqr_fold, attr, 156 * 1024);
+  if (n1 < 1) return hipErrorInvalidValue;
+  const int rn = (rows_new > 0 && rows_new < n1) ? rows_new : n1;
+  const size_t b_doubles = (size_t)rn * (rn + 1) / 2 + (size_t)(n1 - rn) * rn;
+  const size_t both = ((size_t)n1 * (n1 + 1) / 2 + b_doubles) * sizeof(double);
+  if (n1 <= kMaxFoldN1 && both <= 156 * 1024)
+  {
+    static std::atomic<uint64_t> attr{0};
+    hipError_t e = opt_in_lds_once(k_cholqr_fold<false>, attr, 156 * 1024);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_cholqr_fold<false>, dim3(1), dim3(NTD), both, st, R_new, R, n1, rn);
+    return hipGetLastError();
+  }
+  if (b_doubles * sizeof(double) > 156 * 1024) return hipErrorInvalidValue;
+  static std::atomic<uint64_t> attr_g{0};
+  hipError_t e = opt_in_lds_once(k_cholqr_fold<true>, attr_g, 156 * 1024);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(k_cholqr_fold, dim3(1), dim3(NTD), (size_t)n1 * (n1 + 1) * sizeof(double), st, R_new, R, n1);
+  hipLaunchKernelGGL(k_cholqr_fold<true>, dim3(1), dim3(NTD), b_doubles * sizeof(double), st, R_new, R, n1, rn);
   return hipGetLastError();
 }
 

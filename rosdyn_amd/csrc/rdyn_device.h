@@ -32,7 +32,7 @@ struct RdynChainConst
   int32_t n_joints;  // chain joints incl. fixed
   int32_t n_active;  // input joints
   double g[3];       // gravity in the base frame
-  RdynJointConst j[RDYN_MAX_JOINTS];
+  RdynJointConst j[RDYN_MAX_SWEPT_JOINTS];
 };
 
 #endif

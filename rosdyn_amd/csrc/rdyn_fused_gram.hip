@@ -32,9 +32,10 @@ enum
   MODE_REGRESSOR = 0,
   MODE_TORQUE = 1,
   MODE_INERTIA = 2,
-  MODE_REGRESSOR_GRAM = 3
+  MODE_REGRESSOR_GRAM = 3,
+  MODE_REGRESSOR_EXPAND = 4
 };
-#define RDYN_IS_REGRESSOR(MODE) ((MODE) == MODE_REGRESSOR || (MODE) == MODE_REGRESSOR_GRAM)
+#define RDYN_IS_REGRESSOR(MODE) ((MODE) == MODE_REGRESSOR || (MODE) == MODE_REGRESSOR_GRAM || (MODE) == MODE_REGRESSOR_EXPAND)
 #define RDYN_BODY_EXIT break
 
 template <int NJ, int NB>

@@ -71,7 +71,7 @@ __global__ __launch_bounds__(256) void k_gram(const RdynGramArgs a)
     // when the input joints are not in chain order: take the minimum over every row block the 16 rows touch
     int fc = a.first_col[jb];
     int j2 = jb + 1;
-    for (int64_t b2 = bound; b2 <= r + 15 && b2 < R && j2 < RDYN_MAX_JOINTS; b2 += a.row_block, ++j2)
+    for (int64_t b2 = bound; b2 <= r + 15 && b2 < R && j2 < RDYN_MAX_SWEPT_JOINTS; b2 += a.row_block, ++j2)
       if (a.first_col[j2] < fc) fc = a.first_col[j2];
     return fc >> 4;
   };

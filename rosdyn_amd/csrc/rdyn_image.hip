@@ -23,7 +23,7 @@ inline int popcount_u(unsigned x) { return __builtin_popcount(x); }
 // is (n_joints, fix) one of the compiled patterns?
 bool pattern_compiled(int n_joints, unsigned fix, int max_na)
 {
-  if (n_joints < 2 || n_joints > RDYN_MAX_JOINTS || (fix >> n_joints)) return false;
+  if (n_joints < 2 || n_joints > RDYN_MAX_SWEPT_JOINTS || (fix >> n_joints)) return false;
   const int na = n_joints - popcount_u(fix);
   if (na < 2 || na > max_na) return false;
 #define MATCH(H_, T_) \
@@ -38,7 +38,7 @@ bool pattern_compiled(int n_joints, unsigned fix, int max_na)
 // layout (y_sr == 1, y_sc == n_active; y_ss == n_active selects the stacked matrix)
 bool rdyn_image_supported(int n_joints, unsigned fix_mask, int64_t y_ss, bool multi)
 {
-  if (!pattern_compiled(n_joints, fix_mask, multi ? 8 : RDYN_MAX_JOINTS)) return false;
+  if (!pattern_compiled(n_joints, fix_mask, multi ? 8 : RDYN_MAX_SWEPT_JOINTS)) return false;
   const int n_active = n_joints - popcount_u(fix_mask);
   if (y_ss == n_active) return true;  // stacked
   return y_ss > 0 && (y_ss * 8) % 16 == 0 && 64 * y_ss * 8 < (int64_t)0xFFFFFFFFll;

@@ -144,11 +144,11 @@ hipError_t launch_image_multi(const RdynSweepArgs* table, int n_items, int64_t m
   return hipGetLastError();
 }
 
-// one (input joints, fixed head joints, fixed tail joints) pattern; compiled only when the chain fits RDYN_MAX_JOINTS
+// one (input joints, fixed head joints, fixed tail joints) pattern; compiled only when the chain fits RDYN_MAX_SWEPT_JOINTS
 template <int NA, int H, int T, bool MULTI>
 hipError_t image_try(int n_joints, unsigned fix, bool stacked, const RdynSweepArgs* a, int n_items, int64_t max_samples, hipStream_t st, bool* hit)
 {
-  if constexpr (NA + H + T <= RDYN_MAX_JOINTS)
+  if constexpr (NA + H + T <= RDYN_MAX_SWEPT_JOINTS)
   {
     constexpr int NJ = NA + H + T;
     constexpr unsigned FIX = rdyn_image_pattern_mask(NA, H, T);

@@ -26,6 +26,12 @@ struct RdynSweepArgs
   // applied TO the link; getWrench, primitives_impl.h:1225); element e of sample s at ext[s * ext_ss + e * ext_se]
   const double* ext;
   int64_t ext_ss, ext_se;
+  // RDYN_MODE_REGRESSOR_EXPAND only (a chain longer than what the kernels sweep: `chain` is its reduced companion): the ten columns of
+  // chain link g are the columns of reduced link expand_red_of[g] times the constant 10 x 10 block X_g (rdyn_chain.hpp), zero for links
+  // upstream of the first input joint (expand_red_of[g] < 0).  expand_X: device, [expand_n][10][10] row-major X_g(a, p).
+  const double* expand_X;
+  int expand_n;
+  signed char expand_red_of[RDYN_MAX_JOINTS];
 };
 
 // split / jerk sweeps (rdyn_kin_ext.hip); every output record is links x 6
@@ -56,8 +62,8 @@ struct RdynIkArgs
   double* sol;                       // same addressing as seed (may alias it)
   int64_t n_samples, in_ss, in_sj;
   double weight[6];                  // all 1 for computeLocalIk
-  double q_min[RDYN_MAX_JOINTS];     // per CHAIN joint
-  double q_max[RDYN_MAX_JOINTS];
+  double q_min[RDYN_MAX_SWEPT_JOINTS];     // per CHAIN joint
+  double q_max[RDYN_MAX_SWEPT_JOINTS];
   double toll;
   double damping;                    // Levenberg term: damping^2 is added to the diagonal of J'WJ (0 = the reference's QP)
   int max_iter;
@@ -113,7 +119,7 @@ struct RdynGramArgs
   // input joint j and are structurally zero in columns < first_col[j] (primitives_impl.h:690-691, 1341-1347).
   // row_block == 0: no structure assumed.  Column blocks (16 wide) left of first_col[j] are neither loaded nor multiplied.
   int64_t row_block;
-  int first_col[RDYN_MAX_JOINTS];
+  int first_col[RDYN_MAX_SWEPT_JOINTS];
   // finish only: > 0 = the slabs hold the columns in the wave-pair kernel's order [tau_meas | link desc_nj - 1 | ... | link 0]
   // (rdyn_duo_gram.hip: the zero band of every row group then ends at a 16-column boundary more often); 0 = natural order
   int desc_nj;
@@ -128,7 +134,7 @@ struct RdynGramExpandArgs
 {
   const double *G_red, *c_red, *bb_red;  // (10 n_red + K)^2, 10 n_red + K, 1
   const double* X;                       // device: [n_joints][10][10]
-  int red_of[RDYN_MAX_JOINTS];
+  int red_of[RDYN_MAX_JOINTS];   // per CHAIN joint (the chain may be longer than what the kernels sweep)
   int n_joints, n_red, n_comp_cols;
   int add_to_output;
   double *G, *c, *bb;                    // (10 n_joints + K)^2, 10 n_joints + K, 1 (c, bb may be null)
@@ -140,7 +146,7 @@ struct RdynFusedGramArgs
 {
   RdynSweepArgs sweep;   // chain, q/dq/ddq/bcol, n_samples, input strides (Y fields ignored)
   int n_active;
-  int first_col[RDYN_MAX_JOINTS];
+  int first_col[RDYN_MAX_SWEPT_JOINTS];
   double* images;        // [blocks][(P + 1) * n * 256] per-workgroup tile images
   double* slabs;         // [blocks][NT * 256] per-workgroup Gram slabs
   int debug;             // timing experiments only (RDYN_FUSED_DEBUG): bit 0 skip phase 1 after the first tile, bit 1 skip phase 2
@@ -163,10 +169,10 @@ struct RdynLdsGramArgs
   int64_t n_samples, in_ss, in_sj;
   int n_active;
   int all_revolute;                    // every chain joint is revolute (selects the sweeper without joint-kind selects)
-  int first_col[RDYN_MAX_JOINTS];      // per input joint: 10 * chain index
-  int lds_off[RDYN_MAX_JOINTS];        // per link: byte offset of its first column in the tile
-  int lds_stride[RDYN_MAX_JOINTS];     // per link: bytes between its columns = (16 m_f + 4) * 8
-  int lds_m[RDYN_MAX_JOINTS];          // per link: number of input joints whose rows can be non-zero (stored rows = 16 m_f)
+  int first_col[RDYN_MAX_SWEPT_JOINTS];      // per input joint: 10 * chain index
+  int lds_off[RDYN_MAX_SWEPT_JOINTS];        // per link: byte offset of its first column in the tile
+  int lds_stride[RDYN_MAX_SWEPT_JOINTS];     // per link: bytes between its columns = (16 m_f + 4) * 8
+  int lds_m[RDYN_MAX_SWEPT_JOINTS];          // per link: number of input joints whose rows can be non-zero (stored rows = 16 m_f)
   int lds_off_b;                       // byte offset of column P (measured torque), 16 n rows
   int lds_dummy_off;                   // pipelined kernel only: 64 x 8 bytes where lanes drop rows a link does not store
   int tile_bytes;                      // one wave's tile
@@ -198,7 +204,8 @@ hipError_t rdyn_launch_regressor_gram_duo(int n_cols, const RdynLdsGramArgs& a, 
 // xb = 1: one more 16-column block for the component columns of rdyn_identification_tsqr (chains of <= 6 joints)
 int rdyn_cholqr_pairs(int n_joints, int tile_bytes, int xb);  // 4: W in LDS beside four tiles; -4: four tiles, W in global memory; 2: two pairs on four SIMDs (7 joints + components); 0: unsupported
 size_t rdyn_cholqr_w_doubles(int n_joints, int xb);           // W in MFMA operand order
-hipError_t rdyn_launch_cholqr_fold(const double* R_new, double* R, int n1, hipStream_t st);  // R <- qr([R ; R_new]), n1 <= 136
+// R <- qr([R ; R_new]); rows_new > 0: R_new is zero below that many rows (an expanded factor); any n1 whose packed R_new fits 156 KB of LDS
+hipError_t rdyn_launch_cholqr_fold(const double* R_new, double* R, int n1, hipStream_t st, int rows_new = 0);
 hipError_t rdyn_launch_regressor_pgram(int n_joints, const RdynLdsGramArgs& a, const double* W, const int* run_flag, int blocks, int pairs, hipStream_t st);
 // the same pass over a materialised column-major matrix [A | b] (rdyn_tsqr): n_cols + (b != null) <= 96 columns, natural column order
 hipError_t rdyn_launch_pgram_rows(const double* A, const double* b, int64_t rows, int64_t lda, int n_cols, const double* W, double* slabs,
@@ -260,7 +267,7 @@ struct RdynComponentArgs
 };
 hipError_t rdyn_launch_components(const RdynComponentArgs& a, hipStream_t st);
 
-enum { RDYN_MODE_REGRESSOR = 0, RDYN_MODE_TORQUE = 1, RDYN_MODE_INERTIA = 2, RDYN_MODE_REGRESSOR_GRAM = 3 };
+enum { RDYN_MODE_REGRESSOR = 0, RDYN_MODE_TORQUE = 1, RDYN_MODE_INERTIA = 2, RDYN_MODE_REGRESSOR_GRAM = 3, RDYN_MODE_REGRESSOR_EXPAND = 4 };
 
 hipError_t rdyn_launch_local_sweep(int n_joints, int mode, const RdynSweepArgs& a, hipStream_t st);
 hipError_t rdyn_launch_base_sweep(int n_joints, const RdynKinArgs& a, hipStream_t st);

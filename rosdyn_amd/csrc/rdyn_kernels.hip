@@ -43,9 +43,12 @@ enum
   MODE_INERTIA = 2,
   // regressor image that only the Gram kernel will read (rdyn_regressor_gram): structural zeros are stored only
   // where k_gram still loads them, i.e. inside 16-column blocks that also hold non-zero columns of that row
-  MODE_REGRESSOR_GRAM = 3
+  MODE_REGRESSOR_GRAM = 3,
+  // dense regressor of a chain LONGER than the kernels sweep: the reduced companion is swept and every (row, body) ten-vector is
+  // multiplied by the constant 10 x 10 blocks of the chain links that ride on that body (Y_f = Y_body X_f, rdyn_chain.hpp)
+  MODE_REGRESSOR_EXPAND = 4
 };
-#define RDYN_IS_REGRESSOR(MODE) ((MODE) == MODE_REGRESSOR || (MODE) == MODE_REGRESSOR_GRAM)
+#define RDYN_IS_REGRESSOR(MODE) ((MODE) == MODE_REGRESSOR || (MODE) == MODE_REGRESSOR_GRAM || (MODE) == MODE_REGRESSOR_EXPAND)
 #define RDYN_BODY_EXIT return
 
 // one chain, one batch: grid.x = ceil(N / 256)
@@ -215,6 +218,7 @@ hipError_t launch_local_nj(int mode, const RdynSweepArgs& a, hipStream_t st)
   {
   case MODE_REGRESSOR: hipLaunchKernelGGL((k_local_sweep<NJ, MODE_REGRESSOR>), dim3(grid), dim3(256), 0, st, a); break;
   case MODE_REGRESSOR_GRAM: hipLaunchKernelGGL((k_local_sweep<NJ, MODE_REGRESSOR_GRAM>), dim3(grid), dim3(256), 0, st, a); break;
+  case MODE_REGRESSOR_EXPAND: hipLaunchKernelGGL((k_local_sweep<NJ, MODE_REGRESSOR_EXPAND>), dim3(grid), dim3(256), 0, st, a); break;
   case MODE_TORQUE: hipLaunchKernelGGL((k_local_sweep<NJ, MODE_TORQUE>), dim3(grid), dim3(256), 0, st, a); break;
   default: hipLaunchKernelGGL((k_local_sweep<NJ, MODE_INERTIA>), dim3(grid), dim3(256), 0, st, a); break;
   }

@@ -71,11 +71,20 @@ def test_limits_follow_reference_rules():
 
 def test_too_many_joints_is_reported():
     from rosdyn_amd import Chain, RdynError
-    links = "".join("<link name='l%d'/>" % i for i in range(13))
-    joints = "".join("<joint name='j%d' type='revolute'><parent link='l%d'/><child link='l%d'/><axis xyz='0 0 1'/>"
-                     "<limit lower='-1' upper='1' effort='1' velocity='1'/></joint>" % (i, i, i + 1) for i in range(12))
-    with pytest.raises(RdynError, match="at most"):
-        Chain("<robot name='long'>%s%s</robot>" % (links, joints), "l0", "l12")
+    def xml(nj):
+        links = "".join("<link name='l%d'/>" % i for i in range(nj + 1))
+        joints = "".join("<joint name='j%d' type='revolute'><parent link='l%d'/><child link='l%d'/><axis xyz='0 0 1'/>"
+                         "<limit lower='-1' upper='1' effort='1' velocity='1'/></joint>" % (i, i, i + 1) for i in range(nj))
+        return "<robot name='long'>%s%s</robot>" % (links, joints)
+    with pytest.raises(RdynError, match="at most 32"):
+        Chain(xml(33), "l0", "l33")
+    # 12 moving joints: ingested (names, limits, parameters), but no kernel sweeps more than 10 input joints -- the workspace queries
+    # say so before anything touches a device; with at most 10 of them as input joints the chain is served
+    c = Chain(xml(12), "l0", "l12")
+    from rosdyn_amd._lib import lib
+    assert c.getJointsNumber() == 12 and lib().rdyn_regressor_tsqr_workspace_bytes(c._h) == 0 and lib().rdyn_regressor_gram_workspace_bytes(c._h, 0) == 0
+    c.setInputJointsName(["j%d" % i for i in range(2, 9)])
+    assert c.getActiveJointsNumber() == 7 and lib().rdyn_regressor_tsqr_workspace_bytes(c._h) > 0
 
 
 def test_generated_chain_variants_ingest_identically():
@@ -287,3 +296,28 @@ def test_tsqr_report_answers_without_a_device_where_it_can():
     assert L.rdyn_tsqr_last_report(ur6._h, None, 0, 1000, None, -1, None, C.byref(rep)) != 0          # null workspace
     assert L.rdyn_tsqr_last_report(ur6._h, None, 0, -1, C.byref(dummy), -1, None, C.byref(rep)) != 0  # negative batch size
     assert L.rdyn_tsqr_last_report(None, None, 0, 1000, C.byref(dummy), -1, None, C.byref(rep)) != 0  # null chain
+
+
+def test_chains_longer_than_the_kernels_sweep_are_ingested():
+    """Host-only: 14 chain joints (ur10_public + five fixed frames, one mid-chain) -- names, types, nominal
+    parameters and the rigid-body reduction are there; the limit is RDYN_MAX_JOINTS = 32 chain joints and 10 input joints."""
+    import ctypes as C
+    from oracle.oracle import OracleChain
+    from rosdyn_amd import Chain
+    from rosdyn_amd._lib import RDYN_MAX_JOINTS, lib
+    path = os.path.join(FIXTURES, "ur10_public_long.urdf")
+    chain, ref = Chain(path, "base_link", "tcp", (0, 0, -9.806)), OracleChain(path, "base_link", "tcp", (0, 0, -9.806))
+    assert chain.getJointsNumber() == 14 and chain.getActiveJointsNumber() == 6 and RDYN_MAX_JOINTS == 32
+    assert np.abs(chain.getNominalParameters() - ref.nominal_parameters()).max() == 0.0
+    L = lib()
+    body = (C.c_int32 * 14)()
+    assert L.rdyn_chain_reduction(chain._h, body, None, None) == 6      # six rigid bodies
+    assert list(body)[:2] == [-1, 2] or list(body)[0] == -1             # the frame in front of the first input joint never moves
+    assert L.rdyn_regressor_tsqr_workspace_bytes(chain._h) > 0 and L.rdyn_regressor_gram_workspace_bytes(chain._h, 0) > 0
+    # 33 joints: refused at ingest
+    links = "".join("<link name='l%d'/>" % i for i in range(34))
+    joints = "".join("<joint name='j%d' type='fixed'><parent link='l%d'/><child link='l%d'/></joint>" % (i, i, i + 1) for i in range(33))
+    h = C.c_void_p()
+    g = (C.c_double * 3)(0, 0, 0)
+    assert L.rdyn_chain_from_urdf(("<robot name='r'>%s%s</robot>" % (links, joints)).encode(), b"l0", b"l33", g, C.byref(h)) == 5
+    assert b"at most 32" in L.rdyn_last_error()

@@ -87,6 +87,28 @@ for rws, cols in ((6000000, 60), (6000000, 85), (1000000, 111)):
     rows.append(("rdyn_tsqr: %d rows x (%d + 1) columns from memory" % (rws, cols), t * 1e6, rws / t, 8 * (cols + 1), 8 * (cols + 1) * rws / t / 1e9))
     del Am, bm
 
+# round 4: what the chains OFF the fast kernels cost -- a fixed frame in the MIDDLE of the chain, permuted input joints, and a chain
+# longer than the kernels sweep (14 joints: the reduced companion is swept, the folded links' columns restored by 10 x 10 blocks)
+longc = Chain(os.path.join(ROOT, "tests/fixtures/ur10_public_long.urdf"), "base_link", "tcp", (0, 0, -9.806))
+Bl = 3 * 48 + 48 + 6 * 140 * 8
+row("ur10_public_long base_link->tcp (14 joints, P = 140): getRegressor + tau (element-major)", lambda: longc.getRegressor(q, dq, ddq, layout=E, with_torque=True), Bl, reps=5)
+row("ur10_public_long base_link->tcp: getRegressor + tau (per-sample images)", lambda: longc.getRegressor(qs, dqs, ddqs, with_torque=True), Bl, reps=5)
+row("ur10_public_long base_link->tcp: getJointTorque", lambda: longc.getJointTorque(q, dq, ddq, layout=E), 192)
+row("ur10_public_long base_link->tcp: regressor -> Gram (P = 140)", lambda: longc.getRegressorGram(q, dq, ddq, tau, layout=E), 192, reps=5)
+row("ur10_public_long base_link->tcp: R factor of [A | tau] (141 x 141)", lambda: longc.getRegressorTsqr(q, dq, ddq, tau, layout=E), 192, reps=5)
+midc = Chain(os.path.join(ROOT, "tests/fixtures/ur10_public_long.urdf"), "base_link", "wrist_3_link", (0, 0, -9.806))   # 8 joints, fixed head + fixed MIDDLE
+Bm = 3 * 48 + 48 + 6 * 80 * 8
+row("fixed frame mid-chain (8 joints, P = 80): getRegressor + tau (stacked)", lambda: midc.getRegressor(qs, dqs, ddqs, y_layout="stacked", with_torque=True), Bm, reps=5)
+row("fixed frame mid-chain: getRegressor + tau (per-sample images)", lambda: midc.getRegressor(qs, dqs, ddqs, with_torque=True), Bm, reps=5)
+row("fixed frame mid-chain: regressor -> Gram", lambda: midc.getRegressorGram(q, dq, ddq, tau, layout=E), 192, reps=5)
+row("fixed frame mid-chain: R factor of [A | tau]", lambda: midc.getRegressorTsqr(q, dq, ddq, tau, layout=E), 192, reps=5)
+perm = Chain(os.path.join(ROOT, "tests/fixtures/ur10_like.urdf"), "base_link", "wrist_3_link", (0, 0, -9.806))
+perm.setInputJointsName(list(reversed(perm.getActiveJointsName())))
+row("permuted input joints (6 joints): getRegressor + tau (stacked)", lambda: perm.getRegressor(qs, dqs, ddqs, y_layout="stacked", with_torque=True), 3072, reps=5)
+row("permuted input joints: getRegressor + tau (per-sample images)", lambda: perm.getRegressor(qs, dqs, ddqs, with_torque=True), 3072, reps=5)
+row("permuted input joints: getRegressor + tau (element-major)", lambda: perm.getRegressor(q, dq, ddq, layout=E, with_torque=True), 3072, reps=5)
+row("permuted input joints: regressor -> Gram", lambda: perm.getRegressorGram(q, dq, ddq, tau, layout=E), 192, reps=5)
+
 print("%-60s %10s %14s %10s %10s" % ("entry point (N = 1e6 per call)", "us / call", "evals/s", "B / eval", "GB/s"))
 for r in rows:
     print("%-60s %10.1f %14.3e %10d %10.0f" % r)
