@@ -20,6 +20,7 @@
 //     SIMD): the kernel-wide register allocation must cover both roles inside 256 registers -> 444 B of spills,
 //     1.49 ms (n = 7: 20 ms).  It needs per-role register budgets, i.e. two cooperating kernels.
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include "rdyn_device.h"
 #include "rdyn_devmath.h"
 #include "rdyn_kernels.h"

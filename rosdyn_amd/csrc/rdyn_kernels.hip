@@ -29,6 +29,7 @@
 // the store path decides the speed: with the element-major layout every store instruction of a wave
 // writes 512 contiguous bytes.
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include "rdyn_device.h"
 #include "rdyn_devmath.h"
 #include "rdyn_kernels.h"

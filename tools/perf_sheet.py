@@ -93,6 +93,7 @@ longc = Chain(os.path.join(ROOT, "tests/fixtures/ur10_public_long.urdf"), "base_
 Bl = 3 * 48 + 48 + 6 * 140 * 8
 row("ur10_public_long base_link->tcp (14 joints, P = 140): getRegressor + tau (element-major)", lambda: longc.getRegressor(q, dq, ddq, layout=E, with_torque=True), Bl, reps=5)
 row("ur10_public_long base_link->tcp: getRegressor + tau (per-sample images)", lambda: longc.getRegressor(qs, dqs, ddqs, with_torque=True), Bl, reps=5)
+row("ur10_public_long base_link->tcp: getRegressor + tau (stacked)", lambda: longc.getRegressor(qs, dqs, ddqs, y_layout="stacked", with_torque=True), Bl, reps=5)
 row("ur10_public_long base_link->tcp: getJointTorque", lambda: longc.getJointTorque(q, dq, ddq, layout=E), 192)
 row("ur10_public_long base_link->tcp: regressor -> Gram (P = 140)", lambda: longc.getRegressorGram(q, dq, ddq, tau, layout=E), 192, reps=5)
 row("ur10_public_long base_link->tcp: R factor of [A | tau] (141 x 141)", lambda: longc.getRegressorTsqr(q, dq, ddq, tau, layout=E), 192, reps=5)
