@@ -2,7 +2,10 @@
  * (ur10 base_link -> tool0: a fixed joint in front, two behind; rosdyn_speed_test.cpp:44-45): measured torques of a trajectory batch ->
  *   (a) normal equations on the fp64 matrix cores   rdyn_regressor_gram  + rdyn_solve_normal_equations
  *   (b) the R factor without the normal equations   rdyn_regressor_tsqr  + rdyn_solve_r_factor
- * -> minimum-norm inertial parameters, which must reproduce the torques.  The regressor (N n x 90) is never stored.
+ *   (c) friction too: one FirstOrderPolynomialFriction per input joint (friction_polynomial1.h:126) stacked beside getRegressor, as the
+ *       external identification step does (README.md:15): [Y | C | tau] -> rdyn_identification_tsqr + rdyn_solve_r_factor
+ * -> minimum-norm inertial parameters, which must reproduce the torques, and the friction coefficients the torques were made with.
+ * The regressor (N n x 90) is never stored.
  *   gcc -std=c99 -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -Iinclude examples/identify.c \
  *       -Lrosdyn_amd -lrdyn_hip -L/opt/rocm/lib -lamdhip64 -Wl,-rpath,$PWD/rosdyn_amd -o identify
  *   ./identify tests/fixtures/ur10_public.urdf base_link tool0 400000
@@ -52,7 +55,7 @@ int main(int argc, char** argv)
   void *ws_g, *ws_r;
   size_t nb_g, nb_r;
   rdyn_batch b;
-  double e_ne = 0.0, e_qr = 0.0, tmax = 0.0;
+  double e_ne = 0.0, e_qr = 0.0, tmax = 0.0, e_fr = 0.0;
   if (argc < 4)
   {
     fprintf(stderr, "usage: %s <urdf> <base link> <tool link> [samples]\n", argv[0]);
@@ -155,6 +158,53 @@ int main(int argc, char** argv)
     hipFree(d_Y);
     free(h_Y);
   }
+  /* (c) the same with friction: tau_meas = tau_rigid + Coulomb + viscous friction of every input joint; unknowns [inertial ; friction] */
+  {
+    rdyn_component comps[RDYN_MAX_SWEPT_JOINTS];
+    int K, n1c, rank_c = 0, j;
+    void* ws_c;
+    size_t nb_c;
+    double *d_R1c, *R1c, *x_c;
+    for (j = 0; j < n; ++j)
+    {
+      comps[j].type = RDYN_COMP_FRICTION1;
+      comps[j].joint = j;
+      comps[j].min_velocity = 1e-3;
+      comps[j].max_velocity = 10.0;
+      comps[j].parameters[0] = 0.5 + 0.1 * j;  /* Coulomb */
+      comps[j].parameters[1] = 1.0 + 0.2 * j;  /* viscous */
+      comps[j].parameters[2] = 0.0;
+    }
+    K = rdyn_components_columns(comps, n);
+    n1c = P + K + 1;
+    CHECK(rdyn_components_regressor(comps, n, n, &b, NULL, NULL, d_tau));  /* tau += the friction torques */
+    nb_c = rdyn_identification_tsqr_workspace_bytes(chain, comps, n);
+    if (nb_c == 0)
+    {
+      fprintf(stderr, "rdyn_identification_tsqr does not serve this chain\n");
+      return 1;
+    }
+    hipMalloc(&ws_c, nb_c);
+    hipMalloc((void**)&d_R1c, sizeof(double) * (size_t)n1c * n1c);
+    CHECK(rdyn_identification_tsqr(chain, comps, n, &b, d_tau, d_R1c, 0, ws_c, nb_c));
+    hipDeviceSynchronize();
+    R1c = (double*)malloc(sizeof(double) * (size_t)n1c * n1c);
+    x_c = (double*)malloc(sizeof(double) * (size_t)(P + K));
+    hipMemcpy(R1c, d_R1c, sizeof(double) * (size_t)n1c * n1c, hipMemcpyDeviceToHost);
+    CHECK(rdyn_solve_r_factor(R1c, n1c, P + K, P + K, R1c + (size_t)(P + K) * n1c, 1e-9, x_c, &rank_c));
+    for (j = 0; j < n; ++j)
+    {
+      const double ec = fabs(x_c[P + 2 * j] - comps[j].parameters[0]), ev = fabs(x_c[P + 2 * j + 1] - comps[j].parameters[1]);
+      if (ec > e_fr) e_fr = ec;
+      if (ev > e_fr) e_fr = ev;
+    }
+    printf("with %d friction components (%d columns): rank %d, max |identified - true friction coefficient| = %.3e, residual %.3e\n", n, K, rank_c, e_fr,
+           fabs(R1c[(size_t)(P + K) * n1c + (P + K)]));
+    hipFree(ws_c);
+    hipFree(d_R1c);
+    free(R1c);
+    free(x_c);
+  }
   printf("chain %s -> %s: n = %d, P = %d (%d rigid bodies), %lld samples\n", argv[2], argv[3], n, P, bodies, (long long)N);
   printf("normal equations: rank %d, max |Y x - tau| = %.3e;  R factor: rank %d, max |Y x - tau| = %.3e  (max |tau| = %.3e)\n", rank_ne, e_ne,
          rank_qr, e_qr, tmax);
@@ -165,5 +215,5 @@ int main(int argc, char** argv)
   hipFree(d_R1);
   hipFree(ws_g);
   hipFree(ws_r);
-  return (e_ne < 1e-6 * tmax && e_qr < 1e-7 * tmax && rank_qr == rank_ne) ? 0 : 1;
+  return (e_ne < 1e-6 * tmax && e_qr < 1e-7 * tmax && rank_qr == rank_ne && e_fr < 1e-7) ? 0 : 1;
 }

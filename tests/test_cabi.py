@@ -180,6 +180,11 @@ def test_c_identification_example_runs(tmp_path):
     r = subprocess.run([exe, os.path.join(FIXTURES, "ur10_public.urdf"), "base_link", "tool0", "400000"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "n = 6, P = 90 (6 rigid bodies)" in r.stdout
+    assert "with 6 friction components (12 columns)" in r.stdout      # round 4: friction identified too (rdyn_identification_tsqr)
+    # the 7-joint arm with its fixed flange and hand frames, friction columns included
+    r = subprocess.run([exe, os.path.join(FIXTURES, "panda_like.urdf"), "link0", "hand", "100000"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "n = 7, P = 90 (7 rigid bodies)" in r.stdout and "with 7 friction components (14 columns)" in r.stdout
 
 
 def test_hostile_urdf_is_rejected_not_crashed():
