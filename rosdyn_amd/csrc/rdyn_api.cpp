@@ -1473,6 +1473,17 @@ static bool tsqr_plan(const rdyn_chain* c, const rdyn_component* comps, int n_co
       (K == 0 || rdyn_regressor_gram_duo_supports_components(10 * p->nJ, K)) && build_lds_tile(cs, K, false, &p->la))
   {
     p->pairs = rdyn_cholqr_pairs(p->nJ, p->la.tile_bytes, p->xb);
+    if (p->pairs == -1)
+    {
+      // every wave sweeps and consumes its own COMPACT tile (k_regressor_pgram_solo): four of them fill the LDS, W stays in global memory
+      RdynLdsGramArgs compact;
+      memset(&compact, 0, sizeof compact);
+      build_lds_tile(cs, K, false, &compact, true);
+      if (4 * (size_t)compact.tile_bytes <= 160 * 1024)
+        p->la = compact;
+      else
+        p->pairs = rdyn_cholqr_pairs(p->nJ, -p->la.tile_bytes, p->xb);  // too many component columns: two pairs beside W, or nothing
+    }
     if (p->pairs != 0)
     {
       build_lds_tile(cs, K, false, &p->la_sub);
@@ -1612,10 +1623,11 @@ static int regressor_tsqr_run(const rdyn_chain* c, const rdyn_component* comps, 
     const int64_t sub_tiles = (tiles + sub.tile_stride - 1) / sub.tile_stride;
     la.slabs = ws + L.slabs;
     sub.slabs = la.slabs;
-    const int np = pairs < 0 ? -pairs : pairs;
+    const int np = pairs == -1 ? 4 : (pairs < 0 ? -pairs : pairs);  // tiles a workgroup works on at a time
     const int blocks = (int)((tiles + np - 1) / np < kCholqrBlocks ? (tiles + np - 1) / np : kCholqrBlocks);
     int* const flag = (int*)(ws + L.flag);
-    const int col_shift = rdyn_cholqr_col_shift(nJ, p.xb);
+    const int col_shift = pairs == -1 ? rdyn_cholqr_solo_col_shift(nJ, K) : rdyn_cholqr_col_shift(nJ, p.xb);
+    la.col_shift = col_shift;
     {
       // the plain regressor -> Gram kernel (rdyn_duo_gram.hip) on the subsample: its slab layout (descending link order, component
       // columns in front), its workgroups of four pairs

@@ -23,13 +23,16 @@ __device__ __forceinline__ double quad_bcast(double x, int k)
   default: return quad_bcast_k<3>(x);
   }
 }
-// LDS byte offset of link f's first column when every chain joint is an input joint (rows j <= f stored: stride (16 (f + 1) + 4) * 8)
-__device__ __forceinline__ constexpr int duo_direct_off(int f)
+// LDS byte offset of link f's first column when every chain joint is an input joint (rows j <= f stored: stride (16 (f + 1) + pad) * 8)
+__device__ __forceinline__ constexpr int duo_direct_off(int f, int pad = 4)
 {
   int off = 0;
-  for (int g = 0; g < f; ++g) off += 10 * (16 * (g + 1) + 4) * 8;
+  for (int g = 0; g < f; ++g) off += 10 * (16 * (g + 1) + pad) * 8;
   return off;
 }
+#ifndef RDYN_DUO_TILE_PAD
+#define RDYN_DUO_TILE_PAD 4  // (a kernel that sweeps into the compact tile redefines it around its include of rdyn_duo_link_body.inc)
+#endif
 
 }  // namespace
 #endif

@@ -185,6 +185,7 @@ struct RdynLdsGramArgs
   // it is stored as ONE 16-row group (stride 160 bytes) at lds_off_c + 160 k; the measured torque moves to column P + n_comp_cols.
   int n_comps, n_comp_cols;
   int lds_off_c, comp_stride;          // component column k at lds_off_c + comp_stride * k (160, or 144 in the compact layout)
+  int col_shift;                       // k_regressor_pgram_solo only: columns of padding in front of the natural order in the consumer's column space
   int comp_row_step;                   // 0: a component column stores its own joint's 16-row group only; 128: all row groups (rectangular tile of rdyn_tsqr_wide.hip)
   signed char comp_col_row[96];        // per component column: the input joint (row group) it belongs to
   RdynComponent comps[RDYN_MAX_COMPONENTS];
@@ -202,7 +203,7 @@ hipError_t rdyn_launch_regressor_gram_duo(int n_cols, const RdynLdsGramArgs& a, 
 //   W = R1^-1 of a Householder factor R1 of a row SUBSAMPLE (rdyn_tsqr.hip);  G2 = (A W)'(A W) over ALL rows: sweep -> LDS tile -> the
 //   consumer wave multiplies every 16-row group by W (MFMA) and accumulates the Gram of the product (MFMA);  R = chol(G2) R1.
 // xb = 1: one more 16-column block for the component columns of rdyn_identification_tsqr (chains of <= 6 joints)
-int rdyn_cholqr_pairs(int n_joints, int tile_bytes, int xb);  // 4: W in LDS beside four tiles; -4: four tiles, W in global memory; 2: two pairs on four SIMDs (7 joints + components); 0: unsupported
+int rdyn_cholqr_pairs(int n_joints, int tile_bytes, int xb);  // 4: W in LDS beside four tiles; -4: four tiles, W in global memory; 2: two pairs on four SIMDs, -1: four waves that sweep and consume their own compact tile (7 joints + components); 0: unsupported
 size_t rdyn_cholqr_w_doubles(int n_joints, int xb);           // W in MFMA operand order
 // R <- qr([R ; R_new]); rows_new > 0: R_new is zero below that many rows (an expanded factor); any n1 whose packed R_new fits 156 KB of LDS
 hipError_t rdyn_launch_cholqr_fold(const double* R_new, double* R, int n1, hipStream_t st, int rows_new = 0);
@@ -224,6 +225,7 @@ hipError_t rdyn_launch_cholqr_precond(const double* R1, const double* Gs, const 
                                       double* gamma_out, hipStream_t st);
 int rdyn_cholqr_max_cols();  // widest factor (right-hand side included) the dense steps of the preconditioned route hold in LDS
 int rdyn_cholqr_col_shift(int n_joints, int xb);
+int rdyn_cholqr_solo_col_shift(int n_joints, int n_comp_cols);  // pairs == -1 at 7 joints + components (k_regressor_pgram_solo: compact tile, every wave sweeps and consumes)
 // G2 = [G c; c' bb] -> R = chol(G2) T (n1 x n1 upper, column-major; zero rows at the confirmed null columns); flags[round] = 1 when the
 // round is not accepted (rho_out, may be null: [0] the conditioning measure of the equilibrated Q, [2] gamma on the norms of all rows);
 // round 0 clears flags[1]
