@@ -56,6 +56,9 @@ using Vector3d = Eigen::Vector3d;
 using Affine3d = Eigen::Affine3d;
 using VectorOfAffine3d = std::vector<Eigen::Affine3d, Eigen::aligned_allocator<Eigen::Affine3d>>;
 using VectorOfVector6d = std::vector<Vector6d, Eigen::aligned_allocator<Vector6d>>;
+// the argument type of the component classes: the reference passes const Eigen::Ref<Eigen::VectorXd>& (base_component.h:124-161,
+// friction_polynomial1.h:89-133, ideal_spring.h:57-72) -- a writable vector or vector block is bound without a copy
+using VectorArg = Eigen::Ref<Eigen::VectorXd>;
 namespace detail
 {
 inline void set_affine(Affine3d& T, const double* m34)  // column-major 3x4 [R | p]
@@ -121,6 +124,7 @@ struct Affine3d  // 3x4 [R | p], column-major
 };
 using VectorOfAffine3d = std::vector<Affine3d>;
 using VectorOfVector6d = std::vector<Vector6d>;
+using VectorArg = VectorXd;
 namespace detail
 {
 inline void set_affine(Affine3d& T, const double* m34) { std::memcpy(T.m, m34, sizeof T.m); }
@@ -995,7 +999,7 @@ protected:
   rdyn_component m_desc;
   detail::SmallStage m_stage;
 
-  void computeRegressor(const VectorXd& q, const VectorXd& Dq)
+  void computeRegressor(const VectorArg& q, const VectorArg& Dq)
   {
     const unsigned n = m_joints_number;
     if ((unsigned)q.rows() != n || (unsigned)Dq.rows() != n) throw std::invalid_argument("Input data dimensions mismatch");
@@ -1041,19 +1045,19 @@ public:
   virtual ~ComponentBase() {}
   ComponentBase(const ComponentBase&) = delete;
   ComponentBase& operator=(const ComponentBase&) = delete;
-  virtual VectorXd getTorque(const VectorXd& q, const VectorXd& Dq, const VectorXd& DDq) = 0;
-  virtual VectorXd getAdditiveTorque(const VectorXd& q, const VectorXd& Dq, const VectorXd& DDq) { return getTorque(q, Dq, DDq); }  // base_component.h:130
-  virtual VectorXd getNonAdditiveTorque(const VectorXd&, const VectorXd&, const VectorXd&, const VectorXd&)  // base_component.h:135-141
+  virtual VectorXd getTorque(const VectorArg& q, const VectorArg& Dq, const VectorArg& DDq) = 0;
+  virtual VectorXd getAdditiveTorque(const VectorArg& q, const VectorArg& Dq, const VectorArg& DDq) { return getTorque(q, Dq, DDq); }  // base_component.h:130
+  virtual VectorXd getNonAdditiveTorque(const VectorArg&, const VectorArg&, const VectorArg&, const VectorArg&)  // base_component.h:135-141
   {
     VectorXd t((int)m_joints_number);
     for (unsigned i = 0; i < m_joints_number; ++i) t((int)i) = 0.0;
     return t;
   }
-  virtual MatrixXd getRegressor(const VectorXd& q, const VectorXd& Dq, const VectorXd& DDq) = 0;
+  virtual MatrixXd getRegressor(const VectorArg& q, const VectorArg& Dq, const VectorArg& DDq) = 0;
   unsigned int getParametersNumber() { return (unsigned)m_nominal_parameters.rows(); }
   VectorXd getNominalParameters() { return m_nominal_parameters; }
   const std::string& getJointName() const { return m_component_joint_name; }
-  virtual bool setParameters(const VectorXd& parameters)
+  virtual bool setParameters(const VectorArg& parameters)
   {
     if (parameters.rows() != m_nominal_parameters.rows()) return false;  // ideal_spring.h:74-78
     m_nominal_parameters = parameters;
@@ -1073,7 +1077,7 @@ class FirstOrderPolynomialFriction : public ComponentBase
 {
 protected:
   double m_Dq_threshold, m_Dq_max;
-  VectorXd frictionNonAdditive(const VectorXd& Dq, const VectorXd& additive_torque)
+  VectorXd frictionNonAdditive(const VectorArg& Dq, const VectorArg& additive_torque)
   {
     VectorXd tau = additive_torque;
     const int j = (int)m_component_joint_number;
@@ -1104,28 +1108,28 @@ public:
     m_nominal_parameters(1) = viscous;
     m_regressor.resize((int)m_joints_number, (int)m_nominal_parameters.rows());
   }
-  VectorXd getTorque(const VectorXd& q, const VectorXd& Dq, const VectorXd&) override
+  VectorXd getTorque(const VectorArg& q, const VectorArg& Dq, const VectorArg&) override
   {
     computeRegressor(q, Dq);
     m_torques((int)m_component_joint_number) = rowTimesParameters(0);
     return m_torques;
   }
-  VectorXd getAdditiveTorque(const VectorXd& q, const VectorXd& Dq, const VectorXd&) override  // viscous part only, :97-103
+  VectorXd getAdditiveTorque(const VectorArg& q, const VectorArg& Dq, const VectorArg&) override  // viscous part only, :97-103
   {
     computeRegressor(q, Dq);
     m_torques((int)m_component_joint_number) = rowTimesParameters(1);
     return m_torques;
   }
-  VectorXd getNonAdditiveTorque(const VectorXd&, const VectorXd& Dq, const VectorXd&, const VectorXd& additive_torque) override
+  VectorXd getNonAdditiveTorque(const VectorArg&, const VectorArg& Dq, const VectorArg&, const VectorArg& additive_torque) override
   {
     return frictionNonAdditive(Dq, additive_torque);
   }
-  MatrixXd getRegressor(const VectorXd& q, const VectorXd& Dq, const VectorXd&) override
+  MatrixXd getRegressor(const VectorArg& q, const VectorArg& Dq, const VectorArg&) override
   {
     computeRegressor(q, Dq);
     return m_regressor;
   }
-  bool setParameters(const VectorXd& parameters) override  // the reference accepts any size here (:133-145); sizes are checked
+  bool setParameters(const VectorArg& parameters) override  // the reference accepts any size here (:133-145); sizes are checked
   {
     return ComponentBase::setParameters(parameters);
   }
@@ -1157,13 +1161,13 @@ public:
     m_nominal_parameters(1) = offset_effort;
     m_regressor.resize((int)m_joints_number, 2);
   }
-  VectorXd getTorque(const VectorXd& q, const VectorXd& Dq, const VectorXd&) override
+  VectorXd getTorque(const VectorArg& q, const VectorArg& Dq, const VectorArg&) override
   {
     computeRegressor(q, Dq);
     m_torques((int)m_component_joint_number) = rowTimesParameters(0);
     return m_torques;
   }
-  MatrixXd getRegressor(const VectorXd& q, const VectorXd& Dq, const VectorXd&) override
+  MatrixXd getRegressor(const VectorArg& q, const VectorArg& Dq, const VectorArg&) override
   {
     computeRegressor(q, Dq);
     return m_regressor;

@@ -22,7 +22,7 @@ def test_eigen_and_urdfdom_typed_branches_compile_and_run(tmp_path):
     urdfdom names they touch (tests/mock_include: neither library is installed here).  createChain(const urdf::ModelInterface&, ...)
     must build the same chain as the XML route; host-only, runs on the CPU box."""
     exe = tmp_path / "typed"
-    subprocess.check_call(["g++", "-std=c++17", "-Wall", "-Wextra", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include",
+    subprocess.check_call(["g++", "-std=c++17", "-Wall", "-Wextra", "-Werror", "-pedantic", "-D__HIP_PLATFORM_AMD__", "-isystem", "/opt/rocm/include",
                            "-I" + os.path.join(ROOT, "tests", "mock_include"), "-I" + os.path.join(ROOT, "rosdyn_amd", "csrc"),
                            os.path.join(ROOT, "tests", "cpp", "facade_typed_surface.cpp"), "-o", str(exe),
                            "-L" + os.path.join(ROOT, "rosdyn_amd"), "-lrdyn_hip", "-L/opt/rocm/lib", "-lamdhip64",
@@ -140,3 +140,35 @@ def test_facade_single_sample_values_match_oracle(binary, types):
     x = vals["S"][2:]
     Yq = ref.regressor(q, dq, ddq)[0]
     close(Yq @ x, ref.joint_torque(q, dq, ddq)[0])
+
+
+def _build_eigen_caller(tmp_path):
+    exe = tmp_path / "eigen_caller"
+    subprocess.check_call(["g++", "-std=c++17", "-Wall", "-Wextra", "-Werror", "-pedantic", "-D__HIP_PLATFORM_AMD__", "-isystem", "/opt/rocm/include",
+                           "-I" + os.path.join(ROOT, "tests", "mock_include"), "-I" + os.path.join(ROOT, "rosdyn_amd", "csrc"),
+                           os.path.join(ROOT, "tests", "cpp", "eigen_caller.cpp"), "-o", str(exe),
+                           "-L" + os.path.join(ROOT, "rosdyn_amd"), "-lrdyn_hip", "-L/opt/rocm/lib", "-lamdhip64",
+                           "-Wl,-rpath," + os.path.join(ROOT, "rosdyn_amd"), "-Wl,-rpath,/opt/rocm/lib"])
+    return str(exe)
+
+
+def test_eigen_caller_and_harness_compile_pedantic(tmp_path):
+    """VERDICT r3 item 7: a CALLER of the reference's Eigen-typed signatures -- const Eigen::Ref<Eigen::VectorXd>& into the component classes
+    (base_component.h:124-161), .col() / .block() on the returned Jacobian, .linear() / .translation() on the returned Affine3d -- and the
+    harness port compile with -Wall -Wextra -Werror -pedantic against the stand-in headers; tools/build_with_real_eigen.sh does the same
+    against real Eigen on a machine that has it (it refuses the stand-in and reports a missing Eigen with exit code 3)."""
+    _build_eigen_caller(tmp_path)
+    subprocess.check_call(["g++", "-std=c++17", "-Wall", "-Wextra", "-Werror", "-pedantic", "-fsyntax-only", "-D__HIP_PLATFORM_AMD__", "-isystem", "/opt/rocm/include",
+                           "-I" + os.path.join(ROOT, "tests", "mock_include"), "-I" + os.path.join(ROOT, "rosdyn_amd", "csrc"),
+                           os.path.join(ROOT, "rosdyn_amd", "csrc", "rdyn_speed_test.cpp")])
+    script = os.path.join(ROOT, "tools", "build_with_real_eigen.sh")
+    r = subprocess.run([script, os.path.join(ROOT, "tests", "mock_include")], capture_output=True, text=True)
+    assert r.returncode == 3 and "stand-in" in r.stdout
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("urdf,base,tool", [("ur10_like.urdf", "base_link", "tool0"), ("panda_like.urdf", "link0", "hand"), ("mixed_joints.urdf", "world", "tip")])
+def test_eigen_caller_runs_on_gpu(tmp_path, urdf, base, tool):
+    exe = _build_eigen_caller(tmp_path)
+    r = subprocess.run([exe, os.path.join(FIXTURES, urdf), base, tool], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.startswith("ok"), r.stdout + r.stderr
