@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage (on the GPU box, from the repo root): tools/r4_run.sh <tag> [tests] -- GPU suite (or the named test files) + perf sheet into gpurun_out/<tag>_*
+# usage (on the GPU box, from the repo root): tools/gpu_suite.sh <tag> [tests] -- GPU suite (or the named test files) + perf sheet into gpurun_out/<tag>_*
 T=${1:-r4}; shift
 mkdir -p gpurun_out
 python -m pytest ${@:-tests} -x -q -m gpu 2>&1 | grep -v "^RCCL\|^HIP ver\|^ROCm\|^Hostname\|^Librccl" > gpurun_out/${T}_gputests.log

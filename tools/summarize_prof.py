@@ -27,7 +27,7 @@ order = defaultdict(list)  # (start timestamp, duration) per kernel, to single o
 meta = {}
 for r in rows("trace/**/*kernel_trace.csv"):
     name = r.get("Kernel_Name", "")
-    if any(k in name for k in ("k_local_sweep", "k_base_sweep", "k_base_ext", "k_gram", "k_rowpair", "k_image_sweep", "k_regressor_gram", "k_regressor_tsqr", "k_tsqr", "k_local_ik", "k_components")):
+    if any(k in name for k in ("k_local_sweep", "k_base_sweep", "k_base_ext", "k_gram", "k_rowpair", "k_image_sweep", "k_regressor_gram", "k_regressor_tsqr", "k_regressor_pgram", "k_pgram", "k_cholqr", "k_tsqr", "k_local_ik", "k_components")):
         dur[name].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
         order[name].append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
         meta[name] = (r.get("VGPR_Count"), r.get("Accum_VGPR_Count"), r.get("SGPR_Count"), r.get("LDS_Block_Size"), r.get("Scratch_Size"), r.get("Grid_Size"), r.get("Workgroup_Size"))
