@@ -76,15 +76,18 @@ __global__ __launch_bounds__(256) void k_local_sweep_multi(const RdynSweepArgs* 
 
 // ---------------------------------------------------------------------------------------------------
 // Base-frame kinematics, stated as the reference states them.
-template <int NJ>
+// LEVEL: what the caller asked for -- 0 frames only (getTransformation(s)), 1 + the Jacobian (screws and origins kept), 2 + twists,
+// 3 + spatial accelerations.  One instantiation per level: a getTransformation call does not pay for the velocity / acceleration
+// recursions of getDTwist (750 -> 420 fp64 instructions per sample at 6 joints).
+template <int NJ, int LEVEL>
 __global__ __launch_bounds__(256) void k_base_sweep(const RdynKinArgs a)
 {
   ChainPtr c = as_const(a.chain);
   const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (s >= a.n_samples) return;
   const double* __restrict__ qp = a.q + s * a.in_ss;
-  const double* __restrict__ dqp = a.dq ? a.dq + s * a.in_ss : nullptr;
-  const double* __restrict__ ddqp = a.ddq ? a.ddq + s * a.in_ss : nullptr;
+  const double* __restrict__ dqp = (LEVEL >= 2 && a.dq) ? a.dq + s * a.in_ss : nullptr;
+  const double* __restrict__ ddqp = (LEVEL >= 3 && a.ddq) ? a.ddq + s * a.in_ss : nullptr;
   const int64_t es = a.out_se;  // element stride of every output record
 
   double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
@@ -107,8 +110,8 @@ __global__ __launch_bounds__(256) void k_base_sweep(const RdynKinArgs a)
   };
 
   if (a.T_links) put3x4(a.T_links + s * a.tl_ss);
-  if (a.twists) put6(a.twists + s * a.tw_ss, vlin, vang);
-  if (a.dtwists) put6(a.dtwists + s * a.tw_ss, alin, aang);
+  if (LEVEL >= 2 && a.twists) put6(a.twists + s * a.tw_ss, vlin, vang);
+  if (LEVEL >= 3 && a.dtwists) put6(a.dtwists + s * a.tw_ss, alin, aang);
 
 #pragma unroll
   for (int f = 0; f < NJ; ++f)
@@ -121,8 +124,8 @@ __global__ __launch_bounds__(256) void k_base_sweep(const RdynKinArgs a)
     {
       const int64_t o = idx * a.in_sj;
       qf = qp[o];
-      if (dqp) dqf = dqp[o];
-      if (ddqp) ddqf = ddqp[o];
+      if (LEVEL >= 2 && dqp) dqf = dqp[o];
+      if (LEVEL >= 3 && ddqp) ddqf = ddqp[o];
     }
     double Rpc[9];
     V3 t = ld3(J.t);
@@ -141,7 +144,7 @@ __global__ __launch_bounds__(256) void k_base_sweep(const RdynKinArgs a)
       if (type == RDYN_PRISMATIC) t = axpy(t, ld3(J.up), qf);
     }
     // screw axis of the child in the base frame, rotated by the PARENT frame (computeScrews, primitives_impl.h:879)
-    const V3 zl = rot(R, ld3(J.up));
+    const V3 zl = LEVEL >= 1 ? rot(R, ld3(J.up)) : mk(0, 0, 0);
     const V3 d = rot(R, t);  // p_l - p_{l-1}
     // T_bl[l] = T_bl[l-1] * T_pc   (computeFrames, primitives_impl.h:869)
     double Rn[9];
@@ -153,26 +156,35 @@ __global__ __launch_bounds__(256) void k_base_sweep(const RdynKinArgs a)
 #pragma unroll
     for (int i = 0; i < 9; ++i) R[i] = Rn[i];
     p = p + d;
-    z[f] = zl;
-    po[f] = p;
-    // twists (getTwist, primitives_impl.h:1007-1008) and spatial accelerations (getDTwist, 1116-1117)
-    V3 Sl = mk(0, 0, 0), Sa = mk(0, 0, 0);
-    if (type == RDYN_REVOLUTE) Sa = zl;
-    else if (type == RDYN_PRISMATIC) Sl = zl;
-    const V3 nvl = axpy(vlin + cross(vang, d), Sl, dqf);
-    const V3 nva = axpy(vang, Sa, dqf);
-    const V3 cl = cross(nva, Sl) + cross(nvl, Sa);  // spatialCrossProduct(v, S), sva.h:88-93
-    const V3 ca = cross(nva, Sa);
-    alin = axpy(axpy(alin + cross(aang, d), cl, dqf), Sl, ddqf);
-    aang = axpy(axpy(aang, ca, dqf), Sa, ddqf);
-    vlin = nvl;
-    vang = nva;
+    if (LEVEL >= 1)
+    {
+      z[f] = zl;
+      po[f] = p;
+    }
+    if (LEVEL >= 2)
+    {
+      // twists (getTwist, primitives_impl.h:1007-1008) and spatial accelerations (getDTwist, 1116-1117)
+      V3 Sl = mk(0, 0, 0), Sa = mk(0, 0, 0);
+      if (type == RDYN_REVOLUTE) Sa = zl;
+      else if (type == RDYN_PRISMATIC) Sl = zl;
+      const V3 nvl = axpy(vlin + cross(vang, d), Sl, dqf);
+      const V3 nva = axpy(vang, Sa, dqf);
+      if (LEVEL >= 3)
+      {
+        const V3 cl = cross(nva, Sl) + cross(nvl, Sa);  // spatialCrossProduct(v, S), sva.h:88-93
+        const V3 ca = cross(nva, Sa);
+        alin = axpy(axpy(alin + cross(aang, d), cl, dqf), Sl, ddqf);
+        aang = axpy(axpy(aang, ca, dqf), Sa, ddqf);
+      }
+      vlin = nvl;
+      vang = nva;
+    }
     if (a.T_links) put3x4(a.T_links + s * a.tl_ss + (int64_t)(12 * (f + 1)) * es);
-    if (a.twists) put6(a.twists + s * a.tw_ss + (int64_t)(6 * (f + 1)) * es, vlin, vang);
-    if (a.dtwists) put6(a.dtwists + s * a.tw_ss + (int64_t)(6 * (f + 1)) * es, alin, aang);
+    if (LEVEL >= 2 && a.twists) put6(a.twists + s * a.tw_ss + (int64_t)(6 * (f + 1)) * es, vlin, vang);
+    if (LEVEL >= 3 && a.dtwists) put6(a.dtwists + s * a.tw_ss + (int64_t)(6 * (f + 1)) * es, alin, aang);
   }
   if (a.T_bt) put3x4(a.T_bt + s * a.tb_ss);
-  if (a.J)
+  if (LEVEL >= 1 && a.J)
   {
     // getJacobian, primitives_impl.h:939-945: column k = spatialTranslation(S_l, p_tool - p_l);
     // getJacobianLink, primitives_impl.h:951-979: the same referred to the origin of link j_link; only the FIRST
@@ -229,7 +241,11 @@ template <int NJ>
 hipError_t launch_base_nj(const RdynKinArgs& a, hipStream_t st)
 {
   const unsigned grid = (unsigned)((a.n_samples + 255) / 256);
-  hipLaunchKernelGGL((k_base_sweep<NJ>), dim3(grid), dim3(256), 0, st, a);
+  // the cheapest instantiation that produces everything asked for
+  if (a.dtwists) hipLaunchKernelGGL((k_base_sweep<NJ, 3>), dim3(grid), dim3(256), 0, st, a);
+  else if (a.twists) hipLaunchKernelGGL((k_base_sweep<NJ, 2>), dim3(grid), dim3(256), 0, st, a);
+  else if (a.J) hipLaunchKernelGGL((k_base_sweep<NJ, 1>), dim3(grid), dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((k_base_sweep<NJ, 0>), dim3(grid), dim3(256), 0, st, a);
   return hipGetLastError();
 }
 

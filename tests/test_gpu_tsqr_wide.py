@@ -288,3 +288,33 @@ def test_matrix_tsqr_solves_what_the_normal_equations_cannot_at_scale():
     assert rank == n
     err = np.abs(x_qr - x_true).max() / np.abs(x_true).max()
     assert err <= 1e-5, (err, rep)
+
+
+@pytest.mark.parametrize("urdf,base,tool,N", [("panda_like.urdf", "link0", "hand", 4000000), ("ur10_public.urdf", "base_link", "tool0", 1000000),
+                                              ("ur10_public_long.urdf", "base_link", "tcp", 1000000)], ids=["config3_size_panda_hand", "ur10_public_tool0", "14_joints"])
+def test_full_size_identification_factor_reproduces_the_normal_equations(urdf, base, tool, N):
+    """BASELINE configs[2] size with the friction columns of the identification step: two independent reductions of the same 28e6 rows
+    of [Y | C | tau] -- the robust R factor (preconditioned CholeskyQR: k_regressor_pgram_solo for the 7-joint arm, reduced companion +
+    expansion for the fixed frames) and the fp64-MFMA normal equations (rdyn_identification_gram) -- must agree: R1'R1 = [G c; c' bb].
+    A size-independent property: the oracle cannot produce 28e6 rows in seconds."""
+    torch = pytest.importorskip("torch")
+    from rosdyn_amd import Chain
+    from rosdyn_amd.components import ComponentSet
+    chain = Chain(os.path.join(FIXTURES, urdf), base, tool, GRAV)
+    n, P = chain.getActiveJointsNumber(), 10 * chain.getJointsNumber()
+    comps = ComponentSet([dict(type=j % 3, joint=j, min_velocity=1e-3, max_velocity=5.0, parameters=[0.3, 0.8, 0.02][:3 if j % 3 == 1 else 2]) for j in range(n)], n)
+    K = comps.columns
+    gen = torch.Generator(device="cuda").manual_seed(0x5EED0003)
+    q, dq, ddq, tau = (torch.rand((N, n), dtype=torch.float64, device="cuda", generator=gen) * 2 - 1 for _ in range(4))
+    R1 = chain.getIdentificationTsqr(comps, q, dq, ddq, tau)
+    G, c, bb = chain.getIdentificationGram(comps, q, dq, ddq, tau)
+    C = P + K
+    full = torch.zeros((C + 1, C + 1), dtype=torch.float64, device="cuda")
+    full[:C, :C], full[:C, C], full[C, :C], full[C, C] = G, c, c, bb[0]
+    # every column to its own scale -- down to 1e-7 of the largest: a structurally null column of this arm (m c_z of the second link: its
+    # entries are rounding noise ~1e-17, which the robust factor reports as an exactly zero row) has no scale of its own
+    d = full.diagonal().sqrt()
+    d = d.clamp_min(1e-7 * d.max().item())
+    err = ((R1.t() @ R1 - full) / torch.outer(d, d)).abs().max().item()
+    assert err <= 1e-10, err
+    assert torch.equal(torch.tril(R1, -1), torch.zeros_like(R1))
