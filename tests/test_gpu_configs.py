@@ -121,3 +121,20 @@ def test_config4_share_two_ranks_on_one_gpu(tmp_path):
     assert d["world"] == 2 and d["count"] == d["n_total"]
     assert d["rel_G"] <= 1e-12 and d["rel_c"] <= 1e-12 and d["rel_bb"] <= 1e-12, d
     assert d["param_err"] <= 1e-6, d
+
+
+def test_config3_share_two_ranks_on_one_gpu(tmp_path):
+    """The R-factor exchange of SURVEY 8(e) end to end on the real HIP path, world size 2 on device 0: every rank the robust factor of
+    [Y | 7 friction columns | tau] of its shard (7-joint arm with fixed flange / hand frames), ONE all-gather, the fold of the stack
+    on every rank -- equal to the factor of the whole batch from one call and to the normal equations, the same bits on both ranks."""
+    script = os.path.join(ROOT, "tests", "_world2_tsqr.py")
+    out = tmp_path / "result.json"
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29578", script, str(out)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-3000:]
+    d = json.loads(out.read_text())
+    assert d["world"] == 2 and d["n1"] == 105 and d["upper"] and d["same_bits_on_all_ranks"], d
+    assert d["rel_gram"] <= 1e-11 and d["rel_one_call"] <= 1e-11 and d["sv_err"] <= 1e-9, d
