@@ -53,8 +53,13 @@ enum
 #define RDYN_BODY_EXIT return
 
 // one chain, one batch: grid.x = ceil(N / 256)
+#ifdef RDYN_LOCAL_WAVES  // A/B builds only: an occupancy target for the one-thread-per-sample sweeps
+#define RDYN_LOCAL_ATTR __attribute__((amdgpu_waves_per_eu(RDYN_LOCAL_WAVES, RDYN_LOCAL_WAVES)))
+#else
+#define RDYN_LOCAL_ATTR
+#endif
 template <int NJ, int MODE>
-__global__ __launch_bounds__(256) void k_local_sweep(const RdynSweepArgs a)
+__global__ __launch_bounds__(256) RDYN_LOCAL_ATTR void k_local_sweep(const RdynSweepArgs a)
 {
   const unsigned blk = blockIdx.x;
 #include "rdyn_local_sweep_body.inc"
