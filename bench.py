@@ -752,7 +752,7 @@ def main():
     b_eval = algorithmic_bytes_per_eval(n, P)
     kernel_ms = dev_ms / args.steps                       # one launch per step, back to back on one stream
     achieved = b_eval * N / (kernel_ms * 1e-3) / 1e9      # GB/s, algorithmic bytes per launch / launch duration
-    kernel = {"element": "k_local_sweep<6, REGRESSOR>", "stacked": "k_image_sweep<6, 6, nt, stacked>", "per_sample": "k_image_sweep<6, 6, nt, image>"}[args.y_layout]
+    kernel = {"element": "k_local_sweep<6, REGRESSOR>", "stacked": "k_image_sweep<6, 0u, true, true> (NJ = 6, no fixed joints, nontemporal, stacked)", "per_sample": "k_image_sweep<6, 0u, true, false> (NJ = 6, no fixed joints, nontemporal, per-sample image)"}[args.y_layout]
     traffic = committed_traffic("regressor_%s_n%d_P%d_N%d" % (args.y_layout, n, P, N))
 
     out = {
