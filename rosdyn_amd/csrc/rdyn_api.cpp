@@ -864,10 +864,17 @@ static const int kFusedBlocks = 256;  // upper bound used for the workspace size
 extern "C" int rdyn_identification_gram(const rdyn_chain* c, const rdyn_component* comps, int n_comps, const rdyn_batch* b, const double* tau_meas,
                                         double* G, double* cvec, double* bb, int accumulate, void* workspace, size_t workspace_bytes);
 
+// A chain whose own columns exceed what the Gram kernels hold (111) but whose REDUCED companion does not (fixed frames: 10 joints with
+// 7 input joints = 100 columns + friction columns) is served through the companion like a chain longer than the kernels sweep.
+static bool gram_only_through_reduced(const rdyn_chain* c, int n_comp_cols)
+{
+  return c->long_chain() || (c->reduced && rdyn_gram_blocks_for(10 * c->n_joints() + n_comp_cols) > 7);
+}
+
 size_t rdyn_regressor_gram_workspace_bytes(const rdyn_chain* c, int64_t chunk_samples)
 {
   if (!c) return 0;
-  if (c->long_chain())
+  if (gram_only_through_reduced(c, 0))
   {
     // only the reduced companion is swept: its workspace + its normal equations behind it
     const size_t w = c->reduced ? rdyn_regressor_gram_workspace_bytes(c->reduced.get(), 0) : 0;
@@ -963,7 +970,7 @@ int rdyn_regressor_gram(const rdyn_chain* c, const rdyn_batch* b, const double* 
     return RDYN_ERR_INVALID_ARGUMENT;
   }
   const int n = c->n_active(), P = 10 * c->n_joints();
-  if (c->long_chain())
+  if (gram_only_through_reduced(c, 0))
   {
     const size_t need = rdyn_regressor_gram_workspace_bytes(c, 0);
     if (need == 0 || workspace_bytes < need)
@@ -1744,9 +1751,9 @@ size_t rdyn_identification_gram_workspace_bytes(const rdyn_chain* c, const rdyn_
 {
   if (!c) return 0;
   const int K = n_comps > 0 ? rdyn_components_columns(comps, n_comps) : 0;
-  if (c->long_chain())
+  if (K >= 0 && gram_only_through_reduced(c, K))
   {
-    const size_t w = (c->reduced && K >= 0) ? rdyn_identification_gram_workspace_bytes(c->reduced.get(), comps, n_comps) : 0;
+    const size_t w = c->reduced ? rdyn_identification_gram_workspace_bytes(c->reduced.get(), comps, n_comps) : 0;
     return w ? w + reduce_tmp_bytes(10 * c->reduced->n_joints() + K) : 0;
   }
   const int cols = 10 * c->n_joints() + (K > 0 ? K : 0);
@@ -1768,7 +1775,7 @@ int rdyn_identification_gram(const rdyn_chain* c, const rdyn_component* comps, i
   const int n = c->n_active(), P = 10 * c->n_joints();
   const int K = n_comps > 0 ? rdyn_components_columns(comps, n_comps) : 0;
   const int cols = P + K;
-  if (c->long_chain())
+  if (K >= 0 && gram_only_through_reduced(c, K))
   {
     const size_t need = rdyn_identification_gram_workspace_bytes(c, comps, n_comps);
     if (need == 0 || workspace_bytes < need)

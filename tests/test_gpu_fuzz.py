@@ -261,3 +261,77 @@ def test_extreme_input_ranges(scale_q, scale_dq, scale_ddq):
     close(chain.getJointInertia(tq).cpu().numpy().transpose(0, 2, 1), ref.joint_inertia(q), "M")
     close(chain.getTransformations(tq).cpu().numpy().transpose(0, 1, 3, 2), ref.fk(q), "T")
     close(chain.getDTwist(tq, tdq, tddq).cpu().numpy(), ref.dtwist(q, dq, ddq), "dtwist")
+
+
+def random_long_chain_xml(seed):
+    """2..16 chain joints, at most 7 of them moving (revolute / continuous / prismatic), fixed frames anywhere -- head, middle, tail --
+    so that chains LONGER than the kernels sweep (> 10 joints) and every reduced-companion shape occur."""
+    rng = np.random.default_rng(seed)
+    nj = int(rng.integers(2, 17))
+    n_move = int(rng.integers(2, min(7, nj) + 1))
+    moving = set(rng.choice(nj, size=n_move, replace=False).tolist())
+    links, joints = ["<link name='L0'/>"], []
+    for i in range(nj):
+        kind = str(rng.choice(["revolute", "continuous", "prismatic"], p=[0.6, 0.2, 0.2])) if i in moving else str(rng.choice(["fixed", "floating", "planar"], p=[0.8, 0.1, 0.1]))
+        origin = "<origin xyz='%s' rpy='%s'/>" % (_fmt(0.3 * rng.uniform(-1, 1, 3)), _fmt(rng.uniform(-3.1, 3.1, 3))) if rng.random() < 0.9 else ""
+        axis = "<axis xyz='%s'/>" % _fmt(rng.uniform(-1, 1, 3)) if rng.random() < 0.85 else ""
+        limit = "<limit lower='-2' upper='2' effort='50' velocity='2'/>" if kind in ("revolute", "prismatic") else ""
+        joints.append("<joint name='J%d' type='%s'><parent link='L%d'/><child link='L%d'/>%s%s%s</joint>" % (i, kind, i, i + 1, origin, axis, limit))
+        inertial = ""
+        if rng.random() < 0.8:
+            B = rng.normal(size=(3, 3))
+            I = B @ B.T * 0.01 + 0.01 * np.eye(3)
+            io = "<origin xyz='%s' rpy='%s'/>" % (_fmt(0.1 * rng.uniform(-1, 1, 3)), _fmt(rng.uniform(-3, 3, 3)))
+            inertial = ("<inertial>%s<mass value='%.17g'/><inertia ixx='%.17g' ixy='%.17g' ixz='%.17g' iyy='%.17g' iyz='%.17g' "
+                        "izz='%.17g'/></inertial>" % (io, rng.uniform(0.2, 5), I[0, 0], I[0, 1], I[0, 2], I[1, 1], I[1, 2], I[2, 2]))
+        links.append("<link name='L%d'>%s</link>" % (i + 1, inertial))
+    return "<robot name='long%d'>%s%s</robot>" % (seed, "".join(links), "".join(joints)), "L0", "L%d" % nj, rng
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_fuzzed_chain_identification_step(seed):
+    """Round 4: the identification step on random chains of 2..16 joints (fixed frames in front, in the middle, behind; prismatic joints;
+    more than 10 joints) with random friction / spring components: dense regressor, torque, normal equations and the R factor of
+    [Y | C | tau] against the oracle's rows -- through every route the shape and the batch size select (register / LDS-resident
+    Householder folds below 4 096 samples, preconditioned CholeskyQR above; reduced companion + expansion wherever a joint is fixed)."""
+    torch = pytest.importorskip("torch")
+    from oracle.oracle import OracleChain, components_regressor
+    from rosdyn_amd import Chain
+    from rosdyn_amd.components import ComponentSet
+    from rosdyn_amd.samples import trajectory_batch
+    xml, base, tool, rng = random_long_chain_xml(5000 + seed)
+    grav = tuple(rng.uniform(-10, 10, 3))
+    chain, ref = Chain(xml, base, tool, grav), OracleChain(xml, base, tool, grav)
+    n, P = ref.n, ref.P
+    N = 300 if seed % 2 == 0 else 5000
+    q, dq, ddq = trajectory_batch(seed, N, n)
+    n_c = int(rng.integers(1, n + 1))
+    specs = []
+    for j in rng.permutation(n)[:n_c]:
+        ty = int(rng.integers(0, 3))
+        specs.append((ty, int(j), 1e-3, 5.0, [0.4, 0.9, 0.03][:3 if ty == 1 else 2]))
+    comps = ComponentSet([dict(type=s[0], joint=s[1], min_velocity=s[2], max_velocity=s[3], parameters=s[4]) for s in specs], n)
+    K = comps.columns
+    Cm, tau_c = components_regressor(specs, n, q, dq)
+    Yr, tr = ref.regressor(q, dq, ddq), ref.joint_torque(q, dq, ddq)
+    tau = tr + tau_c + 1e-3 * rng.normal(size=(N, n))
+    M = np.column_stack([Yr.reshape(-1, P), Cm.reshape(N * n, K), tau.reshape(-1)])
+    G = M.T @ M
+    tq, tdq, tddq, ttau = (torch.from_numpy(x).cuda() for x in (q, dq, ddq, tau))
+    Y, tg = chain.getRegressor(tq, tdq, tddq, with_torque=True)
+    assert np.abs(Y.cpu().numpy().transpose(0, 2, 1) - Yr).max() <= TOL * max(1.0, np.abs(Yr).max())
+    assert np.abs(tg.cpu().numpy() - tr).max() <= TOL * max(1.0, np.abs(tr).max())
+    assert np.abs(chain.getJointTorque(tq, tdq, tddq).cpu().numpy() - tr).max() <= TOL * max(1.0, np.abs(tr).max())
+    Gg, cg, bbg = chain.getIdentificationGram(comps, tq, tdq, tddq, ttau)
+    C = P + K
+    full = np.zeros((C + 1, C + 1))
+    full[:C, :C], full[:C, C], full[C, :C], full[C, C] = Gg.cpu().numpy(), cg.cpu().numpy(), cg.cpu().numpy(), float(bbg.item())
+    assert np.linalg.norm(full - G) <= 1e-10 * np.linalg.norm(G)
+    R1 = chain.getIdentificationTsqr(comps, tq, tdq, tddq, ttau).cpu().numpy()
+    assert R1.shape == (C + 1, C + 1) and np.allclose(np.tril(R1, -1), 0.0)
+    assert np.abs(R1.T @ R1 - G).max() <= 1e-11 * np.abs(G).max()
+    s_ref = np.linalg.svd(np.linalg.qr(M, mode="r"), compute_uv=False) if M.shape[0] >= C + 1 else None
+    if s_ref is not None:
+        s_gpu = np.linalg.svd(R1, compute_uv=False)
+        keep = s_ref > 1e-8 * s_ref[0]
+        assert np.abs(s_gpu[keep] / s_ref[keep] - 1.0).max() <= 1e-8
