@@ -2,7 +2,8 @@
 # Host-side sanitizer run (CPU only; GPU sanitizers are not available on the pool): the URDF reader and chain ingest
 # (rdyn_urdf.cpp, rdyn_chain.cpp) under ASan + UBSan over 300 fuzzed chains (tests/test_gpu_fuzz.py generator) and 400
 # malformed variants of a fixture (truncations, byte flips, deleted / duplicated chunks); round 3: plus the rigid-body reduction of
-# every parsed chain (as parsed, with every other input joint dropped, on a clone).  Expected: no report.
+# every parsed chain (as parsed, with every other input joint dropped, on a clone); round 4: plus 100 chains of up to 16 joints.
+# Expected: no report.
 set -e
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 W=$(mktemp -d)
@@ -11,11 +12,14 @@ python3 - "$ROOT" <<'PY'
 import os, random, sys
 root = sys.argv[1]
 sys.path.insert(0, os.path.join(root, "tests")); sys.path.insert(0, root)
-from test_gpu_fuzz import random_chain_xml
+from test_gpu_fuzz import random_chain_xml, random_long_chain_xml
 os.makedirs("in", exist_ok=True)
 for s in range(300):
     xml, b, t, _ = random_chain_xml(5000 + s)
     open("in/f%03d.txt" % s, "w").write(b + "\n" + t + "\n" + xml)
+for s in range(100):   # round 4: chains of up to 16 joints (longer than the kernels sweep: host_joints / the reduced companion carry them)
+    xml, b, t, _ = random_long_chain_xml(9000 + s)
+    open("in/l%03d.txt" % s, "w").write(b + "\n" + t + "\n" + xml)
 rnd = random.Random(1)
 base_xml = open(os.path.join(root, "tests/fixtures/mixed_joints.urdf")).read()
 for s in range(400):
