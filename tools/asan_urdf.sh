@@ -53,22 +53,22 @@ int main(int argc, char** argv)
     if (rdyn_chain_from_urdf(ss.str().c_str(), base.c_str(), tool.c_str(), g, &c) == RDYN_OK)
     {
       ++ok;
-      double pi[128], lim[5][16];
+      double pi[10 * RDYN_MAX_JOINTS], lim[5][RDYN_MAX_JOINTS];
       rdyn_nominal_parameters(c, pi);
       rdyn_chain_limits(c, lim[0], lim[1], lim[2], lim[3], lim[4]);
       for (int k = 0; k < rdyn_chain_links_number(c); ++k) (void)rdyn_chain_link_name(c, k);
       // round 3: the rigid-body reduction (rdyn_chain.cpp: build_reduced) on the chain as parsed and after dropping every other
       // input joint (non-input moving joints fold like fixed ones)
-      int32_t body[16];
-      double X[16 * 100], pib[160];
+      int32_t body[RDYN_MAX_JOINTS];
+      double X[RDYN_MAX_JOINTS * 100], pib[10 * RDYN_MAX_JOINTS];
       (void)rdyn_chain_reduction(c, body, X, pib);
       const int na = rdyn_chain_active_joints_number(c);
       if (na >= 2)
       {
-        const char* keep[16];
+        const char* keep[RDYN_MAX_JOINTS];
         int nk = 0;
         for (int k = 0; k < na; k += 2) keep[nk++] = rdyn_chain_active_joint_name(c, k);
-        std::string names[16];
+        std::string names[RDYN_MAX_JOINTS];
         for (int k = 0; k < nk; ++k) names[k] = keep[k];   // the pointers die with the re-finalised chain
         for (int k = 0; k < nk; ++k) keep[k] = names[k].c_str();
         if (rdyn_chain_set_input_joints(c, keep, nk) == RDYN_OK) (void)rdyn_chain_reduction(c, body, X, pib);
