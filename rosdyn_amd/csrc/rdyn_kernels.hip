@@ -11,12 +11,14 @@
 //                (= rot(R_f^T, spatialTranslation(S_l, p_f - p_l)); it is the transposed operator the
 //                reference applies to the wrench regressor at primitives_impl.h:1341-1347, and the
 //                link-f Jacobian column of primitives_impl.h:1371-1372)
-//   and from them, without a backward pass and without materialising any 6x10 block:
+//   and from them, without materialising any 6x10 block (and, the torque mode excepted, without a backward pass):
 //     MODE_REGRESSOR  Y(l, 10 f .. 10 f + 9) = j_l^T W'_f   with the closed form of the reference's ten
 //                     basis-matrix products (primitives_impl.h:1324-1339):
 //                        W'_f = [ d | [al]x + [w]x[w]x | 0 ;  0 | -[d]x | L(al) + [w]x L(w) ],   d = a + w x vl
 //                     and tau = Y * pi fused (== getJointTorque, primitives_impl.h:1264-1272);
-//     MODE_TORQUE     tau_l = sum_f j_l . (I_f a_f + v_f x* I_f v_f + gravity)   (primitives_impl.h:1240-1257, 1270)
+//     MODE_TORQUE     tau_l = sum_f j_l . (I_f a_f + v_f x* I_f v_f + gravity)   (primitives_impl.h:1240-1257, 1270) -- evaluated as the
+//                     reference does, by a backward pass over the link wrenches (S_l . sum of the downstream wrenches about joint l), the
+//                     joint transforms rebuilt from the saved sin / 1 - cos: O(n) instead of n (n + 1) / 2 carried unit twists
 //     MODE_INERTIA    M(l1,l2) = sum_f j_l1^T I_f j_l2                            (primitives_impl.h:1357-1379)
 //   Structural zeros of the regressor (rows of joints downstream of link f) are written explicitly: the
 //   output is the reference's dense n x P matrix.

@@ -11,7 +11,7 @@ if [[ $SRC == *.cpp ]]; then
   g++ -O3 -std=c++17 -fPIC -Wall -Wextra -Wno-unused-parameter -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include "$@" -c $SRC -o $OBJ
 else
   EXTRA=""
-  if [[ $SRC == rdyn_image_part.hip ]]; then EXTRA="-mllvm -pragma-unroll-threshold=1000000"; fi
+  if [[ $SRC == rdyn_image_part.hip || $SRC == rdyn_kernels.hip ]]; then EXTRA="-mllvm -pragma-unroll-threshold=1000000"; fi
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wextra -Wno-unused-parameter -Wno-cuda-compat -ffp-contract=on $EXTRA "$@" -c $SRC -o $OBJ
 fi
 # STOCK_OBJ=<object the variant replaces> when it is not _obj/<stem>.o (the slices of rdyn_image_part.hip: _obj/rdyn_image_na6.o ...)
