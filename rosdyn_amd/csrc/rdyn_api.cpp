@@ -1187,8 +1187,9 @@ static TsqrLayout tsqr_layout(size_t householder_doubles, int n1, int nb, int n1
   L.r_swept = take((size_t)n1 * n1);
   L.v = take((size_t)n1 * n1);
   L.r_full = take((size_t)n1_full * n1_full);  // the expanded factor of a call that accumulates (folded into the caller's afterwards)
-  L.flag = take(64);  // ints: [0] run round 1, [1] run the stand-by (Householder) call, [2] run round 0, [16 ..] the deferred columns;
-                      // doubles [50 .. 55]: gamma (preconditioner), rho, gamma (factor kernel) of the two rounds (diagnostics)
+  L.flag = take(96);  // ints: [0] run round 1, [1] run the stand-by (Householder) call, [2] run round 0, [16 .. 111] the deferred columns;
+                      // doubles [56 .. 61]: gamma (preconditioner), rho, gamma (factor kernel) of the two rounds (diagnostics) -- behind
+                      // the 96 column flags (until round 4 they sat at [50 .. 55], on top of the flags of columns 84 .. 95)
   L.total_doubles = off;
   return L;
 }
@@ -1218,15 +1219,15 @@ static int cholqr_rounds(double* ws, const TsqrLayout& L, int n1, int col_shift,
     const int* const run = round == 0 ? flag + 2 : flag;
     if (round == 0)
       RDYN_HIP_TRY(rdyn_launch_cholqr_precond(nullptr, ga.G, ga.c, ga.bb, n1, col_shift, nb, row_scale, ws + L.r1p, ws + L.w, ws + L.v, flag + 16, flag, 0,
-                                              nullptr, ws + L.flag + 50, stream));
+                                              nullptr, ws + L.flag + 56, stream));
     else
       RDYN_HIP_TRY(rdyn_launch_cholqr_precond(R_out, nullptr, nullptr, nullptr, n1, col_shift, nb, 1.0, ws + L.r1p, ws + L.w, ws + L.v, flag + 16, flag, 1,
-                                              flag, ws + L.flag + 51, stream));
+                                              flag, ws + L.flag + 57, stream));
     int st = run_pass_b(ws + L.w, run, ws + L.slabs);
     if (st != RDYN_OK) return st;
     ga.run_flag = run;
     RDYN_HIP_TRY(rdyn_launch_gram_finish(ga, blocks, stream));
-    RDYN_HIP_TRY(rdyn_launch_cholqr_factor(ga.G, ga.c, ga.bb, n1, has_b, ws + L.r1p, ws + L.v, flag + 16, R_out, flag, round, run, ws + L.flag + 52 + round,
+    RDYN_HIP_TRY(rdyn_launch_cholqr_factor(ga.G, ga.c, ga.bb, n1, has_b, ws + L.r1p, ws + L.v, flag + 16, R_out, flag, round, run, ws + L.flag + 58 + round,
                                            stream));
   }
   return RDYN_OK;
@@ -1242,13 +1243,13 @@ static void read_report(const double* raw, int n1, rdyn_tsqr_report* out)
   for (int k = 0; k < n1 && 16 + k < 128; ++k) out->n_deferred += flags[16 + k] ? 1 : 0;
   if (round0)
   {
-    out->gamma[0] = raw[54];
-    out->rho[0] = raw[52];
+    out->gamma[0] = raw[60];
+    out->rho[0] = raw[58];
   }
   if (round1)
   {
-    out->gamma[1] = raw[55];
-    out->rho[1] = raw[53];
+    out->gamma[1] = raw[61];
+    out->rho[1] = raw[59];
   }
 }
 
@@ -1382,7 +1383,7 @@ int rdyn_tsqr_rows_last_report(int n_cols_with_rhs, int64_t rows, const void* wo
   DeviceGuard g;
   int st = g.enter(device);
   if (st != RDYN_OK) return st;
-  double raw[64];
+  double raw[96];
   RDYN_HIP_TRY(hipMemcpyAsync(raw, (const double*)workspace + p.L.flag, sizeof raw, hipMemcpyDeviceToHost, (hipStream_t)stream));
   RDYN_HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
   read_report(raw, p.n1, out);
@@ -1737,7 +1738,7 @@ int rdyn_tsqr_last_report(const rdyn_chain* c, const rdyn_component* comps, int 
   DeviceGuard g;
   int st = g.enter(device);
   if (st != RDYN_OK) return st;
-  double raw[64];
+  double raw[96];
   RDYN_HIP_TRY(hipMemcpyAsync(raw, (const double*)workspace + p.L.flag, sizeof raw, hipMemcpyDeviceToHost, (hipStream_t)stream));
   RDYN_HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
   read_report(raw, p.n1s, out);

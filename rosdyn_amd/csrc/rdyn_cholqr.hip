@@ -694,8 +694,15 @@ constexpr int kMaxFoldN1 = 136;  // k_cholqr_fold: two packed triangles in LDS (
 #endif
 #ifdef RDYN_CHOLQR_STAMPS  // timing experiments: phase stamps (100 MHz wall clock) behind the diagnostics of the factor kernel
 #define STAMP(i) do { if (threadIdx.x == 0 && rho_out) rho_out[4 + (i)] = (double)wall_clock64(); } while (0)
+#define STAMP_P(i) do { if (threadIdx.x == 0 && gamma_out) gamma_out[14 + (i)] = (double)wall_clock64(); } while (0)  // (round 0: flag doubles 70 ..)
 #else
 #define STAMP(i) do { } while (0)
+#define STAMP_P(i) do { } while (0)
+#endif
+#ifdef RDYN_CHOLQR_CHOL_LDS  // A/B builds: the factorisation that keeps its matrices in LDS (rounds 3, 4)
+#define RDYN_CHOL_WITH_INVERSE chol_with_inverse_lds
+#else
+#define RDYN_CHOL_WITH_INVERSE chol_with_inverse_regs
 #endif
 constexpr int NTD = RDYN_CHOLQR_DENSE_THREADS;  // threads of the single-workgroup dense kernels (256 / 512 / 1024: 1.45 / 1.41 / 1.40 ms for the whole call at config-2 size; >= 128)
 
@@ -794,8 +801,8 @@ __device__ __forceinline__ void tri_inverse_lds(const double* U, const double* r
 // Cholesky-type factorisation of the symmetric matrix in the upper triangle of M (n x n, column-major, LDS) TOGETHER with the inverse
 // of the factor: an identity rides along in E (n x n, LDS) and receives the same row operations (forward substitution), so the
 // dependent chain of the factorisation pays for both.  One barrier per eliminating pivot: everybody evaluates the (uniform) decision
-// pol(k, d) -> {elim, diag}; the trailing updates work from the UNSCALED row k while the scaled rows are parked where nothing reads
-// them during the loop:
+// decide(k, d) -> eliminate or not, diagf(k, d, elim) -> the diagonal; the trailing updates work from the UNSCALED row k while the
+// scaled rows are parked where nothing reads them during the loop:
 //   row k of the factor F (F'F = M on the eliminating pivots)  -> column k of the strict LOWER triangle of M, diagonal in fdiag[k]
 //   row k of F^-T = column k of F^-1                           -> column k of the strict UPPER triangle of E, diagonal in xdiag[k]
 // A pivot that does not eliminate (elim = 0) leaves row k of F as diag e_k' (diag = 0: the row is left out altogether, X too).
@@ -807,14 +814,17 @@ struct PivotAct
   int elim;
   double diag;
 };
-template <class Policy>
-__device__ __forceinline__ void chol_with_inverse_lds(double* M, double* E, int n, int tid, double* fdiag, double* xdiag, Policy pol)
+template <class Decide, class Diag, class Idle>
+__device__ __forceinline__ void chol_with_inverse_lds(double* M, double* E, int n, int tid, double* fdiag, double* xdiag, Decide decide, Diag diagf, Idle idle_work)
 {
   const int tx = tid & 31, ty = tid >> 5;
+  if (tid >= 384) idle_work();
   for (int k = 0; k < n; ++k)
   {
     const double d = M[k * n + k];
-    const PivotAct act = pol(k, d);
+    PivotAct act;
+    act.elim = decide(k, d) ? 1 : 0;
+    act.diag = diagf(k, d, act.elim != 0);
     if (tid == 0)
     {
       fdiag[k] = act.diag;
@@ -845,6 +855,171 @@ __device__ __forceinline__ void chol_with_inverse_lds(double* M, double* E, int 
     for (int j = k + 1 + tid; j < n; j += NTD) M[k * n + j] = M[j * n + k] * inv_p;
     for (int c = tid; c < k; c += NTD) E[k * n + c] = E[c * n + k] * inv_p;
     __syncthreads();
+  }
+  __syncthreads();
+}
+
+// The same factorisation with the working matrices in REGISTERS (round 4).  The LDS version spends 0.7 us per pivot at ANY thread count:
+// every one of its 16 waves repeats the pivot's square root and division and streams its share of ~ (n - k) n elements through LDS, a
+// dependent LDS round trip per loop level.
+//   waves 0-3   M's upper triangle and E's lower triangle as one n x n square on a 16 x 16 thread grid (thread (ty, tx) owns rows
+//               16 a + ty, columns 16 b + tx).  The owners of row k publish it once per step -- rM(x) = M(k, x) for x > k, else 0;
+//               rE(x) = E(k, x) for x < k, 1 at x = k, else 0;  d = M(k, k) -- and with those zeros the trailing update needs no masks:
+//               f_i = rM(i) / d vanishes for i <= k,  M(i, x) -= f_i rM(x) (blocks b >= a),  E(i, x) -= f_i rE(x) (blocks a >= b);
+//               what that leaves in the halves of the diagonal blocks that belong to the other triangle is never published.  The block
+//               row AK = k / 16 of the pivot is a compile-time constant of the step's code (six copies): which blocks are live, which
+//               registers hold row k + 1 -- straight-line code, ALL the step's LDS reads in one round trip, one barrier per step, two row
+//               buffers, one division and no square root in the dependent chain.
+//   waves 4, 5  park the published rows UNSCALED where the LDS version parks the scaled ones.
+//   the rest    keep the barrier count.
+// Afterwards, in parallel: the diagonals (square roots), the row scales, one pass over the parked rows.  decide(k, d) -> eliminate or
+// not (uniform; its side effects are thread 0's), diagf(k, d, elim) -> the diagonal of row k of the factor (pure); idle_work(): run by
+// the waves that only keep the barrier count (threads 384 ..) before they do -- their barriers carry no fence, so global loads issued
+// there stay in flight through the whole factorisation.
+constexpr int kCholRS = 96;  // row buffer: rM | rE | d
+template <int NB, class Decide>
+__device__ __forceinline__ void chol_compute_waves(const double* M, const double* E, int n, int tid, double* fdiag, double* xdiag, double (*s_row)[2 * kCholRS + 2],
+                                                   Decide decide)
+{
+  constexpr int RS = kCholRS;
+  const int tx = tid & 15, ty = tid >> 4;
+  double Mr[NB][NB], Er[NB][NB];
+#pragma unroll
+  for (int a = 0; a < NB; ++a)
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+    {
+      const int i = 16 * a + ty, x = 16 * b + tx;
+      const bool in = i < n && x < n;
+      if (b >= a) Mr[a][b] = in ? M[x * n + i] : 0.0;
+      if (a >= b) Er[a][b] = in ? E[x * n + i] : 0.0;
+    }
+  auto publish = [&](auto akc, int k) {
+    constexpr int AK = decltype(akc)::value;  // the block row of row k
+    if constexpr (AK < NB)
+    {
+      if (k >= n || ty != (k & 15)) return;
+      double* const rb = s_row[k & 1];
+#pragma unroll
+      for (int b = 0; b < NB; ++b)
+      {
+        const int x = 16 * b + tx;
+        if (b >= AK) rb[x] = x > k ? Mr[AK][b] : 0.0;
+        if (b <= AK) rb[RS + x] = x < k ? Er[AK][b] : (x == k ? 1.0 : 0.0);
+      }
+      if (tx == (k & 15)) rb[2 * RS] = Mr[AK][AK];
+    }
+  };
+  auto block_row = [&](auto akc) {
+    constexpr int AK = decltype(akc)::value;
+    for (int k = 16 * AK; k < 16 * AK + 16 && k < n; ++k)
+    {
+      __syncthreads();
+      const double* const rb = s_row[k & 1];
+      const double d = rb[2 * RS];
+      double rm[NB], re[NB], fr[NB];
+#pragma unroll
+      for (int b = 0; b < NB; ++b)
+      {
+        if (b >= AK) rm[b] = rb[16 * b + tx];
+        if (b >= AK) fr[b] = rb[16 * b + ty];
+        if (b <= AK) re[b] = rb[RS + 16 * b + tx];
+      }
+      const bool elim = decide(k, d);
+      if (tid == 0)
+      {
+        fdiag[k] = d;  // (the diagonals and scales follow after the loop)
+        xdiag[k] = elim ? 1.0 : 0.0;
+      }
+      // block row AK first: it holds row k + 1 (unless that is the first row of the next block row), whose owners publish it before
+      // the other block rows are updated -- the LDS writes complete behind that arithmetic
+      const bool next_in_block = k + 1 < 16 * AK + 16;
+      double inv_d = 0.0;
+      auto update_rows = [&](auto a0c, auto a1c) {
+#pragma unroll
+        for (int a = decltype(a0c)::value; a < decltype(a1c)::value; ++a)
+        {
+          const double fi = fr[a] * inv_d;
+#pragma unroll
+          for (int b = 0; b < NB; ++b)
+          {
+            if (b >= a) Mr[a][b] = fma(-fi, rm[b], Mr[a][b]);
+            if (b <= AK) Er[a][b] = fma(-fi, re[b], Er[a][b]);
+          }
+        }
+      };
+      if (elim)
+      {
+        // 1 / d by v_rcp_f64 and two Newton steps (<= 1 ulp; the IEEE division's scaling and fix-up are another ~100 cycles of the chain)
+        inv_d = __builtin_amdgcn_rcp(d);
+        inv_d = fma(fma(-d, inv_d, 1.0), inv_d, inv_d);
+        inv_d = fma(fma(-d, inv_d, 1.0), inv_d, inv_d);
+        update_rows(std::integral_constant<int, AK>(), std::integral_constant<int, AK + 1>());
+      }
+      // (a pivot that does not eliminate leaves row k + 1 as it is)
+      if (next_in_block) publish(std::integral_constant<int, AK>(), k + 1);
+      if (elim) update_rows(std::integral_constant<int, AK + 1>(), std::integral_constant<int, NB>());
+      if (!next_in_block) publish(std::integral_constant<int, AK + 1>(), k + 1);
+    }
+  };
+  publish(std::integral_constant<int, 0>(), 0);
+  block_row(std::integral_constant<int, 0>());
+  if constexpr (NB > 1) block_row(std::integral_constant<int, 1>());
+  if constexpr (NB > 2) block_row(std::integral_constant<int, 2>());
+  if constexpr (NB > 3) block_row(std::integral_constant<int, 3>());
+  if constexpr (NB > 4) block_row(std::integral_constant<int, 4>());
+  if constexpr (NB > 5) block_row(std::integral_constant<int, 5>());
+}
+template <class Decide, class Diag, class Idle>
+__device__ __forceinline__ void chol_with_inverse_regs(double* M, double* E, int n, int tid, double* fdiag, double* xdiag, Decide decide, Diag diagf, Idle idle_work)
+{
+  static_assert(NTD >= 384 && NTD % 128 == 0 && kMaxN1 <= 96, "four computing waves, two parking waves; six 16-wide blocks per side");
+  constexpr int RS = kCholRS;
+  __shared__ double s_row[2][2 * RS + 2], s_scm[kMaxN1], s_sce[kMaxN1];
+  if (tid < 256)
+  {
+    if (n <= 64) chol_compute_waves<4>(M, E, n, tid, fdiag, xdiag, s_row, decide);
+    else if (n <= 80) chol_compute_waves<5>(M, E, n, tid, fdiag, xdiag, s_row, decide);
+    else chol_compute_waves<6>(M, E, n, tid, fdiag, xdiag, s_row, decide);
+  }
+  else if (tid < 384)
+  {
+    const int l = tid & 63;
+    for (int k = 0; k < n; ++k)
+    {
+      __syncthreads();
+      const double* const rb = s_row[k & 1];
+      if (tid < 320)
+        for (int j = k + 1 + l; j < n; j += 64) M[k * n + j] = rb[j];
+      else
+        for (int c = l; c < k; c += 64) E[k * n + c] = rb[RS + c];
+    }
+  }
+  else
+  {
+    idle_work();
+    for (int k = 0; k < n; ++k) __builtin_amdgcn_s_barrier();  // (nothing of theirs to publish or to see: no fence)
+  }
+  __syncthreads();
+  if (tid < n)
+  {
+    const double d = fdiag[tid];
+    const bool elim = xdiag[tid] != 0.0;
+    const double dg = diagf(tid, d, elim), inv = dg > 0.0 ? 1.0 / dg : 0.0;
+    fdiag[tid] = dg;
+    xdiag[tid] = inv;
+    s_scm[tid] = elim ? dg / d : 0.0;   // 1 / sqrt(d) = sqrt(d) / d;  no elimination: row k of F is diag e_k'
+    s_sce[tid] = elim ? dg / d : inv;  // no elimination: X(k, :) = E(k, :) / diag (left out altogether at diag = 0)
+  }
+  __syncthreads();
+  {
+    const int i = tid & 127;
+    if (i < n)
+      for (int k = tid >> 7; k < n; k += NTD / 128)
+      {
+        if (i > k) M[k * n + i] = s_scm[k] != 0.0 ? M[k * n + i] * s_scm[k] : 0.0;
+        else if (i < k) E[k * n + i] = s_sce[k] != 0.0 ? E[k * n + i] * s_sce[k] : 0.0;
+      }
   }
   __syncthreads();
 }
@@ -884,6 +1059,7 @@ __global__ __launch_bounds__(NTD) void k_cholqr_precond(const double* __restrict
   __shared__ double s_part[kMaxN1], s_norm[kMaxN1], s_lift[kMaxN1], s_g[kMaxN1];
   __shared__ int s_z[kMaxN1], s_cmap[kMaxN1], s_rend[kMaxN1], s_nc;
   const int tid = threadIdx.x;
+  STAMP_P(0);
   if (Gs)
   {
     // ---- from the Gram matrix [G c; c' bb] of the subsample: Cholesky in which a deferred pivot eliminates nothing.  Row k of T is
@@ -912,14 +1088,16 @@ __global__ __launch_bounds__(NTD) void k_cholqr_precond(const double* __restrict
       s_lift[tid] = mx > 0.0 ? 1e-13 * mx : 1.0;
     }
     __syncthreads();
-    chol_with_inverse_lds(B, A0, n1, tid, s_part, s_g, [&](int k, double d) {
+    STAMP_P(1);
+    RDYN_CHOL_WITH_INVERSE(B, A0, n1, tid, s_part, s_g, [&](int k, double d) {
       // the squared sine of the angle to the columns on the left: a Gram matrix resolves it down to ~1e-14; below 1e-10 (sine 1e-5, the
       // own-norm rule of the other branch) or below the residue floor the column is deferred.  The last column eliminates nothing.
       const double g0 = s_norm[k] * s_norm[k];  // d / g0 = the squared sine
       const bool defer = !(d >= (k + 1 < n1 ? 1e-10 : 1e-14) * g0) || !(g0 > 0.0) || !(d >= s_lift[k] * s_lift[k]);
       if (tid == 0) s_z[k] = defer ? 1 : 0;
-      return defer ? PivotAct{0, s_lift[k]} : PivotAct{1, sqrt(d)};
-    });
+      return !defer;
+    }, [&](int k, double d, bool elim) { return elim ? sqrt(d) : s_lift[k]; }, [] {});
+    STAMP_P(2);
     // T (rows parked in the lower triangle of B) -> upper triangle of A0; V = T^-1 (parked in the upper triangle of A0) -> B
     for (int e = tid; e < n1 * n1; e += NTD)
     {
@@ -999,6 +1177,7 @@ __global__ __launch_bounds__(NTD) void k_cholqr_precond(const double* __restrict
   if (tid < n1 && s_z[tid]) A0[tid * n1 + tid] = s_lift[tid];
   __syncthreads();
   }
+  STAMP_P(3);
   for (int i = tid; i < n1 * n1; i += NTD) Tout[i] = A0[i];
   if (tid < n1) zmask[tid] = s_z[tid];
   if (!Gs)
@@ -1010,6 +1189,7 @@ __global__ __launch_bounds__(NTD) void k_cholqr_precond(const double* __restrict
     tri_inverse_lds(A0, s_g, B, n1, tid, nullptr);
   }
   __syncthreads();
+  STAMP_P(4);
   for (int i = tid; i < n1 * n1; i += NTD) Vout[i] = B[i];  // T^-1 in natural order: the factor kernel re-evaluates gamma on the norms of ALL rows
   if (tid < n1)
   {
@@ -1040,6 +1220,7 @@ __global__ __launch_bounds__(NTD) void k_cholqr_precond(const double* __restrict
       flags[1] = 1;  // the stand-by runs
     }
   }
+  STAMP_P(5);
   // operand order of k_regressor_pgram, in its column space (natural order shifted right by col_shift)
   // (every operand block the consumer loads is written: what lies beyond n1 + col_shift columns is zero, not stale workspace)
   const int nb = nb_w, nt = nb * (nb + 1) / 2;
@@ -1052,6 +1233,7 @@ __global__ __launch_bounds__(NTD) void k_cholqr_precond(const double* __restrict
     const int r = 16 * cb1 + 4 * kk + (ln >> 4) - col_shift, c = 16 * cb2 + (ln & 15) - col_shift;
     W[i] = (r >= 0 && c >= 0 && r < n1 && c < n1 && r <= c) ? B[c * n1 + r] : 0.0;
   }
+  STAMP_P(6);
 }
 
 // G2 = [G c; c' bb] (the Gram of Q = [A b] W over ALL rows) -> R = chol(G2) T.
@@ -1091,19 +1273,24 @@ __global__ __launch_bounds__(NTD) void k_cholqr_factor(const double* __restrict_
   if (tid == 0) s_flag = 0;
   __syncthreads();
   if (tid < n1) s_g0[tid] = M[tid * n1 + tid];  // |Q(:, k)|^2 before anything is eliminated
+  // T (global, written by the preconditioner kernel) is needed after the factorisation: the waves that only keep the barrier count
+  // during it fetch their share then and hold it in registers (loaded afterwards, the dependent misses cost 8 us)
+  static_assert(NTD > 384, "the waves behind the four computing and two parking ones prefetch T");
+  constexpr int kTPre = (kMaxN1 * kMaxN1 + (NTD - 384) - 1) / (NTD - 384);
+  double tpre[kTPre];
   __syncthreads();
   STAMP(1);
-  chol_with_inverse_lds(M, T, n1, tid, s_sc, s_xd, [&](int k, double d) {
+  RDYN_CHOL_WITH_INVERSE(M, T, n1, tid, s_sc, s_xd, [&](int k, double d) {
     // d / g0 = the squared sine of the angle between Q(:, k) and the columns to its left; "resolved": >= 1e-12
     const bool resolved = d >= 1e-12 * s_g0[k] && s_g0[k] > 0.0;
-    const double piv = sqrt(d > 1e-30 ? d : 1e-30);
+    const bool large = d >= 0.01;  // the pivot sqrt(d) against the 1/10 mark (in units of the lift for a deferred column)
     int skip = 0, flag = 0;
     if (s_z[k])
     {
       // residue in all rows (in units of the lift)?  Or nothing left after its own elimination: null as far as this round can tell --
       // but if the column was large (its elimination's own rounding, u |Q(:, k)|^2, is above the 1/10 mark), that proves nothing
-      skip = !(piv >= 0.1 && resolved);
-      flag = piv >= 0.1 && !resolved;
+      skip = !(large && resolved);
+      flag = large && !resolved;
     }
     else if (!resolved)
       skip = flag = 1;  // a kept column that turns out to be numerically dependent on its left neighbours in the whole batch
@@ -1113,7 +1300,14 @@ __global__ __launch_bounds__(NTD) void k_cholqr_factor(const double* __restrict_
       if (flag) s_flag = 1;
     }
     // a skipped pivot: null direction, its Schur complement is rounding residue -- row k of the factor is zero, nothing is eliminated
-    return skip ? PivotAct{0, 0.0} : PivotAct{1, piv};
+    return !skip;
+  }, [&](int, double d, bool elim) { return elim ? sqrt(d > 1e-30 ? d : 1e-30) : 0.0; }, [&] {
+#pragma unroll
+    for (int m = 0; m < kTPre; ++m)
+    {
+      const int e = tid - 384 + (NTD - 384) * m;
+      tpre[m] = T_in[e < n1 * n1 ? e : n1 * n1 - 1];  // (unconditional: the loads go out back to back)
+    }
   });
   STAMP(2);
   // rho: Re = R2 diag(1 / |Q(:, j)|) over the pivoted columns; Re^-1(i, c) = |Q(:, i)| R2^-1(i, c), R2^-1 parked in the upper triangle of
@@ -1130,49 +1324,88 @@ __global__ __launch_bounds__(NTD) void k_cholqr_factor(const double* __restrict_
     if ((tid & 63) == 0) s_wave[tid >> 6] = part;
   }
   __syncthreads();
-  // the factor back into the upper triangle: M(i, j) <- row i parked in column i; T from global memory into its place
-  for (int e = tid; e < n1 * n1; e += NTD)
+  // the factor back into the upper triangle: M(i, j) <- row i parked in column i (the lower triangle keeps the parked rows: masked
+  // below); T into its place
   {
-    const int i = e % n1, j = e / n1;
-    if (i < j) M[e] = M[i * n1 + j];
-    else if (i == j) M[e] = s_sc[i];
-    T[e] = T_in[e];
+    const int i = tid & 127;
+    if (i < n1)
+      for (int j = tid >> 7; j < n1; j += NTD / 128)
+      {
+        if (i < j) M[j * n1 + i] = M[i * n1 + j];
+        else if (i == j) M[j * n1 + i] = s_sc[i];
+      }
+  }
+  if (tid >= 384)
+  {
+#pragma unroll
+    for (int m = 0; m < kTPre; ++m)
+    {
+      const int e = tid - 384 + (NTD - 384) * m;
+      if (e < n1 * n1) T[e] = tpre[m];
+    }
   }
   __syncthreads();
-  // R = R2 T (upper x upper)
-  for (int e = tid; e < n1 * n1; e += NTD)
+  // R = R2 T (upper x upper) on the matrix cores: 16 x 16 tiles of R over the waves, tile (ti, tj) = sum over the column blocks
+  // ti .. tj of R2(ti, kb) T(kb, tj), operands straight from LDS (A: lane (cl, g) holds R2(16 ti + cl, k), B: T(k, 16 tj + cl),
+  // k = 16 kb + 4 kk + g); tiles below the diagonal are written as zeros
   {
-    const int i = e % n1, j = e / n1;
-    double s = 0.0;
-    if (i <= j)
-      for (int k = i; k <= j; ++k) s = fma(M[k * n1 + i], T[j * n1 + k], s);
-    Rout[e] = s;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), cl = lane & 15, g = lane >> 4;
+    const int nbk = (n1 + 15) >> 4;
+    for (int tile = wave; tile < nbk * nbk; tile += NTD / 64)
+    {
+      const int ti = tile % nbk, tj = tile / nbk;
+      d4 acc = (d4){0.0, 0.0, 0.0, 0.0};
+      const int ia = 16 * ti + cl, jb = 16 * tj + cl;
+      for (int kb = ti; kb <= tj; ++kb)
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+        {
+          const int k = 16 * kb + 4 * kk + g;
+          const bool ka = k < n1 && ia <= k, kt = k < n1 && jb < n1;
+          const double a = ka ? M[k * n1 + ia] : 0.0;   // R2(ia, k), zero below the diagonal
+          const double b = kt ? T[jb * n1 + k] : 0.0;   // T(k, jb) (its own lower triangle is zero)
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+        }
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+      {
+        const int i = 16 * ti + g + 4 * t;  // (the f64 MFMA's own result map: row = (lane >> 4) + 4 reg)
+        if (i < n1 && jb < n1) Rout[jb * n1 + i] = acc[t];
+      }
+    }
   }
   __syncthreads();
   STAMP(3);
   // the growth factor of the round on the column norms of ALL rows (|a_j| = |R(:, j)|; the preconditioner's own figure used the norms
-  // of its input factor: the subsample's in round 0, which may say little about the batch)
-  if (tid < n1)
-  {
-    double q = 0.0;
-    for (int i = 0; i <= tid; ++i) q = fma(Rout[tid * n1 + i], Rout[tid * n1 + i], q);
-    s_part[tid] = sqrt(q);
-  }
+  // of its input factor: the subsample's in round 0, which may say little about the batch).  Three column-wise sums over the rows
+  // <= j (R and V from global memory), sixteen lanes per column with their loads in flight together: one thread per column and a
+  // dependent load per row took 9-19 us.
+  auto column_sums = [&](double* out, auto term) {
+    for (int j = tid >> 4; j < n1; j += NTD / 16)
+    {
+      double sum = 0.0;
+#pragma unroll
+      for (int m = 0; m < kMaxN1 / 16; ++m)
+      {
+        const int i = (tid & 15) + 16 * m;
+        sum += term(i <= j ? i : j, j, i <= j);
+      }
+      sum += __shfl_xor(sum, 1);
+      sum += __shfl_xor(sum, 2);
+      sum += __shfl_xor(sum, 4);
+      sum += __shfl_xor(sum, 8);
+      if ((tid & 15) == 0) out[j] = sum;
+    }
+  };
+  column_sums(s_part, [&](int i, int j, bool on) { const double r = Rout[j * n1 + i]; return on ? r * r : 0.0; });
   __syncthreads();
-  double g_own = 0.0;
-  if (tid < n1)
-    for (int i = 0; i <= tid; ++i) g_own = fma(s_part[i], fabs(V[tid * n1 + i]), g_own);
+  if (tid < n1) s_part[tid] = sqrt(s_part[tid]);
   __syncthreads();
-  const double norm_own = tid < n1 ? s_part[tid] : 0.0;
+  column_sums(s_gam, [&](int i, int j, bool on) { return on ? s_part[i] * fabs(V[j * n1 + i]) : 0.0; });  // g_j
   __syncthreads();
-  if (tid < n1) s_part[tid] = g_own;
+  column_sums(s_sc, [&](int l, int j, bool on) { return on ? s_gam[l] * fabs(T[j * n1 + l]) : 0.0; });
   __syncthreads();
-  if (tid < n1)
-  {
-    double g = 0.0;
-    for (int l = 0; l <= tid; ++l) g = fma(s_part[l], fabs(T[tid * n1 + l]), g);
-    s_gam[tid] = norm_own > 0.0 ? g / norm_own : 0.0;
-  }
+  if (tid < n1) s_gam[tid] = s_part[tid] > 0.0 ? s_sc[tid] / s_part[tid] : 0.0;
   __syncthreads();
   STAMP(4);
   if (tid == 0)
@@ -1470,7 +1703,7 @@ hipError_t rdyn_launch_cholqr_precond(const double* R1, const double* Gs, const 
 {
   if (n1 < 1 || n1 > kMaxN1 || 16 * nb_w < n1 + col_shift) return hipErrorInvalidValue;
   static std::atomic<uint64_t> attr{0};
-  hipError_t e = opt_in_lds_once(k_cholqr_precond, attr, 154 * 1024);
+  hipError_t e = opt_in_lds_once(k_cholqr_precond, attr, 146 * 1024);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(k_cholqr_precond, dim3(1), dim3(NTD), ((size_t)2 * n1 * n1 + n1) * sizeof(double), st, R1, Gs, cs, bbs, n1, col_shift, nb_w, row_scale, T, W, V, zmask, flags, round, run_flag,
                      gamma_out);
@@ -1482,7 +1715,7 @@ hipError_t rdyn_launch_cholqr_factor(const double* G, const double* c, const dou
 {
   if (n1 < 2 || n1 > kMaxN1 || round < 0 || round > 1) return hipErrorInvalidValue;
   static std::atomic<uint64_t> attr{0};
-  hipError_t e = opt_in_lds_once(k_cholqr_factor, attr, 154 * 1024);
+  hipError_t e = opt_in_lds_once(k_cholqr_factor, attr, 146 * 1024);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(k_cholqr_factor, dim3(1), dim3(NTD), (size_t)2 * n1 * n1 * sizeof(double), st, G, c, bb, n1, has_b, T, V, zmask, R, flags, round, run_flag, rho_out);
   return hipGetLastError();

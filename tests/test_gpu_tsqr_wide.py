@@ -251,6 +251,26 @@ def test_matrix_tsqr_on_the_matrix_cores(rows, n, with_b):
     assert np.array_equal(R1, tsqr(At, bt).cpu().numpy())
 
 
+def test_wide_factor_defers_nothing_on_a_well_conditioned_matrix():
+    """85..96 columns: the flags of columns 84..95 used to share their workspace words with the diagnostics (gamma, rho), so those
+    columns were reported -- and treated -- as deferred.  A well-conditioned matrix defers nothing and is accepted in round 0."""
+    torch = pytest.importorskip("torch")
+    from rosdyn_amd._lib import lib
+    from rosdyn_amd.gram import tsqr, tsqr_last_report
+    rng = np.random.default_rng(11)
+    rows, n = 50000, 95
+    A = rng.normal(size=(rows, n))
+    b = rng.normal(size=rows)
+    ws = torch.empty((lib().rdyn_tsqr_workspace_bytes(n + 1),), dtype=torch.uint8, device="cuda")
+    R1 = tsqr(torch.from_numpy(np.ascontiguousarray(A.T)).cuda(), torch.from_numpy(b).cuda(), workspace=ws).cpu().numpy()
+    rep = tsqr_last_report(n + 1, rows, ws)
+    assert rep["route"] == 1 and rep["stage"] == 0 and rep["n_deferred"] == 0, rep
+    assert 0.0 < rep["gamma"][0] < 100.0 and 0.0 < rep["rho"][0] <= 4.0, rep
+    M = np.column_stack([A, b])
+    G = M.T @ M
+    assert np.allclose(np.tril(R1, -1), 0.0) and np.abs(R1.T @ R1 - G).max() <= 1e-12 * np.abs(G).max()
+
+
 def test_matrix_tsqr_beyond_the_dense_kernels_width():
     """97..112 columns with many rows: the dense steps of the preconditioned route do not hold the factor; the LDS-resident folds do."""
     torch = pytest.importorskip("torch")

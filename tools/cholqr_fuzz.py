@@ -54,7 +54,7 @@ def main(n_cases=24, N=66000, seed0=0, only=None):
         ws = torch.zeros((lib().rdyn_regressor_tsqr_workspace_bytes(chain._h) // 8,), dtype=torch.float64, device="cuda")
         L, n1 = layout(n, ws.numel() * 8)
         R = chain.getRegressorTsqr(*(torch.from_numpy(x).cuda() for x in (q, dq, ddq, tau)), workspace=ws.view(torch.uint8)).cpu().numpy()
-        ints = ws[L["flag"]:L["flag"] + 64].cpu().numpy().view(np.int32)
+        ints = ws[L["flag"]:L["flag"] + 96].cpu().numpy().view(np.int32)
         G = M.T @ M
         s_ref = np.linalg.svd(np.linalg.qr(M, mode="r"), compute_uv=False)
         s = np.linalg.svd(R, compute_uv=False)
@@ -64,7 +64,7 @@ def main(n_cases=24, N=66000, seed0=0, only=None):
         e3 = (s[~keep].max() / s_ref[0]) if (~keep).any() else 0.0
         path_taken = "stand-by" if ints[1] else ("round 1" if ints[0] else ("round 0" if ints[2] else "stand-by (round 0 called off)"))
         worst = max(worst, e1, e2 * 1e-3)
-        dg = ws[L["flag"] + 50:L["flag"] + 56].cpu().numpy()
+        dg = ws[L["flag"] + 56:L["flag"] + 62].cpu().numpy()
         print(f"{case:3d} n={n} {what:55s} {path_taken:10s} R'R-G {e1:.1e}  sv {e2:.1e}  null {e3:.1e}   "
               f"gamma {dg[0]:.0e}/{dg[4]:.0e} rho {dg[2]:.3g} | gamma {dg[1]:.0e}/{dg[5]:.0e} rho {dg[3]:.3g}", flush=True)
     print("worst", worst)

@@ -17,7 +17,7 @@ def layout(nJ, workspace_bytes=None):
     n1 = 10 * nJ + 1; nb = (n1 + 15) // 16; nt = nb * (nb + 1) // 2
     off = ((256 + 128 + 2) * n1 * n1 + 31) & ~31
     L = {}
-    for name, d in (("slabs", 256 * nt * 256), ("w", nt * 256), ("r1p", n1 * n1), ("g2", n1 * n1 + 1), ("r_swept", n1 * n1), ("v", n1 * n1), ("flag", 64)):
+    for name, d in (("slabs", 256 * nt * 256), ("w", nt * 256), ("r1p", n1 * n1), ("g2", n1 * n1 + 1), ("r_swept", n1 * n1), ("v", n1 * n1), ("flag", 96)):
         L[name] = off; off = (off + d + 31) & ~31
     assert workspace_bytes is None or workspace_bytes == off * 8, "tools/debug_cholqr3.py: layout() is out of step with rdyn_api.cpp"
     return L, n1
@@ -49,8 +49,8 @@ def main():
         R = chain.getRegressorTsqr(*args, workspace=ws.view(torch.uint8))
         ev[1].record()
         torch.cuda.synchronize()
-        ints = ws[L["flag"]:L["flag"] + 64].cpu().numpy().view(np.int32)
-        gam = ws[L["flag"] + 50:L["flag"] + 56].cpu().numpy()
+        ints = ws[L["flag"]:L["flag"] + 96].cpu().numpy().view(np.int32)
+        gam = ws[L["flag"] + 56:L["flag"] + 62].cpu().numpy()
         R = R.cpu().numpy()
         G = M.T @ M
         s_ref = np.linalg.svd(np.linalg.qr(M, mode="r"), compute_uv=False)
