@@ -246,7 +246,14 @@ int run_local(const rdyn_chain* c, const rdyn_batch* b, int mode, double* tau, d
     a.y_sr = yl->stride_row;
     a.y_sc = yl->stride_col;
   }
-  if (yl && (mode == RDYN_MODE_REGRESSOR || mode == RDYN_MODE_REGRESSOR_EXPAND))
+  if (mode == RDYN_MODE_REGRESSOR_EXPAND && yl && yl->stride_row == 1 && ((uintptr_t)Y & 15) == 0 && !probe_env("RDYN_NO_EXPAND_STAGING"))
+  {
+    // row-contiguous layouts: every link's block through the wave's LDS tile, copied out 16 bytes per lane (k_expand_staged)
+    if (yl->stride_col == n && yl->stride_sample % 2 == 0) a.expand_stage = 1;        // per-sample images
+    else if (yl->stride_sample == n && yl->stride_col % 2 == 0) a.expand_stage = 2;   // stacked (N n) x P matrix
+    if (a.expand_stage) mode = RDYN_MODE_REGRESSOR_EXPAND_STAGED;
+  }
+  if (yl && (mode == RDYN_MODE_REGRESSOR || mode == RDYN_MODE_REGRESSOR_EXPAND || mode == RDYN_MODE_REGRESSOR_EXPAND_STAGED))
   {
     // the one-thread-per-sample kernel addresses a workgroup's 256 samples with 32-bit lane offsets: free strides must be
     // positive and keep 255 * stride_sample * 8 inside 32 bits (the presets of rdyn.h are far below that)

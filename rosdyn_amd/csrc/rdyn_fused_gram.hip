@@ -34,9 +34,11 @@ enum
   MODE_TORQUE = 1,
   MODE_INERTIA = 2,
   MODE_REGRESSOR_GRAM = 3,
-  MODE_REGRESSOR_EXPAND = 4
+  MODE_REGRESSOR_EXPAND = 4,
+  MODE_REGRESSOR_EXPAND_STAGED = 5
 };
-#define RDYN_IS_REGRESSOR(MODE) ((MODE) == MODE_REGRESSOR || (MODE) == MODE_REGRESSOR_GRAM || (MODE) == MODE_REGRESSOR_EXPAND)
+#define RDYN_IS_EXPAND(MODE) ((MODE) == MODE_REGRESSOR_EXPAND || (MODE) == MODE_REGRESSOR_EXPAND_STAGED)
+#define RDYN_IS_REGRESSOR(MODE) ((MODE) == MODE_REGRESSOR || (MODE) == MODE_REGRESSOR_GRAM || RDYN_IS_EXPAND(MODE))
 #define RDYN_BODY_EXIT break
 
 template <int NJ, int NB>
@@ -82,6 +84,7 @@ __global__ __launch_bounds__(256) void k_regressor_gram_fused(const RdynFusedGra
       a.y_sr = 256;
       a.y_sc = lda;
       const unsigned blk = 0;
+      constexpr double* expand_tile = nullptr;  // (rdyn_kernels.hip: k_expand_staged)
       bool done = false;
       do
       {

@@ -32,6 +32,10 @@ struct RdynSweepArgs
   const double* expand_X;
   int expand_n;
   signed char expand_red_of[RDYN_MAX_JOINTS];
+  // RDYN_MODE_REGRESSOR_EXPAND_STAGED: the row-contiguous layout the wave's LDS tile is copied out to -- 1: per-sample images
+  // (stride_col == rows, a link's block is one run of 10 rows doubles per sample), 2: stacked matrix (stride_sample == rows, a column is
+  // one run of 64 rows doubles per wave)
+  int expand_stage;
 };
 
 // split / jerk sweeps (rdyn_kin_ext.hip); every output record is links x 6
@@ -269,7 +273,8 @@ struct RdynComponentArgs
 };
 hipError_t rdyn_launch_components(const RdynComponentArgs& a, hipStream_t st);
 
-enum { RDYN_MODE_REGRESSOR = 0, RDYN_MODE_TORQUE = 1, RDYN_MODE_INERTIA = 2, RDYN_MODE_REGRESSOR_GRAM = 3, RDYN_MODE_REGRESSOR_EXPAND = 4 };
+enum { RDYN_MODE_REGRESSOR = 0, RDYN_MODE_TORQUE = 1, RDYN_MODE_INERTIA = 2, RDYN_MODE_REGRESSOR_GRAM = 3, RDYN_MODE_REGRESSOR_EXPAND = 4,
+       RDYN_MODE_REGRESSOR_EXPAND_STAGED = 5 };
 
 hipError_t rdyn_launch_local_sweep(int n_joints, int mode, const RdynSweepArgs& a, hipStream_t st);
 hipError_t rdyn_launch_base_sweep(int n_joints, const RdynKinArgs& a, hipStream_t st);

@@ -49,9 +49,13 @@ enum
   MODE_REGRESSOR_GRAM = 3,
   // dense regressor of a chain LONGER than the kernels sweep: the reduced companion is swept and every (row, body) ten-vector is
   // multiplied by the constant 10 x 10 blocks of the chain links that ride on that body (Y_f = Y_body X_f, rdyn_chain.hpp)
-  MODE_REGRESSOR_EXPAND = 4
+  MODE_REGRESSOR_EXPAND = 4,
+  // the same into a row-contiguous layout (per-sample images, stacked matrix): 64-thread workgroups, every link's block staged in the
+  // wave's LDS tile and copied out 16 bytes per lane (8-byte pieces scattered over 64 lines per store instruction: 3-4 ms per 1e6)
+  MODE_REGRESSOR_EXPAND_STAGED = 5
 };
-#define RDYN_IS_REGRESSOR(MODE) ((MODE) == MODE_REGRESSOR || (MODE) == MODE_REGRESSOR_GRAM || (MODE) == MODE_REGRESSOR_EXPAND)
+#define RDYN_IS_EXPAND(MODE) ((MODE) == MODE_REGRESSOR_EXPAND || (MODE) == MODE_REGRESSOR_EXPAND_STAGED)
+#define RDYN_IS_REGRESSOR(MODE) ((MODE) == MODE_REGRESSOR || (MODE) == MODE_REGRESSOR_GRAM || RDYN_IS_EXPAND(MODE))
 #define RDYN_BODY_EXIT return
 
 // one chain, one batch: grid.x = ceil(N / 256)
@@ -63,6 +67,19 @@ enum
 template <int NJ, int MODE>
 __global__ __launch_bounds__(256) RDYN_LOCAL_ATTR void k_local_sweep(const RdynSweepArgs a)
 {
+  const unsigned blk = blockIdx.x;
+  constexpr double* expand_tile = nullptr;  // (the staged expanding sweep's LDS tile: k_expand_staged)
+#include "rdyn_local_sweep_body.inc"
+}
+// the staged expanding sweep: one wave per workgroup, its tile in dynamic LDS (64 x (CG NJ + 2) doubles, CG columns of a link at a time)
+#ifndef RDYN_EXPAND_WAVES
+#define RDYN_EXPAND_WAVES 2
+#endif
+template <int NJ>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RDYN_EXPAND_WAVES, RDYN_EXPAND_WAVES))) void k_expand_staged(const RdynSweepArgs a)
+{
+  constexpr int MODE = MODE_REGRESSOR_EXPAND_STAGED;
+  extern __shared__ __attribute__((aligned(16))) double expand_tile[];
   const unsigned blk = blockIdx.x;
 #include "rdyn_local_sweep_body.inc"
 }
@@ -78,6 +95,7 @@ __global__ __launch_bounds__(256) void k_local_sweep_multi(const RdynSweepArgs* 
   const RDYN_CONST_AS RdynSweepArgs& a = *((const RDYN_CONST_AS RdynSweepArgs*)table + blockIdx.y);
 #pragma clang diagnostic pop
   const unsigned blk = blockIdx.x;
+  constexpr double* expand_tile = nullptr;
 #include "rdyn_local_sweep_body.inc"
 }
 
@@ -236,6 +254,9 @@ hipError_t launch_local_nj(int mode, const RdynSweepArgs& a, hipStream_t st)
   const unsigned grid = (unsigned)((a.n_samples + 255) / 256);
   switch (mode)
   {
+  case MODE_REGRESSOR_EXPAND_STAGED:
+    hipLaunchKernelGGL((k_expand_staged<NJ>), dim3((unsigned)((a.n_samples + 63) / 64)), dim3(64), (size_t)64 * (RDYN_EXPAND_CG * NJ + 2) * sizeof(double), st, a);
+    break;
   case MODE_REGRESSOR: hipLaunchKernelGGL((k_local_sweep<NJ, MODE_REGRESSOR>), dim3(grid), dim3(256), 0, st, a); break;
   case MODE_REGRESSOR_GRAM: hipLaunchKernelGGL((k_local_sweep<NJ, MODE_REGRESSOR_GRAM>), dim3(grid), dim3(256), 0, st, a); break;
   case MODE_REGRESSOR_EXPAND: hipLaunchKernelGGL((k_local_sweep<NJ, MODE_REGRESSOR_EXPAND>), dim3(grid), dim3(256), 0, st, a); break;

@@ -321,6 +321,8 @@ def test_fuzzed_chain_identification_step(seed):
     Y, tg = chain.getRegressor(tq, tdq, tddq, with_torque=True)
     assert np.abs(Y.cpu().numpy().transpose(0, 2, 1) - Yr).max() <= TOL * max(1.0, np.abs(Yr).max())
     assert np.abs(tg.cpu().numpy() - tr).max() <= TOL * max(1.0, np.abs(tr).max())
+    Ys = chain.getRegressor(tq, tdq, tddq, y_layout="stacked").cpu().numpy().reshape(P, N, n).transpose(1, 2, 0)
+    assert np.abs(Ys - Yr).max() <= TOL * max(1.0, np.abs(Yr).max())   # (long chains: the LDS-staged expanding sweep, odd row counts too)
     assert np.abs(chain.getJointTorque(tq, tdq, tddq).cpu().numpy() - tr).max() <= TOL * max(1.0, np.abs(tr).max())
     Gg, cg, bbg = chain.getIdentificationGram(comps, tq, tdq, tddq, ttau)
     C = P + K
