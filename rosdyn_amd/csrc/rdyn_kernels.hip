@@ -255,7 +255,7 @@ hipError_t launch_local_nj(int mode, const RdynSweepArgs& a, hipStream_t st)
   switch (mode)
   {
   case MODE_REGRESSOR_EXPAND_STAGED:
-    hipLaunchKernelGGL((k_expand_staged<NJ>), dim3((unsigned)((a.n_samples + 63) / 64)), dim3(64), (size_t)64 * (RDYN_EXPAND_CG * NJ + 2) * sizeof(double), st, a);
+    hipLaunchKernelGGL((k_expand_staged<NJ>), dim3((unsigned)((a.n_samples + 63) / 64)), dim3(64), (size_t)64 * ((((RDYN_EXPAND_CG * NJ) % 2 == 0) ? RDYN_EXPAND_CG : 2) * NJ + 2) * sizeof(double), st, a);
     break;
   case MODE_REGRESSOR: hipLaunchKernelGGL((k_local_sweep<NJ, MODE_REGRESSOR>), dim3(grid), dim3(256), 0, st, a); break;
   case MODE_REGRESSOR_GRAM: hipLaunchKernelGGL((k_local_sweep<NJ, MODE_REGRESSOR_GRAM>), dim3(grid), dim3(256), 0, st, a); break;

@@ -88,6 +88,8 @@ elif what == "long":
         c.getRegressor(qe, dqe, ddqe, layout="element")
     for _ in range(3):
         c.getRegressor(q, dq, ddq)
+    for _ in range(3):
+        c.getRegressor(q, dq, ddq, y_layout="stacked")
     for _ in range(4):
         c.getRegressorGram(q, dq, ddq, tm)
         c.getRegressorTsqr(q, dq, ddq, tm)
