@@ -248,9 +248,22 @@ __global__ __launch_bounds__(NTW) void k_tsqr_wide_rows(const double* __restrict
   const int n1 = n_cols + (b ? 1 : 0), tri = tri_off(n1);
   double* const Rp = (double*)lds_raw;
   double* const pub = (double*)(lds_raw + (((size_t)tri * 8 + 255) & ~(size_t)255));
-  for (int i = tid; i < tri; i += NTW) Rp[i] = 0.0;
-  const int64_t row_lo = (int64_t)blockIdx.x * rows_per_wg;
+  int64_t row_lo = (int64_t)blockIdx.x * rows_per_wg;
   const int64_t row_hi = row_lo + rows_per_wg < rows ? row_lo + rows_per_wg : rows;
+  if (seg_rows == n1 && row_lo % n1 == 0 && row_lo + n1 <= row_hi && !b)
+  {
+    // tree levels: the workgroup's first factor IS a running factor -- taken as it stands instead of folded into zeros (a fold is
+    // n1 dependent steps whatever its rows hold: 12 -> 8 folds on the way from 125 leaves to the result at 78 columns)
+    const double* const F = A + (row_lo / n1) * seg_stride;
+    for (int e = tid; e < n1 * n1; e += NTW)
+    {
+      const int i = e % n1, jj = e / n1;
+      if (i <= jj) Rp[tri_off(jj) + i] = F[(int64_t)jj * lda + i];
+    }
+    row_lo += n1;
+  }
+  else
+    for (int i = tid; i < tri; i += NTW) Rp[i] = 0.0;
   __syncthreads();
   for (int64_t r0 = row_lo; r0 < row_hi; r0 += RB)
   {
@@ -316,7 +329,13 @@ size_t tri_bytes(int n1) { return (((size_t)n1 * (n1 + 1) / 2) * 8 + 255) & ~(si
 constexpr size_t kPubBytes = 2 * PUB * 8;
 constexpr int kRowsPerBlock = 4 * RPT_MAX;
 
-// count factors (n1 x n1, column-major, contiguous) at `in` -> R, four per workgroup and level; scratch: room for 64 + 16 + 4 factors
+int wide_tree_fan(int n1)
+{
+  const int f = 1 + 2 * kRowsPerBlock / n1;
+  return f < 3 ? 3 : (f > 8 ? 8 : f);
+}
+// count factors (n1 x n1, column-major, contiguous) at `in` -> R, `fan` per workgroup and level; scratch: room for the levels' factors
+// (count / 3 + count / 9 + ... < count / 2 + one per level)
 hipError_t wide_tree(const double* in, int count, double* scratch, double* R, int n1, const double* extra, const int* run_flag, hipStream_t st,
                      int64_t in_stride = 0)
 {
@@ -325,7 +344,9 @@ hipError_t wide_tree(const double* in, int count, double* scratch, double* R, in
   hipError_t e = opt_in((const void*)k_tsqr_wide_rows, attr);
   if (e != hipSuccess) return e;
   const size_t lds = tri_bytes(n1) + kPubBytes;
-  const int fan = 4;  // 256 leaves: four levels of at most 448 rows (3.5 blocks) each; a 16 : 1 tree folds 2 x 14 blocks
+  // a level costs ceil((fan - 1) n1 / 128) folds of n1 dependent steps each (the first factor is taken as it stands): the widest fan
+  // whose other factors fill two row blocks -- 3 at 112 columns, 4 at 78, 5 at 61, at most 8
+  const int fan = wide_tree_fan(n1);
   while (true)
   {
     const int nout = (count + fan - 1) / fan;
@@ -337,7 +358,7 @@ hipError_t wide_tree(const double* in, int count, double* scratch, double* R, in
     in = scratch;
     stride = (int64_t)n1 * n1;
     count = nout;
-    scratch = scratch + (size_t)nout * n1 * n1;  // (256 leaves -> 64 -> 16 -> 4 -> R)
+    scratch = scratch + (size_t)nout * n1 * n1;
   }
 }
 }  // namespace
@@ -354,7 +375,7 @@ size_t rdyn_regressor_tsqr_wide_lds_bytes(int n1, int n_active)
 }
 
 // doubles of workspace: the leaves' factors + the tree's intermediate level
-size_t rdyn_tsqr_wide_workspace_doubles(int n1, int blocks) { return (size_t)(blocks + (blocks + 3) / 4 + (blocks + 15) / 16 + (blocks + 63) / 64 + 4) * n1 * n1; }
+size_t rdyn_tsqr_wide_workspace_doubles(int n1, int blocks) { return (size_t)(blocks + (blocks + 1) / 2 + 12) * n1 * n1; }
 
 hipError_t rdyn_launch_regressor_tsqr_wide(int n_joints, const RdynLdsGramArgs& a, int blocks, double* workspace, double* R, int accumulate, hipStream_t st)
 {

@@ -27,7 +27,7 @@ order = defaultdict(list)  # (start timestamp, duration) per kernel, to single o
 meta = {}
 for r in rows("trace/**/*kernel_trace.csv"):
     name = r.get("Kernel_Name", "")
-    if any(k in name for k in ("k_local_sweep", "k_base_sweep", "k_base_ext", "k_gram", "k_rowpair", "k_image_sweep", "k_regressor_gram", "k_regressor_tsqr", "k_regressor_pgram", "k_pgram", "k_cholqr", "k_tsqr", "k_local_ik", "k_components")):
+    if any(k in name for k in ("k_local_sweep", "k_expand_staged", "k_base_sweep", "k_base_ext", "k_gram", "k_rowpair", "k_image_sweep", "k_regressor_gram", "k_regressor_tsqr", "k_regressor_pgram", "k_pgram", "k_cholqr", "k_tsqr", "k_local_ik", "k_components")):
         dur[name].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
         order[name].append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
         meta[name] = (r.get("VGPR_Count"), r.get("Accum_VGPR_Count"), r.get("SGPR_Count"), r.get("LDS_Block_Size"), r.get("Scratch_Size"), r.get("Grid_Size"), r.get("Workgroup_Size"))
@@ -50,7 +50,7 @@ for tag in ("fetch", "write"):
     acc = defaultdict(list)
     for r in rows("pmc_%s/**/*counter_collection.csv" % tag):
         name = r.get("Kernel_Name", "")
-        if any(k in name for k in ("k_local_sweep", "k_base_sweep", "k_gram", "k_rowpair", "k_image_sweep", "k_regressor_gram")):
+        if any(k in name for k in ("k_local_sweep", "k_expand_staged", "k_base_sweep", "k_gram", "k_rowpair", "k_image_sweep", "k_regressor_gram")):
             acc[(name[:60], r.get("Counter_Name"))].append(float(r.get("Counter_Value", 0)))
     for (k, c), v in acc.items():
         print("pmc %-60s %s: n=%d avg=%.1f (KB units -> %.1f MB per launch)" % (k, c, len(v), sum(v) / len(v), sum(v) / len(v) / 1024.0))
@@ -63,7 +63,7 @@ for tag, store in (("fetch", fetch), ("write", write)):
     acc = defaultdict(list)
     for r in rows("pmc_%s/**/*counter_collection.csv" % tag):
         name = r.get("Kernel_Name", "")
-        if "k_local_sweep" in name or "k_gram" in name or "k_rowpair" in name or "k_image_sweep" in name:
+        if "k_local_sweep" in name or "k_expand_staged" in name or "k_gram" in name or "k_rowpair" in name or "k_image_sweep" in name:
             acc[name].append(float(r.get("Counter_Value", 0)))
     for k, v in acc.items():
         store[k] = sum(v) / len(v)
