@@ -224,7 +224,7 @@ int run_local(const rdyn_chain* c, const rdyn_batch* b, int mode, double* tau, d
       st = device_expand(full, &a.expand_X);
       if (st != RDYN_OK) return st;
       a.expand_n = full->n_joints();
-      for (int f = 0; f < full->n_joints(); ++f) a.expand_red_of[f] = (signed char)full->red_of[f];
+      for (int f = 0; f < full->n_joints(); ++f) a.expand_red_of[f] = full->red_of[f];
     }
     c = full->reduced.get();
   }

@@ -31,7 +31,7 @@ struct RdynSweepArgs
   // upstream of the first input joint (expand_red_of[g] < 0).  expand_X: device, [expand_n][10][10] row-major X_g(a, p).
   const double* expand_X;
   int expand_n;
-  signed char expand_red_of[RDYN_MAX_JOINTS];
+  int expand_red_of[RDYN_MAX_JOINTS];  // (ints: a dynamically indexed byte of the kernel arguments is a VECTOR load, whose wait drains every store in flight)
   // RDYN_MODE_REGRESSOR_EXPAND_STAGED: the row-contiguous layout the wave's LDS tile is copied out to -- 1: per-sample images
   // (stride_col == rows, a link's block is one run of 10 rows doubles per sample), 2: stacked matrix (stride_sample == rows, a column is
   // one run of 64 rows doubles per wave)

@@ -72,6 +72,7 @@ __global__ __launch_bounds__(256) RDYN_LOCAL_ATTR void k_local_sweep(const RdynS
 #include "rdyn_local_sweep_body.inc"
 }
 // the staged expanding sweep: one wave per workgroup, its tile in dynamic LDS (64 x (CG NJ + 2) doubles, CG columns of a link at a time)
+// and behind it the lanes' inputs (64 x (3 NJ + 1) doubles)
 #ifndef RDYN_EXPAND_WAVES
 #define RDYN_EXPAND_WAVES 2
 #endif
@@ -255,7 +256,7 @@ hipError_t launch_local_nj(int mode, const RdynSweepArgs& a, hipStream_t st)
   switch (mode)
   {
   case MODE_REGRESSOR_EXPAND_STAGED:
-    hipLaunchKernelGGL((k_expand_staged<NJ>), dim3((unsigned)((a.n_samples + 63) / 64)), dim3(64), (size_t)64 * ((((RDYN_EXPAND_CG * NJ) % 2 == 0) ? RDYN_EXPAND_CG : 2) * NJ + 2) * sizeof(double), st, a);
+    hipLaunchKernelGGL((k_expand_staged<NJ>), dim3((unsigned)((a.n_samples + 63) / 64)), dim3(64), (size_t)64 * (RDYN_EXPAND_TILE_COLS(NJ) * NJ + 2 + 3 * NJ + 1) * sizeof(double), st, a);
     break;
   case MODE_REGRESSOR: hipLaunchKernelGGL((k_local_sweep<NJ, MODE_REGRESSOR>), dim3(grid), dim3(256), 0, st, a); break;
   case MODE_REGRESSOR_GRAM: hipLaunchKernelGGL((k_local_sweep<NJ, MODE_REGRESSOR_GRAM>), dim3(grid), dim3(256), 0, st, a); break;
