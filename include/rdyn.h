@@ -148,13 +148,14 @@ int rdyn_chain_joint_constants(const rdyn_chain* chain, int i, double R_pj[9], d
 int rdyn_chain_link_parameters(const rdyn_chain* chain, int i, double pi[10], double* mass, double cog[3]);
 /* Chain::getNominalParameters primitives_impl.h:1382 -> pi[10 * joints_number] (HOST pointer) */
 int rdyn_nominal_parameters(const rdyn_chain* chain, double* pi);
-/* Rigid-body reduction of a chain whose input joints are a subset of its joints, in chain order (fixed joints, primitives_impl.h:74-83,
+/* Rigid-body reduction of a chain whose input joints are a subset of its joints, listed in any order (fixed joints, primitives_impl.h:74-83,
  * or joints left out of setInputJointsName): links joined by non-input joints move as one body, so the ten regressor columns of a
  * link f + 1 hanging from a non-input joint are a CONSTANT linear image of the ten columns of the link the body's input joint
  * carries:  Y(:, 10 f + p) = sum_a Y(:, 10 body_joint[f] + a) X[f][a][p]   (zero for links upstream of the first input joint).
  * The regressor -> Gram / R-factor entry points use it internally (they sweep the reduced chain and expand the small result);
- * exposed for callers that reduce the parameter vector themselves.  Returns the number of bodies (= input joints), 0 when the
- * chain has no reduction (every joint an input joint, or input joints not in chain order), < 0 on a null chain.
+ * exposed for callers that reduce the parameter vector themselves.  Returns the number of bodies (= input joints; the bodies are
+ * numbered in CHAIN order whatever the order of the input list), 0 when the chain has no reduction (every joint an input joint, or
+ * more than RDYN_MAX_SWEPT_JOINTS input joints), < 0 on a null chain.
  * body_joint[n_joints]: chain index of the input joint whose child link is the body's reference frame, -1 = rides on the base;
  * X[n_joints][10][10] row-major (a, p); pi_body[10 * bodies]: the merged nominal parameters.  HOST pointers, each may be NULL. */
 int rdyn_chain_reduction(const rdyn_chain* chain, int32_t* body_joint, double* X, double* pi_body);

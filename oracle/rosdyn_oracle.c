@@ -40,7 +40,7 @@
 #include <omp.h>
 #endif
 
-#define ORC_MAX_LINKS 17
+#define ORC_MAX_LINKS 33
 #define ORC_REVOLUTE 0   /* primitives.h:67  enum Type {REVOLUTE, PRISMATIC, FIXED} */
 #define ORC_PRISMATIC 1
 #define ORC_FIXED 2

@@ -101,6 +101,30 @@ int device_const(const rdyn_chain* c, const RdynChainConst** out)
   return RDYN_OK;
 }
 
+// constants of a chain of more than RDYN_MAX_SWEPT_JOINTS joints for the run-time-length kinematic kernels (rdyn_long_kin.hip)
+int device_const_long(const rdyn_chain* c, const RdynLongChainConst** out)
+{
+  int dev = 0;
+  RDYN_HIP_TRY(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> lk(c->mu);
+  auto it = c->dev_long.find(dev);
+  if (it == c->dev_long.end())
+  {
+    RdynLongChainConst* d = nullptr;
+    RDYN_HIP_TRY(hipMalloc((void**)&d, sizeof(RdynLongChainConst)));
+    hipError_t e = hipMemcpy(d, &c->host_long, sizeof(RdynLongChainConst), hipMemcpyHostToDevice);
+    if (e != hipSuccess)
+    {
+      (void)hipFree(d);
+      rdyn_set_error("HIP error: %s (upload of chain constants)", hipGetErrorString(e));
+      return RDYN_ERR_HIP;
+    }
+    it = c->dev_long.emplace(dev, d).first;
+  }
+  *out = it->second;
+  return RDYN_OK;
+}
+
 // device copy of the expansion blocks X_f of a chain with a reduced companion (rdyn_chain.hpp), current device
 int device_expand(const rdyn_chain* c, const double** out)
 {
@@ -129,21 +153,25 @@ int device_expand(const rdyn_chain* c, const double** out)
 // temporary normal equations of the reduced chain at the end of a Gram workspace: G_red | c_red | bb_red
 size_t reduce_tmp_bytes(int cols_red) { return (((size_t)cols_red * cols_red + cols_red + 1) * sizeof(double) + 255) & ~(size_t)255; }
 
-// long_ok: the entry point serves chains of more than RDYN_MAX_SWEPT_JOINTS joints (through the reduced companion)
-int check_batch(const rdyn_chain* c, const rdyn_batch* b, bool need_dq, bool need_ddq, const char* fn, bool long_ok = false)
+// How an entry point serves a chain of more than RDYN_MAX_SWEPT_JOINTS joints: through its reduced companion (regressor, torque,
+// inertia, normal equations, R factors, IK: at most RDYN_MAX_SWEPT_JOINTS input joints) or by the run-time-length kinematic kernels
+// (frames, Jacobians, twists, wrenches: any number of input joints)
+enum { LONG_NONE = 0, LONG_COMPANION = 1, LONG_KERNELS = 2 };
+int check_batch(const rdyn_chain* c, const rdyn_batch* b, bool need_dq, bool need_ddq, const char* fn, int long_mode)
 {
   if (!c || !b)
   {
     rdyn_set_error("%s: null chain or batch", fn);
     return RDYN_ERR_INVALID_ARGUMENT;
   }
-  if (c->long_chain() && !(long_ok && c->reduced))
+  if (c->long_chain() && long_mode == LONG_NONE)
   {
-    if (!long_ok)
-      rdyn_set_error("%s: chains of more than %d joints are not served by this entry point (regressor, torque, inertia, normal equations and R "
-                     "factors are)", fn, RDYN_MAX_SWEPT_JOINTS);
-    else
-      rdyn_set_error("%s: a chain of %d joints needs at most %d input joints, in chain order", fn, c->n_joints(), RDYN_MAX_SWEPT_JOINTS);
+    rdyn_set_error("%s: chains of more than %d joints are not served by this entry point", fn, RDYN_MAX_SWEPT_JOINTS);
+    return RDYN_ERR_UNSUPPORTED;
+  }
+  if (c->long_chain() && long_mode == LONG_COMPANION && !c->reduced)
+  {
+    rdyn_set_error("%s: a chain of %d joints needs at most %d input joints", fn, c->n_joints(), RDYN_MAX_SWEPT_JOINTS);
     return RDYN_ERR_UNSUPPORTED;
   }
   if (b->n_samples < 0 || (b->layout != RDYN_LAYOUT_SAMPLE_MAJOR && b->layout != RDYN_LAYOUT_ELEMENT_MAJOR))
@@ -306,7 +334,7 @@ extern "C"
 
 int rdyn_joint_torque(const rdyn_chain* c, const rdyn_batch* b, double* tau)
 {
-  int st = check_batch(c, b, true, true, "rdyn_joint_torque", true);
+  int st = check_batch(c, b, true, true, "rdyn_joint_torque", LONG_COMPANION);
   if (st != RDYN_OK) return st;
   if (!tau && b->n_samples > 0)
   {
@@ -318,7 +346,7 @@ int rdyn_joint_torque(const rdyn_chain* c, const rdyn_batch* b, double* tau)
 
 int rdyn_joint_torque_nonlinear(const rdyn_chain* c, const rdyn_batch* b, double* tau)
 {
-  int st = check_batch(c, b, true, false, "rdyn_joint_torque_nonlinear", true);
+  int st = check_batch(c, b, true, false, "rdyn_joint_torque_nonlinear", LONG_COMPANION);
   if (st != RDYN_OK) return st;
   if (!tau && b->n_samples > 0)
   {
@@ -330,7 +358,7 @@ int rdyn_joint_torque_nonlinear(const rdyn_chain* c, const rdyn_batch* b, double
 
 int rdyn_regressor(const rdyn_chain* c, const rdyn_batch* b, double* tau, double* Y, const rdyn_regressor_layout* yl)
 {
-  int st = check_batch(c, b, true, true, "rdyn_regressor", true);
+  int st = check_batch(c, b, true, true, "rdyn_regressor", LONG_COMPANION);
   if (st != RDYN_OK) return st;
   if (b->n_samples > 0 && (!Y || !yl))
   {
@@ -342,7 +370,7 @@ int rdyn_regressor(const rdyn_chain* c, const rdyn_batch* b, double* tau, double
 
 int rdyn_joint_inertia(const rdyn_chain* c, const rdyn_batch* b, double* M)
 {
-  int st = check_batch(c, b, false, false, "rdyn_joint_inertia", true);
+  int st = check_batch(c, b, false, false, "rdyn_joint_inertia", LONG_COMPANION);
   if (st != RDYN_OK) return st;
   if (!M && b->n_samples > 0)
   {
@@ -361,7 +389,7 @@ static int run_base(const rdyn_chain* c, const rdyn_batch* b, double* T_bt, doub
   if (st != RDYN_OK) return st;
   RdynKinArgs a;
   memset(&a, 0, sizeof a);
-  st = device_const(c, &a.chain);
+  st = c->long_chain() ? device_const_long(c, &a.chain_long) : device_const(c, &a.chain);
   if (st != RDYN_OK) return st;
   const int n = c->n_active(), L = c->n_joints() + 1;
   a.q = b->q;
@@ -381,7 +409,13 @@ static int run_base(const rdyn_chain* c, const rdyn_batch* b, double* T_bt, doub
   a.dtwists = dtw;
   rec_strides(b, 6 * (int64_t)L, &a.tw_ss, &se);
   a.out_se = se;
-  RDYN_HIP_TRY(rdyn_launch_base_sweep(c->n_joints(), a, (hipStream_t)b->stream));
+  if (c->long_chain())
+  {
+    for (int l = 0; l < a.j_link; ++l) a.j_up += c->host_joints[l].in_idx >= 0 ? 1 : 0;
+    RDYN_HIP_TRY(rdyn_launch_long_base(a, (hipStream_t)b->stream));
+  }
+  else
+    RDYN_HIP_TRY(rdyn_launch_base_sweep(c->n_joints(), a, (hipStream_t)b->stream));
   return RDYN_OK;
 }
 
@@ -395,7 +429,7 @@ int rdyn_local_ik(const rdyn_chain* c, const rdyn_batch* b, const double* T_targ
 int rdyn_local_ik_damped(const rdyn_chain* c, const rdyn_batch* b, const double* T_target, const double* weight, double toll,
                          double damping, int max_iterations, double* sol, int32_t* status, int32_t* iterations)
 {
-  int st = check_batch(c, b, false, false, "rdyn_local_ik");  // batch->q = the seeds
+  int st = check_batch(c, b, false, false, "rdyn_local_ik", LONG_COMPANION);  // batch->q = the seeds
   if (st != RDYN_OK) return st;
   if (b->n_samples > 0 && (!T_target || !sol))
   {
@@ -413,6 +447,15 @@ int rdyn_local_ik_damped(const rdyn_chain* c, const rdyn_batch* b, const double*
   if (st != RDYN_OK) return st;
   RdynIkArgs a;
   memset(&a, 0, sizeof a);
+  if (c->long_chain())
+  {
+    // the pose and the Jacobian of the tool need only the input joints: the reduced companion (the fixed frames folded into the
+    // joint origins) is iterated, its tool frame followed by the constant frames behind the last input joint
+    a.has_tail = 1;
+    memcpy(a.tail_R, c->tail_R, sizeof a.tail_R);
+    memcpy(a.tail_t, c->tail_t, sizeof a.tail_t);
+    c = c->reduced.get();
+  }
   st = device_const(c, &a.chain);
   if (st != RDYN_OK) return st;
   a.T_target = T_target;
@@ -493,7 +536,7 @@ int rdyn_frame_distance(int64_t n_pairs, const double* T_wa, const double* T_wb,
 // ---- split / jerk sweeps, external wrenches ---------------------------------------------------------------
 int rdyn_twist_parts(const rdyn_chain* c, const rdyn_batch* b, const double* dddq, double* dtw_lin, double* dtw_nonlin, double* ddtw)
 {
-  int st = check_batch(c, b, dtw_nonlin || ddtw, dtw_lin || ddtw, "rdyn_twist_parts");
+  int st = check_batch(c, b, dtw_nonlin || ddtw, dtw_lin || ddtw, "rdyn_twist_parts", LONG_KERNELS);
   if (st != RDYN_OK) return st;
   if ((!dtw_lin && !dtw_nonlin && !ddtw) || (ddtw && !dddq && b->n_samples > 0))
   {
@@ -506,7 +549,7 @@ int rdyn_twist_parts(const rdyn_chain* c, const rdyn_batch* b, const double* ddd
   if (st != RDYN_OK) return st;
   RdynKinExtArgs a;
   memset(&a, 0, sizeof a);
-  st = device_const(c, &a.chain);
+  st = c->long_chain() ? device_const_long(c, &a.chain_long) : device_const(c, &a.chain);
   if (st != RDYN_OK) return st;
   a.q = b->q;
   a.dq = b->dq;
@@ -518,13 +561,16 @@ int rdyn_twist_parts(const rdyn_chain* c, const rdyn_batch* b, const double* ddd
   a.dtw_lin = dtw_lin;
   a.dtw_nonlin = dtw_nonlin;
   a.ddtw = ddtw;
-  RDYN_HIP_TRY(rdyn_launch_base_ext(c->n_joints(), a, (hipStream_t)b->stream));
+  if (c->long_chain())
+    RDYN_HIP_TRY(rdyn_launch_long_ext(c->n_joints(), a, (hipStream_t)b->stream));
+  else
+    RDYN_HIP_TRY(rdyn_launch_base_ext(c->n_joints(), a, (hipStream_t)b->stream));
   return RDYN_OK;
 }
 
 int rdyn_jerk_parts(const rdyn_chain* c, const rdyn_batch* b, const double* dddq, double* ddtw_lin, double* ddtw_nonlin)
 {
-  int st = check_batch(c, b, ddtw_nonlin != nullptr, ddtw_nonlin != nullptr, "rdyn_jerk_parts");
+  int st = check_batch(c, b, ddtw_nonlin != nullptr, ddtw_nonlin != nullptr, "rdyn_jerk_parts", LONG_KERNELS);
   if (st != RDYN_OK) return st;
   if ((!ddtw_lin && !ddtw_nonlin) || (ddtw_lin && !dddq && b->n_samples > 0))
   {
@@ -537,7 +583,7 @@ int rdyn_jerk_parts(const rdyn_chain* c, const rdyn_batch* b, const double* dddq
   if (st != RDYN_OK) return st;
   RdynKinExtArgs a;
   memset(&a, 0, sizeof a);
-  st = device_const(c, &a.chain);
+  st = c->long_chain() ? device_const_long(c, &a.chain_long) : device_const(c, &a.chain);
   if (st != RDYN_OK) return st;
   a.q = b->q;
   a.dq = ddtw_nonlin ? b->dq : nullptr;
@@ -548,13 +594,16 @@ int rdyn_jerk_parts(const rdyn_chain* c, const rdyn_batch* b, const double* dddq
   rec_strides(b, 6 * (int64_t)(c->n_joints() + 1), &a.out_ss, &a.out_se);
   a.ddtw_lin = ddtw_lin;
   a.ddtw_nonlin = ddtw_nonlin;
-  RDYN_HIP_TRY(rdyn_launch_base_ext(c->n_joints(), a, (hipStream_t)b->stream));
+  if (c->long_chain())
+    RDYN_HIP_TRY(rdyn_launch_long_ext(c->n_joints(), a, (hipStream_t)b->stream));
+  else
+    RDYN_HIP_TRY(rdyn_launch_base_ext(c->n_joints(), a, (hipStream_t)b->stream));
   return RDYN_OK;
 }
 
 int rdyn_wrench(const rdyn_chain* c, const rdyn_batch* b, const double* ext, double* wrenches)
 {
-  int st = check_batch(c, b, true, true, "rdyn_wrench");
+  int st = check_batch(c, b, true, true, "rdyn_wrench", LONG_KERNELS);
   if (st != RDYN_OK) return st;
   if (!wrenches && b->n_samples > 0)
   {
@@ -567,7 +616,7 @@ int rdyn_wrench(const rdyn_chain* c, const rdyn_batch* b, const double* ext, dou
   if (st != RDYN_OK) return st;
   RdynKinExtArgs a;
   memset(&a, 0, sizeof a);
-  st = device_const(c, &a.chain);
+  st = c->long_chain() ? device_const_long(c, &a.chain_long) : device_const(c, &a.chain);
   if (st != RDYN_OK) return st;
   a.q = b->q;
   a.dq = b->dq;
@@ -579,13 +628,16 @@ int rdyn_wrench(const rdyn_chain* c, const rdyn_batch* b, const double* ext, dou
   a.ext = ext;
   a.ext_ss = a.out_ss;
   a.ext_se = a.out_se;
-  RDYN_HIP_TRY(rdyn_launch_base_ext(c->n_joints(), a, (hipStream_t)b->stream));
+  if (c->long_chain())
+    RDYN_HIP_TRY(rdyn_launch_long_ext(c->n_joints(), a, (hipStream_t)b->stream));
+  else
+    RDYN_HIP_TRY(rdyn_launch_base_ext(c->n_joints(), a, (hipStream_t)b->stream));
   return RDYN_OK;
 }
 
 int rdyn_joint_torque_ext(const rdyn_chain* c, const rdyn_batch* b, const double* ext, double* tau)
 {
-  int st = check_batch(c, b, true, true, "rdyn_joint_torque_ext");
+  int st = check_batch(c, b, true, true, "rdyn_joint_torque_ext", LONG_KERNELS);
   if (st != RDYN_OK) return st;
   if ((!tau || !ext) && b->n_samples > 0)
   {
@@ -596,6 +648,26 @@ int rdyn_joint_torque_ext(const rdyn_chain* c, const rdyn_batch* b, const double
   DeviceGuard g;
   st = g.enter(b->device);
   if (st != RDYN_OK) return st;
+  if (c->long_chain())
+  {
+    // the wrench recursion of the run-time-length kernels, the joint torques read off the link wrenches (primitives_impl.h:1264-1272)
+    RdynKinExtArgs e;
+    memset(&e, 0, sizeof e);
+    st = device_const_long(c, &e.chain_long);
+    if (st != RDYN_OK) return st;
+    e.q = b->q;
+    e.dq = b->dq;
+    e.ddq = b->ddq;
+    e.n_samples = b->n_samples;
+    rec_strides(b, c->n_active(), &e.in_ss, &e.in_sj);
+    e.tau = tau;
+    e.tau_ss = e.in_ss;
+    e.tau_sj = e.in_sj;
+    e.ext = ext;
+    rec_strides(b, 6 * (int64_t)(c->n_joints() + 1), &e.ext_ss, &e.ext_se);
+    RDYN_HIP_TRY(rdyn_launch_long_ext(c->n_joints(), e, (hipStream_t)b->stream));
+    return RDYN_OK;
+  }
   RdynSweepArgs a;
   memset(&a, 0, sizeof a);
   st = device_const(c, &a.chain);
@@ -723,7 +795,7 @@ int rdyn_multi_plan_create(const rdyn_multi_item* items, int n_items, rdyn_multi
   for (int i = 0; i < n_items; ++i)
   {
     const rdyn_multi_item& it = items[i];
-    st = check_batch(it.chain, &it.batch, true, true, "rdyn_multi_plan_create");
+    st = check_batch(it.chain, &it.batch, true, true, "rdyn_multi_plan_create", LONG_NONE);
     if (st != RDYN_OK) return st;
     if (it.batch.n_samples > 0 && !it.Y)
     {
@@ -969,7 +1041,7 @@ static bool build_lds_tile(const rdyn_chain* c, int n_comp_cols, bool dummy_slot
 int rdyn_regressor_gram(const rdyn_chain* c, const rdyn_batch* b, const double* tau_meas, double* G, double* cvec, double* bb,
                         int accumulate, int64_t chunk_samples, void* workspace, size_t workspace_bytes)
 {
-  int st = check_batch(c, b, true, true, "rdyn_regressor_gram", true);
+  int st = check_batch(c, b, true, true, "rdyn_regressor_gram", LONG_COMPANION);
   if (st != RDYN_OK) return st;
   if (!G || !workspace)
   {
@@ -1535,7 +1607,7 @@ static bool tsqr_plan(const rdyn_chain* c, const rdyn_component* comps, int n_co
 static int regressor_tsqr_run(const rdyn_chain* c, const rdyn_component* comps, int n_comps, const rdyn_batch* b, const double* tau_meas, double* R,
                               int accumulate, void* workspace, size_t workspace_bytes, const char* who)
 {
-  int st = check_batch(c, b, true, true, who, true);
+  int st = check_batch(c, b, true, true, who, LONG_COMPANION);
   if (st != RDYN_OK) return st;
   if (!R || !workspace || n_comps < 0 || n_comps > RDYN_MAX_COMPONENTS || (n_comps > 0 && !comps))
   {
@@ -1773,7 +1845,7 @@ size_t rdyn_identification_gram_workspace_bytes(const rdyn_chain* c, const rdyn_
 int rdyn_identification_gram(const rdyn_chain* c, const rdyn_component* comps, int n_comps, const rdyn_batch* b, const double* tau_meas,
                              double* G, double* cvec, double* bb, int accumulate, void* workspace, size_t workspace_bytes)
 {
-  int st = check_batch(c, b, true, true, "rdyn_identification_gram", true);
+  int st = check_batch(c, b, true, true, "rdyn_identification_gram", LONG_COMPANION);
   if (st != RDYN_OK) return st;
   if (!G || !workspace || n_comps < 0 || n_comps > RDYN_MAX_COMPONENTS || (n_comps > 0 && !comps))
   {
@@ -1945,7 +2017,7 @@ int rdyn_identification_gram(const rdyn_chain* c, const rdyn_component* comps, i
 
 int rdyn_transformation(const rdyn_chain* c, const rdyn_batch* b, double* T_bt, double* T_links)
 {
-  int st = check_batch(c, b, false, false, "rdyn_transformation");
+  int st = check_batch(c, b, false, false, "rdyn_transformation", LONG_KERNELS);
   if (st != RDYN_OK) return st;
   if (!T_bt && !T_links && b->n_samples > 0)
   {
@@ -1957,7 +2029,7 @@ int rdyn_transformation(const rdyn_chain* c, const rdyn_batch* b, double* T_bt, 
 
 int rdyn_jacobian(const rdyn_chain* c, const rdyn_batch* b, double* J)
 {
-  int st = check_batch(c, b, false, false, "rdyn_jacobian");
+  int st = check_batch(c, b, false, false, "rdyn_jacobian", LONG_KERNELS);
   if (st != RDYN_OK) return st;
   if (!J && b->n_samples > 0)
   {
@@ -1969,7 +2041,7 @@ int rdyn_jacobian(const rdyn_chain* c, const rdyn_batch* b, double* J)
 
 int rdyn_jacobian_link(const rdyn_chain* c, const rdyn_batch* b, int link_index, double* J)
 {
-  int st = check_batch(c, b, false, false, "rdyn_jacobian_link");
+  int st = check_batch(c, b, false, false, "rdyn_jacobian_link", LONG_KERNELS);
   if (st != RDYN_OK) return st;
   if (link_index < 0 || link_index > c->n_joints())
   {
@@ -1986,7 +2058,7 @@ int rdyn_jacobian_link(const rdyn_chain* c, const rdyn_batch* b, int link_index,
 
 int rdyn_twist(const rdyn_chain* c, const rdyn_batch* b, double* twists, double* dtwists)
 {
-  int st = check_batch(c, b, true, dtwists != nullptr, "rdyn_twist");
+  int st = check_batch(c, b, true, dtwists != nullptr, "rdyn_twist", LONG_KERNELS);
   if (st != RDYN_OK) return st;
   if (!twists && !dtwists && b->n_samples > 0)
   {

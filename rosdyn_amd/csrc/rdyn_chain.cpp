@@ -115,6 +115,16 @@ void free_device_copies(rdyn_chain* c)
     }
   }
   c->dev_const.clear();
+  for (auto& kv : c->dev_long)
+  {
+    int prev = -1;
+    if (hipGetDevice(&prev) == hipSuccess && hipSetDevice(kv.first) == hipSuccess)
+    {
+      (void)hipFree(kv.second);
+      (void)hipSetDevice(prev);
+    }
+  }
+  c->dev_long.clear();
   for (auto& kv : c->dev_expand)
   {
     int prev = -1;
@@ -167,10 +177,11 @@ void build_reduced(rdyn_chain* c)
   c->red_of.clear();
   c->expand_X.clear();
   const int nj = c->n_joints(), n = c->n_active();
+  c->red_chain.clear();
   if (n < 1 || n == nj) return;
-  for (int k = 1; k < n; ++k)
-    if (c->active[k] <= c->active[k - 1]) return;  // input joints not in chain order: no companion
   if (n > RDYN_MAX_SWEPT_JOINTS) return;  // the companion itself would be longer than what the kernels sweep
+  // (the input joints may come in any order, primitives_impl.h:705-737: the companion keeps them in CHAIN order and carries the
+  // input index of each as its in_idx -- the kernels read q, Dq, DDq and write their rows through that map)
   const std::vector<RdynJointConst>& HJ = c->host_joints;
   std::unique_ptr<rdyn_chain> r(new rdyn_chain());
   r->joints.resize(n);
@@ -184,6 +195,12 @@ void build_reduced(rdyn_chain* c)
   for (int i = 0; i < 3; ++i) K.g[i] = c->gravity[i];
   c->red_of.assign(nj, -1);
   c->expand_X.assign((size_t)nj * 100, 0.0);
+  r->active.assign(n, 0);
+  r->q_max.assign(n, 1e10);
+  r->q_min.assign(n, -1e10);
+  r->dq_max.assign(n, 1e10);
+  r->ddq_max.assign(n, 1e11);
+  r->tau_max.assign(n, 1e10);
   // frame of the current rigid body -> frame of the link being visited: x_body = Rc x_link + pc
   double Rc[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, pc[3] = {0, 0, 0};
   int red = -1;  // reduced link the current body is (index of its joint in the reduced chain)
@@ -212,11 +229,17 @@ void build_reduced(rdyn_chain* c)
         Q.up[i] = Rn[i * 3] * J.u[0] + Rn[i * 3 + 1] * J.u[1] + Rn[i * 3 + 2] * J.u[2];
       }
       Q.type = J.type;
-      Q.in_idx = red;
+      Q.in_idx = J.in_idx;
       snprintf(r->joints[red].name, sizeof r->joints[red].name, "%s", c->joints[f].name);
       snprintf(r->links[red + 1].name, sizeof r->links[red + 1].name, "%s", c->links[f + 1].name);
-      r->active.push_back(red);
+      r->active[J.in_idx] = red;
       r->moveable_names.push_back(c->joints[f].name);
+      c->red_chain.push_back(f);
+      r->q_max[red] = c->q_max[f];
+      r->q_min[red] = c->q_min[f];
+      r->dq_max[red] = c->dq_max[f];
+      r->ddq_max[red] = c->ddq_max[f];
+      r->tau_max[red] = c->tau_max[f];
       // the child link of an input joint IS the new body's reference frame
       const double I3[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
       memcpy(Rc, I3, sizeof I3);
@@ -245,11 +268,9 @@ void build_reduced(rdyn_chain* c)
     }
   }
   r->host_joints.assign(K.j, K.j + n);
-  r->q_max.assign(n, 1e10);
-  r->q_min.assign(n, -1e10);
-  r->dq_max.assign(n, 1e10);
-  r->ddq_max.assign(n, 1e11);
-  r->tau_max.assign(n, 1e10);
+  // the frames behind the last input joint: x_lastbody = tail_R x_tool + tail_t (the tool frame of the chain seen from the companion's)
+  memcpy(c->tail_R, Rc, sizeof Rc);
+  memcpy(c->tail_t, pc, sizeof pc);
   c->reduced = std::move(r);
 }
 }  // namespace
@@ -334,6 +355,16 @@ void rdyn_chain_finalize(rdyn_chain* c)
     H.n_active = c->n_active();
     for (int i = 0; i < 3; ++i) H.g[i] = c->gravity[i];
     for (int j = 0; j < nj; ++j) H.j[j] = HJ[j];
+  }
+  if (c->long_chain())
+  {
+    // the run-time-length kinematic kernels (rdyn_long_kin.hip) read the chain as it is
+    RdynLongChainConst& Lc = c->host_long;
+    memset(&Lc, 0, sizeof Lc);
+    Lc.n_joints = nj;
+    Lc.n_active = c->n_active();
+    for (int i = 0; i < 3; ++i) Lc.g[i] = c->gravity[i];
+    for (int j = 0; j < nj; ++j) Lc.j[j] = HJ[j];
   }
   build_reduced(c);
 }
@@ -530,7 +561,7 @@ int rdyn_chain_reduction(const rdyn_chain* c, int32_t* body_joint, double* X, do
   const int nj = c->n_joints(), nb = c->reduced->n_joints();
   for (int f = 0; f < nj; ++f)
   {
-    if (body_joint) body_joint[f] = c->red_of[f] < 0 ? -1 : c->active[c->red_of[f]];
+    if (body_joint) body_joint[f] = c->red_of[f] < 0 ? -1 : c->red_chain[c->red_of[f]];
     if (X) memcpy(X + (size_t)f * 100, c->expand_X.data() + (size_t)f * 100, sizeof(double) * 100);
   }
   for (int r = 0; pi_body && r < nb; ++r)

@@ -22,6 +22,7 @@ struct rdyn_chain
   std::vector<double> q_max, q_min, dq_max, ddq_max, tau_max;
 
   std::vector<RdynJointConst> host_joints;  // per chain joint (any number up to RDYN_MAX_JOINTS): constants + child-link parameters
+  RdynLongChainConst host_long;             // the same for a chain of more than RDYN_MAX_SWEPT_JOINTS joints (rdyn_long_kin.hip)
   RdynChainConst host_const;                // flat constants for the kernels: valid for chains of <= RDYN_MAX_SWEPT_JOINTS joints only
   // a chain with more joints than the kernels sweep: served through its reduced companion (regressor, torque, inertia, normal
   // equations, R factors); the by-link kinematic outputs are not available for it
@@ -30,6 +31,7 @@ struct rdyn_chain
   // lazily created device copies, one per HIP device ordinal; invalidated by set_input_joints
   mutable std::mutex mu;
   mutable std::map<int, RdynChainConst*> dev_const;
+  mutable std::map<int, RdynLongChainConst*> dev_long;  // chains of more than RDYN_MAX_SWEPT_JOINTS joints: constants of the run-time-length kernels
 
   // "Reduced" companion for the regressor -> Gram / factor paths (rdyn_chain_finalize; null when every chain joint is an input joint
   // or the input joints are not in chain order).  Every joint that is not an input joint (fixed, primitives_impl.h:74-83, or left
@@ -40,6 +42,8 @@ struct rdyn_chain
   // and identically zero for links upstream of the first input joint.  Gram / R-factor kernels therefore run on the reduced chain
   // (10 n columns, every joint an input joint: the fastest kernel variants) and a tiny epilogue forms G = E' G_red E.
   std::unique_ptr<rdyn_chain> reduced;
+  std::vector<int> red_chain;     // per reduced joint: its chain index
+  double tail_R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, tail_t[3] = {0, 0, 0};  // tool frame of the chain in the companion's tool frame (row-major R)
   std::vector<int> red_of;        // per chain link f + 1 (index f): reduced link it rides on, -1 = upstream of the first input joint
   std::vector<double> expand_X;   // [n_joints][10][10] row-major: X_f(a, p), column p of link f = sum_a Y_red(10 r + a) X_f(a, p)
   mutable std::map<int, double*> dev_expand;  // device copies of expand_X, one per HIP device ordinal

@@ -35,4 +35,14 @@ struct RdynChainConst
   RdynJointConst j[RDYN_MAX_SWEPT_JOINTS];
 };
 
+// The same for a chain of up to RDYN_MAX_JOINTS joints (12 KB): read by the run-time-length kinematic kernels (rdyn_long_kin.hip), whose
+// link loop is rolled -- joint f's constants arrive by scalar loads at a wave-uniform run-time offset.
+struct RdynLongChainConst
+{
+  int32_t n_joints;
+  int32_t n_active;
+  double g[3];
+  RdynJointConst j[RDYN_MAX_JOINTS];
+};
+
 #endif

@@ -211,6 +211,19 @@ __device__ __forceinline__ void ik_pose(const RdynIkArgs& a, ChainPtr c, const i
 #pragma unroll
       for (int i = 0; i < 9; ++i) R[i] = Rn[i];
     }
+    if (a.has_tail)
+    {
+      // a chain served through its reduced companion: the constant frames behind the last input joint
+      p = p + rot(R, mk(a.tail_t[0], a.tail_t[1], a.tail_t[2]));
+      double Rn[9];
+#pragma unroll
+      for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int cc = 0; cc < 3; ++cc)
+          Rn[r * 3 + cc] = fma(R[r * 3 + 0], a.tail_R[cc], fma(R[r * 3 + 1], a.tail_R[3 + cc], R[r * 3 + 2] * a.tail_R[6 + cc]));
+#pragma unroll
+      for (int i = 0; i < 9; ++i) R[i] = Rn[i];
+    }
     // ---- getFrameDistance(T_target, T_bt): e = [p_a - p_b ; -R_a * (angle * axis)(R_a^T R_b)]   (frame_distance.h:44-49)
     double Rab[9];
 #pragma unroll

@@ -53,8 +53,15 @@ struct RdynKinExtArgs
   double* wrench;       // getWrench: base-frame link wrenches
   const double* ext;    // wrench only, may be null: external wrenches, links x 6, element e of sample s at ext[s * ext_ss + e * ext_se]
   int64_t ext_ss, ext_se;
+  // rdyn_long_kin.hip only (chains of more than RDYN_MAX_SWEPT_JOINTS joints): the constants, the joint torques of the wrench pass
+  // (getJointTorque with external wrenches; layout of q) and the lanes of a wave that carry a sample (set by the launcher)
+  const RdynLongChainConst* chain_long;
+  double* tau;
+  int64_t tau_ss, tau_sj;
+  int lanes;
 };
 hipError_t rdyn_launch_base_ext(int n_joints, const RdynKinExtArgs& a, hipStream_t st);
+hipError_t rdyn_launch_long_ext(int n_joints, const RdynKinExtArgs& a, hipStream_t st);  // a.chain_long; any chain length
 
 // batched local inverse kinematics (rdyn_ik.hip)
 struct RdynIkArgs
@@ -68,6 +75,10 @@ struct RdynIkArgs
   double weight[6];                  // all 1 for computeLocalIk
   double q_min[RDYN_MAX_SWEPT_JOINTS];     // per CHAIN joint
   double q_max[RDYN_MAX_SWEPT_JOINTS];
+  // a constant frame behind the last swept joint (a chain served through its reduced companion: the fixed frames after the last
+  // input joint): T_tool = T_last [tail_R | tail_t]; tail_R row-major
+  int has_tail;
+  double tail_R[9], tail_t[3];
   double toll;
   double damping;                    // Levenberg term: damping^2 is added to the diagonal of J'WJ (0 = the reference's QP)
   int max_iter;
@@ -104,7 +115,12 @@ struct RdynKinArgs
   int j_link;                       // Jacobian reference link (chain link index); n_joints = the tool (getJacobian)
   double* twists;                   // 6 * links per sample
   double* dtwists; int64_t tw_ss;
+  // rdyn_long_kin.hip only (chains of more than RDYN_MAX_SWEPT_JOINTS joints): the constants; j_up = input joints upstream of link
+  // j_link (the first j_up input columns of the Jacobian are filled, primitives_impl.h:965-972)
+  const RdynLongChainConst* chain_long;
+  int j_up;
 };
+hipError_t rdyn_launch_long_base(const RdynKinArgs& a, hipStream_t st);
 
 // Gram / normal equations of a column-major rows x P matrix (rdyn_gram.hip)
 struct RdynGramArgs

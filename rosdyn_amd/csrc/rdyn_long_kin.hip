@@ -1,0 +1,386 @@
+// rdyn_long_kin.hip -- base-frame kinematics of chains LONGER than the unrolled kernels sweep (11 .. RDYN_MAX_JOINTS chain joints).
+//
+// The reference's default build has no bound on the chain length (rosdyn_core/CMakeLists.txt:12-16, internal/types.h:120-129); the
+// kernels of rdyn_kernels.hip / rdyn_kin_ext.hip are instantiated per joint count with every per-link quantity in registers.  The
+// by-link kinematic outputs need none of that: frames, twists and their derivatives are RUNNING quantities of a base -> tool
+// recursion, one record per link streamed out as it is finished.  Here the link loop is rolled (run-time trip count, joint f's
+// constants by scalar loads at a wave-uniform offset into RdynLongChainConst), any number of input joints in any order:
+//   k_long_base<LEVEL>   getTransformation(s) :863-912, getJacobian / getJacobianLink :927-979, getTwist :981-1013, getDTwist :1082-1124
+//   k_long_ext<WRENCH>   getDTwistLinearPart / NonLinearPart :1029-1080, getDDTwist* :1126-1223, getWrench :1225-1262,
+//                        getJointTorque with external wrenches :1264-1272
+// (paths under /root/reference/rosdyn_core/include/rosdyn_core/internal/primitives_impl.h).  Same arithmetic, statement by
+// statement, as the unrolled kernels: the parity tests hold both against the same oracle.
+//
+// Jacobian: column k needs the reference point (origin of the requested link), known only once the recursion has reached it; the
+// frames are cheap (one sincos and ~70 fma per joint), so a first pass runs them up to that link and the main pass forms the columns
+// as it goes -- no per-joint storage.  Wrench: the tool -> base suffix sums need every link's own wrench and origin again; they wait
+// in wave-private LDS (9 doubles per link and lane, 12 when the joint torques are asked for: the joint axis too), sized at launch.
+#include <hip/hip_runtime.h>
+#include "rdyn_device.h"
+#include "rdyn_devmath.h"
+#include "rdyn_kernels.h"
+
+namespace
+{
+typedef const RDYN_CONST_AS RdynLongChainConst* LongChainPtr;
+__device__ __forceinline__ LongChainPtr as_const_long(const RdynLongChainConst* p)
+{
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wold-style-cast"
+  return (LongChainPtr)p;
+#pragma clang diagnostic pop
+}
+
+struct S6
+{
+  V3 l, a;
+};
+__device__ __forceinline__ S6 xs(S6 v, S6 s)  // spatialCrossProduct, spacevect_algebra.h:88-93
+{
+  S6 r;
+  r.a = cross(v.a, s.a);
+  r.l = cross(v.a, s.l) + cross(v.l, s.a);
+  return r;
+}
+__device__ __forceinline__ S6 shift(S6 t, V3 d)  // spatialTranslation, spacevect_algebra.h:129-133
+{
+  S6 r;
+  r.l = t.l + cross(t.a, d);
+  r.a = t.a;
+  return r;
+}
+__device__ __forceinline__ S6 axpy6(S6 a, S6 b, double s)
+{
+  S6 r;
+  r.l = axpy(a.l, b.l, s);
+  r.a = axpy(a.a, b.a, s);
+  return r;
+}
+
+// One step of computeFrames / computeScrews (primitives_impl.h:863-882): on entry R, p = frame of the parent link; on exit of the
+// child.  zl = the joint axis in the base frame (rotated by the PARENT frame, :879), d = p_child - p_parent.
+__device__ __forceinline__ void frame_step(JointRef J, double qf, double (&R)[9], V3& p, V3& zl, V3& d)
+{
+  const int type = J.type;
+  double Rpc[9];
+  V3 t = ld3(J.t);
+  if (type == RDYN_REVOLUTE)
+  {
+    double sn, cs;
+    rdyn_sincos(qf, &sn, &cs);
+    const double oc = 1.0 - cs;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) Rpc[i] = fma(sn, J.B[i], fma(oc, J.C[i], J.A[i]));
+  }
+  else
+  {
+#pragma unroll
+    for (int i = 0; i < 9; ++i) Rpc[i] = J.A[i];
+    if (type == RDYN_PRISMATIC) t = axpy(t, ld3(J.up), qf);
+  }
+  zl = rot(R, ld3(J.up));
+  d = rot(R, t);
+  double Rn[9];
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int cc = 0; cc < 3; ++cc) Rn[r * 3 + cc] = fma(R[r * 3 + 0], Rpc[cc], fma(R[r * 3 + 1], Rpc[3 + cc], R[r * 3 + 2] * Rpc[6 + cc]));
+#pragma unroll
+  for (int i = 0; i < 9; ++i) R[i] = Rn[i];
+  p = p + d;
+}
+
+// LEVEL as in k_base_sweep: 0 frames only, 1 + the Jacobian, 2 + twists, 3 + spatial accelerations
+template <int LEVEL>
+__global__ __launch_bounds__(256) void k_long_base(const RdynKinArgs a)
+{
+  LongChainPtr c = as_const_long(a.chain_long);
+  const int nj = c->n_joints;
+  const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (s >= a.n_samples) return;
+  const double* __restrict__ qp = a.q + s * a.in_ss;
+  const double* __restrict__ dqp = (LEVEL >= 2 && a.dq) ? a.dq + s * a.in_ss : nullptr;
+  const double* __restrict__ ddqp = (LEVEL >= 3 && a.ddq) ? a.ddq + s * a.in_ss : nullptr;
+  const int64_t es = a.out_se;
+
+  double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+  V3 p = mk(0, 0, 0);
+  auto put3x4 = [&](double* __restrict__ o) {
+#pragma unroll
+    for (int cc = 0; cc < 3; ++cc)
+#pragma unroll
+      for (int r = 0; r < 3; ++r) o[(int64_t)(cc * 3 + r) * es] = R[r * 3 + cc];
+    o[9 * es] = p.x;
+    o[10 * es] = p.y;
+    o[11 * es] = p.z;
+  };
+  auto put6 = [&](double* __restrict__ o, V3 l, V3 g) {
+    o[0] = l.x; o[es] = l.y; o[2 * es] = l.z; o[3 * es] = g.x; o[4 * es] = g.y; o[5 * es] = g.z;
+  };
+
+  // Jacobian: origin of the reference link (j_link == nj: the tool) by a first pass over the frames upstream of it
+  V3 pref = mk(0, 0, 0);
+  if (LEVEL >= 1 && a.J)
+  {
+#pragma unroll 1
+    for (int f = 0; f < a.j_link; ++f)
+    {
+      JointRef J = c->j[f];
+      const int idx = J.in_idx;
+      V3 zl, d;
+      frame_step(J, idx >= 0 ? qp[idx * a.in_sj] : 0.0, R, p, zl, d);
+    }
+    pref = p;
+    p = mk(0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) R[i] = (i % 4 == 0) ? 1.0 : 0.0;
+  }
+
+  V3 vlin = mk(0, 0, 0), vang = mk(0, 0, 0), alin = mk(0, 0, 0), aang = mk(0, 0, 0);
+  if (a.T_links) put3x4(a.T_links + s * a.tl_ss);
+  if (LEVEL >= 2 && a.twists) put6(a.twists + s * a.tw_ss, vlin, vang);
+  if (LEVEL >= 3 && a.dtwists) put6(a.dtwists + s * a.tw_ss, alin, aang);
+#pragma unroll 1
+  for (int f = 0; f < nj; ++f)
+  {
+    JointRef J = c->j[f];
+    const int type = J.type;
+    const int idx = J.in_idx;
+    double qf = 0.0, dqf = 0.0, ddqf = 0.0;
+    if (idx >= 0)
+    {
+      const int64_t o = idx * a.in_sj;
+      qf = qp[o];
+      if (LEVEL >= 2 && dqp) dqf = dqp[o];
+      if (LEVEL >= 3 && ddqp) ddqf = ddqp[o];
+    }
+    V3 zl, d;
+    frame_step(J, qf, R, p, zl, d);
+    if (LEVEL >= 2)
+    {
+      // twists (getTwist, :1007-1008) and spatial accelerations (getDTwist, :1116-1117)
+      V3 Sl = mk(0, 0, 0), Sa = mk(0, 0, 0);
+      if (type == RDYN_REVOLUTE) Sa = zl;
+      else if (type == RDYN_PRISMATIC) Sl = zl;
+      const V3 nvl = axpy(vlin + cross(vang, d), Sl, dqf);
+      const V3 nva = axpy(vang, Sa, dqf);
+      if (LEVEL >= 3)
+      {
+        const V3 cl = cross(nva, Sl) + cross(nvl, Sa);  // spatialCrossProduct(v, S), sva.h:88-93
+        const V3 ca = cross(nva, Sa);
+        alin = axpy(axpy(alin + cross(aang, d), cl, dqf), Sl, ddqf);
+        aang = axpy(axpy(aang, ca, dqf), Sa, ddqf);
+      }
+      vlin = nvl;
+      vang = nva;
+    }
+    if (a.T_links) put3x4(a.T_links + s * a.tl_ss + (int64_t)(12 * (f + 1)) * es);
+    if (LEVEL >= 2 && a.twists) put6(a.twists + s * a.tw_ss + (int64_t)(6 * (f + 1)) * es, vlin, vang);
+    if (LEVEL >= 3 && a.dtwists) put6(a.dtwists + s * a.tw_ss + (int64_t)(6 * (f + 1)) * es, alin, aang);
+    if (LEVEL >= 1 && a.J && idx >= 0)
+    {
+      // getJacobian :939-945 / getJacobianLink :951-979: column k = spatialTranslation(S_l, p_ref - p_l) for the FIRST j_up input
+      // columns (j_up = input joints upstream of the link, counted by the host), zero beyond
+      V3 jlin = mk(0, 0, 0), jang = mk(0, 0, 0);
+      if (idx < a.j_up)
+      {
+        if (type == RDYN_REVOLUTE)
+        {
+          jlin = cross(zl, pref - p);
+          jang = zl;
+        }
+        else if (type == RDYN_PRISMATIC)
+          jlin = zl;
+      }
+      put6(a.J + s * a.j_ss + (int64_t)(6 * idx) * es, jlin, jang);
+    }
+  }
+  if (a.T_bt) put3x4(a.T_bt + s * a.tb_ss);
+}
+
+// WRENCH: 64-thread workgroups of which the first a.lanes (64, or 32 where 64 records do not fit the LDS) carry a sample
+template <bool WRENCH>
+__global__ __launch_bounds__(WRENCH ? 64 : 256) void k_long_ext(const RdynKinExtArgs a)
+{
+  extern __shared__ __attribute__((aligned(16))) double own_lds[];  // WRENCH: [PK (nj + 1)][lanes], PK = 9 or 12
+  LongChainPtr c = as_const_long(a.chain_long);
+  const int nj = c->n_joints;
+  const int LN = WRENCH ? a.lanes : 256;
+  if (WRENCH && (int)threadIdx.x >= LN) return;
+  const int64_t s = (int64_t)blockIdx.x * LN + threadIdx.x;
+  if (s >= a.n_samples) return;
+  const double* __restrict__ qp = a.q + s * a.in_ss;
+  const double* __restrict__ dqp = a.dq ? a.dq + s * a.in_ss : nullptr;
+  const double* __restrict__ ddqp = a.ddq ? a.ddq + s * a.in_ss : nullptr;
+  const double* __restrict__ dddqp = a.dddq ? a.dddq + s * a.in_ss : nullptr;
+  const int64_t es = a.out_se;
+  auto put6 = [&](double* base, int64_t first_elem, S6 x) {
+    double* __restrict__ o = base + s * a.out_ss + first_elem * es;
+    o[0] = x.l.x; o[es] = x.l.y; o[2 * es] = x.l.z; o[3 * es] = x.a.x; o[4 * es] = x.a.y; o[5 * es] = x.a.z;
+  };
+  const S6 zero = {mk(0, 0, 0), mk(0, 0, 0)};
+  double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+  S6 v = zero, acc = zero, aL = zero, aN = zero, jk = zero, jL = zero, jN = zero;
+  if (!WRENCH)
+  {
+    if (a.dtw_lin) put6(a.dtw_lin, 0, zero);
+    if (a.dtw_nonlin) put6(a.dtw_nonlin, 0, zero);
+    if (a.ddtw) put6(a.ddtw, 0, zero);
+    if (a.ddtw_lin) put6(a.ddtw_lin, 0, zero);
+    if (a.ddtw_nonlin) put6(a.ddtw_nonlin, 0, zero);
+  }
+  const int PK = a.tau ? 12 : 9;  // doubles parked per link: own wrench about the base origin (6), origin (3), axis of the parent joint (3)
+  auto park = [&](int link, S6 x, V3 po, V3 z) {
+    double* const o = own_lds + (PK * link) * LN + threadIdx.x;
+    o[0] = x.l.x; o[LN] = x.l.y; o[2 * LN] = x.l.z; o[3 * LN] = x.a.x; o[4 * LN] = x.a.y; o[5 * LN] = x.a.z;
+    o[6 * LN] = po.x; o[7 * LN] = po.y; o[8 * LN] = po.z;
+    if (a.tau)
+    {
+      o[9 * LN] = z.x; o[10 * LN] = z.y; o[11 * LN] = z.z;
+    }
+  };
+  V3 p = mk(0, 0, 0);
+  const V3 grav = mk(c->g[0], c->g[1], c->g[2]);
+  auto ext_of = [&](int link) -> S6 {  // -ext_wrenches_in_link_frame.at(link), :1255
+    S6 e = zero;
+    if (a.ext)
+    {
+      const double* __restrict__ ep = a.ext + s * a.ext_ss + (int64_t)(6 * link) * a.ext_se;
+      e.l = mk(-ep[0], -ep[a.ext_se], -ep[2 * a.ext_se]);
+      e.a = mk(-ep[3 * a.ext_se], -ep[4 * a.ext_se], -ep[5 * a.ext_se]);
+    }
+    return e;
+  };
+  if (WRENCH) park(0, ext_of(0), p, mk(0, 0, 0));  // spatialTranformation(-ext, identity); no inertial / gravity term on the base link (:1233-1237)
+#pragma unroll 1
+  for (int f = 0; f < nj; ++f)
+  {
+    JointRef J = c->j[f];
+    const int type = J.type;
+    const int idx = J.in_idx;
+    double qf = 0.0, dqf = 0.0, ddqf = 0.0, dddqf = 0.0;
+    if (idx >= 0)
+    {
+      const int64_t o = idx * a.in_sj;
+      qf = qp[o];
+      if (dqp) dqf = dqp[o];
+      if (ddqp) ddqf = ddqp[o];
+      if (dddqp) dddqf = dddqp[o];
+    }
+    V3 zl, d;
+    frame_step(J, qf, R, p, zl, d);
+    S6 S = zero;
+    if (type == RDYN_REVOLUTE) S.a = zl;
+    else if (type == RDYN_PRISMATIC) S.l = zl;
+    v = axpy6(shift(v, d), S, dqf);
+    const S6 vxs = xs(v, S);
+    acc = axpy6(axpy6(shift(acc, d), vxs, dqf), S, ddqf);  // getDTwist, :1116-1117
+    if (!WRENCH)
+    {
+      aL = axpy6(shift(aL, d), S, ddqf);
+      aN = axpy6(shift(aN, d), vxs, dqf);
+      const S6 axs = xs(acc, S), vvxs = xs(v, vxs);
+      S6 cq;
+      cq.l = axs.l + vvxs.l;
+      cq.a = axs.a + vvxs.a;
+      jk = axpy6(axpy6(axpy6(shift(jk, d), S, dddqf), vxs, ddqf), cq, dqf);
+      jL = axpy6(shift(jL, d), S, dddqf);
+      jN = axpy6(axpy6(shift(jN, d), vxs, ddqf), cq, dqf);
+      if (a.dtw_lin) put6(a.dtw_lin, 6 * (f + 1), aL);
+      if (a.dtw_nonlin) put6(a.dtw_nonlin, 6 * (f + 1), aN);
+      if (a.ddtw) put6(a.ddtw, 6 * (f + 1), jk);
+      if (a.ddtw_lin) put6(a.ddtw_lin, 6 * (f + 1), jL);
+      if (a.ddtw_nonlin) put6(a.ddtw_nonlin, 6 * (f + 1), jN);
+    }
+    else
+    {
+      // link f + 1: spatial inertia about its origin from the nominal parameters [m, m c, Io] (primitives_impl.h:399-417)
+      const double m = J.pi[0];
+      const V3 mc = mk(J.pi[1], J.pi[2], J.pi[3]);
+      auto Imul = [&](S6 x) -> S6 {  // [[m 1, m c^T],[m c^, Io]] x   (spacevect_algebra.h:232-239)
+        S6 r;
+        r.l = mk(m * x.l.x, m * x.l.y, m * x.l.z) - cross(mc, x.a);
+        r.a = cross(mc, x.l) + symv(J.pi + 4, x.a);
+        return r;
+      };
+      S6 al, vloc;
+      al.l = rotT(R, acc.l); al.a = rotT(R, acc.a);      // spatialRotation(m_Dtwists, R^T), :1242
+      vloc.l = rotT(R, v.l); vloc.a = rotT(R, v.a);      // :1245
+      const S6 Iv = Imul(vloc), Ia = Imul(al);
+      S6 wl;  // I a + v x* (I v), spatialDualCrossProduct spacevect_algebra.h:108-113
+      wl.l = Ia.l + cross(vloc.a, Iv.l);
+      wl.a = Ia.a + cross(vloc.a, Iv.a) + cross(vloc.l, Iv.l);
+      S6 own;
+      own.l = rot(R, wl.l);                              // :1248
+      own.a = rot(R, wl.a);
+      own.l = own.l - mk(m * grav.x, m * grav.y, m * grav.z);   // gravity wrench, :1249-1250
+      own.a = own.a - cross(rot(R, mc), grav);
+      const S6 e = ext_of(f + 1);                        // spatialTranformation(-ext, T_bl): twist form, :1255 / spacevect_algebra.h:193-197
+      const V3 Ra = rot(R, e.a);
+      own.l = own.l + rot(R, e.l) + cross(Ra, p);
+      own.a = own.a + Ra;
+      own.a = own.a + cross(p, own.l);  // referred to the base origin: the suffix sums need no per-pair translation
+      park(f + 1, own, p, zl);
+    }
+  }
+  if (WRENCH)
+  {
+    // w[l] = sum over links f >= l, referred to link l's origin: spatialDualTranslation(w, p_l - p_f), :1255 (ang += lin x d);
+    // tau of joint l - 1 = w[l] . screw of that joint at link l's origin (:1264-1272)
+    S6 run = zero;
+    double* __restrict__ tp = a.tau ? a.tau + s * a.tau_ss : nullptr;
+#pragma unroll 1
+    for (int l = nj; l >= 0; --l)
+    {
+      const double* const o = own_lds + (PK * l) * LN + threadIdx.x;
+      run.l = run.l + mk(o[0], o[LN], o[2 * LN]);
+      run.a = run.a + mk(o[3 * LN], o[4 * LN], o[5 * LN]);
+      const V3 po = mk(o[6 * LN], o[7 * LN], o[8 * LN]);
+      S6 w;
+      w.l = run.l;
+      w.a = run.a - cross(po, run.l);
+      if (a.wrench) put6(a.wrench, 6 * l, w);
+      if (tp && l >= 1)
+      {
+        JointRef J = c->j[l - 1];
+        const int idx = J.in_idx;
+        const V3 z = mk(o[9 * LN], o[10 * LN], o[11 * LN]);
+        if (idx >= 0) tp[idx * a.tau_sj] = J.type == RDYN_REVOLUTE ? dot(z, w.a) : (J.type == RDYN_PRISMATIC ? dot(z, w.l) : 0.0);
+      }
+    }
+  }
+}
+
+}  // namespace
+
+hipError_t rdyn_launch_long_base(const RdynKinArgs& a, hipStream_t st)
+{
+  if (a.n_samples <= 0) return hipSuccess;
+  const unsigned grid = (unsigned)((a.n_samples + 255) / 256);
+  if (a.dtwists) hipLaunchKernelGGL((k_long_base<3>), dim3(grid), dim3(256), 0, st, a);
+  else if (a.twists) hipLaunchKernelGGL((k_long_base<2>), dim3(grid), dim3(256), 0, st, a);
+  else if (a.J) hipLaunchKernelGGL((k_long_base<1>), dim3(grid), dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((k_long_base<0>), dim3(grid), dim3(256), 0, st, a);
+  return hipGetLastError();
+}
+
+hipError_t rdyn_launch_long_ext(int n_joints, const RdynKinExtArgs& a_in, hipStream_t st)
+{
+  if (a_in.n_samples <= 0) return hipSuccess;
+  RdynKinExtArgs a = a_in;
+  if (a.wrench || a.tau)
+  {
+    const size_t per_lane = (size_t)(a.tau ? 12 : 9) * (n_joints + 1) * sizeof(double);
+    a.lanes = per_lane * 64 <= 160 * 1024 ? 64 : 32;
+    const size_t lds = per_lane * a.lanes;
+    if (lds > 64 * 1024)
+    {
+      hipError_t e = hipFuncSetAttribute((const void*)k_long_ext<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL((k_long_ext<true>), dim3((unsigned)((a.n_samples + a.lanes - 1) / a.lanes)), dim3(64), lds, st, a);
+  }
+  else
+    hipLaunchKernelGGL((k_long_ext<false>), dim3((unsigned)((a.n_samples + 255) / 256)), dim3(256), 0, st, a);
+  return hipGetLastError();
+}

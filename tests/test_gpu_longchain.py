@@ -111,9 +111,14 @@ def test_long_chain_regressor_torque_inertia():
     close(chain.getNominalParameters(), ref.nominal_parameters(), "pi")
     # Y pi = tau with the chain's own 140 parameters
     close(np.einsum("snp,p->sn", Yr, chain.getNominalParameters()), tr, "Y pi")
-    # the by-link kinematic outputs are not served for such a chain: a clean error, not a wrong answer
-    with pytest.raises(Exception, match="more than 10 joints"):
-        chain.getTransformation(tq)
+    # the by-link kinematic outputs: the run-time-length kernels (rdyn_long_kin.hip; tests/test_gpu_longkin.py has the full set)
+    T = ref.fk(q)
+    close(chain.getTransformation(tq).cpu().numpy().transpose(0, 2, 1), T[:, -1], "T tool")
+    close(chain.getTransformations(tq).cpu().numpy().transpose(0, 1, 3, 2), T, "T links")
+    close(chain.getJacobian(tq).cpu().numpy().transpose(0, 2, 1), ref.jacobian(q), "J")
+    close(chain.getTwist(tq, tdq).cpu().numpy(), ref.twist(q, dq), "twists")
+    close(chain.getDTwist(tq, tdq, tddq).cpu().numpy(), ref.dtwist(q, dq, ddq), "dtwists")
+    close(chain.getWrench(tq, tdq, tddq).cpu().numpy(), ref.joint_torque(q, dq, ddq, wrenches=True)[1], "wrenches")
 
 
 @pytest.mark.parametrize("N", [500, 30000])

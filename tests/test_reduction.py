@@ -56,14 +56,15 @@ def test_expansion_blocks_match_oracle_columns(case):
     assert np.abs(Yb @ pi_body.reshape(-1) - tau).max() <= 1e-11 * max(1.0, np.abs(tau).max())
 
 
-def test_no_reduction_without_fixed_joints_or_with_permuted_inputs():
+def test_no_reduction_without_fixed_joints_and_reduction_in_any_input_order():
     from rosdyn_amd import Chain
     c = Chain(os.path.join(FIXTURES, "ur10_like.urdf"), "base_link", "wrist_3_link", GRAV)
     assert c.getBodyReduction() is None
     c = Chain(os.path.join(FIXTURES, "ur10_like.urdf"), "base_link", "tool0", GRAV)
     assert c.getBodyReduction() is not None
-    assert c.setInputJointsName(["wrist_3_joint", "shoulder_pan_joint"])     # not in chain order
-    assert c.getBodyReduction() is None
+    assert c.setInputJointsName(["wrist_3_joint", "shoulder_pan_joint"])     # not in chain order: the bodies stay in chain order
+    body, _, _ = c.getBodyReduction()
+    assert list(body) == [0, 0, 0, 0, 0, 5, 5]
     assert c.setInputJointsName(["shoulder_pan_joint", "wrist_3_joint"])
     body, _, _ = c.getBodyReduction()
     assert list(body) == [0, 0, 0, 0, 0, 5, 5]
