@@ -1001,6 +1001,13 @@ static int gram_through_reduced(const rdyn_chain* c, const rdyn_component* comps
   return RDYN_OK;
 }
 
+// the chain the tile kernels sweep: the sorted view when the input joints were listed out of chain order (rdyn_chain.hpp)
+static const rdyn_chain* ordered(const rdyn_chain* c) { return c->sorted ? c->sorted.get() : c; }
+static void fill_in_map(const rdyn_chain* c, RdynLdsGramArgs* la)
+{
+  for (int r = 0; r < 8; ++r) la->in_map[r] = (r < c->n_active() && r < (int)c->row_input.size()) ? c->row_input[r] : r;
+}
+
 // Tile layout of the LDS-resident regressor -> Gram kernels (rdyn_lds_gram.hip, rdyn_pipe_gram.hip, rdyn_duo_gram.hip): the columns
 // of link f keep the rows of the input joints at chain index <= f; K component columns (one 16-row group each) and the measured
 // torque follow.  Returns false when the input joints are not in chain order (the packed rows must be a prefix).
@@ -1035,6 +1042,7 @@ static bool build_lds_tile(const rdyn_chain* c, int n_comp_cols, bool dummy_slot
   la->tile_bytes = (off + 255) & ~255;
   la->n_active = n;
   for (int j = 0; j < n; ++j) la->first_col[j] = 10 * c->active[j];
+  fill_in_map(c, la);
   return monotonic;
 }
 
@@ -1120,14 +1128,17 @@ int rdyn_regressor_gram(const rdyn_chain* c, const rdyn_batch* b, const double* 
     // wave-pair kernel (rdyn_duo_gram.hip) by default; RDYN_GRAM_PATH=pipe / lds0 keep the single-wave kernels (A/B)
     const bool duo = rdyn_regressor_gram_duo_supported(P) && !(path_env && (!strcmp(path_env, "lds0") || !strcmp(path_env, "pipe")));
     const bool pipe = !duo && rdyn_regressor_gram_pipe_supported(P) && !(path_env && !strcmp(path_env, "lds0"));
-    const bool monotonic = build_lds_tile(c, 0, pipe, &la);
+    // input joints listed out of chain order: the sorted view is swept, every row's inputs read through its map
+    const rdyn_chain* const co = ordered(c);
+    const bool monotonic = build_lds_tile(co, 0, pipe, &la);
     const int nb = rdyn_gram_blocks_for(P);
     size_t lds_bytes = 4 * (size_t)la.tile_bytes;
     const size_t red_bytes = (size_t)(nb * (nb + 1) / 2) * 256 * sizeof(double);
     if (lds_bytes < red_bytes) lds_bytes = red_bytes;
     if (monotonic && lds_bytes <= 160 * 1024)
     {
-      la.chain = dc;
+      st = device_const(co, &la.chain);
+      if (st != RDYN_OK) return st;
       la.q = b->q;
       la.dq = b->dq;
       la.ddq = b->ddq;
@@ -1473,7 +1484,7 @@ int rdyn_tsqr_rows_last_report(int n_cols_with_rhs, int64_t rows, const void* wo
 // the chain whose rows are swept: the reduced companion when the chain has non-input joints (component columns belong to input
 // joints, which the companion keeps in the same order: they ride along unchanged).  A companion of ONE joint is below what the
 // sweeping kernels are built for: such a chain is swept as it is.
-static const rdyn_chain* swept_chain(const rdyn_chain* c) { return (c->reduced && c->reduced->n_joints() >= 2) ? c->reduced.get() : c; }
+static const rdyn_chain* swept_chain(const rdyn_chain* c) { return ordered((c->reduced && c->reduced->n_joints() >= 2) ? c->reduced.get() : c); }
 
 // rectangular 16-sample tile of rdyn_tsqr_wide.hip: every column 16 n rows + 4 doubles, structural zeros stored
 static bool build_rect_tile(const rdyn_chain* c, int n_comp_cols, RdynLdsGramArgs* la)
@@ -1499,6 +1510,7 @@ static bool build_rect_tile(const rdyn_chain* c, int n_comp_cols, RdynLdsGramArg
   la->tile_bytes = (10 * nJ + n_comp_cols + 1) * cs;
   la->n_active = n;
   for (int j = 0; j < n; ++j) la->first_col[j] = 10 * c->active[j];
+  fill_in_map(c, la);
   return monotonic;
 }
 
@@ -1521,10 +1533,10 @@ struct TsqrPlan
 static bool tsqr_plan(const rdyn_chain* c, const rdyn_component* comps, int n_comps, TsqrPlan* p)
 {
   p->cs = swept_chain(c);
-  p->expand = p->cs != c;
+  p->expand = p->cs != ordered(c);
   if (c->long_chain() && !p->expand)
   {
-    p->why = "a chain of more than 10 joints needs at most 10 input joints, in chain order";
+    p->why = "a chain of more than 10 joints needs 2 .. 10 input joints";
     return false;
   }
   const rdyn_chain* cs = p->cs;
@@ -1545,7 +1557,7 @@ static bool tsqr_plan(const rdyn_chain* c, const rdyn_component* comps, int n_co
   memset(&p->la_wide, 0, sizeof p->la_wide);
   if (p->n < 1 || p->n > 8 || p->nJ < 1 || !build_rect_tile(cs, K, &p->la_wide))
   {
-    p->why = "chains of 1..8 input joints in chain order are supported";
+    p->why = "chains of 1..8 input joints are supported";
     return false;
   }
   const bool tile_ok = build_lds_tile(cs, K, false, &p->la) && 4 * (size_t)p->la.tile_bytes <= 160 * 1024;
@@ -1662,8 +1674,9 @@ static int regressor_tsqr_run(const rdyn_chain* c, const rdyn_component* comps, 
     for (int i = 0; i < n_comps; ++i)
     {
       la.comps[i] = ca.comps[i];
+      la.comps[i].joint = cs->input_row[ca.comps[i].joint];  // the tile row of the component's input joint (sorted view)
       const int w = ca.comps[i].type == RDYN_COMP_FRICTION2 ? 3 : 2;
-      for (int k = 0; k < w; ++k) la.comp_col_row[col++] = (signed char)ca.comps[i].joint;
+      for (int k = 0; k < w; ++k) la.comp_col_row[col++] = (signed char)la.comps[i].joint;
     }
   };
   bind(p.la);
@@ -1920,15 +1933,17 @@ int rdyn_identification_gram(const rdyn_chain* c, const rdyn_component* comps, i
   {
     RdynLdsGramArgs la;
     memset(&la, 0, sizeof la);
-    bool monotonic = build_lds_tile(c, K, false, &la);
-    if (4 * (size_t)la.tile_bytes > 160 * 1024) monotonic = build_lds_tile(c, K, false, &la, true);  // compact layout (7 joints + components)
+    const rdyn_chain* const co = ordered(c);  // (input joints out of chain order: the sorted view, rdyn_chain.hpp)
+    bool monotonic = build_lds_tile(co, K, false, &la);
+    if (4 * (size_t)la.tile_bytes > 160 * 1024) monotonic = build_lds_tile(co, K, false, &la, true);  // compact layout (7 joints + components)
     const int nbt = K > 0 ? rdyn_gram_blocks_for(P) + 1 : rdyn_gram_blocks_for(P);  // the kernel's slab layout (XB = 1 with components)
     size_t lds_bytes = 4 * (size_t)la.tile_bytes;
     const size_t red_bytes = (size_t)(nbt * (nbt + 1) / 2) * 256 * sizeof(double);
     if (lds_bytes < red_bytes) lds_bytes = red_bytes;
     if (monotonic && lds_bytes <= 160 * 1024)
     {
-      la.chain = dc;
+      st = device_const(co, &la.chain);
+      if (st != RDYN_OK) return st;
       la.q = b->q;
       la.dq = b->dq;
       la.ddq = b->ddq;
@@ -1942,8 +1957,9 @@ int rdyn_identification_gram(const rdyn_chain* c, const rdyn_component* comps, i
       for (int i = 0; i < n_comps; ++i)
       {
         la.comps[i] = ca.comps[i];
+        la.comps[i].joint = co->input_row[ca.comps[i].joint];  // the tile row of the component's input joint
         const int w = ca.comps[i].type == RDYN_COMP_FRICTION2 ? 3 : 2;
-        for (int k = 0; k < w; ++k) la.comp_col_row[col++] = (signed char)ca.comps[i].joint;
+        for (int k = 0; k < w; ++k) la.comp_col_row[col++] = (signed char)la.comps[i].joint;
       }
       const int64_t tiles = (N + 15) / 16;
       const int blocks = (int)((tiles + 3) / 4 < kFusedBlocks ? (tiles + 3) / 4 : kFusedBlocks);

@@ -136,6 +136,7 @@ void free_device_copies(rdyn_chain* c)
   }
   c->dev_expand.clear();
   if (c->reduced) free_device_copies(c->reduced.get());
+  if (c->sorted) free_device_copies(c->sorted.get());
 }
 
 // inertial parameters [m, m c, Ixx Ixy Ixz Iyy Iyz Izz about the frame origin] of a body given in frame f, re-expressed in frame r,
@@ -167,6 +168,50 @@ void transform_parameters(const double R[9], const double p[3], const double in[
   out[7] = Io[4];
   out[8] = Io[5];
   out[9] = Io[8];
+}
+
+// see rdyn_chain.hpp: the copy of a chain (host_joints / host_const / active already final) with its input joints renumbered in chain order
+void build_sorted_view(rdyn_chain* c)
+{
+  c->sorted.reset();
+  const int nj = c->n_joints(), n = c->n_active();
+  c->row_input.resize(n);
+  c->input_row.resize(n);
+  bool monotonic = true;
+  int rank = 0;
+  for (int f = 0; f < nj; ++f)
+  {
+    const int k = c->host_joints[f].in_idx;
+    if (k < 0) continue;
+    monotonic = monotonic && k == rank;
+    c->row_input[rank] = k;
+    c->input_row[k] = rank;
+    ++rank;
+  }
+  if (monotonic || c->long_chain()) return;
+  std::unique_ptr<rdyn_chain> s(new rdyn_chain());
+  s->joints = c->joints;
+  s->links = c->links;
+  s->moveable_names = c->moveable_names;
+  memcpy(s->gravity, c->gravity, sizeof s->gravity);
+  s->q_max = c->q_max;
+  s->q_min = c->q_min;
+  s->dq_max = c->dq_max;
+  s->ddq_max = c->ddq_max;
+  s->tau_max = c->tau_max;
+  s->host_joints = c->host_joints;
+  s->host_const = c->host_const;
+  s->active.resize(n);
+  for (int f = 0; f < nj; ++f)
+  {
+    const int k = c->host_joints[f].in_idx;
+    if (k < 0) continue;
+    s->host_joints[f].in_idx = s->host_const.j[f].in_idx = c->input_row[k];
+    s->active[c->input_row[k]] = f;
+  }
+  s->row_input = c->row_input;
+  s->input_row = c->input_row;
+  c->sorted = std::move(s);
 }
 
 // see rdyn_chain.hpp: the reduced companion and the expansion blocks X_f
@@ -271,6 +316,7 @@ void build_reduced(rdyn_chain* c)
   // the frames behind the last input joint: x_lastbody = tail_R x_tool + tail_t (the tool frame of the chain seen from the companion's)
   memcpy(c->tail_R, Rc, sizeof Rc);
   memcpy(c->tail_t, pc, sizeof pc);
+  build_sorted_view(r.get());
   c->reduced = std::move(r);
 }
 }  // namespace
@@ -367,6 +413,7 @@ void rdyn_chain_finalize(rdyn_chain* c)
     for (int j = 0; j < nj; ++j) Lc.j[j] = HJ[j];
   }
   build_reduced(c);
+  build_sorted_view(c);
 }
 
 static int build_chain(std::vector<rdyn_joint_desc>& joints, std::vector<rdyn_link_desc>& links, const double gravity[3], rdyn_chain** out)

@@ -42,6 +42,15 @@ struct rdyn_chain
   // and identically zero for links upstream of the first input joint.  Gram / R-factor kernels therefore run on the reduced chain
   // (10 n columns, every joint an input joint: the fastest kernel variants) and a tiny epilogue forms G = E' G_red E.
   std::unique_ptr<rdyn_chain> reduced;
+  // "Sorted view" for the kernels that sweep 16-sample tiles into LDS (normal equations, R factors): they number a sample's rows by
+  // the CHAIN order of the input joints (the rows a link's columns store are then a prefix).  A'A, A'tau and the R factor do not
+  // depend on the order of the rows inside a sample, so a chain whose input joints were listed in another order
+  // (setInputJointsName, primitives_impl.h:705-737) is swept through this copy -- same joints, in_idx = rank in chain order -- and
+  // the lane that owns row r reads q, Dq, DDq and tau_meas at the caller's input index row_input[r].  Null when the input joints
+  // are in chain order already (row_input / input_row are then the identity); chains of <= RDYN_MAX_SWEPT_JOINTS joints only.
+  std::unique_ptr<rdyn_chain> sorted;
+  std::vector<int> row_input;     // per row of the tile kernels (rank in chain order): the caller's input index
+  std::vector<int> input_row;     // the inverse: per input index, its row
   std::vector<int> red_chain;     // per reduced joint: its chain index
   double tail_R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, tail_t[3] = {0, 0, 0};  // tool frame of the chain in the companion's tool frame (row-major R)
   std::vector<int> red_of;        // per chain link f + 1 (index f): reduced link it rides on, -1 = upstream of the first input joint

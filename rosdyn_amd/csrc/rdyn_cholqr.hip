@@ -99,6 +99,7 @@ __global__ __launch_bounds__(128 * NPAIR) void k_regressor_pgram(const RdynLdsGr
     ChainPtr c = as_const(fa.chain);
     const int s_loc = lane >> 2, k = lane & 3;
     const int r0 = k, r1 = k + 4;
+    RDYN_DUO_INPUT_OFFSETS(fa, k, in_oa, in_ob);
     const int fB = 4;
     double nqa = 0.0, ndqa = 0.0, nddqa = 0.0, nqb = 0.0, ndqb = 0.0, nddqb = 0.0, nb0 = 0.0, nb1 = 0.0;
     auto fetch = [&](int64_t tile_index) {
@@ -107,20 +108,20 @@ __global__ __launch_bounds__(128 * NPAIR) void k_regressor_pgram(const RdynLdsGr
       const int64_t o = sx * fa.in_ss;
       if (fa.bcol)
       {
-        if (r0 < n) nb0 = fa.bcol[o + r0 * fa.in_sj];
-        if (r1 < n) nb1 = fa.bcol[o + r1 * fa.in_sj];
+        if (r0 < n) nb0 = fa.bcol[o + in_oa];
+        if (r1 < n) nb1 = fa.bcol[o + in_ob];
       }
       if (k < n)
       {
-        nqa = fa.q[o + k * fa.in_sj];
-        ndqa = fa.dq[o + k * fa.in_sj];
-        nddqa = fa.ddq[o + k * fa.in_sj];
+        nqa = fa.q[o + in_oa];
+        ndqa = fa.dq[o + in_oa];
+        nddqa = fa.ddq[o + in_oa];
       }
       if (k + 4 < n)
       {
-        nqb = fa.q[o + (k + 4) * fa.in_sj];
-        ndqb = fa.dq[o + (k + 4) * fa.in_sj];
-        nddqb = fa.ddq[o + (k + 4) * fa.in_sj];
+        nqb = fa.q[o + in_ob];
+        ndqb = fa.dq[o + in_ob];
+        nddqb = fa.ddq[o + in_ob];
       }
     };
     if (t_first < n_tiles) fetch(t_first);
@@ -375,6 +376,7 @@ __global__ __launch_bounds__(64 * NW) void k_regressor_pgram_solo(const RdynLdsG
   ChainPtr c = as_const(fa.chain);
   const int s_loc = lane >> 2, k = lane & 3;
   const int r0 = k, r1 = k + 4;
+    RDYN_DUO_INPUT_OFFSETS(fa, k, in_oa, in_ob);
   const int fB = 4;
   double nqa = 0.0, ndqa = 0.0, nddqa = 0.0, nqb = 0.0, ndqb = 0.0, nddqb = 0.0, nb0 = 0.0, nb1 = 0.0;
   auto fetch = [&](int64_t tile_index) {
@@ -383,20 +385,20 @@ __global__ __launch_bounds__(64 * NW) void k_regressor_pgram_solo(const RdynLdsG
     const int64_t o = sx * fa.in_ss;
     if (fa.bcol)
     {
-      if (r0 < n) nb0 = fa.bcol[o + r0 * fa.in_sj];
-      if (r1 < n) nb1 = fa.bcol[o + r1 * fa.in_sj];
+      if (r0 < n) nb0 = fa.bcol[o + in_oa];
+      if (r1 < n) nb1 = fa.bcol[o + in_ob];
     }
     if (k < n)
     {
-      nqa = fa.q[o + k * fa.in_sj];
-      ndqa = fa.dq[o + k * fa.in_sj];
-      nddqa = fa.ddq[o + k * fa.in_sj];
+      nqa = fa.q[o + in_oa];
+      ndqa = fa.dq[o + in_oa];
+      nddqa = fa.ddq[o + in_oa];
     }
     if (k + 4 < n)
     {
-      nqb = fa.q[o + (k + 4) * fa.in_sj];
-      ndqb = fa.dq[o + (k + 4) * fa.in_sj];
-      nddqb = fa.ddq[o + (k + 4) * fa.in_sj];
+      nqb = fa.q[o + in_ob];
+      ndqb = fa.dq[o + in_ob];
+      nddqb = fa.ddq[o + in_ob];
     }
   };
   // ---------------- consumer state

@@ -30,6 +30,10 @@ __device__ __forceinline__ constexpr int duo_direct_off(int f, int pad = 4)
   for (int g = 0; g < f; ++g) off += 10 * (16 * (g + 1) + pad) * 8;
   return off;
 }
+// element offsets of the inputs of the rows that lane k of a quad owns (rows k and k + 4): in_map[row] * in_sj (rdyn_kernels.h: in_map)
+#define RDYN_DUO_INPUT_OFFSETS(fa, k, oa, ob)                                                                                       \
+  const int64_t oa = (int64_t)((k) == 0 ? (fa).in_map[0] : ((k) == 1 ? (fa).in_map[1] : ((k) == 2 ? (fa).in_map[2] : (fa).in_map[3]))) * (fa).in_sj; \
+  const int64_t ob = (int64_t)((k) == 0 ? (fa).in_map[4] : ((k) == 1 ? (fa).in_map[5] : ((k) == 2 ? (fa).in_map[6] : (fa).in_map[7]))) * (fa).in_sj
 #ifndef RDYN_DUO_TILE_PAD
 #define RDYN_DUO_TILE_PAD 4  // (a kernel that sweeps into the compact tile redefines it around its include of rdyn_duo_link_body.inc)
 #endif

@@ -88,6 +88,7 @@ __global__ __launch_bounds__(512) void k_regressor_gram_duo(const RdynLdsGramArg
     // Rows >= 4 belong to joints that sit at chain index >= fB: before link fB slot 1 is identically zero and is skipped
     // (wave-uniform), which removes a third of the row work of a 6-joint chain.
     const int r0 = k, r1 = k + 4;
+    RDYN_DUO_INPUT_OFFSETS(fa, k, in_oa, in_ob);
     int fB = DIRECT ? 4 : NJ;
     if (!DIRECT)
       for (int f = NJ - 1; f >= 0; --f)
@@ -99,20 +100,20 @@ __global__ __launch_bounds__(512) void k_regressor_gram_duo(const RdynLdsGramArg
       const int64_t o = sx * fa.in_ss;
       if (fa.bcol)
       {
-        if (r0 < n) nb0 = fa.bcol[o + r0 * fa.in_sj];
-        if (r1 < n) nb1 = fa.bcol[o + r1 * fa.in_sj];
+        if (r0 < n) nb0 = fa.bcol[o + in_oa];
+        if (r1 < n) nb1 = fa.bcol[o + in_ob];
       }
       if (k < n)
       {
-        nqa = fa.q[o + k * fa.in_sj];
-        ndqa = fa.dq[o + k * fa.in_sj];
-        nddqa = fa.ddq[o + k * fa.in_sj];
+        nqa = fa.q[o + in_oa];
+        ndqa = fa.dq[o + in_oa];
+        nddqa = fa.ddq[o + in_oa];
       }
       if (k + 4 < n)
       {
-        nqb = fa.q[o + (k + 4) * fa.in_sj];
-        ndqb = fa.dq[o + (k + 4) * fa.in_sj];
-        nddqb = fa.ddq[o + (k + 4) * fa.in_sj];
+        nqb = fa.q[o + in_ob];
+        ndqb = fa.dq[o + in_ob];
+        nddqb = fa.ddq[o + in_ob];
       }
     };
     if (t_first < n_tiles) fetch(t_first);

@@ -188,6 +188,9 @@ struct RdynLdsGramArgs
   const double *q, *dq, *ddq, *bcol;   // bcol may be null
   int64_t n_samples, in_ss, in_sj;
   int n_active;
+  // the caller's input index behind tile row r (rdyn_chain.hpp: sorted view): q, Dq, DDq, tau_meas of row r are read at in_map[r] * in_sj;
+  // the identity for input joints in chain order
+  int in_map[8];
   int all_revolute;                    // every chain joint is revolute (selects the sweeper without joint-kind selects)
   int first_col[RDYN_MAX_SWEPT_JOINTS];      // per input joint: 10 * chain index
   int lds_off[RDYN_MAX_SWEPT_JOINTS];        // per link: byte offset of its first column in the tile

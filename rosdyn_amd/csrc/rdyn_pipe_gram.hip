@@ -32,6 +32,7 @@
 #include "rdyn_devmath.h"
 #include "rdyn_kernels.h"
 #include "rdyn_gram_common.h"
+#include "rdyn_duo_common.h"
 
 #ifndef RDYN_PIPE_UNROLL_MAX
 #define RDYN_PIPE_UNROLL_MAX 6  // chains up to this many joints: unrolled link loop; longer: rolled (A/B: tools/probe_pipe.py)
@@ -77,6 +78,10 @@ __global__ __launch_bounds__(256) void k_regressor_gram_pipe(const RdynLdsGramAr
   const int cl = lane & 15, g = lane >> 4;                   // MFMA role: column within a block, row quad
   const int n = fa.n_active;
   const int r0 = 2 * k, r1 = 2 * k + 1;
+  // inputs of rows k and k + 4, measured torques of rows 2 k and 2 k + 1: read at the caller's input index of each (rdyn_kernels.h: in_map)
+  RDYN_DUO_INPUT_OFFSETS(fa, k, in_oa, in_ob);
+  const int64_t in_o0 = (int64_t)(k == 0 ? fa.in_map[0] : (k == 1 ? fa.in_map[2] : (k == 2 ? fa.in_map[4] : fa.in_map[6]))) * fa.in_sj;
+  const int64_t in_o1 = (int64_t)(k == 0 ? fa.in_map[1] : (k == 1 ? fa.in_map[3] : (k == 2 ? fa.in_map[5] : fa.in_map[7]))) * fa.in_sj;
 
   int colbase[NB], colm[NB];
 #pragma unroll
@@ -115,20 +120,20 @@ __global__ __launch_bounds__(256) void k_regressor_gram_pipe(const RdynLdsGramAr
     const int64_t o = sx * fa.in_ss;
     if (fa.bcol)
     {
-      if (r0 < n) nb0 = fa.bcol[o + r0 * fa.in_sj];
-      if (r1 < n) nb1 = fa.bcol[o + r1 * fa.in_sj];
+      if (r0 < n) nb0 = fa.bcol[o + in_o0];
+      if (r1 < n) nb1 = fa.bcol[o + in_o1];
     }
     if (k < n)
     {
-      nqa = fa.q[o + k * fa.in_sj];
-      ndqa = fa.dq[o + k * fa.in_sj];
-      nddqa = fa.ddq[o + k * fa.in_sj];
+      nqa = fa.q[o + in_oa];
+      ndqa = fa.dq[o + in_oa];
+      nddqa = fa.ddq[o + in_oa];
     }
     if (k + 4 < n)
     {
-      nqb = fa.q[o + (k + 4) * fa.in_sj];
-      ndqb = fa.dq[o + (k + 4) * fa.in_sj];
-      nddqb = fa.ddq[o + (k + 4) * fa.in_sj];
+      nqb = fa.q[o + in_ob];
+      ndqb = fa.dq[o + in_ob];
+      nddqb = fa.ddq[o + in_ob];
     }
   };
   const int64_t n_tiles = (fa.n_samples + 15) / 16;

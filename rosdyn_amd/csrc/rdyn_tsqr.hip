@@ -274,6 +274,7 @@ __global__ __launch_bounds__(256) void k_regressor_tsqr(const RdynLdsGramArgs fa
   const int n = fa.n_active;
   const int s_loc = lane >> 2, k = lane & 3;
   const int r0 = k, r1 = k + 4;
+    RDYN_DUO_INPUT_OFFSETS(fa, k, in_oa, in_ob);
   int fB = NJ;
   for (int f = NJ - 1; f >= 0; --f)
     if (fa.lds_m[f] >= 5) fB = f;
@@ -334,20 +335,20 @@ __global__ __launch_bounds__(256) void k_regressor_tsqr(const RdynLdsGramArgs fa
     double qa = 0.0, dqa = 0.0, ddqa = 0.0, qb = 0.0, dqb = 0.0, ddqb = 0.0, tb0 = 0.0, tb1 = 0.0;
     if (fa.bcol)
     {
-      if (r0 < n) tb0 = fa.bcol[o + r0 * fa.in_sj];
-      if (r1 < n) tb1 = fa.bcol[o + r1 * fa.in_sj];
+      if (r0 < n) tb0 = fa.bcol[o + in_oa];
+      if (r1 < n) tb1 = fa.bcol[o + in_ob];
     }
     if (k < n)
     {
-      qa = fa.q[o + k * fa.in_sj];
-      dqa = fa.dq[o + k * fa.in_sj];
-      ddqa = fa.ddq[o + k * fa.in_sj];
+      qa = fa.q[o + in_oa];
+      dqa = fa.dq[o + in_oa];
+      ddqa = fa.ddq[o + in_oa];
     }
     if (k + 4 < n)
     {
-      qb = fa.q[o + (k + 4) * fa.in_sj];
-      dqb = fa.dq[o + (k + 4) * fa.in_sj];
-      ddqb = fa.ddq[o + (k + 4) * fa.in_sj];
+      qb = fa.q[o + in_ob];
+      dqb = fa.dq[o + in_ob];
+      ddqb = fa.ddq[o + in_ob];
     }
     if (!valid) tb0 = tb1 = 0.0;
     const int m0idx = valid ? r0 : -2, m1idx = valid ? r1 : -2;

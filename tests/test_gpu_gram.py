@@ -99,7 +99,7 @@ def test_gram_of_materialised_regressor_equals_fused(torch_cuda):
 
 
 def test_regressor_gram_with_permuted_subset_of_input_joints(torch_cuda):
-    """Input joints not in chain order (setInputJointsName): the LDS path must hand over to the image path; same Gram."""
+    """Input joints not in chain order (setInputJointsName): the sorted view is swept (until round 4: the image path); same Gram."""
     from oracle.oracle import OracleChain
     from rosdyn_amd import Chain
     from rosdyn_amd.samples import trajectory_batch
@@ -118,6 +118,54 @@ def test_regressor_gram_with_permuted_subset_of_input_joints(torch_cuda):
     G, c, bb = chain.getRegressorGram(*args, layout="element")
     assert _fro(G.cpu().numpy(), A.T @ A) <= 1e-10
     assert _fro(c.cpu().numpy(), A.T @ bvec) <= 1e-10
+
+
+@pytest.mark.parametrize("tool,names", [
+    ("wrist_3_link", ["wrist_2_joint", "shoulder_pan_joint", "wrist_3_joint", "elbow_joint", "shoulder_lift_joint", "wrist_1_joint"]),
+    ("tool0", ["wrist_3_joint", "shoulder_lift_joint", "elbow_joint", "wrist_1_joint", "shoulder_pan_joint"])])
+@pytest.mark.parametrize("N", [700, 9000])
+def test_normal_equations_and_r_factor_with_input_joints_in_any_order(torch_cuda, tool, names, N):
+    """setInputJointsName in an order that is not the chain's (primitives_impl.h:705-737), every joint an input joint and with
+    joints left out / fixed frames: the tile kernels sweep the sorted view and read q, Dq, DDq, tau_meas of every row through
+    its index map (A'A, A'tau and R do not depend on the order of the rows inside a sample); friction columns follow their joint."""
+    from oracle.oracle import OracleChain, components_regressor
+    from rosdyn_amd import Chain
+    from rosdyn_amd.components import ComponentSet
+    from rosdyn_amd.samples import trajectory_batch
+    torch = torch_cuda
+    path = os.path.join(FIXTURES, "ur10_like.urdf")
+    chain = Chain(path, "base_link", tool, GRAV)
+    assert chain.setInputJointsName(names)
+    ref = OracleChain(path, "base_link", tool, GRAV, names)
+    n, P = ref.n, ref.P
+    q, dq, ddq = trajectory_batch(23, N, n)
+    rng = np.random.default_rng(N)
+    tau = ref.joint_torque(q, dq, ddq) + 1e-3 * rng.normal(size=(N, n))
+    A = ref.regressor(q, dq, ddq).reshape(N * n, P)
+    M = np.column_stack([A, tau.reshape(-1)])
+    Gr = M.T @ M
+    args = [torch.from_numpy(x).cuda() for x in (q, dq, ddq, tau)]
+    G, c, bb = chain.getRegressorGram(*args)
+    full = np.zeros((P + 1, P + 1))
+    full[:P, :P], full[:P, P], full[P, :P], full[P, P] = G.cpu().numpy(), c.cpu().numpy(), c.cpu().numpy(), float(bb.item())
+    assert _fro(full, Gr) <= 1e-10
+    R1 = chain.getRegressorTsqr(*args).cpu().numpy()
+    assert np.allclose(np.tril(R1, -1), 0.0) and np.abs(R1.T @ R1 - Gr).max() <= 1e-11 * np.abs(Gr).max()
+    # friction on input joints 0, 2 and n - 1 (INPUT indices: the joints named names[0], names[2], names[-1])
+    specs = [(0, j, 1e-3, 5.0, [0.4 + 0.1 * j, 1.0]) for j in (0, 2, n - 1)]
+    comps = ComponentSet([dict(type=0, joint=sp[1], min_velocity=1e-3, max_velocity=5.0, parameters=sp[4]) for sp in specs], n)
+    Cm, tau_c = components_regressor(specs, n, q, dq)
+    tau2 = tau + tau_c
+    M2 = np.column_stack([A, Cm.reshape(N * n, comps.columns), tau2.reshape(-1)])
+    G2r = M2.T @ M2
+    args2 = args[:3] + [torch.from_numpy(tau2).cuda()]
+    G2, c2, bb2 = chain.getIdentificationGram(comps, *args2)
+    C = P + comps.columns
+    full2 = np.zeros((C + 1, C + 1))
+    full2[:C, :C], full2[:C, C], full2[C, :C], full2[C, C] = G2.cpu().numpy(), c2.cpu().numpy(), c2.cpu().numpy(), float(bb2.item())
+    assert _fro(full2, G2r) <= 1e-10
+    R3 = chain.getIdentificationTsqr(comps, *args2).cpu().numpy()
+    assert np.allclose(np.tril(R3, -1), 0.0) and np.abs(R3.T @ R3 - G2r).max() <= 1e-11 * np.abs(G2r).max()
 
 
 def test_config3_full_size_properties(torch_cuda):
