@@ -1005,7 +1005,29 @@ static int gram_through_reduced(const rdyn_chain* c, const rdyn_component* comps
 static const rdyn_chain* ordered(const rdyn_chain* c) { return c->sorted ? c->sorted.get() : c; }
 static void fill_in_map(const rdyn_chain* c, RdynLdsGramArgs* la)
 {
-  for (int r = 0; r < 8; ++r) la->in_map[r] = (r < c->n_active() && r < (int)c->row_input.size()) ? c->row_input[r] : r;
+  const int n = c->n_active();
+  for (int r = 0; r < 8; ++r) la->in_map[r] = (r < n && r < (int)c->row_input.size()) ? c->row_input[r] : r;
+  // rows of the three row waves of the one-lane-per-sample sweepers (rdyn_duo_gram.hip, KIN): row l (input joints in chain order) is
+  // carried through n - l links; longest row first, each to the wave with the least work so far (three slots per wave: n <= 8)
+  for (int i = 0; i < 9; ++i) la->sw_rows[i] = 99;
+  int load[3] = {0, 0, 0}, used[3] = {0, 0, 0};
+  for (int l = 0; l < n && l < 8; ++l)
+  {
+    int best = -1;
+    for (int w = 0; w < 3; ++w)
+      if (used[w] < 3 && (best < 0 || load[w] < load[best])) best = w;
+    la->sw_rows[3 * best + used[best]++] = l;
+    load[best] += n - l;
+  }
+  la->sweep_lanes = 0;
+}
+// the one-lane-per-sample sweepers of the wave-pair Gram kernel serve this chain (every joint an input joint): the tile padding they
+// use (4, or 2 = the compact layout), 0 = no
+static int kin_sweeper_pad(const rdyn_chain* c, int n_comp_cols)
+{
+  if (probe_env("RDYN_GRAM_SWEEPER") && !strcmp(probe_env("RDYN_GRAM_SWEEPER"), "pair")) return 0;
+  if (c->n_active() != c->n_joints()) return 0;
+  return rdyn_regressor_gram_duo_kin_pad(c->n_joints(), n_comp_cols);
 }
 
 // Tile layout of the LDS-resident regressor -> Gram kernels (rdyn_lds_gram.hip, rdyn_pipe_gram.hip, rdyn_duo_gram.hip): the columns
@@ -1130,9 +1152,11 @@ int rdyn_regressor_gram(const rdyn_chain* c, const rdyn_batch* b, const double* 
     const bool pipe = !duo && rdyn_regressor_gram_pipe_supported(P) && !(path_env && !strcmp(path_env, "lds0"));
     // input joints listed out of chain order: the sorted view is swept, every row's inputs read through its map
     const rdyn_chain* const co = ordered(c);
-    const bool monotonic = build_lds_tile(co, 0, pipe, &la);
+    const int kin_pad = duo ? kin_sweeper_pad(co, 0) : 0;
+    const bool monotonic = build_lds_tile(co, 0, pipe, &la, kin_pad == 2);
     const int nb = rdyn_gram_blocks_for(P);
-    size_t lds_bytes = 4 * (size_t)la.tile_bytes;
+    size_t lds_bytes = 4 * (size_t)la.tile_bytes + (kin_pad ? RDYN_KIN_XCH_BYTES(co->n_joints()) : 0);
+    la.sweep_lanes = kin_pad != 0;
     const size_t red_bytes = (size_t)(nb * (nb + 1) / 2) * 256 * sizeof(double);
     if (lds_bytes < red_bytes) lds_bytes = red_bytes;
     if (monotonic && lds_bytes <= 160 * 1024)
@@ -1938,6 +1962,11 @@ int rdyn_identification_gram(const rdyn_chain* c, const rdyn_component* comps, i
     if (4 * (size_t)la.tile_bytes > 160 * 1024) monotonic = build_lds_tile(co, K, false, &la, true);  // compact layout (7 joints + components)
     const int nbt = K > 0 ? rdyn_gram_blocks_for(P) + 1 : rdyn_gram_blocks_for(P);  // the kernel's slab layout (XB = 1 with components)
     size_t lds_bytes = 4 * (size_t)la.tile_bytes;
+    if (kin_sweeper_pad(co, K) == 4 && lds_bytes + RDYN_KIN_XCH_BYTES(co->n_joints()) <= 160 * 1024 && la.lds_stride[0] == (16 + 4) * 8)
+    {
+      la.sweep_lanes = 1;  // one lane per sample: the exchange area behind the tiles
+      lds_bytes += RDYN_KIN_XCH_BYTES(co->n_joints());
+    }
     const size_t red_bytes = (size_t)(nbt * (nbt + 1) / 2) * 256 * sizeof(double);
     if (lds_bytes < red_bytes) lds_bytes = red_bytes;
     if (monotonic && lds_bytes <= 160 * 1024)

@@ -64,6 +64,7 @@ __device__ __forceinline__ V3 symv(Ptr I, V3 v)
 // for |x| <= 2^20 a two-constant Cody-Waite reduction is exact to ~5e-21 (n = rint(x 2/pi) has <= 20 bits, pio2_1 has 33:
 // n pio2_1 is exact, and so is x - n pio2_1 in one fma; the tail constant carries the next 53 bits), followed by the fdlibm kernel
 // polynomials on [-pi/4, pi/4] (< 1 ulp) and a quadrant select -- 40 instructions, branch-free.  Beyond 2^20 (or NaN / Inf): ocml.
+__device__ __forceinline__ void rdyn_sincos_small(double x, double* sn, double* cs);  // the range-limited part alone: |x| <= 2^20
 __device__ __forceinline__ void rdyn_sincos(double x, double* sn, double* cs)
 {
   if (__builtin_expect(!(fabs(x) <= 1048576.0), 0))
@@ -71,6 +72,10 @@ __device__ __forceinline__ void rdyn_sincos(double x, double* sn, double* cs)
     sincos(x, sn, cs);
     return;
   }
+  rdyn_sincos_small(x, sn, cs);
+}
+__device__ __forceinline__ void rdyn_sincos_small(double x, double* sn, double* cs)
+{
   const double fn = __builtin_rint(x * 6.36619772367581382433e-01);
   const double r = fma(-fn, 1.57079632673412561417e+00, x);  // exact
   const double w = fn * 6.07710050650619224932e-11;

@@ -37,12 +37,21 @@ namespace
 // all 8 waves; LDS traffic of this wave retired first.  Plain s_barrier (not __syncthreads): no vmcnt(0), so the sweeper's
 // global prefetch of the next tile's inputs stays in flight across the barriers.
 #ifdef RDYN_DUO_STAMPS  // diagnostic build only (tools/kbench KB_STAMPS=1): cycles every wave spends inside the barriers
-#define DUO_STAMP_DECL unsigned long long st_wait = 0, st_t0 = __builtin_amdgcn_s_memtime(), st_tmp
-#define DUO_BARRIER_LDS() do { st_tmp = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); st_wait += __builtin_amdgcn_s_memtime() - st_tmp; } while (0)
-#define DUO_BARRIER() do { st_tmp = __builtin_amdgcn_s_memtime(); asm volatile("s_barrier" ::: "memory"); st_wait += __builtin_amdgcn_s_memtime() - st_tmp; } while (0)
+// (+ a timeline: workgroup 0, trip RDYN_DUO_STAMP_TRIP, every wave's clock before and after each of its barriers -> slab slot 600)
+#ifndef RDYN_DUO_STAMP_TRIP
+#define RDYN_DUO_STAMP_TRIP 7
+#endif
+#define DUO_STAMP_DECL unsigned long long st_wait = 0, st_t0 = __builtin_amdgcn_s_memtime(), st_tmp; long long st_it = -1; int st_n = 0
+#define DUO_STAMP_TRIP(it_) st_it = (it_)
+#define DUO_STAMP_MARK(t_) do { if (blockIdx.x == 0 && st_it == RDYN_DUO_STAMP_TRIP && (threadIdx.x & 63) == 0 && st_n < 32) fa.slabs[(int64_t)600 * 4096 + (threadIdx.x >> 6) * 32 + st_n++] = (double)((t_) - st_t0); } while (0)
+#define DUO_STAMP_HERE(wait_lds) do { if (wait_lds) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); DUO_STAMP_MARK(__builtin_amdgcn_s_memtime()); } while (0)
+#define DUO_BARRIER_LDS() do { st_tmp = __builtin_amdgcn_s_memtime(); DUO_STAMP_MARK(st_tmp); asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); const unsigned long long st_e = __builtin_amdgcn_s_memtime(); st_wait += st_e - st_tmp; DUO_STAMP_MARK(st_e); } while (0)
+#define DUO_BARRIER() do { st_tmp = __builtin_amdgcn_s_memtime(); DUO_STAMP_MARK(st_tmp); asm volatile("s_barrier" ::: "memory"); const unsigned long long st_e = __builtin_amdgcn_s_memtime(); st_wait += st_e - st_tmp; DUO_STAMP_MARK(st_e); } while (0)
 #define DUO_STAMP_OUT(NT_) do { if (lane == 0) { double* o = fa.slabs + ((int64_t)(256 + blockIdx.x) * (NT_ * 256)) + wave * 2; o[0] = (double)(__builtin_amdgcn_s_memtime() - st_t0); o[1] = (double)st_wait; } } while (0)
 #else
 #define DUO_STAMP_DECL
+#define DUO_STAMP_TRIP(it_)
+#define DUO_STAMP_HERE(wait_lds)
 #define DUO_BARRIER_LDS() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 #define DUO_BARRIER() asm volatile("s_barrier" ::: "memory")
 #define DUO_STAMP_OUT(NT_)
@@ -53,7 +62,9 @@ typedef double d4h __attribute__((ext_vector_type(4), aligned(16)));  // operand
 
 // ALLREV: every chain joint is revolute (the UR / Panda arms of BASELINE.json): the sweeper drops the joint-kind selects and the
 // prismatic terms (14 % of its instructions; only instantiated with DIRECT)
-template <int NJ, bool DIRECT, int XB, bool ALLREV>
+// KIN != 0: the one-lane-per-sample sweepers (DIRECT only; KIN = the padding of the tile columns in doubles, 4 or 2): sweeper wave 0
+// runs the link kinematics of the workgroup's 64 samples once, waves 1-3 the regressor rows -- the consumers do not see the difference
+template <int NJ, bool DIRECT, int XB, bool ALLREV, int KIN = 0>
 __global__ __launch_bounds__(512) void k_regressor_gram_duo(const RdynLdsGramArgs fa)
 {
   constexpr int NB = (10 * NJ + 1 + 15) / 16 + XB;
@@ -76,7 +87,321 @@ __global__ __launch_bounds__(512) void k_regressor_gram_duo(const RdynLdsGramArg
   const int64_t trips = trips_raw > 0 ? trips_raw : 0;
   DUO_STAMP_DECL;
 
-  if (sweeper)
+  if (sweeper && KIN)
+  {
+    // ================================================================ one lane per sample: 64 samples, the link kinematics ONCE
+    // Sweeper wave 0 runs the link recursion of the workgroup's 64 samples (lane = sample: sincos, R, the four carried 3-vectors, the
+    // joint's motion, d) one link AHEAD and publishes what the rows of that link need -- R, the joint offset, w, al, d and the
+    // b-matrix: 30 doubles per sample (7 joints, where the tiles leave 12 KB of LDS: sin, 1 - cos, the prismatic displacement, w, al,
+    // d, and the row waves rebuild the rest) -- in a double-buffered exchange area behind the tiles.  Sweeper waves 1-3 own the
+    // regressor ROWS (fa.sw_rows: three slots each, balanced by the number of links a row is carried through): they carry their rows'
+    // unit twists into the link, form the ten-vectors and drop them into the 16-sample sub-tile of their lane.  The row-pair sweeper repeats the kinematics in the four lanes of every sample (2 113 VALU instructions per SIMD and
+    // 64 samples); here a SIMD pays ~130 (wave 0) or 36 + 69 per active row (waves 1-3) per link.  Same closed forms as
+    // rdyn_duo_link_body.inc, statement by statement: the tile is bit-identical, the consumers do not see the difference.
+    ChainPtr c = as_const(fa.chain);
+    const int sub = lane >> 4, s_loc = lane & 15;
+    char* const tile = lds_raw + (size_t)sub * fa.tile_bytes;  // the 16-sample sub-tile of my sample
+    // doubles per sample and exchange buffer: 30 (R, the joint offset, w, al, d, the b-matrix) where the LDS has room, 12 at 7 joints
+    constexpr int XV = NJ <= 6 ? 30 : 12;
+    double* const xch = (double*)(lds_raw + (size_t)4 * fa.tile_bytes) + lane;  // [2][XV][64]
+    const int64_t t_mine = (int64_t)blockIdx.x * 4 + sub;
+    // sub-tile p of the workgroup's trip `it` is the 16-sample tile (blockIdx.x * 4 + p) + it * t_step of the pair kernels' numbering
+    auto sample_offset = [&](int64_t tile_index) -> int64_t {
+      if (tile_index >= n_tiles) tile_index = n_tiles - 1;
+      int64_t sx = tile_index * t_mul * 16 + s_loc;
+      if (sx >= fa.n_samples) sx = fa.n_samples - 1;
+      return sx * fa.in_ss;
+    };
+    if (wave == 0)
+    {
+      // ---- the kinematics wave.  The inputs of joint j wait in q_[j], dq_[j], ddq_[j]; link j consumes them and refills the same
+      // registers with the NEXT tile's (a full tile period in flight, no second set of registers)
+      double q_[NJ], dq_[NJ], ddq_[NJ];
+      {
+        const int64_t o = sample_offset(t_mine);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+        {
+          const int64_t oj = o + (int64_t)fa.in_map[j] * fa.in_sj;
+          q_[j] = fa.q[oj];
+          dq_[j] = fa.dq[oj];
+          ddq_[j] = fa.ddq[oj];
+        }
+      }
+      V3 w = mk(0, 0, 0), vl = mk(0, 0, 0), al = mk(0, 0, 0), lin = mk(-c->g[0], -c->g[1], -c->g[2]);
+      int64_t o_next = sample_offset(t_mine + t_step);
+      // sin and 1 - cos of all the tile's joint angles at once: NJ independent chains (one sincos per link leaves the wave waiting on
+      // its own results: measured 1 900 cycles per link against 600 of issue)
+      double sn_[NJ], oc_[NJ];
+      // (code size matters: three roles share the instruction cache -- the range-limited evaluation inline, ocml's for angles
+      // beyond 2^20 ONCE, in a cold rolled loop: same results as rdyn_sincos)
+      auto all_sincos = [&]() {
+        bool big = false;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+        {
+          double cs;
+          rdyn_sincos_small(q_[j], &sn_[j], &cs);
+          oc_[j] = 1.0 - cs;
+          big = big || !(fabs(q_[j]) <= 1048576.0);
+        }
+        if (__builtin_expect(big, 0))
+        {
+#pragma unroll 1
+          for (int j = 0; j < NJ; ++j)
+          {
+            double x = q_[0];
+#pragma unroll
+            for (int k = 1; k < NJ; ++k) x = (j == k) ? q_[k] : x;
+            if (!(fabs(x) <= 1048576.0))
+            {
+              double s1, c1;
+              sincos(x, &s1, &c1);
+#pragma unroll
+              for (int k = 0; k < NJ; ++k)
+                if (j == k)
+                {
+                  sn_[k] = s1;
+                  oc_[k] = 1.0 - c1;
+                }
+            }
+          }
+        }
+      };
+      all_sincos();
+      {
+        constexpr int g = 0;
+#include "rdyn_kin_link_body.inc"
+      }
+      DUO_BARRIER_LDS();  // prologue: link 0 of the first tile is published
+      for (int64_t it = 0; it < trips; ++it)
+      {
+        DUO_STAMP_TRIP(it);
+        // (o_next was the offset of THIS tile's successor while link 0 was consumed in the previous trip; links 1 .. NJ - 1 refill from it too)
+#pragma unroll
+        for (int f = 0; f < NJ; ++f)
+        {
+          if (f + 1 < NJ)
+          {
+            const int g = f + 1;
+#include "rdyn_kin_link_body.inc"
+          }
+          else
+            all_sincos();  // the NEXT tile's (q_[] holds its angles: every link refilled its joint's registers) -- behind the row waves' longest step
+          DUO_BARRIER_LDS();  // B_f: link f + 1 is published; the rows of link f are computed (their stores follow)
+        }
+        // the next tile: fresh state, its link 0 (buffer 0: the last reads of it are behind B_{NJ-1})
+        w = mk(0, 0, 0); vl = mk(0, 0, 0); al = mk(0, 0, 0); lin = mk(-c->g[0], -c->g[1], -c->g[2]);
+        o_next = sample_offset(t_mine + (it + 2) * t_step);
+        {
+          constexpr int g = 0;
+#include "rdyn_kin_link_body.inc"
+        }
+        DUO_BARRIER_LDS();  // the tile is complete
+      }
+    }
+    else
+    {
+      // ---- a row wave
+      const int ra = fa.sw_rows[3 * (wave - 1)], rb = fa.sw_rows[3 * (wave - 1) + 1], rc = fa.sw_rows[3 * (wave - 1) + 2];  // wave-uniform; RDYN_LANE_NO_ROW = none
+      const int64_t oba = ra < 8 ? (int64_t)fa.in_map[ra] * fa.in_sj : 0, obb = rb < 8 ? (int64_t)fa.in_map[rb] * fa.in_sj : 0,
+                    obc = rc < 8 ? (int64_t)fa.in_map[rc] * fa.in_sj : 0;
+      // measured torque of my rows; position and velocity of their joints (component columns only): one tile ahead
+      double nba = 0.0, nbb = 0.0, nbc = 0.0, nqa = 0.0, nqb = 0.0, nqc = 0.0, nda = 0.0, ndb = 0.0, ndc = 0.0;
+      auto fetch = [&](int64_t tile_index) {
+        const int64_t o = sample_offset(tile_index);
+        if (fa.bcol)
+        {
+          if (ra < 8) nba = fa.bcol[o + oba];
+          if (rb < 8) nbb = fa.bcol[o + obb];
+          if (rc < 8) nbc = fa.bcol[o + obc];
+        }
+        if (XB > 0 || fa.n_comps > 0)
+        {
+          if (ra < 8) { nqa = fa.q[o + oba]; nda = fa.dq[o + oba]; }
+          if (rb < 8) { nqb = fa.q[o + obb]; ndb = fa.dq[o + obb]; }
+          if (rc < 8) { nqc = fa.q[o + obc]; ndc = fa.dq[o + obc]; }
+        }
+      };
+      fetch(t_mine);
+      DUO_BARRIER();  // prologue
+      for (int64_t it = 0; it < trips; ++it)
+      {
+        DUO_STAMP_TRIP(it);
+        const int64_t tl = t_mine + it * t_step;
+        const bool valid = tl < n_tiles && tl * t_mul * 16 + s_loc < fa.n_samples;
+        const double tba = valid ? nba : 0.0, tbb = valid ? nbb : 0.0, tbc = valid ? nbc : 0.0;
+        const double qra = nqa, qrb = nqb, qrc = nqc, dqra = nda, dqrb = ndb, dqrc = ndc;
+        fetch(tl + t_step);  // in flight during this tile's sweep
+        V3 La = mk(0, 0, 0), Aa = mk(0, 0, 0), Lb = mk(0, 0, 0), Ab = mk(0, 0, 0), Lc = mk(0, 0, 0), Ac = mk(0, 0, 0);
+        int col_off = 0;  // byte offset of link f's first column in the sub-tile
+        // (a ROLLED link loop: nothing in it depends on f at compile time, and the three roles share the instruction cache)
+        // what the kinematics wave published for the link: requested right behind the barrier that releases it, IN FRONT of the
+        // stores of the previous link (the LDS serves a wave's requests in order)
+        double xv[XV];
+#pragma unroll
+        for (int k = 0; k < XV; ++k) xv[k] = xch[k * 64];
+#pragma unroll 1
+        for (int f = 0; f < NJ; ++f)
+        {
+          double R[9], b00, b01, b02, b10, b11, b12, b20, b21, b22;
+          V3 tt, w, al, d;
+          if constexpr (XV == 12)
+          {
+            asm volatile("" : "+s"(c));
+            JointRef J = c->j[f];
+            const double sn = xv[0], oc = xv[1], qp = xv[2];
+            w = mk(xv[3], xv[4], xv[5]);
+            al = mk(xv[6], xv[7], xv[8]);
+            d = mk(xv[9], xv[10], xv[11]);
+#pragma unroll
+            for (int i = 0; i < 9; ++i) R[i] = fma(sn, J.B[i], fma(oc, J.C[i], J.A[i]));
+            tt = ALLREV ? ld3(J.t) : axpy(ld3(J.t), ld3(J.up), qp);
+            const double wxy = w.x * w.y, wxz = w.x * w.z, wyz = w.y * w.z;
+            const double wxx = w.x * w.x, wyy = w.y * w.y, wzz = w.z * w.z;
+            b00 = -(wyy + wzz); b01 = wxy - al.z; b02 = wxz + al.y;
+            b10 = wxy + al.z; b11 = -(wxx + wzz); b12 = wyz - al.x;
+            b20 = wxz - al.y; b21 = wyz + al.x; b22 = -(wxx + wyy);
+          }
+          else
+          {
+#pragma unroll
+            for (int i = 0; i < 9; ++i) R[i] = xv[i];
+            tt = mk(xv[9], xv[10], xv[11]);
+            w = mk(xv[12], xv[13], xv[14]);
+            al = mk(xv[15], xv[16], xv[17]);
+            d = mk(xv[18], xv[19], xv[20]);
+            b00 = xv[21]; b01 = xv[22]; b02 = xv[23];
+            b10 = xv[24]; b11 = xv[25]; b12 = xv[26];
+            b20 = xv[27]; b21 = xv[28]; b22 = xv[29];
+          }
+          if (f > ra)  // (before its joint a row's unit twist is zero: nothing to carry)
+          {
+            const V3 nL = rotT(R, La + cross(Aa, tt));
+            Aa = rotT(R, Aa);
+            La = nL;
+          }
+          if (f > rb)
+          {
+            const V3 nL = rotT(R, Lb + cross(Ab, tt));
+            Ab = rotT(R, Ab);
+            Lb = nL;
+          }
+          if (f > rc)
+          {
+            const V3 nL = rotT(R, Lc + cross(Ac, tt));
+            Ac = rotT(R, Ac);
+            Lc = nL;
+          }
+          if (f == ra || f == rb || f == rc)
+          {
+            // the row of joint f starts here with the joint's own unit twist (zero for a sample beyond the batch: all its entries stay 0)
+            asm volatile("" : "+s"(c));
+            JointRef J = c->j[f];
+            const int type = J.type;
+            const bool rev = ALLREV || type == RDYN_REVOLUTE, pri = !ALLREV && type == RDYN_PRISMATIC;
+            const V3 u = ld3(J.u);
+            const V3 sl = mk((pri && valid) ? u.x : 0.0, (pri && valid) ? u.y : 0.0, (pri && valid) ? u.z : 0.0);
+            const V3 sa = mk((rev && valid) ? u.x : 0.0, (rev && valid) ? u.y : 0.0, (rev && valid) ? u.z : 0.0);
+            if (f == ra) { La = sl; Aa = sa; }
+            else if (f == rb) { Lb = sl; Ab = sa; }
+            else { Lc = sl; Ac = sa; }
+          }
+          auto row_y = [&](V3 L, V3 A, double (&y)[10]) {
+            const V3 dxA = cross(d, A), x = cross(A, w);
+            y[0] = dot(L, d);
+            y[1] = fma(L.x, b00, fma(L.y, b10, fma(L.z, b20, dxA.x)));
+            y[2] = fma(L.x, b01, fma(L.y, b11, fma(L.z, b21, dxA.y)));
+            y[3] = fma(L.x, b02, fma(L.y, b12, fma(L.z, b22, dxA.z)));
+            y[4] = fma(A.x, al.x, x.x * w.x);
+            y[5] = fma(A.x, al.y, fma(A.y, al.x, fma(x.x, w.y, x.y * w.x)));
+            y[6] = fma(A.x, al.z, fma(A.z, al.x, fma(x.x, w.z, x.z * w.x)));
+            y[7] = fma(A.y, al.y, x.y * w.y);
+            y[8] = fma(A.y, al.z, fma(A.z, al.y, fma(x.y, w.z, x.z * w.y)));
+            y[9] = fma(A.z, al.z, x.z * w.z);
+          };
+          double ya[10], yb[10], yc[10];
+          if (f >= ra) row_y(La, Aa, ya);
+          if (f >= rb) row_y(Lb, Ab, yb);
+          if (f >= rc) row_y(Lc, Ac, yc);
+          // B_f: the consumers have read row group f of the previous tile -- the columns of link f may be overwritten now -- and link
+          // f + 1 waits in the other exchange buffer (my reads of this one have returned: it is rewritten behind this barrier)
+          DUO_BARRIER_LDS();
+          if (f + 1 < NJ)
+          {
+            const double* const xi = xch + ((f + 1) & 1) * (XV * 64);
+#pragma unroll
+            for (int k = 0; k < XV; ++k) xv[k] = xi[k * 64];
+          }
+          const int stride = (16 * (f + 1) + KIN) * 8;
+          char* const lf = tile + col_off + s_loc * 8;
+          col_off += 10 * stride;
+          if (f >= ra)
+          {
+#pragma unroll
+            for (int p = 0; p < 10; ++p) *(double*)(lf + p * stride + ra * 128) = ya[p];
+          }
+          if (f >= rb)
+          {
+#pragma unroll
+            for (int p = 0; p < 10; ++p) *(double*)(lf + p * stride + rb * 128) = yb[p];
+          }
+          if (f >= rc)
+          {
+#pragma unroll
+            for (int p = 0; p < 10; ++p) *(double*)(lf + p * stride + rc * 128) = yc[p];
+          }
+          DUO_STAMP_HERE(0);  // (diagnostic builds) stores and exchange reads issued
+          DUO_STAMP_HERE(1);  // ... and completed
+        }
+        if (XB > 0 || fa.n_comps > 0)
+        {
+          // the consumers have read every row group of the previous tile by now (the last link's barrier is behind us): the component
+          // columns of my rows (friction_polynomial1.h:45-52, friction_polynomial2.h:42-58, ideal_spring.h:64-70)
+          int col = 0;
+          for (int ci = 0; ci < fa.n_comps; ++ci)
+          {
+            const int type = fa.comps[ci].type, jc = fa.comps[ci].joint;
+            const int cols = type == RDYN_COMP_FRICTION2 ? 3 : 2;
+            if (jc == ra || jc == rb || jc == rc)
+            {
+              const double qv = jc == ra ? qra : (jc == rb ? qrb : qrc), dv = jc == ra ? dqra : (jc == rb ? dqrb : dqrc);
+              double row[3] = {0.0, 0.0, 0.0};
+              if (type == RDYN_COMP_SPRING)
+              {
+                row[0] = qv;
+                row[1] = 1.0;
+              }
+              else
+              {
+                const double vmax = fa.comps[ci].max_velocity, vmin = fa.comps[ci].min_velocity;
+                const double omega = fmin(fmax(dv, -vmax), vmax);
+                double sg;
+                if (type == RDYN_COMP_FRICTION1)
+                  sg = fmin(fmax(omega / vmin, -1.0), 1.0);
+                else
+                  sg = (omega == 0.0) ? 0.0 : (omega > vmin ? 1.0 : (omega < -vmin ? -1.0 : omega / vmin));
+                row[0] = sg;
+                row[1] = omega;
+                row[2] = omega * omega * sg;
+              }
+              char* const lc = tile + fa.lds_off_c + col * fa.comp_stride + jc * fa.comp_row_step + s_loc * 8;
+              for (int e = 0; e < cols; ++e) *(double*)(lc + e * fa.comp_stride) = valid ? row[e] : 0.0;
+            }
+            col += cols;
+          }
+        }
+        {
+          char* const lb = tile + fa.lds_off_b + s_loc * 8;
+          if (ra < 8) *(double*)(lb + ra * 128) = tba;
+          if (rb < 8) *(double*)(lb + rb * 128) = tbb;
+          if (rc < 8) *(double*)(lb + rc * 128) = tbc;
+        }
+        DUO_BARRIER_LDS();  // the tile is complete
+      }
+    }
+  }
+  else if (sweeper)
   {
     // ================================================================ sweeper: 16 samples x 4 lanes, rows 2k, 2k + 1
     ChainPtr c = as_const(fa.chain);
@@ -251,8 +576,10 @@ __global__ __launch_bounds__(512) void k_regressor_gram_duo(const RdynLdsGramArg
     // scratch in the hot loop): ONE operand set there -- the next group's loads are issued behind this group's MFMAs instead of in front
     constexpr bool ONEBUF = NJ >= 7 && XB > 0;
     d4 opa[NB], opb[ONEBUF ? 1 : NB];
+    if (KIN) DUO_BARRIER();  // the prologue of the one-lane-per-sample sweepers (link 0 of the first tile is published)
     for (int64_t it = 0; it <= trips; ++it)
     {
+      DUO_STAMP_TRIP(it);
       // it > 0: the tile in LDS is complete (nothing to consume while the first tile is being swept): group 0
       const bool have = it > 0;
       if (have) lds_group(0, (KF + 10 * NJ) >> 4, opa);
@@ -317,7 +644,7 @@ __global__ __launch_bounds__(512) void k_regressor_gram_duo(const RdynLdsGramArg
   }
 }
 
-template <int NJ, bool DIRECT, int XB, bool ALLREV = false>
+template <int NJ, bool DIRECT, int XB, bool ALLREV = false, int KIN = 0>
 hipError_t launch_duo_nj2(const RdynLdsGramArgs& a, int blocks, size_t lds_bytes, hipStream_t st)
 {
   static std::atomic<uint64_t> attr_set{0};
@@ -327,11 +654,11 @@ hipError_t launch_duo_nj2(const RdynLdsGramArgs& a, int blocks, size_t lds_bytes
   const uint64_t bit = 1ull << (dev & 63);
   if (!(attr_set.load(std::memory_order_acquire) & bit))
   {
-    e = hipFuncSetAttribute((const void*)k_regressor_gram_duo<NJ, DIRECT, XB, ALLREV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    e = hipFuncSetAttribute((const void*)k_regressor_gram_duo<NJ, DIRECT, XB, ALLREV, KIN>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
     attr_set.fetch_or(bit, std::memory_order_release);
   }
-  hipLaunchKernelGGL((k_regressor_gram_duo<NJ, DIRECT, XB, ALLREV>), dim3(blocks), dim3(512), lds_bytes, st, a);
+  hipLaunchKernelGGL((k_regressor_gram_duo<NJ, DIRECT, XB, ALLREV, KIN>), dim3(blocks), dim3(512), lds_bytes, st, a);
   return hipGetLastError();
 }
 template <int NJ>
@@ -342,6 +669,22 @@ hipError_t launch_duo_nj(const RdynLdsGramArgs& a, int blocks, size_t lds_bytes,
   for (int f = 0; direct && f < NJ; ++f) direct = a.lds_m[f] == f + 1 && a.first_col[f] == 10 * f && a.lds_stride[f] == (16 * (f + 1) + 4) * 8;
   // component columns always take the XB = 1 instantiation (one more column block, the component columns in front of the order)
   const int xb = a.n_comp_cols > 0 ? 1 : 0;
+  if (a.sweep_lanes)
+  {
+    // one lane per sample: the link kinematics once per workgroup and 64 samples, the rows on three waves.  The exchange area sits
+    // behind the four tiles (the host sized lds_bytes for it); 7 joints: the compact tile layout (2 doubles of column padding).
+    bool compact = a.n_active == NJ;
+    for (int f = 0; compact && f < NJ; ++f) compact = a.lds_m[f] == f + 1 && a.first_col[f] == 10 * f && a.lds_stride[f] == (16 * (f + 1) + 2) * 8;
+    if constexpr (NJ <= 6)
+    {
+      if (direct && xb == 0) return a.all_revolute ? launch_duo_nj2<NJ, true, 0, true, 4>(a, blocks, lds_bytes, st) : launch_duo_nj2<NJ, true, 0, false, 4>(a, blocks, lds_bytes, st);
+      if constexpr (NJ >= 5)
+        if (direct && xb == 1) return a.all_revolute ? launch_duo_nj2<NJ, true, 1, true, 4>(a, blocks, lds_bytes, st) : launch_duo_nj2<NJ, true, 1, false, 4>(a, blocks, lds_bytes, st);
+    }
+    else if (compact && xb == 0)
+      return a.all_revolute ? launch_duo_nj2<NJ, true, 0, true, 2>(a, blocks, lds_bytes, st) : launch_duo_nj2<NJ, true, 0, false, 2>(a, blocks, lds_bytes, st);
+    return hipErrorInvalidValue;  // (the host asks for these sweepers only where they exist)
+  }
   if (xb == 0 && direct && a.all_revolute) return launch_duo_nj2<NJ, true, 0, true>(a, blocks, lds_bytes, st);
   if (xb == 0) return direct ? launch_duo_nj2<NJ, true, 0>(a, blocks, lds_bytes, st) : launch_duo_nj2<NJ, false, 0>(a, blocks, lds_bytes, st);
   if constexpr (NJ >= 5)  // identification with component columns: one extra column block, arms of 5-7 joints
@@ -354,6 +697,11 @@ hipError_t launch_duo_nj(const RdynLdsGramArgs& a, int blocks, size_t lds_bytes,
 }  // namespace
 
 bool rdyn_regressor_gram_duo_supported(int n_cols) { return n_cols >= 20 && n_cols <= 70; }
+int rdyn_regressor_gram_duo_kin_pad(int n_joints, int n_comp_cols)
+{
+  if (n_joints >= 2 && n_joints <= 6) return (n_comp_cols == 0 || n_joints >= 5) ? 4 : 0;
+  return (n_joints == 7 && n_comp_cols == 0) ? 2 : 0;
+}
 bool rdyn_regressor_gram_duo_supports_components(int n_cols, int n_comp_cols)
 {
   if (!rdyn_regressor_gram_duo_supported(n_cols) || n_comp_cols < 0 || n_comp_cols > 96) return false;

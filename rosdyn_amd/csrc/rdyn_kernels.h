@@ -191,6 +191,11 @@ struct RdynLdsGramArgs
   // the caller's input index behind tile row r (rdyn_chain.hpp: sorted view): q, Dq, DDq, tau_meas of row r are read at in_map[r] * in_sj;
   // the identity for input joints in chain order
   int in_map[8];
+  // one-lane-per-sample sweepers (rdyn_duo_gram.hip, KIN): sweep_lanes != 0 selects them (the host then sized the dynamic LDS for the
+  // exchange area behind the tiles, RDYN_KIN_XCH_BYTES); sw_rows[3 (w - 1) + slot] = the tile rows sweeper wave w = 1 .. 3 computes (99 =
+  // none), balanced over the waves by the cost of a row (a row of joint l is carried through the links l .. n - 1)
+  int sweep_lanes;
+  int sw_rows[9];
   int all_revolute;                    // every chain joint is revolute (selects the sweeper without joint-kind selects)
   int first_col[RDYN_MAX_SWEPT_JOINTS];      // per input joint: 10 * chain index
   int lds_off[RDYN_MAX_SWEPT_JOINTS];        // per link: byte offset of its first column in the tile
@@ -219,6 +224,9 @@ bool rdyn_regressor_gram_pipe_supported(int n_cols);
 hipError_t rdyn_launch_regressor_gram_pipe(int n_cols, const RdynLdsGramArgs& a, int blocks, size_t lds_bytes, hipStream_t st);
 // the two streams on two co-resident waves (rdyn_duo_gram.hip): chains of 2..7 joints, 512-thread workgroups
 bool rdyn_regressor_gram_duo_supported(int n_cols);
+#define RDYN_KIN_XCH_BYTES(n_joints) (2 * ((n_joints) <= 6 ? 30 : 12) * 64 * 8)
+// the one-lane-per-sample sweepers exist for this shape: 0 no, 4 / 2 = with the standard / the compact tile layout (column padding in doubles)
+int rdyn_regressor_gram_duo_kin_pad(int n_joints, int n_comp_cols);
 // n_cols = 10 * chain joints; a.n_comp_cols extra component columns may add at most one 16-column block
 bool rdyn_regressor_gram_duo_supports_components(int n_cols, int n_comp_cols);
 hipError_t rdyn_launch_regressor_gram_duo(int n_cols, const RdynLdsGramArgs& a, int blocks, size_t lds_bytes, hipStream_t st);

@@ -220,6 +220,20 @@ int main(int argc, char** argv)
         }
         std::printf("    stamps: sweeper cycles %.0f (in barriers %.0f = %.0f%%), consumer cycles %.0f (in barriers %.0f = %.0f%%)\n", tot[0][0] / 24, tot[0][1] / 24,
                     100 * tot[0][1] / tot[0][0], tot[1][0] / 24, tot[1][1] / 24, 100 * tot[1][1] / tot[1][0]);
+        {
+          std::vector<double> tlv(8 * 32);
+          CHECK(hipMemcpy(tlv.data(), (const double*)d_ws + (size_t)600 * 4096, sizeof(double) * tlv.size(), hipMemcpyDeviceToHost));
+          std::printf("    timeline of workgroup 0 (clock at entry / exit of each barrier of one trip, per wave):\n");
+          for (int w = 0; w < 8; ++w)
+          {
+            std::printf("      w%d", w);
+            for (int k = 0; k < 30; ++k) std::printf(" %7.0f", tlv[w * 32 + k] - tlv[0]);
+            std::printf("\n");
+          }
+        }
+        std::printf("    per wave of the last sampled workgroup [cycles, in barriers]:");
+        for (int w = 0; w < 8; ++w) std::printf("  w%d %.0f %.0f", w, st[2 * w], st[2 * w + 1]);
+        std::printf("\n");
       }
       std::printf("  %-44s %9.1f us   checksum %.17g %.17g\n", l.label.c_str(), ms * 1e3 / reps, sum, sq);
       std::fflush(stdout);
