@@ -254,14 +254,23 @@ def config4_library(n_dev, N, steps, warmup):
                          "frac": tf / (FP64_MATRIX_PEAK_TFLOPS * n_dev), "flop_per_eval_dense_syrk": f_eval}}
 
 
+def process_gone(pid):
+    """The process does not exist any more, or is a zombie (its GPU contexts are gone; the launcher has not reaped it yet)."""
+    try:
+        with open("/proc/%d/stat" % pid) as f:
+            return f.read().rsplit(")", 1)[1].split()[0] == "Z"
+    except (OSError, IndexError):
+        return True
+
+
 def wait_for_exit(pids, timeout_s):
-    """True once none of the processes `pids` exists any more (they are siblings, not children: /proc is polled)."""
+    """True once none of the processes `pids` runs any more (they are siblings, not children: /proc is polled)."""
     t_end = time.time() + timeout_s
     while time.time() < t_end:
-        if not any(os.path.exists("/proc/%d" % p) for p in pids):
+        if all(process_gone(p) for p in pids):
             return True
         time.sleep(0.05)
-    return not any(os.path.exists("/proc/%d" % p) for p in pids)
+    return all(process_gone(p) for p in pids)
 
 
 def config4_library_child(n_dev, N, steps, timeout_s=400, no_extras=False):

@@ -369,11 +369,19 @@ int rdyn_multi_gpu_device_count(const rdyn_multi_gpu* ctx);
 int rdyn_multi_gpu_synchronize(rdyn_multi_gpu* ctx);
 int rdyn_regressor_gram_multi(rdyn_multi_gpu* ctx, const rdyn_chain* chain, const rdyn_batch* batches, const double* const* tau_meas,
                               double* const* acc);
+/* The same with accumulate != 0: acc[i] <- acc[i] + the sums over all shards of THIS call (a batch streamed through the devices in
+ * pieces: the first piece with accumulate = 0, the others with 1; the accumulators hold the same totals on every device before and
+ * after).  One ncclAllReduce per call either way.  The per-device part of both calls is issued by one host thread per device. */
+int rdyn_regressor_gram_multi_accumulate(rdyn_multi_gpu* ctx, const rdyn_chain* chain, const rdyn_batch* batches, const double* const* tau_meas,
+                                         double* const* acc, int accumulate);
 /* The R factor WITHOUT the normal equations over the devices of the context (the TSQR alternative):
  * device i computes the robust factor of its shard (rdyn_identification_tsqr with all its routes; comps may be NULL / n_comps 0:
- * rdyn_regressor_tsqr), ONE ncclAllGather moves the n1 x n1 factors (the payload of the Gram all-reduce), and every device folds
- * the same stack in the same fixed order: on completion EVERY R1[i] (device i, n1 x n1 column-major, n1 = 10 joints_number + K + 1)
- * holds the factor of all shards, bitwise identical on all devices.  accumulate != 0: R1[i] <- factor of [previous R1[i] ; all shards].
+ * rdyn_regressor_tsqr), ONE ncclAllGather moves the factors of the SWEPT chain (the reduced companion of a chain with joints that are
+ * not input joints: at most 112 columns whatever the chain's own width -- the payload of the Gram all-reduce or less), every device
+ * folds the same stack in the same fixed order and expands the result: on completion EVERY R1[i] (device i, n1 x n1 column-major,
+ * n1 = 10 joints_number + K + 1) holds the factor of all shards, bitwise identical on all devices.  Every chain the single-device
+ * entry point serves is served.  If a collective fails half-way the communicators are aborted and the context only accepts
+ * rdyn_multi_gpu_destroy.  accumulate != 0: R1[i] <- factor of [previous R1[i] ; all shards].
  * Asynchronous like rdyn_regressor_gram_multi.  Both calls end by making batches[i].stream WAIT (on the device, by an event) for the
  * collective: work queued on the caller's stream afterwards sees the results; a host-side read still needs a synchronisation
  * (rdyn_multi_gpu_synchronize, or of that stream). */

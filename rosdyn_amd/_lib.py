@@ -108,6 +108,7 @@ SYMBOLS = {
     "rdyn_multi_gpu_device_count": (_I, [_VP]),
     "rdyn_multi_gpu_synchronize": (_I, [_VP]),
     "rdyn_regressor_gram_multi": (_I, [_VP, _VP, _BP, C.POINTER(_VP), C.POINTER(_VP)]),
+    "rdyn_regressor_gram_multi_accumulate": (_I, [_VP, _VP, _BP, C.POINTER(_VP), C.POINTER(_VP), _I]),
     "rdyn_identification_tsqr_multi": (_I, [_VP, _VP, _VP, _I, _BP, C.POINTER(_VP), C.POINTER(_VP), _I]),
     "rdyn_regressor_tsqr_multi": (_I, [_VP, _VP, _BP, C.POINTER(_VP), C.POINTER(_VP), _I]),
     "rdyn_tsqr_workspace_bytes": (C.c_size_t, [_I]),

@@ -1640,8 +1640,10 @@ static bool tsqr_plan(const rdyn_chain* c, const rdyn_component* comps, int n_co
   return true;
 }
 
+// swept_only: stop at the factor of the SWEPT chain (n1s x n1s into R, no expansion, no accumulation): the multi-device form gathers
+// and folds these -- the smaller payload, and no limit on the width of the expanded factor -- and expands once per device
 static int regressor_tsqr_run(const rdyn_chain* c, const rdyn_component* comps, int n_comps, const rdyn_batch* b, const double* tau_meas, double* R,
-                              int accumulate, void* workspace, size_t workspace_bytes, const char* who)
+                              int accumulate, void* workspace, size_t workspace_bytes, const char* who, bool swept_only = false)
 {
   int st = check_batch(c, b, true, true, who, LONG_COMPANION);
   if (st != RDYN_OK) return st;
@@ -1657,7 +1659,8 @@ static int regressor_tsqr_run(const rdyn_chain* c, const rdyn_component* comps, 
     return RDYN_ERR_UNSUPPORTED;
   }
   const rdyn_chain* cs = p.cs;  // chains with fixed joints: the reduced companion is swept, the factor expanded
-  const bool expand = p.expand;
+  const bool expand = p.expand && !swept_only;
+  if (swept_only) accumulate = 0;
   const int n = p.n, nJ = p.nJ, K = p.K, n1s = p.n1s, n1 = p.n1;
   const TsqrLayout& L = p.L;
   if (workspace_bytes < L.total_doubles * sizeof(double))
@@ -1681,7 +1684,7 @@ static int regressor_tsqr_run(const rdyn_chain* c, const rdyn_component* comps, 
   hipStream_t stream = (hipStream_t)b->stream;
   if (b->n_samples == 0)
   {
-    if (!accumulate) RDYN_HIP_TRY(hipMemsetAsync(R, 0, sizeof(double) * n1 * n1, stream));
+    if (!accumulate) RDYN_HIP_TRY(hipMemsetAsync(R, 0, sizeof(double) * (swept_only ? (size_t)n1s * n1s : (size_t)n1 * n1), stream));
     return RDYN_OK;
   }
   auto bind = [&](RdynLdsGramArgs& la) {
@@ -1808,6 +1811,45 @@ static int regressor_tsqr_run(const rdyn_chain* c, const rdyn_component* comps, 
   }
   return RDYN_OK;
 }
+
+}  // extern "C"
+// ---- the pieces of a factor call the multi-device form (rdyn_multi_gpu.cpp) needs separately (C++ linkage, not exported)
+__attribute__((visibility("hidden"))) int rdyn_internal_tsqr_widths(const rdyn_chain* c, const rdyn_component* comps, int n_comps, int* n1s, int* n1, int* expands)
+{
+  TsqrPlan p;
+  if (!c || !tsqr_plan(c, comps, n_comps, &p)) return RDYN_ERR_UNSUPPORTED;
+  *n1s = p.n1s;
+  *n1 = p.n1;
+  *expands = p.expand ? 1 : 0;
+  return RDYN_OK;
+}
+__attribute__((visibility("hidden"))) int rdyn_internal_tsqr_swept(const rdyn_chain* c, const rdyn_component* comps, int n_comps, const rdyn_batch* b,
+                                                                   const double* tau_meas, double* R_swept, void* workspace, size_t workspace_bytes)
+{
+  return regressor_tsqr_run(c, comps, n_comps, b, tau_meas, R_swept, 0, workspace, workspace_bytes, "rdyn_identification_tsqr_multi", true);
+}
+// R <- (accumulate ? qr([R ; .]) : .) of  R_swept diag(E, I_K, 1);  scratch: n1 x n1 doubles (used when accumulating); current device
+__attribute__((visibility("hidden"))) int rdyn_internal_tsqr_expand(const rdyn_chain* c, const rdyn_component* comps, int n_comps, const double* R_swept,
+                                                                    double* R, int accumulate, double* scratch, void* stream_v)
+{
+  TsqrPlan p;
+  if (!tsqr_plan(c, comps, n_comps, &p) || !p.expand) return RDYN_ERR_UNSUPPORTED;
+  hipStream_t stream = (hipStream_t)stream_v;
+  RdynGramExpandArgs ea;
+  memset(&ea, 0, sizeof ea);
+  int st = device_expand(c, &ea.X);
+  if (st != RDYN_OK) return st;
+  for (int f = 0; f < c->n_joints(); ++f) ea.red_of[f] = c->red_of[f];
+  ea.n_joints = c->n_joints();
+  ea.n_red = p.nJ;
+  ea.n_comp_cols = p.K;
+  double* const R_exp = accumulate ? scratch : R;
+  RDYN_HIP_TRY(rdyn_launch_cholqr_expand(ea, R_swept, R_exp, stream));
+  if (accumulate) RDYN_HIP_TRY(rdyn_launch_cholqr_fold(R_exp, R, p.n1, stream, p.n1s));
+  return RDYN_OK;
+}
+extern "C"
+{
 
 size_t rdyn_regressor_tsqr_workspace_bytes(const rdyn_chain* c)
 {

@@ -1543,6 +1543,11 @@ __global__ __launch_bounds__(NTD) void k_cholqr_fold(const double* __restrict__ 
       const int i = e % n1, j = e / n1;
       R[e] = i <= j ? A[j * (j + 1) / 2 + i] : 0.0;
     }
+  else
+    // the caller's matrix was updated in place: whatever it held below the diagonal is not part of the factor (the LDS variant
+    // writes zeros there too)
+    for (int e = tid; e < n1 * n1; e += NTD)
+      if (e % n1 > e / n1) R[e] = 0.0;
 }
 
 template <class K>

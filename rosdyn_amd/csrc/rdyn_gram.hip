@@ -291,6 +291,21 @@ hipError_t rdyn_launch_gram_expand(const RdynGramExpandArgs& a, hipStream_t st)
   return hipGetLastError();
 }
 
+namespace
+{
+__global__ __launch_bounds__(256) void k_add_doubles(double* __restrict__ y, const double* __restrict__ x, int64_t n)
+{
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) y[i] += x[i];
+}
+}  // namespace
+hipError_t rdyn_launch_add_doubles(double* y, const double* x, int64_t n, hipStream_t st)
+{
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_add_doubles, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, y, x, n);
+  return hipGetLastError();
+}
+
 hipError_t rdyn_launch_set_double(double* p, double v, hipStream_t st)
 {
   hipLaunchKernelGGL(k_set_double, dim3(1), dim3(1), 0, st, p, v);

@@ -300,6 +300,16 @@ struct RdynComponentArgs
 };
 hipError_t rdyn_launch_components(const RdynComponentArgs& a, hipStream_t st);
 
+// pieces of rdyn_identification_tsqr for the multi-device form (rdyn_api.cpp): widths of the swept / the chain's factor, the factor of
+// the swept chain alone, the expansion (+ accumulation) of a swept factor
+int rdyn_internal_tsqr_widths(const rdyn_chain* c, const rdyn_component* comps, int n_comps, int* n1s, int* n1, int* expands);
+int rdyn_internal_tsqr_swept(const rdyn_chain* c, const rdyn_component* comps, int n_comps, const rdyn_batch* b, const double* tau_meas, double* R_swept,
+                             void* workspace, size_t workspace_bytes);
+int rdyn_internal_tsqr_expand(const rdyn_chain* c, const rdyn_component* comps, int n_comps, const double* R_swept, double* R, int accumulate,
+                              double* scratch, void* stream);
+// y[i] += x[i], i < n, ordered on the stream (rdyn_gram.hip)
+hipError_t rdyn_launch_add_doubles(double* y, const double* x, int64_t n, hipStream_t st);
+
 enum { RDYN_MODE_REGRESSOR = 0, RDYN_MODE_TORQUE = 1, RDYN_MODE_INERTIA = 2, RDYN_MODE_REGRESSOR_GRAM = 3, RDYN_MODE_REGRESSOR_EXPAND = 4,
        RDYN_MODE_REGRESSOR_EXPAND_STAGED = 5 };
 

@@ -18,7 +18,10 @@
 #include <dlfcn.h>
 #include <cstring>
 #include <memory>
+#include <functional>
 #include <mutex>
+#include <string>
+#include <thread>
 #include <vector>
 
 #include <hip/hip_runtime.h>
@@ -38,6 +41,7 @@ struct Rccl
   void* handle = nullptr;
   ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;  // optional
   ncclResult_t (*AllReduce)(const void*, void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*AllGather)(const void*, void*, size_t, int, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*GroupStart)() = nullptr;
@@ -63,6 +67,7 @@ int load_rccl()
   r.handle = h;
   r.CommInitAll = (decltype(r.CommInitAll))dlsym(h, "ncclCommInitAll");
   r.CommDestroy = (decltype(r.CommDestroy))dlsym(h, "ncclCommDestroy");
+  r.CommAbort = (decltype(r.CommAbort))dlsym(h, "ncclCommAbort");
   r.AllReduce = (decltype(r.AllReduce))dlsym(h, "ncclAllReduce");
   r.AllGather = (decltype(r.AllGather))dlsym(h, "ncclAllGather");
   r.GroupStart = (decltype(r.GroupStart))dlsym(h, "ncclGroupStart");
@@ -109,6 +114,7 @@ struct rdyn_multi_gpu
   std::vector<size_t> workspace_bytes;
   std::vector<hipEvent_t> events;  // per device: orders the context's stream behind the caller's stream (batches[i].stream)
   std::vector<hipEvent_t> done;    // per device: orders the caller's stream behind the collective
+  bool broken = false;             // a collective failed half-way: the communicators were aborted, the context only waits to be destroyed
   ~rdyn_multi_gpu()
   {
     int prev = 0;
@@ -117,7 +123,7 @@ struct rdyn_multi_gpu
     {
       if (hipSetDevice(devices[i]) != hipSuccess) continue;
       if (i < streams.size() && streams[i]) (void)hipStreamSynchronize(streams[i]);
-      if (i < comms.size() && comms[i] && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(comms[i]);
+      if (!broken && i < comms.size() && comms[i] && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(comms[i]);
       if (i < workspaces.size() && workspaces[i]) (void)hipFree(workspaces[i]);
       if (i < streams.size() && streams[i]) (void)hipStreamDestroy(streams[i]);
       if (i < events.size() && events[i]) (void)hipEventDestroy(events[i]);
@@ -136,6 +142,62 @@ static int order_callers_behind(rdyn_multi_gpu* ctx, const rdyn_batch* batches)
     RDYN_HIP_TRY2(hipEventRecord(ctx->done[i], ctx->streams[i]));
     RDYN_HIP_TRY2(hipStreamWaitEvent((hipStream_t)batches[i].stream, ctx->done[i], 0));
   }
+  return RDYN_OK;
+}
+
+// The per-device part of a call (a dozen launches each) is ISSUED by one host thread per device: queued from one thread in sequence,
+// device 7 of 8 would start ~0.5 ms after device 0, as long as the kernels themselves take.  fn(i) runs with device i current and
+// returns an rdyn_status; the first failure's status and message (thread-local in the workers) come back to the caller's thread.
+static int for_each_device(rdyn_multi_gpu* ctx, const std::function<int(int)>& fn)
+{
+  const int n_dev = (int)ctx->devices.size();
+  std::vector<int> status(n_dev, RDYN_OK);
+  std::vector<std::string> message(n_dev);
+  auto body = [&](int i) {
+    if (hipSetDevice(ctx->devices[i]) != hipSuccess)
+    {
+      status[i] = RDYN_ERR_NO_DEVICE;
+      message[i] = "hipSetDevice failed";
+      return;
+    }
+    status[i] = fn(i);
+    if (status[i] != RDYN_OK) message[i] = rdyn_last_error();
+  };
+  std::vector<std::thread> workers;
+  for (int i = 1; i < n_dev; ++i) workers.emplace_back(body, i);
+  body(0);
+  for (auto& t : workers) t.join();
+  for (int i = 0; i < n_dev; ++i)
+    if (status[i] != RDYN_OK)
+    {
+      rdyn_set_error("%s", message[i].c_str());
+      return status[i];
+    }
+  return RDYN_OK;
+}
+
+// a collective that failed inside a group: closing the group could wait for ever for the calls that were never made -- the
+// communicators are aborted instead and the context refuses further work
+static int abort_collective(rdyn_multi_gpu* ctx, ncclResult_t r, const char* what, int device)
+{
+  rdyn_set_error("RCCL error: %s (%s on device %d); the communicators were aborted: destroy the context", g_rccl.GetErrorString(r), what, device);
+  if (g_rccl.CommAbort)
+    for (auto& cm : ctx->comms)
+      if (cm) (void)g_rccl.CommAbort(cm);
+  ctx->broken = true;
+  return RDYN_ERR_HIP;
+}
+
+// grows the per-device workspace; whatever is queued on the context's stream has finished with the old one first
+static int ensure_workspace(rdyn_multi_gpu* ctx, int i, size_t need)
+{
+  if (ctx->workspace_bytes[i] >= need) return RDYN_OK;
+  RDYN_HIP_TRY2(hipStreamSynchronize(ctx->streams[i]));
+  if (ctx->workspaces[i]) RDYN_HIP_TRY2(hipFree(ctx->workspaces[i]));
+  ctx->workspaces[i] = nullptr;
+  ctx->workspace_bytes[i] = 0;
+  RDYN_HIP_TRY2(hipMalloc(&ctx->workspaces[i], need));
+  ctx->workspace_bytes[i] = need;
   return RDYN_OK;
 }
 
@@ -223,24 +285,43 @@ int rdyn_multi_gpu_synchronize(rdyn_multi_gpu* ctx)
   return RDYN_OK;
 }
 
-int rdyn_regressor_gram_multi(rdyn_multi_gpu* ctx, const rdyn_chain* chain, const rdyn_batch* batches, const double* const* tau_meas,
-                              double* const* acc)
+int rdyn_regressor_gram_multi_accumulate(rdyn_multi_gpu* ctx, const rdyn_chain* chain, const rdyn_batch* batches, const double* const* tau_meas,
+                                         double* const* acc, int accumulate)
 {
   if (!ctx || !chain || !batches || !acc)
   {
     rdyn_set_error("rdyn_regressor_gram_multi: null argument");
     return RDYN_ERR_INVALID_ARGUMENT;
   }
+  if (ctx->broken)
+  {
+    rdyn_set_error("rdyn_regressor_gram_multi: a collective of this context failed; destroy it");
+    return RDYN_ERR_HIP;
+  }
   const int n_dev = (int)ctx->devices.size();
   const int P = 10 * chain->n_joints();
+  const size_t count = (size_t)P * P + P + 2;
+  // ---- everything that can be refused is checked before anything is queued
   for (int i = 0; i < n_dev; ++i)
   {
-    if (!acc[i] || (batches[i].device >= 0 && batches[i].device != ctx->devices[i]))
+    if (!acc[i] || (batches[i].device >= 0 && batches[i].device != ctx->devices[i]) || batches[i].n_samples < 0 ||
+        (batches[i].n_samples > 0 && (!batches[i].q || !batches[i].dq || !batches[i].ddq)) ||
+        (batches[i].layout != RDYN_LAYOUT_SAMPLE_MAJOR && batches[i].layout != RDYN_LAYOUT_ELEMENT_MAJOR))
     {
-      rdyn_set_error("rdyn_regressor_gram_multi: shard %d: null accumulator, or batch.device differs from the context's device %d", i, ctx->devices[i]);
+      rdyn_set_error("rdyn_regressor_gram_multi: shard %d: null accumulator or inputs, or batch.device differs from the context's device %d", i,
+                     ctx->devices[i]);
       return RDYN_ERR_INVALID_ARGUMENT;
     }
   }
+  const size_t ws_gram = rdyn_regressor_gram_workspace_bytes(chain, 0);
+  if (ws_gram == 0)
+  {
+    rdyn_set_error("rdyn_regressor_gram_multi: the normal-equation entry points do not serve this chain (at most 111 columns after the reduction)");
+    return RDYN_ERR_UNSUPPORTED;
+  }
+  // accumulate: the shard sums go to a buffer behind the Gram workspace, are all-reduced there and added to acc[i] (the caller's
+  // accumulators hold the same totals on every device before and after)
+  const size_t off_tmp = (ws_gram + 255) & ~(size_t)255, need = off_tmp + (accumulate ? count * sizeof(double) : 0);
   int prev = 0;
   RDYN_HIP_TRY2(hipGetDevice(&prev));
   struct Restore
@@ -248,24 +329,10 @@ int rdyn_regressor_gram_multi(rdyn_multi_gpu* ctx, const rdyn_chain* chain, cons
     int d;
     ~Restore() { (void)hipSetDevice(d); }
   } restore{prev};
-  // ---- every device: normal equations of its shard into acc[i] = [G (P*P) | c (P) | bb (1) | count (1)], on its own stream
-  for (int i = 0; i < n_dev; ++i)
-  {
-    RDYN_HIP_TRY2(hipSetDevice(ctx->devices[i]));
-    const size_t need = rdyn_regressor_gram_workspace_bytes(chain, 0);
-    if (need == 0)
-    {
-      rdyn_set_error("rdyn_regressor_gram_multi: at most 111 regressor columns are supported");
-      return RDYN_ERR_UNSUPPORTED;
-    }
-    if (ctx->workspace_bytes[i] < need)
-    {
-      if (ctx->workspaces[i]) RDYN_HIP_TRY2(hipFree(ctx->workspaces[i]));
-      ctx->workspaces[i] = nullptr;
-      ctx->workspace_bytes[i] = 0;
-      RDYN_HIP_TRY2(hipMalloc(&ctx->workspaces[i], need));
-      ctx->workspace_bytes[i] = need;
-    }
+  // ---- every device: normal equations of its shard, on its own stream, issued by its own host thread
+  int st = for_each_device(ctx, [&](int i) -> int {
+    int s = ensure_workspace(ctx, i, need);
+    if (s != RDYN_OK) return s;
     // the context's stream is non-blocking: order it behind whatever the caller has queued on batches[i].stream (NULL = the device's
     // default stream) -- the inputs and acc[i] may still be in production there
     RDYN_HIP_TRY2(hipEventRecord(ctx->events[i], (hipStream_t)batches[i].stream));
@@ -273,28 +340,37 @@ int rdyn_regressor_gram_multi(rdyn_multi_gpu* ctx, const rdyn_chain* chain, cons
     rdyn_batch b = batches[i];
     b.device = ctx->devices[i];
     b.stream = ctx->streams[i];
-    double* a = acc[i];
-    int st = rdyn_regressor_gram(chain, &b, tau_meas ? tau_meas[i] : nullptr, a, a + (size_t)P * P, a + (size_t)P * P + P, 0, 0, ctx->workspaces[i],
-                                 ctx->workspace_bytes[i]);
-    if (st != RDYN_OK) return st;
+    double* const a = accumulate ? (double*)((char*)ctx->workspaces[i] + off_tmp) : acc[i];
+    s = rdyn_regressor_gram(chain, &b, tau_meas ? tau_meas[i] : nullptr, a, a + (size_t)P * P, a + (size_t)P * P + P, 0, 0, ctx->workspaces[i], ws_gram);
+    if (s != RDYN_OK) return s;
     // the shard size travels as a KERNEL ARGUMENT (a pinned host word re-used by the next asynchronous call could be overwritten
     // before this call's copy has run)
     RDYN_HIP_TRY2(rdyn_launch_set_double(a + (size_t)P * P + P + 1, (double)b.n_samples, ctx->streams[i]));
-  }
+    return RDYN_OK;
+  });
+  if (st != RDYN_OK) return st;
   // ---- ONE all-reduce of the accumulators (in place), all devices inside one group
   RDYN_NCCL_TRY(g_rccl.GroupStart());
   for (int i = 0; i < n_dev; ++i)
   {
-    ncclResult_t r = g_rccl.AllReduce(acc[i], acc[i], (size_t)P * P + P + 2, kNcclDouble, kNcclSum, ctx->comms[i], ctx->streams[i]);
-    if (r != kNcclSuccess)
-    {
-      (void)g_rccl.GroupEnd();
-      rdyn_set_error("RCCL error: %s (ncclAllReduce on device %d)", g_rccl.GetErrorString(r), ctx->devices[i]);
-      return RDYN_ERR_HIP;
-    }
+    double* const a = accumulate ? (double*)((char*)ctx->workspaces[i] + off_tmp) : acc[i];
+    ncclResult_t r = g_rccl.AllReduce(a, a, count, kNcclDouble, kNcclSum, ctx->comms[i], ctx->streams[i]);
+    if (r != kNcclSuccess) return abort_collective(ctx, r, "ncclAllReduce", ctx->devices[i]);
   }
   RDYN_NCCL_TRY(g_rccl.GroupEnd());
+  if (accumulate)
+    for (int i = 0; i < n_dev; ++i)
+    {
+      RDYN_HIP_TRY2(hipSetDevice(ctx->devices[i]));
+      RDYN_HIP_TRY2(rdyn_launch_add_doubles(acc[i], (const double*)((char*)ctx->workspaces[i] + off_tmp), (int64_t)count, ctx->streams[i]));
+    }
   return order_callers_behind(ctx, batches);
+}
+
+int rdyn_regressor_gram_multi(rdyn_multi_gpu* ctx, const rdyn_chain* chain, const rdyn_batch* batches, const double* const* tau_meas,
+                              double* const* acc)
+{
+  return rdyn_regressor_gram_multi_accumulate(ctx, chain, batches, tau_meas, acc, 0);
 }
 
 int rdyn_identification_tsqr_multi(rdyn_multi_gpu* ctx, const rdyn_chain* chain, const rdyn_component* comps, int n_comps, const rdyn_batch* batches,
@@ -305,25 +381,29 @@ int rdyn_identification_tsqr_multi(rdyn_multi_gpu* ctx, const rdyn_chain* chain,
     rdyn_set_error("rdyn_identification_tsqr_multi: null argument");
     return RDYN_ERR_INVALID_ARGUMENT;
   }
+  if (ctx->broken)
+  {
+    rdyn_set_error("rdyn_identification_tsqr_multi: a collective of this context failed; destroy it");
+    return RDYN_ERR_HIP;
+  }
   const int n_dev = (int)ctx->devices.size();
-  const int K = n_comps > 0 ? rdyn_components_columns(comps, n_comps) : 0;
   const size_t ws_factor = rdyn_identification_tsqr_workspace_bytes(chain, comps, n_comps);
-  if (K < 0 || ws_factor == 0)
+  // n1s: width of the factor of the SWEPT chain (the reduced companion of a chain with non-input joints): that is what is gathered and
+  // folded -- at most 112 columns by construction, whatever the width n1 of the chain's own factor -- and expanded once per device
+  int n1s = 0, n1 = 0, expands = 0;
+  if (ws_factor == 0 || rdyn_internal_tsqr_widths(chain, comps, n_comps, &n1s, &n1, &expands) != RDYN_OK || n1s > rdyn_tsqr_wide_max_cols())
   {
     rdyn_set_error("rdyn_identification_tsqr_multi: the factor entry points do not serve this chain / these components");
     return RDYN_ERR_UNSUPPORTED;
   }
-  const int n1 = 10 * chain->n_joints() + K + 1;
-  if (n1 > rdyn_tsqr_wide_max_cols())
-  {
-    rdyn_set_error("rdyn_identification_tsqr_multi: at most %d columns (the fold of the gathered factors)", rdyn_tsqr_wide_max_cols());
-    return RDYN_ERR_UNSUPPORTED;
-  }
   for (int i = 0; i < n_dev; ++i)
   {
-    if (!R1[i] || (batches[i].device >= 0 && batches[i].device != ctx->devices[i]))
+    if (!R1[i] || (batches[i].device >= 0 && batches[i].device != ctx->devices[i]) || batches[i].n_samples < 0 ||
+        (batches[i].n_samples > 0 && (!batches[i].q || !batches[i].dq || !batches[i].ddq)) ||
+        (batches[i].layout != RDYN_LAYOUT_SAMPLE_MAJOR && batches[i].layout != RDYN_LAYOUT_ELEMENT_MAJOR))
     {
-      rdyn_set_error("rdyn_identification_tsqr_multi: shard %d: null factor, or batch.device differs from the context's device %d", i, ctx->devices[i]);
+      rdyn_set_error("rdyn_identification_tsqr_multi: shard %d: null factor or inputs, or batch.device differs from the context's device %d", i,
+                     ctx->devices[i]);
       return RDYN_ERR_INVALID_ARGUMENT;
     }
   }
@@ -334,54 +414,43 @@ int rdyn_identification_tsqr_multi(rdyn_multi_gpu* ctx, const rdyn_chain* chain,
     int d;
     ~Restore() { (void)hipSetDevice(d); }
   } restore{prev};
-  // workspace of a device: [the factor call's | own factor n1^2 | gathered factors n_dev n1^2 | the fold's tree levels]
-  const size_t f_bytes = (((size_t)n1 * n1 * sizeof(double)) + 255) & ~(size_t)255;
+  // workspace of a device: [the factor call's | own swept factor n1s^2 | gathered factors n_dev n1s^2 | the fold's tree levels |
+  //                         the folded swept factor n1s^2 | the expanded factor n1^2 (accumulating calls)]
+  const size_t f_bytes = (((size_t)n1s * n1s * sizeof(double)) + 255) & ~(size_t)255, e_bytes = (((size_t)n1 * n1 * sizeof(double)) + 255) & ~(size_t)255;
   const size_t off_own = (ws_factor + 255) & ~(size_t)255, off_gather = off_own + f_bytes, off_tree = off_gather + (size_t)n_dev * f_bytes;
-  const size_t need = off_tree + rdyn_tsqr_wide_workspace_doubles(n1, n_dev) * sizeof(double);
-  for (int i = 0; i < n_dev; ++i)
-  {
-    RDYN_HIP_TRY2(hipSetDevice(ctx->devices[i]));
-    if (ctx->workspace_bytes[i] < need)
-    {
-      // (a larger workspace replaces the old one only after what is queued on the context's stream has finished with it)
-      RDYN_HIP_TRY2(hipStreamSynchronize(ctx->streams[i]));
-      if (ctx->workspaces[i]) RDYN_HIP_TRY2(hipFree(ctx->workspaces[i]));
-      ctx->workspaces[i] = nullptr;
-      ctx->workspace_bytes[i] = 0;
-      RDYN_HIP_TRY2(hipMalloc(&ctx->workspaces[i], need));
-      ctx->workspace_bytes[i] = need;
-    }
+  const size_t off_fold = (off_tree + rdyn_tsqr_wide_workspace_doubles(n1s, n_dev) * sizeof(double) + 255) & ~(size_t)255;
+  const size_t off_exp = off_fold + f_bytes, need = off_exp + (expands ? e_bytes : 0);
+  int st = for_each_device(ctx, [&](int i) -> int {
+    int s = ensure_workspace(ctx, i, need);
+    if (s != RDYN_OK) return s;
     RDYN_HIP_TRY2(hipEventRecord(ctx->events[i], (hipStream_t)batches[i].stream));
     RDYN_HIP_TRY2(hipStreamWaitEvent(ctx->streams[i], ctx->events[i], 0));
     rdyn_batch b = batches[i];
     b.device = ctx->devices[i];
     b.stream = ctx->streams[i];
     char* const ws = (char*)ctx->workspaces[i];
-    int st = rdyn_identification_tsqr(chain, comps, n_comps, &b, tau_meas ? tau_meas[i] : nullptr, (double*)(ws + off_own), 0, ws, ws_factor);
-    if (st != RDYN_OK) return st;
-  }
-  // ---- ONE all-gather of the factors (n1 x n1 doubles each: the payload of the Gram all-reduce), all devices inside one group
+    return rdyn_internal_tsqr_swept(chain, comps, n_comps, &b, tau_meas ? tau_meas[i] : nullptr, (double*)(ws + off_own), ws, ws_factor);
+  });
+  if (st != RDYN_OK) return st;
+  // ---- ONE all-gather of the factors (n1s x n1s doubles each: the payload of the Gram all-reduce), all devices inside one group
   RDYN_NCCL_TRY(g_rccl.GroupStart());
   for (int i = 0; i < n_dev; ++i)
   {
     char* const ws = (char*)ctx->workspaces[i];
     ncclResult_t r = g_rccl.AllGather(ws + off_own, ws + off_gather, f_bytes / sizeof(double), kNcclDouble, ctx->comms[i], ctx->streams[i]);
-    if (r != kNcclSuccess)
-    {
-      (void)g_rccl.GroupEnd();
-      rdyn_set_error("RCCL error: %s (ncclAllGather on device %d)", g_rccl.GetErrorString(r), ctx->devices[i]);
-      return RDYN_ERR_HIP;
-    }
+    if (r != kNcclSuccess) return abort_collective(ctx, r, "ncclAllGather", ctx->devices[i]);
   }
   RDYN_NCCL_TRY(g_rccl.GroupEnd());
-  // ---- every device folds the same stack in the same order: identical bits everywhere
-  for (int i = 0; i < n_dev; ++i)
-  {
-    RDYN_HIP_TRY2(hipSetDevice(ctx->devices[i]));
+  // ---- every device folds the same stack in the same order, then expands: identical bits everywhere
+  st = for_each_device(ctx, [&](int i) -> int {
     char* const ws = (char*)ctx->workspaces[i];
-    RDYN_HIP_TRY2(rdyn_launch_tsqr_fold_factors((const double*)(ws + off_gather), n_dev, (int64_t)(f_bytes / sizeof(double)), n1, (double*)(ws + off_tree), R1[i],
-                                                accumulate ? 1 : 0, ctx->streams[i]));
-  }
+    double* const folded = expands ? (double*)(ws + off_fold) : R1[i];
+    RDYN_HIP_TRY2(rdyn_launch_tsqr_fold_factors((const double*)(ws + off_gather), n_dev, (int64_t)(f_bytes / sizeof(double)), n1s, (double*)(ws + off_tree),
+                                                folded, (!expands && accumulate) ? 1 : 0, ctx->streams[i]));
+    if (expands) return rdyn_internal_tsqr_expand(chain, comps, n_comps, folded, R1[i], accumulate ? 1 : 0, (double*)(ws + off_exp), ctx->streams[i]);
+    return RDYN_OK;
+  });
+  if (st != RDYN_OK) return st;
   return order_callers_behind(ctx, batches);
 }
 

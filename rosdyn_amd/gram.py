@@ -247,9 +247,10 @@ class MultiGpuGram(object):
             lib().rdyn_multi_gpu_destroy(h)
             self._h = None
 
-    def regressor_gram(self, chain, shards, layout="sample", acc=None, sync=True):
+    def regressor_gram(self, chain, shards, layout="sample", acc=None, sync=True, accumulate=False):
         """shards[i] = (q, Dq, DDq, tau_meas) float64 CUDA tensors on devices[i].  Returns the list of per-device accumulators
-        (P*P + P + 2,) (acc= re-uses the caller's): once the context is synchronised every one holds the sums over all shards.
+        (P*P + P + 2,) (acc= re-uses the caller's): once the context is synchronised every one holds the sums over all shards
+        (accumulate=True: added to what acc held -- a batch streamed through the devices in pieces).
         The library orders its streams behind torch's current stream of every device; sync=False returns without waiting
         (call synchronize() before reading)."""
         import torch
@@ -276,7 +277,8 @@ class MultiGpuGram(object):
             assert a.is_cuda and a.device.index == self.devices[i] and a.dtype == torch.float64 and a.numel() == P * P + P + 2 and a.is_contiguous()
             accs[i] = a.data_ptr()
             out.append(a)
-        check(lib().rdyn_regressor_gram_multi(self._h, chain._h, batches, taus, accs))
+        assert not accumulate or acc is not None, "accumulate needs the caller's accumulators"
+        check(lib().rdyn_regressor_gram_multi_accumulate(self._h, chain._h, batches, taus, accs, 1 if accumulate else 0))
         if sync:
             self.synchronize()
         return out

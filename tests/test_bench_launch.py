@@ -35,6 +35,19 @@ def test_self_launch_two_ranks_gloo_dry():
     assert d["distinct_pids"] == 2 and d["other_ranks_exited"] is True
 
 
+def test_self_launch_eight_ranks_gloo_dry():
+    """The driver's largest run (`--gpus 8`) through its CPU plumbing: eight ranks, every leg of the one JSON line."""
+    p = _run("--gpus", "8", "--samples", "500")
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, p.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["n_ranks_seen"] == 8 and d["samples_reduced"] == 4000.0
+    assert d["legs"] == ["config4", "config3_sharded", "config5_sharded"]
+    assert d["r_factor_gather_fold_rel_err"] <= 1e-12
+    assert d["config5_chains_per_rank"] == [32] * 8 and d["distinct_pids"] == 8 and d["other_ranks_exited"] is True
+
+
 def test_single_rank_dry_needs_no_launcher():
     p = _run("--gpus", "1", "--samples", "10")
     assert p.returncode == 0, p.stderr[-2000:]

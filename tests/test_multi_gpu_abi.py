@@ -20,6 +20,7 @@ def test_symbols_and_argument_checks_without_a_gpu():
     assert l.rdyn_multi_gpu_device_count(None) == 0
     assert l.rdyn_multi_gpu_synchronize(None) == 1
     assert l.rdyn_regressor_gram_multi(None, None, None, None, None) == 1
+    assert l.rdyn_regressor_gram_multi_accumulate(None, None, None, None, None, 1) == 1
     assert l.rdyn_regressor_tsqr_multi(None, None, None, None, None, 0) == 1
     assert l.rdyn_identification_tsqr_multi(None, None, None, 0, None, None, None, 0) == 1
     l.rdyn_multi_gpu_destroy(None)      # harmless
@@ -44,6 +45,12 @@ def test_world_one_equals_single_device_gram():
     # a second call reuses communicator, stream and workspace
     acc2 = ctx.regressor_gram(chain, [(q, dq, ddq, tau)])[0].cpu().numpy()
     assert np.array_equal(acc, acc2)
+    # a batch streamed in pieces: the first piece overwrites, the others accumulate -- sums and count of the whole
+    cut = 20000
+    a3 = ctx.regressor_gram(chain, [tuple(t[:cut].contiguous() for t in (q, dq, ddq, tau))])
+    a3 = ctx.regressor_gram(chain, [tuple(t[cut:].contiguous() for t in (q, dq, ddq, tau))], acc=a3, accumulate=True)[0].cpu().numpy()
+    assert a3[P * P + P + 1] == N and abs(a3[P * P + P] - acc[P * P + P]) <= 1e-12 * abs(acc[P * P + P])
+    assert np.linalg.norm(a3[:P * P] - acc[:P * P]) <= 1e-12 * np.linalg.norm(acc[:P * P])
 
 
 @pytest.mark.gpu
@@ -75,7 +82,11 @@ def test_back_to_back_calls_with_different_shard_sizes_and_no_sync():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("urdf,base,tool,with_comps,N", [("ur10_like.urdf", "base_link", "wrist_3_link", False, 30000), ("ur10_public.urdf", "base_link", "tool0", True, 5000),
-                                                        ("panda_like.urdf", "link0", "link7", True, 700)], ids=["ur10_6", "ur10_public_comps", "panda7_comps_small"])
+                                                        ("panda_like.urdf", "link0", "link7", True, 700),
+                                                        # (chains whose EXPANDED factor is wider than 112 columns -- the swept
+                                                        # chain's factors are what is gathered and folded now)
+                                                        ("panda_like.urdf", "link0", "hand", True, 6000), ("ur10_public_long.urdf", "base_link", "tcp", True, 5000)],
+                         ids=["ur10_6", "ur10_public_comps", "panda7_comps_small", "panda_hand_comps_wide", "long14_comps_wide"])
 def test_world_one_r_factor_gather_and_fold(urdf, base, tool, with_comps, N):
     """rdyn_identification_tsqr_multi / rdyn_regressor_tsqr_multi on ONE device: the robust factor of the shard, the all-gather of one
     rank, the fold of the stack -- R'R = M'M against the oracle's rows, accumulation, and the result is visible to work queued on the

@@ -1,3 +1,7 @@
+#!/bin/bash
+# kernel-trace stats of the long-chain workloads (runs on the GPU box via gpurun, from the repo root)
+set -u
+: "${GRAFT_REPO_ROOT:?run through gpurun (GRAFT_REPO_ROOT is the snapshot root)}"
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 O=gpurun_out/prof_long2
