@@ -235,6 +235,28 @@ int rdyn_regressor(const rdyn_chain* chain, const rdyn_batch* batch, double* tau
 /* getJointInertia primitives.h:547 -> n x n column-major per sample */
 int rdyn_joint_inertia(const rdyn_chain* chain, const rdyn_batch* batch, double* M);
 
+/* Every getter of a sample in ONE call (no reference counterpart: the reference caches what a call computed on the way, m_last_q,
+ * primitives_impl.h:886, 985, 1088, so its harness rosdyn_speed_test.cpp:109-185 pays for the frames once per sample).  Outputs as the
+ * single-purpose entry points write them, record layout = batch->layout; any of them may be NULL:
+ *   T_links (links x 12), J (6 x n), twists, dtwists (links x 6), tau, tau_nonlinear (n), M (n x n), Y with y_layout (NULL layout: the
+ *   per-sample Eigen image {n P, 1, n}).  Needs q, dq, ddq.
+ * Chains of <= RDYN_MAX_SWEPT_JOINTS joints: ONE kernel launch, the seven sweeps side by side (made for small batches: a sample per call
+ * costs a launch, not seven -- the C++ facade's evaluateAll reads q / Dq / DDq from and writes the record to pinned host memory, so a
+ * sample costs that launch and a synchronisation); longer chains: the same results by the single-purpose launches on the stream. */
+typedef struct rdyn_all_outputs
+{
+  double* T_links;
+  double* J;
+  double* twists;
+  double* dtwists;
+  double* tau;
+  double* tau_nonlinear;
+  double* M;
+  double* Y;
+  const rdyn_regressor_layout* y_layout;
+} rdyn_all_outputs;
+int rdyn_evaluate_all(const rdyn_chain* chain, const rdyn_batch* batch, const rdyn_all_outputs* out);
+
 /* ---- batched local inverse kinematics.
  * computeLocalIk primitives.h:510 / primitives_impl.h:1398-1433 (weight == NULL) and computeWeigthedLocalIk
  * primitives.h:526 / primitives_impl.h:1436-1468 (weight = 6 HOST doubles), one pose per batch entry:

@@ -92,6 +92,7 @@ SYMBOLS = {
     "rdyn_local_ik": (_I, [_VP, _BP, _VP, _DP, C.c_double, _I, _VP, _VP, _VP]),
     "rdyn_local_ik_damped": (_I, [_VP, _BP, _VP, _DP, C.c_double, C.c_double, _I, _VP, _VP, _VP]),
     "rdyn_frame_distance": (_I, [C.c_int64, _VP, _VP, _I, _I, _VP, _VP, _I, _VP]),
+    "rdyn_evaluate_all": (_I, [_VP, _BP, _VP]),
     "rdyn_components_columns": (_I, [_VP, _I]),
     "rdyn_components_regressor": (_I, [_VP, _I, _I, _BP, _VP, _YP, _VP]),
     "rdyn_multi_plan_create": (_I, [_VP, _I, C.POINTER(_VP)]),

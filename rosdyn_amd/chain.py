@@ -156,6 +156,24 @@ class Chain(object):
             raise ValueError("out must be a contiguous float64 tensor of shape %s" % (shape,))
         return out
 
+    def evaluateAll(self, q, Dq, DDq, layout="sample"):
+        """include/rdyn.h: rdyn_evaluate_all -- every getter of the samples in ONE launch (chains of up to 10 joints; longer chains: the
+        single-purpose launches).  Returns a dict with the records the single-purpose getters return: T_links, J, twists, dtwists, tau,
+        tau_nonlinear, M, Y (per-sample Eigen images (N, P, n), or element-major (P, n, N))."""
+        from ._lib import RegressorLayout
+        b, N, lay = self._batch(layout, q, Dq, DDq)
+        n, L, P = self.getActiveJointsNumber(), self.getLinksNumber(), 10 * self.getJointsNumber()
+        o = dict(T_links=self._out(q, N, lay, (L, 4, 3)), J=self._out(q, N, lay, (n, 6)), twists=self._out(q, N, lay, (L, 6)),
+                 dtwists=self._out(q, N, lay, (L, 6)), tau=self._out(q, N, lay, (n,)), tau_nonlinear=self._out(q, N, lay, (n,)),
+                 M=self._out(q, N, lay, (n, n)), Y=self._out(q, N, lay, (P, n)))
+        yl = RegressorLayout(n * P, 1, n) if lay == LAYOUT_SAMPLE_MAJOR else RegressorLayout(1, N, n * N)
+
+        class _Out(C.Structure):
+            _fields_ = [(k, C.c_void_p) for k in ("T_links", "J", "twists", "dtwists", "tau", "tau_nonlinear", "M", "Y", "y_layout")]
+        rec = _Out(*([o[k].data_ptr() for k in ("T_links", "J", "twists", "dtwists", "tau", "tau_nonlinear", "M", "Y")] + [C.addressof(yl)]))
+        check(lib().rdyn_evaluate_all(self._h, C.byref(b), C.byref(rec)))
+        return o
+
     # ---- kinematics, primitives.h:452-463.  Record shapes are the transposes of the Eigen (column-major) objects:
     #      sample-major T[s] is (4, 3) = columns of the 3x4 [R | p]; use .transpose(-1, -2) for the matrix.
     def getTransformation(self, q, layout="sample", out=None):

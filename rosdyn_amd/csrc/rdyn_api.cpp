@@ -2102,6 +2102,93 @@ int rdyn_identification_gram(const rdyn_chain* c, const rdyn_component* comps, i
   return RDYN_OK;
 }
 
+int rdyn_evaluate_all(const rdyn_chain* c, const rdyn_batch* b, const rdyn_all_outputs* o)
+{
+  int st = check_batch(c, b, true, true, "rdyn_evaluate_all", LONG_COMPANION);
+  if (st != RDYN_OK) return st;
+  if (!o)
+  {
+    rdyn_set_error("rdyn_evaluate_all: null outputs");
+    return RDYN_ERR_INVALID_ARGUMENT;
+  }
+  if (b->n_samples == 0) return RDYN_OK;
+  const int n = c->n_active(), nJ = c->n_joints(), L = nJ + 1;
+  const rdyn_regressor_layout image = {(int64_t)n * 10 * nJ, 1, n};
+  const rdyn_regressor_layout* const yl = o->y_layout ? o->y_layout : &image;
+  if (c->long_chain())
+  {
+    // a chain longer than the unrolled kernels sweep: the single-purpose launches (companion + run-time-length kernels), same stream
+    if (o->T_links && (st = rdyn_transformation(c, b, nullptr, o->T_links)) != RDYN_OK) return st;
+    if (o->J && (st = rdyn_jacobian(c, b, o->J)) != RDYN_OK) return st;
+    if ((o->twists || o->dtwists) && (st = rdyn_twist(c, b, o->twists, o->dtwists)) != RDYN_OK) return st;
+    if (o->tau && (st = rdyn_joint_torque(c, b, o->tau)) != RDYN_OK) return st;
+    if (o->tau_nonlinear && (st = rdyn_joint_torque_nonlinear(c, b, o->tau_nonlinear)) != RDYN_OK) return st;
+    if (o->M && (st = rdyn_joint_inertia(c, b, o->M)) != RDYN_OK) return st;
+    if (o->Y && (st = rdyn_regressor(c, b, nullptr, o->Y, yl)) != RDYN_OK) return st;
+    return RDYN_OK;
+  }
+  if (o->Y && (yl->stride_sample < 1 || yl->stride_row < 1 || yl->stride_col < 1 || yl->stride_sample > (int64_t)0xFFFFFFFFll / (8 * 255)))
+  {
+    rdyn_set_error("rdyn_evaluate_all: regressor strides must be positive and stride_sample below %lld doubles", (long long)((int64_t)0xFFFFFFFFll / (8 * 255)));
+    return RDYN_ERR_INVALID_ARGUMENT;
+  }
+  DeviceGuard g;
+  st = g.enter(b->device);
+  if (st != RDYN_OK) return st;
+  const RdynChainConst* dc = nullptr;
+  st = device_const(c, &dc);
+  if (st != RDYN_OK) return st;
+  RdynAllArgs a;
+  memset(&a, 0, sizeof a);
+  a.n_samples = b->n_samples;
+  int64_t se;
+  auto kin = [&](RdynKinArgs& k) {
+    k.chain = dc;
+    k.q = b->q;
+    k.dq = b->dq;
+    k.ddq = b->ddq;
+    k.n_samples = b->n_samples;
+    rec_strides(b, n, &k.in_ss, &k.in_sj);
+    rec_strides(b, 12 * (int64_t)L, &k.tl_ss, &se);
+    rec_strides(b, 6 * (int64_t)n, &k.j_ss, &se);
+    rec_strides(b, 6 * (int64_t)L, &k.tw_ss, &se);
+    k.out_se = se;
+    k.j_link = nJ;
+  };
+  kin(a.frames);
+  a.frames.T_links = o->T_links;
+  kin(a.jacobian);
+  a.jacobian.J = o->J;
+  kin(a.twists);
+  a.twists.twists = o->twists;
+  a.twists.dtwists = o->dtwists;
+  auto sweep = [&](RdynSweepArgs& w, bool use_ddq) {
+    w.chain = dc;
+    w.q = b->q;
+    w.dq = b->dq;
+    w.ddq = use_ddq ? b->ddq : nullptr;
+    w.n_samples = b->n_samples;
+    rec_strides(b, n, &w.in_ss, &w.in_sj);
+    w.tau_ss = w.in_ss;
+    w.tau_sj = w.in_sj;
+    rec_strides(b, (int64_t)n * n, &w.m_ss, &w.m_se);
+  };
+  sweep(a.torque, true);
+  a.torque.tau = o->tau;
+  sweep(a.torque_nl, false);  // DDq = 0, primitives_impl.h:1287-1288
+  a.torque_nl.tau = o->tau_nonlinear;
+  sweep(a.inertia, false);
+  a.inertia.dq = nullptr;
+  a.inertia.M = o->M;
+  sweep(a.regressor, true);
+  a.regressor.Y = o->Y;
+  a.regressor.y_ss = yl->stride_sample;
+  a.regressor.y_sr = yl->stride_row;
+  a.regressor.y_sc = yl->stride_col;
+  RDYN_HIP_TRY(rdyn_launch_sample_all(nJ, a, (hipStream_t)b->stream));
+  return RDYN_OK;
+}
+
 int rdyn_transformation(const rdyn_chain* c, const rdyn_batch* b, double* T_bt, double* T_links)
 {
   int st = check_batch(c, b, false, false, "rdyn_transformation", LONG_KERNELS);

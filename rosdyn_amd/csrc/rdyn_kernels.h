@@ -310,6 +310,16 @@ int rdyn_internal_tsqr_expand(const rdyn_chain* c, const rdyn_component* comps, 
 // y[i] += x[i], i < n, ordered on the stream (rdyn_gram.hip)
 hipError_t rdyn_launch_add_doubles(double* y, const double* x, int64_t n, hipStream_t st);
 
+// every getter of a sample in one launch (rdyn_kernels.hip: k_sample_all): the argument blocks of the single-purpose kernels, one per role;
+// a role whose outputs are all null leaves at once
+struct RdynAllArgs
+{
+  int64_t n_samples;
+  RdynKinArgs frames, jacobian, twists;
+  RdynSweepArgs torque, torque_nl, inertia, regressor;
+};
+hipError_t rdyn_launch_sample_all(int n_joints, const RdynAllArgs& a, hipStream_t st);
+
 enum { RDYN_MODE_REGRESSOR = 0, RDYN_MODE_TORQUE = 1, RDYN_MODE_INERTIA = 2, RDYN_MODE_REGRESSOR_GRAM = 3, RDYN_MODE_REGRESSOR_EXPAND = 4,
        RDYN_MODE_REGRESSOR_EXPAND_STAGED = 5 };
 

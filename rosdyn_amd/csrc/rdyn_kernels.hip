@@ -105,11 +105,10 @@ __global__ __launch_bounds__(256) void k_local_sweep_multi(const RdynSweepArgs* 
 // LEVEL: what the caller asked for -- 0 frames only (getTransformation(s)), 1 + the Jacobian (screws and origins kept), 2 + twists,
 // 3 + spatial accelerations.  One instantiation per level: a getTransformation call does not pay for the velocity / acceleration
 // recursions of getDTwist (750 -> 420 fp64 instructions per sample at 6 joints).
-template <int NJ, int LEVEL>
-__global__ __launch_bounds__(256) void k_base_sweep(const RdynKinArgs a)
+template <int NJ, int LEVEL, class Args>
+__device__ __forceinline__ void base_sweep_body(const Args& a, const int64_t s)
 {
   ChainPtr c = as_const(a.chain);
-  const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (s >= a.n_samples) return;
   const double* __restrict__ qp = a.q + s * a.in_ss;
   const double* __restrict__ dqp = (LEVEL >= 2 && a.dq) ? a.dq + s * a.in_ss : nullptr;
@@ -249,6 +248,68 @@ __global__ __launch_bounds__(256) void k_base_sweep(const RdynKinArgs a)
   }
 }
 
+template <int NJ, int LEVEL>
+__global__ __launch_bounds__(256) void k_base_sweep(const RdynKinArgs a)
+{
+  base_sweep_body<NJ, LEVEL>(a, (int64_t)blockIdx.x * 256 + threadIdx.x);
+}
+
+// Every getter of a sample in ONE launch (rdyn_evaluate_all): blockIdx.y picks a role -- frames of all links, the tool Jacobian, twists +
+// spatial accelerations (the three levels of the base-frame sweep), joint torque, its non-linear part, joint inertia, regressor (the
+// four modes of the local-frame sweep) -- the same device code as the single-purpose kernels, side by side on the chip.  Made for
+// SMALL batches: one sample per call through the C++ facade costs a launch and a round trip, not seven.
+template <int NJ>
+__global__ __launch_bounds__(256) void k_sample_all(const RdynAllArgs all)
+{
+  const unsigned blk = blockIdx.x;
+  constexpr double* expand_tile = nullptr;
+  switch (blockIdx.y)
+  {
+  case 0:
+    if (all.frames.T_bt || all.frames.T_links) base_sweep_body<NJ, 0>(all.frames, (int64_t)blk * 256 + threadIdx.x);
+    return;
+  case 1:
+    if (all.jacobian.J) base_sweep_body<NJ, 1>(all.jacobian, (int64_t)blk * 256 + threadIdx.x);
+    return;
+  case 2:
+    if (all.twists.dtwists) base_sweep_body<NJ, 3>(all.twists, (int64_t)blk * 256 + threadIdx.x);
+    else if (all.twists.twists) base_sweep_body<NJ, 2>(all.twists, (int64_t)blk * 256 + threadIdx.x);
+    return;
+  case 3:
+  {
+    if (!all.torque.tau) return;
+    constexpr int MODE = MODE_TORQUE;
+    const RdynSweepArgs& a = all.torque;
+#include "rdyn_local_sweep_body.inc"
+    return;
+  }
+  case 4:
+  {
+    if (!all.torque_nl.tau) return;
+    constexpr int MODE = MODE_TORQUE;
+    const RdynSweepArgs& a = all.torque_nl;
+#include "rdyn_local_sweep_body.inc"
+    return;
+  }
+  case 5:
+  {
+    if (!all.inertia.M) return;
+    constexpr int MODE = MODE_INERTIA;
+    const RdynSweepArgs& a = all.inertia;
+#include "rdyn_local_sweep_body.inc"
+    return;
+  }
+  default:
+  {
+    if (!all.regressor.Y) return;
+    constexpr int MODE = MODE_REGRESSOR;
+    const RdynSweepArgs& a = all.regressor;
+#include "rdyn_local_sweep_body.inc"
+    return;
+  }
+  }
+}
+
 template <int NJ>
 hipError_t launch_local_nj(int mode, const RdynSweepArgs& a, hipStream_t st)
 {
@@ -300,6 +361,23 @@ hipError_t rdyn_launch_local_sweep(int n_joints, int mode, const RdynSweepArgs& 
 {
   if (a.n_samples <= 0) return hipSuccess;
 #define CALL(N) launch_local_nj<N>(mode, a, st)
+  RDYN_DISPATCH_NJ(n_joints, CALL)
+#undef CALL
+}
+
+namespace
+{
+template <int NJ>
+hipError_t launch_all_nj(const RdynAllArgs& a, hipStream_t st)
+{
+  hipLaunchKernelGGL((k_sample_all<NJ>), dim3((unsigned)((a.n_samples + 255) / 256), 7), dim3(256), 0, st, a);
+  return hipGetLastError();
+}
+}  // namespace
+hipError_t rdyn_launch_sample_all(int n_joints, const RdynAllArgs& a, hipStream_t st)
+{
+  if (a.n_samples <= 0) return hipSuccess;
+#define CALL(N) launch_all_nj<N>(a, st)
   RDYN_DISPATCH_NJ(n_joints, CALL)
 #undef CALL
 }

@@ -198,6 +198,47 @@ int main(int argc, char** argv)
         for (int r = 0; r < 6; ++r) std::printf(" %.17g", jac(r, c));
       std::printf("\n");
     }
+    // evaluateAll: one launch fills a record every getter answers from -- the same kernels, so the same bits as the calls above
+    {
+      const rosdyn::VectorXd tau1 = chain->getJointTorque(q, Dq, DDq);
+      const rosdyn::VectorXd tnl1 = chain->getJointTorqueNonLinearPart(q, Dq);
+      const rosdyn::MatrixXd Y1 = chain->getRegressor(q, Dq, DDq), M1 = chain->getJointInertia(q);
+      const rosdyn::Matrix6Xd J1 = chain->getJacobian(q);
+      const rosdyn::VectorOfAffine3d T1 = chain->getTransformations(q);
+      const rosdyn::VectorOfVector6d tw1 = chain->getTwist(q, Dq), dtw1 = chain->getDTwist(q, Dq, DDq);
+      chain->evaluateAll(q, Dq, DDq);
+      double diff = chain->isEvaluated(q) ? 0.0 : 1.0;
+      auto upd = [&](double a, double b) { diff = std::max(diff, std::fabs(a - b)); };
+      const rosdyn::VectorXd& tau2 = chain->getJointTorque(q, Dq, DDq);
+      const rosdyn::VectorXd& tnl2 = chain->getJointTorqueNonLinearPart(q, Dq);
+      for (unsigned i = 0; i < n_joints; ++i) { upd(tau1(i), tau2(i)); upd(tnl1(i), tnl2(i)); }
+      const rosdyn::MatrixXd Y2 = chain->getRegressor(q, Dq, DDq);
+      const rosdyn::MatrixXd& M2 = chain->getJointInertia(q);
+      for (int c = 0; c < Y1.cols(); ++c)
+        for (int r = 0; r < Y1.rows(); ++r) upd(Y1(r, c), Y2(r, c));
+      for (int c = 0; c < M1.cols(); ++c)
+        for (int r = 0; r < M1.rows(); ++r) upd(M1(r, c), M2(r, c));
+      const rosdyn::Matrix6Xd& J2 = chain->getJacobian(q);
+      for (int c = 0; c < (int)n_joints; ++c)
+        for (int r = 0; r < 6; ++r) upd(J1(r, c), J2(r, c));
+      const rosdyn::VectorOfAffine3d& T2 = chain->getTransformations(q);
+      const rosdyn::Affine3d& Tt = chain->getTransformation(q);
+      for (size_t l = 0; l < T1.size(); ++l)
+        for (int c = 0; c < 4; ++c)
+          for (int r = 0; r < 3; ++r) upd(T1[l](r, c), T2[l](r, c));
+      for (int c = 0; c < 4; ++c)
+        for (int r = 0; r < 3; ++r) upd(T1.back()(r, c), Tt(r, c));
+      const rosdyn::VectorOfVector6d& tw2 = chain->getTwist(q, Dq);
+      const rosdyn::VectorOfVector6d& dtw2 = chain->getDTwist(q, Dq, DDq);
+      for (size_t l = 0; l < tw1.size(); ++l)
+        for (int i = 0; i < 6; ++i) { upd(tw1[l](i), tw2[l](i)); upd(dtw1[l](i), dtw2[l](i)); }
+      // other inputs: the getters evaluate their own function again and the record stays
+      rosdyn::VectorXd q3 = q;
+      const unsigned jm = n_joints > 1 ? 1 : 0;  // (the first joint of an arm often turns about the gravity axis: its torque ignores its angle)
+      q3(jm) += 0.25;
+      const double t3 = chain->getJointTorque(q3, Dq, DDq)(jm);
+      std::printf("E %.17g %d %d\n", diff, chain->isEvaluated(q) ? 1 : 0, std::fabs(t3 - tau1(jm)) > 1e-9 ? 1 : 0);
+    }
     // identification in C++: Gram of 4 096 seeded samples with the exact torques as measurements, host solve, residual of G x = c
     {
       const int N = 4096, n = (int)n_joints, P = 10 * (int)chain->getJointsNumber();
@@ -273,6 +314,30 @@ int main(int argc, char** argv)
   std::printf("computation time joint torque                          = %9.3f [us]\n", t_torque / ntrial);
   std::printf("computation time joint inertia                         = %9.3f [us]\n", t_inertia / ntrial);
   std::printf("computation time regressor                             = %9.3f [us]\n", t_reg / ntrial);
+
+  // ---- part 1b: every getter of a sample from ONE launch (evaluateAll), the reference's call pattern kept: pose, Jacobian,
+  // twists, acceleration twists, joint torque, its non-linear part, joint inertia, regressor answered from the record
+  {
+    double t_all = 0, t_get = 0;
+    chain->evaluateAll(q, Dq, DDq);  // first use allocates the record
+    for (int idx = 0; idx < ntrial; idx++)
+    {
+      draw();
+      double t0 = now_us();
+      chain->evaluateAll(q, Dq, DDq);
+      const double t1 = now_us();
+      sink += chain->getTransformation(q)(0, 3) + chain->getJacobian(q)(0, 0) + chain->getTwist(q, Dq).back()(0) + chain->getDTwist(q, Dq, DDq).back()(0) +
+              chain->getJointTorque(q, Dq, DDq)(0) + chain->getJointTorqueNonLinearPart(q, Dq)(0) + chain->getJointInertia(q)(0, 0) +
+              chain->getTransformations(q).front()(0, 3);
+      t_all += t1 - t0;
+      t_get += now_us() - t1;
+    }
+    std::printf("computation time evaluateAll (pose of all links + jacobian + twists + acceleration twists + joint torque + non linear part +\n"
+                "                 joint inertia + regressor: ONE kernel launch)    = %9.3f [us]   (+ %.3f us for eight getters answered from its record)\n",
+                t_all / ntrial, t_get / ntrial);
+    std::printf("reference, same laptop-class CPU figures (README.md:29-45): pose 0.76, + jacobian 1.07, + twists 1.26, + acceleration twists 1.84,\n"
+                "                 + jerk 2.69, + joint torque 3.77, pose + jacobian + joint inertia 10.07 [us]\n");
+  }
 
   // ---- part 2: the same number of samples as one batched call per function
   const int N = ntrial, n = (int)n_joints, L = (int)chain->getLinksNumber(), P = 10 * (int)chain->getJointsNumber();

@@ -339,9 +339,59 @@ public:
   }
   const rdyn_chain* handle() const { return m_h; }
 
+  // ---- every getter of ONE sample in one round trip (no reference counterpart; the reference caches what a call computed on the way
+  // -- m_last_q, primitives_impl.h:886, 985, 1088 -- so its harness, rosdyn_speed_test.cpp:109-185, pays for the frames once per
+  // sample).  Here a call through the GPU costs a host round trip (20-30 us) whatever it computes: evaluateAll(q, Dq, DDq) is ONE
+  // kernel launch (rdyn_evaluate_all: frames of all links, tool Jacobian, twists + spatial accelerations, joint torque, its non-linear
+  // part, joint inertia, regressor side by side) that reads the inputs from and writes its record to pinned host memory -- no copy
+  // calls, one synchronisation -- and the getters below answer from that record for as long as they are asked for the same q (Dq,
+  // DDq).  A getter called with other inputs evaluates its own function as before and leaves the record alone.
+  void evaluateAll(const VectorXd& q, const VectorXd& Dq, const VectorXd& DDq)
+  {
+    const size_t n = m_active_joints_number;
+    if ((size_t)q.rows() != n || (size_t)Dq.rows() != n || (size_t)DDq.rows() != n) throw std::invalid_argument("Input data dimensions mismatch");
+    ensure_all();
+    std::memcpy(m_all_pin, q.data(), n * sizeof(double));
+    std::memcpy(m_all_pin + n, Dq.data(), n * sizeof(double));
+    std::memcpy(m_all_pin + 2 * n, DDq.data(), n * sizeof(double));
+    chk(rdyn_evaluate_all(m_h, &m_all_b, &m_all_out));
+    hip(hipStreamSynchronize(nullptr));
+    const double* r = m_all_pin + m_all_in;
+    const int L = (int)m_links_number, ni = (int)n, P = (int)(10 * m_joints_number);
+    m_all_T_bl.resize(L);
+    for (int l = 0; l < L; ++l) detail::set_affine(m_all_T_bl[l], r + m_all_off[0] + 12 * l);
+    m_all_jacobian.resize(6, ni);
+    std::memcpy(m_all_jacobian.data(), r + m_all_off[1], sizeof(double) * 6 * n);
+    m_all_twists.resize(L);
+    m_all_Dtwists.resize(L);
+    for (int l = 0; l < L; ++l)
+      for (int i = 0; i < 6; ++i)
+      {
+        m_all_twists[l](i) = r[m_all_off[2] + 6 * l + i];
+        m_all_Dtwists[l](i) = r[m_all_off[3] + 6 * l + i];
+      }
+    m_all_tau.resize(ni);
+    m_all_tau_nl.resize(ni);
+    for (int i = 0; i < ni; ++i)
+    {
+      m_all_tau(i) = r[m_all_off[4] + i];
+      m_all_tau_nl(i) = r[m_all_off[5] + i];
+    }
+    m_all_inertia.resize(ni, ni);
+    std::memcpy(m_all_inertia.data(), r + m_all_off[6], sizeof(double) * n * n);
+    m_all_regressor.resize(ni, P);
+    std::memcpy(m_all_regressor.data(), r + m_all_off[7], sizeof(double) * n * P);
+    m_all_q = q;
+    m_all_Dq = Dq;
+    m_all_DDq = DDq;
+    m_all_valid = true;
+  }
+  bool isEvaluated(const VectorXd& q) const { return m_all_valid && same(q, m_all_q); }
+
   // ---- single-sample kinematics / dynamics (primitives.h:452-463, 539-547)
   const Affine3d& getTransformation(const VectorXd& q)
   {
+    if (hit(&q, nullptr, nullptr)) return m_all_T_bl.back();
     stage(&q, nullptr, nullptr);
     run(rdyn_transformation(m_h, &m_b, out(0), nullptr), 12);
     detail::set_affine(m_T_bt, m_host.data());
@@ -349,6 +399,7 @@ public:
   }
   const VectorOfAffine3d& getTransformations(const VectorXd& q)
   {
+    if (hit(&q, nullptr, nullptr)) return m_all_T_bl;
     stage(&q, nullptr, nullptr);
     run(rdyn_transformation(m_h, &m_b, nullptr, out(0)), 12 * m_links_number);
     m_T_bl.resize(m_links_number);
@@ -357,6 +408,7 @@ public:
   }
   const Matrix6Xd& getJacobian(const VectorXd& q)
   {
+    if (hit(&q, nullptr, nullptr)) return m_all_jacobian;
     stage(&q, nullptr, nullptr);
     run(rdyn_jacobian(m_h, &m_b, out(0)), 6 * m_active_joints_number);
     m_jacobian.resize(6, (int)m_active_joints_number);
@@ -365,6 +417,7 @@ public:
   }
   const VectorOfVector6d& getTwist(const VectorXd& q, const VectorXd& Dq)
   {
+    if (hit(&q, &Dq, nullptr)) return m_all_twists;
     stage(&q, &Dq, nullptr);
     run(rdyn_twist(m_h, &m_b, out(0), nullptr), 6 * m_links_number);
     return fill6(m_twists);
@@ -399,6 +452,7 @@ public:
   }
   const VectorOfVector6d& getDTwist(const VectorXd& q, const VectorXd& Dq, const VectorXd& DDq)
   {
+    if (hit(&q, &Dq, &DDq)) return m_all_Dtwists;
     stage(&q, &Dq, &DDq);
     run(rdyn_twist(m_h, &m_b, nullptr, out(0)), 6 * m_links_number);
     return fill6(m_Dtwists);
@@ -503,12 +557,14 @@ public:
   }
   const VectorXd& getJointTorque(const VectorXd& q, const VectorXd& Dq, const VectorXd& DDq)
   {
+    if (hit(&q, &Dq, &DDq)) return m_all_tau;
     stage(&q, &Dq, &DDq);
     run(rdyn_joint_torque(m_h, &m_b, out(0)), m_active_joints_number);
     return fillv(m_active_joint_torques);
   }
   const VectorXd& getJointTorqueNonLinearPart(const VectorXd& q, const VectorXd& Dq)
   {
+    if (hit(&q, &Dq, nullptr)) return m_all_tau_nl;
     stage(&q, &Dq, nullptr);
     run(rdyn_joint_torque_nonlinear(m_h, &m_b, out(0)), m_active_joints_number);
     return fillv(m_active_joint_torques);
@@ -517,6 +573,7 @@ public:
   {
     if (q.rows() != Dq.rows() || Dq.rows() != DDq.rows())
       throw std::invalid_argument("Input data dimensions mismatch");  // primitives_impl.h:1299-1309
+    if (hit(&q, &Dq, &DDq)) return m_all_regressor;
     stage(&q, &Dq, &DDq);
     const int n = (int)m_active_joints_number, P = (int)(10 * m_joints_number);
     rdyn_regressor_layout yl = {(int64_t)n * P, 1, n};
@@ -527,6 +584,7 @@ public:
   }
   const MatrixXd& getJointInertia(const VectorXd& q)
   {
+    if (hit(&q, nullptr, nullptr)) return m_all_inertia;
     stage(&q, nullptr, nullptr);
     const int n = (int)m_active_joints_number;
     run(rdyn_joint_inertia(m_h, &m_b, out(0)), (size_t)n * n);
@@ -694,6 +752,20 @@ private:
   VectorOfVector6d m_twists, m_Dtwists, m_Dtwists_linear_part, m_Dtwists_nonlinear_part, m_DDtwists, m_DDtwists_linear_part,
       m_DDtwists_nonlinear_part, m_wrenches;
   MatrixXd m_joint_inertia;
+  // evaluateAll: its pinned host record (inputs | outputs; the device reads and writes it in place), what it brought back
+  double* m_all_pin = nullptr;
+  double* m_all_devptr = nullptr;  // the device's address of the same memory
+  rdyn_batch m_all_b;
+  rdyn_all_outputs m_all_out;
+  rdyn_regressor_layout m_all_yl;
+  size_t m_all_in = 0;                                 // doubles the inputs take at the head of both records (3 n, rounded to 16 bytes)
+  size_t m_all_off[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};  // T_links | J | twists | dtwists | tau | tau_nl | M | Y | end (doubles, behind the inputs)
+  bool m_all_valid = false;
+  VectorXd m_all_q, m_all_Dq, m_all_DDq, m_all_tau, m_all_tau_nl;
+  VectorOfAffine3d m_all_T_bl;
+  Matrix6Xd m_all_jacobian;
+  VectorOfVector6d m_all_twists, m_all_Dtwists;
+  MatrixXd m_all_inertia, m_all_regressor;
   // staging: pinned host + device buffers for ONE sample
   double* m_dev = nullptr;
   double* m_pin = nullptr;
@@ -710,8 +782,66 @@ private:
   {
     if (e != hipSuccess) throw std::runtime_error(std::string("HIP: ") + hipGetErrorString(e));
   }
+  static bool same(const VectorXd& a, const VectorXd& b)
+  {
+    if (a.rows() != b.rows()) return false;
+    for (int i = 0; i < (int)a.rows(); ++i)
+      if (!(a(i) == b(i))) return false;
+    return true;
+  }
+  // the getter is asked for the sample evaluateAll holds (the arguments it does not take are not compared)
+  bool hit(const VectorXd* q, const VectorXd* dq, const VectorXd* ddq) const
+  {
+    return m_all_valid && same(*q, m_all_q) && (!dq || same(*dq, m_all_Dq)) && (!ddq || same(*ddq, m_all_DDq));
+  }
+  void release_all()
+  {
+    m_all_valid = false;
+    if (m_all_pin) (void)hipHostFree(m_all_pin);
+    m_all_pin = m_all_devptr = nullptr;
+  }
+  void ensure_all()
+  {
+    if (m_all_pin) return;
+    const size_t n = m_active_joints_number, L = m_links_number, P = 10 * (size_t)m_joints_number;
+    const size_t sizes[8] = {12 * L, 6 * n, 6 * L, 6 * L, n, n, n * n, n * P};
+    size_t off = 0;
+    for (int k = 0; k < 8; ++k)
+    {
+      m_all_off[k] = off;
+      off += (sizes[k] + 1) & ~(size_t)1;
+    }
+    m_all_off[8] = off;
+    m_all_in = (3 * n + 1) & ~(size_t)1;
+    hip(hipHostMalloc((void**)&m_all_pin, (m_all_in + off) * sizeof(double), hipHostMallocMapped));
+    std::memset(m_all_pin, 0, (m_all_in + off) * sizeof(double));
+    if (hipHostGetDevicePointer((void**)&m_all_devptr, m_all_pin, 0) != hipSuccess)
+    {
+      release_all();
+      throw std::runtime_error("HIP: pinned host memory is not addressable by the device");
+    }
+    std::memset(&m_all_b, 0, sizeof m_all_b);
+    m_all_b.n_samples = 1;
+    m_all_b.layout = RDYN_LAYOUT_SAMPLE_MAJOR;
+    m_all_b.device = -1;
+    m_all_b.q = m_all_devptr;
+    m_all_b.dq = m_all_devptr + n;
+    m_all_b.ddq = m_all_devptr + 2 * n;
+    double* const o = m_all_devptr + m_all_in;
+    m_all_yl = {(int64_t)(n * P), 1, (int64_t)n};
+    m_all_out.T_links = o + m_all_off[0];
+    m_all_out.J = o + m_all_off[1];
+    m_all_out.twists = o + m_all_off[2];
+    m_all_out.dtwists = o + m_all_off[3];
+    m_all_out.tau = o + m_all_off[4];
+    m_all_out.tau_nonlinear = o + m_all_off[5];
+    m_all_out.M = o + m_all_off[6];
+    m_all_out.Y = o + m_all_off[7];
+    m_all_out.y_layout = &m_all_yl;
+  }
   void release()
   {
+    release_all();
     if (m_dev) (void)hipFree(m_dev);
     if (m_pin) (void)hipHostFree(m_pin);
     m_dev = m_pin = nullptr;
@@ -721,6 +851,7 @@ private:
   }
   void refresh()
   {
+    release_all();  // (setInputJointsName: other sizes)
     m_links_number = (unsigned)rdyn_chain_links_number(m_h);
     m_joints_number = (unsigned)rdyn_chain_joints_number(m_h);
     m_active_joints_number = (unsigned)rdyn_chain_active_joints_number(m_h);

@@ -109,7 +109,43 @@ row("permuted input joints (6 joints): getRegressor + tau (stacked)", lambda: pe
 row("permuted input joints: getRegressor + tau (per-sample images)", lambda: perm.getRegressor(qs, dqs, ddqs, with_torque=True), 3072, reps=5)
 row("permuted input joints: getRegressor + tau (element-major)", lambda: perm.getRegressor(q, dq, ddq, layout=E, with_torque=True), 3072, reps=5)
 row("permuted input joints: regressor -> Gram", lambda: perm.getRegressorGram(q, dq, ddq, tau, layout=E), 192, reps=5)
+row("permuted input joints: R factor of [A | tau]", lambda: perm.getRegressorTsqr(q, dq, ddq, tau, layout=E), 192, reps=5)
+
+# round 5: the by-link kinematic outputs of a chain longer than the unrolled kernels sweep (run-time-length kernels, rdyn_long_kin.hip):
+# 14 joints / 15 links, 6 input joints
+Ll = 15
+extl = torch.rand((Ll, 6, N), dtype=torch.float64, device="cuda")
+row("ur10_public_long (15 links): getTransformation (tool)", lambda: longc.getTransformation(q, layout=E), 48 + 96, reps=5)
+row("ur10_public_long: getTransformations (all links)", lambda: longc.getTransformations(q, layout=E), 48 + 96 * Ll, reps=5)
+row("ur10_public_long: getJacobian", lambda: longc.getJacobian(q, layout=E), 48 + 288, reps=5)
+row("ur10_public_long: getTwist (all links)", lambda: longc.getTwist(q, dq, layout=E), 96 + 48 * Ll, reps=5)
+row("ur10_public_long: getDTwist (all links)", lambda: longc.getDTwist(q, dq, ddq, layout=E), 144 + 48 * Ll, reps=5)
+row("ur10_public_long: getDDTwist (all links)", lambda: longc.getDDTwist(q, dq, ddq, dddq, layout=E), 192 + 48 * Ll, reps=5)
+row("ur10_public_long: getWrench (all links, external wrenches)", lambda: longc.getWrench(q, dq, ddq, extl, layout=E), 144 + 96 * Ll, reps=5)
+row("ur10_public_long: getJointTorque with external wrenches", lambda: longc.getJointTorqueExt(q, dq, ddq, extl, layout=E), 192 + 48 * Ll, reps=5)
+Tl = longc.getTransformation(q, layout=E)
+row("ur10_public_long: computeLocalIk, <= 8 updates", lambda: longc.computeLocalIk(Tl, seeds, toll=1e-6, max_iterations=8, layout=E), 200, reps=3)
+del extl
 
 print("%-60s %10s %14s %10s %10s" % ("entry point (N = 1e6 per call)", "us / call", "evals/s", "B / eval", "GB/s"))
 for r in rows:
     print("%-60s %10.1f %14.3e %10d %10.0f" % r)
+
+# round 5: small batches -- what a call costs when the batch does not fill the chip (device-resident inputs, time per CALL; the C++
+# facade's single-sample getters add the host round trip: rdyn_speed_test prints those beside the reference's README figures)
+print()
+print("%-60s %12s %12s %12s" % ("small batches: us per call", "N = 1", "N = 64", "N = 4096"))
+small = []
+for name, fn in (("getRegressor + tau (per-sample Eigen image)", lambda a, b, c, t: chain.getRegressor(a, b, c, with_torque=True)),
+                 ("getJointTorque", lambda a, b, c, t: chain.getJointTorque(a, b, c)),
+                 ("getJointInertia", lambda a, b, c, t: chain.getJointInertia(a)),
+                 ("getTransformations (all links)", lambda a, b, c, t: chain.getTransformations(a)),
+                 ("getJacobian", lambda a, b, c, t: chain.getJacobian(a)),
+                 ("getDTwist (all links)", lambda a, b, c, t: chain.getDTwist(a, b, c)),
+                 ("regressor -> Gram [A|tau]'[A|tau]", lambda a, b, c, t: chain.getRegressorGram(a, b, c, t)),
+                 ("regressor -> R factor of [A | tau]", lambda a, b, c, t: chain.getRegressorTsqr(a, b, c, t))):
+    cells = []
+    for Ns in (1, 64, 4096):
+        args = [x[:Ns].contiguous() for x in (qs, dqs, ddqs)] + [tau.T[:Ns].contiguous()]
+        cells.append(timeit(lambda: fn(*args), reps=200, warm=10) * 1e6)
+    print("%-60s %12.1f %12.1f %12.1f" % ((name,) + tuple(cells)))
