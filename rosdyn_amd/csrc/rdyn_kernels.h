@@ -53,12 +53,11 @@ struct RdynKinExtArgs
   double* wrench;       // getWrench: base-frame link wrenches
   const double* ext;    // wrench only, may be null: external wrenches, links x 6, element e of sample s at ext[s * ext_ss + e * ext_se]
   int64_t ext_ss, ext_se;
-  // rdyn_long_kin.hip only (chains of more than RDYN_MAX_SWEPT_JOINTS joints): the constants, the joint torques of the wrench pass
-  // (getJointTorque with external wrenches; layout of q) and the lanes of a wave that carry a sample (set by the launcher)
+  // rdyn_long_kin.hip only (chains of more than RDYN_MAX_SWEPT_JOINTS joints): the constants and the joint torques of the wrench pass
+  // (getJointTorque with external wrenches; layout of q)
   const RdynLongChainConst* chain_long;
   double* tau;
   int64_t tau_ss, tau_sj;
-  int lanes;
 };
 hipError_t rdyn_launch_base_ext(int n_joints, const RdynKinExtArgs& a, hipStream_t st);
 hipError_t rdyn_launch_long_ext(int n_joints, const RdynKinExtArgs& a, hipStream_t st);  // a.chain_long; any chain length

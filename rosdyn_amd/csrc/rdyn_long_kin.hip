@@ -13,8 +13,7 @@
 //
 // Jacobian: column k needs the reference point (origin of the requested link), known only once the recursion has reached it; the
 // frames are cheap (one sincos and ~70 fma per joint), so a first pass runs them up to that link and the main pass forms the columns
-// as it goes -- no per-joint storage.  Wrench: the tool -> base suffix sums need every link's own wrench and origin again; they wait
-// in wave-private LDS (9 doubles per link and lane, 12 when the joint torques are asked for: the joint axis too), sized at launch.
+// as it goes -- no per-joint storage.  Wrench: two forward passes (the total, then total - upstream), see k_long_ext.
 #include <hip/hip_runtime.h>
 #include "rdyn_device.h"
 #include "rdyn_devmath.h"
@@ -198,16 +197,18 @@ __global__ __launch_bounds__(256) void k_long_base(const RdynKinArgs a)
   if (a.T_bt) put3x4(a.T_bt + s * a.tb_ss);
 }
 
-// WRENCH: 64-thread workgroups of which the first a.lanes (64, or 32 where 64 records do not fit the LDS) carry a sample
+// The split / jerk recursions (WRENCH = false) and the wrench recursion (true).  The reference sums the link wrenches tool -> base
+// (primitives_impl.h:1231-1259); a forward sweep knows a link's own wrench only when it gets there, and parking one record per link
+// and lane in LDS (as the unrolled kernel does) leaves two waves per CU at 14 links.  Here the sweep runs TWICE: the first pass adds
+// up every link's own wrench about the base origin, the second forms w[l] = total - (the links upstream of l) as it goes, refers it to
+// the link's origin, and reads the joint torque off it -- no per-link storage, full occupancy; the arithmetic differs from the suffix
+// sums by the rounding of one subtraction (1e-16 of the chain's total wrench).
 template <bool WRENCH>
-__global__ __launch_bounds__(WRENCH ? 64 : 256) void k_long_ext(const RdynKinExtArgs a)
+__global__ __launch_bounds__(256) void k_long_ext(const RdynKinExtArgs a)
 {
-  extern __shared__ __attribute__((aligned(16))) double own_lds[];  // WRENCH: [PK (nj + 1)][lanes], PK = 9 or 12
   LongChainPtr c = as_const_long(a.chain_long);
   const int nj = c->n_joints;
-  const int LN = WRENCH ? a.lanes : 256;
-  if (WRENCH && (int)threadIdx.x >= LN) return;
-  const int64_t s = (int64_t)blockIdx.x * LN + threadIdx.x;
+  const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (s >= a.n_samples) return;
   const double* __restrict__ qp = a.q + s * a.in_ss;
   const double* __restrict__ dqp = a.dq ? a.dq + s * a.in_ss : nullptr;
@@ -219,27 +220,6 @@ __global__ __launch_bounds__(WRENCH ? 64 : 256) void k_long_ext(const RdynKinExt
     o[0] = x.l.x; o[es] = x.l.y; o[2 * es] = x.l.z; o[3 * es] = x.a.x; o[4 * es] = x.a.y; o[5 * es] = x.a.z;
   };
   const S6 zero = {mk(0, 0, 0), mk(0, 0, 0)};
-  double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
-  S6 v = zero, acc = zero, aL = zero, aN = zero, jk = zero, jL = zero, jN = zero;
-  if (!WRENCH)
-  {
-    if (a.dtw_lin) put6(a.dtw_lin, 0, zero);
-    if (a.dtw_nonlin) put6(a.dtw_nonlin, 0, zero);
-    if (a.ddtw) put6(a.ddtw, 0, zero);
-    if (a.ddtw_lin) put6(a.ddtw_lin, 0, zero);
-    if (a.ddtw_nonlin) put6(a.ddtw_nonlin, 0, zero);
-  }
-  const int PK = a.tau ? 12 : 9;  // doubles parked per link: own wrench about the base origin (6), origin (3), axis of the parent joint (3)
-  auto park = [&](int link, S6 x, V3 po, V3 z) {
-    double* const o = own_lds + (PK * link) * LN + threadIdx.x;
-    o[0] = x.l.x; o[LN] = x.l.y; o[2 * LN] = x.l.z; o[3 * LN] = x.a.x; o[4 * LN] = x.a.y; o[5 * LN] = x.a.z;
-    o[6 * LN] = po.x; o[7 * LN] = po.y; o[8 * LN] = po.z;
-    if (a.tau)
-    {
-      o[9 * LN] = z.x; o[10 * LN] = z.y; o[11 * LN] = z.z;
-    }
-  };
-  V3 p = mk(0, 0, 0);
   const V3 grav = mk(c->g[0], c->g[1], c->g[2]);
   auto ext_of = [&](int link) -> S6 {  // -ext_wrenches_in_link_frame.at(link), :1255
     S6 e = zero;
@@ -251,101 +231,119 @@ __global__ __launch_bounds__(WRENCH ? 64 : 256) void k_long_ext(const RdynKinExt
     }
     return e;
   };
-  if (WRENCH) park(0, ext_of(0), p, mk(0, 0, 0));  // spatialTranformation(-ext, identity); no inertial / gravity term on the base link (:1233-1237)
-#pragma unroll 1
-  for (int f = 0; f < nj; ++f)
+  if (!WRENCH)
   {
-    JointRef J = c->j[f];
-    const int type = J.type;
-    const int idx = J.in_idx;
-    double qf = 0.0, dqf = 0.0, ddqf = 0.0, dddqf = 0.0;
-    if (idx >= 0)
-    {
-      const int64_t o = idx * a.in_sj;
-      qf = qp[o];
-      if (dqp) dqf = dqp[o];
-      if (ddqp) ddqf = ddqp[o];
-      if (dddqp) dddqf = dddqp[o];
-    }
-    V3 zl, d;
-    frame_step(J, qf, R, p, zl, d);
-    S6 S = zero;
-    if (type == RDYN_REVOLUTE) S.a = zl;
-    else if (type == RDYN_PRISMATIC) S.l = zl;
-    v = axpy6(shift(v, d), S, dqf);
-    const S6 vxs = xs(v, S);
-    acc = axpy6(axpy6(shift(acc, d), vxs, dqf), S, ddqf);  // getDTwist, :1116-1117
-    if (!WRENCH)
-    {
-      aL = axpy6(shift(aL, d), S, ddqf);
-      aN = axpy6(shift(aN, d), vxs, dqf);
-      const S6 axs = xs(acc, S), vvxs = xs(v, vxs);
-      S6 cq;
-      cq.l = axs.l + vvxs.l;
-      cq.a = axs.a + vvxs.a;
-      jk = axpy6(axpy6(axpy6(shift(jk, d), S, dddqf), vxs, ddqf), cq, dqf);
-      jL = axpy6(shift(jL, d), S, dddqf);
-      jN = axpy6(axpy6(shift(jN, d), vxs, ddqf), cq, dqf);
-      if (a.dtw_lin) put6(a.dtw_lin, 6 * (f + 1), aL);
-      if (a.dtw_nonlin) put6(a.dtw_nonlin, 6 * (f + 1), aN);
-      if (a.ddtw) put6(a.ddtw, 6 * (f + 1), jk);
-      if (a.ddtw_lin) put6(a.ddtw_lin, 6 * (f + 1), jL);
-      if (a.ddtw_nonlin) put6(a.ddtw_nonlin, 6 * (f + 1), jN);
-    }
-    else
-    {
-      // link f + 1: spatial inertia about its origin from the nominal parameters [m, m c, Io] (primitives_impl.h:399-417)
-      const double m = J.pi[0];
-      const V3 mc = mk(J.pi[1], J.pi[2], J.pi[3]);
-      auto Imul = [&](S6 x) -> S6 {  // [[m 1, m c^T],[m c^, Io]] x   (spacevect_algebra.h:232-239)
-        S6 r;
-        r.l = mk(m * x.l.x, m * x.l.y, m * x.l.z) - cross(mc, x.a);
-        r.a = cross(mc, x.l) + symv(J.pi + 4, x.a);
-        return r;
-      };
-      S6 al, vloc;
-      al.l = rotT(R, acc.l); al.a = rotT(R, acc.a);      // spatialRotation(m_Dtwists, R^T), :1242
-      vloc.l = rotT(R, v.l); vloc.a = rotT(R, v.a);      // :1245
-      const S6 Iv = Imul(vloc), Ia = Imul(al);
-      S6 wl;  // I a + v x* (I v), spatialDualCrossProduct spacevect_algebra.h:108-113
-      wl.l = Ia.l + cross(vloc.a, Iv.l);
-      wl.a = Ia.a + cross(vloc.a, Iv.a) + cross(vloc.l, Iv.l);
-      S6 own;
-      own.l = rot(R, wl.l);                              // :1248
-      own.a = rot(R, wl.a);
-      own.l = own.l - mk(m * grav.x, m * grav.y, m * grav.z);   // gravity wrench, :1249-1250
-      own.a = own.a - cross(rot(R, mc), grav);
-      const S6 e = ext_of(f + 1);                        // spatialTranformation(-ext, T_bl): twist form, :1255 / spacevect_algebra.h:193-197
-      const V3 Ra = rot(R, e.a);
-      own.l = own.l + rot(R, e.l) + cross(Ra, p);
-      own.a = own.a + Ra;
-      own.a = own.a + cross(p, own.l);  // referred to the base origin: the suffix sums need no per-pair translation
-      park(f + 1, own, p, zl);
-    }
+    if (a.dtw_lin) put6(a.dtw_lin, 0, zero);
+    if (a.dtw_nonlin) put6(a.dtw_nonlin, 0, zero);
+    if (a.ddtw) put6(a.ddtw, 0, zero);
+    if (a.ddtw_lin) put6(a.ddtw_lin, 0, zero);
+    if (a.ddtw_nonlin) put6(a.ddtw_nonlin, 0, zero);
   }
-  if (WRENCH)
-  {
-    // w[l] = sum over links f >= l, referred to link l's origin: spatialDualTranslation(w, p_l - p_f), :1255 (ang += lin x d);
-    // tau of joint l - 1 = w[l] . screw of that joint at link l's origin (:1264-1272)
-    S6 run = zero;
-    double* __restrict__ tp = a.tau ? a.tau + s * a.tau_ss : nullptr;
+  S6 total = zero;
+  double* __restrict__ tp = (WRENCH && a.tau) ? a.tau + s * a.tau_ss : nullptr;
 #pragma unroll 1
-    for (int l = nj; l >= 0; --l)
+  for (int pass = 0; pass < (WRENCH ? 2 : 1); ++pass)
+  {
+    double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    V3 p = mk(0, 0, 0);
+    S6 v = zero, acc = zero, aL = zero, aN = zero, jk = zero, jL = zero, jN = zero;
+    S6 upstream = zero;  // second pass: own wrenches of the links before the current one, about the base origin
+    if (WRENCH)
     {
-      const double* const o = own_lds + (PK * l) * LN + threadIdx.x;
-      run.l = run.l + mk(o[0], o[LN], o[2 * LN]);
-      run.a = run.a + mk(o[3 * LN], o[4 * LN], o[5 * LN]);
-      const V3 po = mk(o[6 * LN], o[7 * LN], o[8 * LN]);
-      S6 w;
-      w.l = run.l;
-      w.a = run.a - cross(po, run.l);
-      if (a.wrench) put6(a.wrench, 6 * l, w);
-      if (tp && l >= 1)
+      const S6 own0 = ext_of(0);  // spatialTranformation(-ext, identity); no inertial / gravity term on the base link (:1233-1237)
+      if (pass == 0)
+        total = own0;
+      else
       {
-        JointRef J = c->j[l - 1];
-        const int idx = J.in_idx;
-        const V3 z = mk(o[9 * LN], o[10 * LN], o[11 * LN]);
-        if (idx >= 0) tp[idx * a.tau_sj] = J.type == RDYN_REVOLUTE ? dot(z, w.a) : (J.type == RDYN_PRISMATIC ? dot(z, w.l) : 0.0);
+        if (a.wrench) put6(a.wrench, 0, total);  // the base link carries the whole chain; its origin IS the base origin
+        upstream = own0;
+      }
+    }
+#pragma unroll 1
+    for (int f = 0; f < nj; ++f)
+    {
+      JointRef J = c->j[f];
+      const int type = J.type;
+      const int idx = J.in_idx;
+      double qf = 0.0, dqf = 0.0, ddqf = 0.0, dddqf = 0.0;
+      if (idx >= 0)
+      {
+        const int64_t o = idx * a.in_sj;
+        qf = qp[o];
+        if (dqp) dqf = dqp[o];
+        if (ddqp) ddqf = ddqp[o];
+        if (dddqp) dddqf = dddqp[o];
+      }
+      V3 zl, d;
+      frame_step(J, qf, R, p, zl, d);
+      S6 S = zero;
+      if (type == RDYN_REVOLUTE) S.a = zl;
+      else if (type == RDYN_PRISMATIC) S.l = zl;
+      v = axpy6(shift(v, d), S, dqf);
+      const S6 vxs = xs(v, S);
+      acc = axpy6(axpy6(shift(acc, d), vxs, dqf), S, ddqf);  // getDTwist, :1116-1117
+      if (!WRENCH)
+      {
+        aL = axpy6(shift(aL, d), S, ddqf);
+        aN = axpy6(shift(aN, d), vxs, dqf);
+        const S6 axs = xs(acc, S), vvxs = xs(v, vxs);
+        S6 cq;
+        cq.l = axs.l + vvxs.l;
+        cq.a = axs.a + vvxs.a;
+        jk = axpy6(axpy6(axpy6(shift(jk, d), S, dddqf), vxs, ddqf), cq, dqf);
+        jL = axpy6(shift(jL, d), S, dddqf);
+        jN = axpy6(axpy6(shift(jN, d), vxs, ddqf), cq, dqf);
+        if (a.dtw_lin) put6(a.dtw_lin, 6 * (f + 1), aL);
+        if (a.dtw_nonlin) put6(a.dtw_nonlin, 6 * (f + 1), aN);
+        if (a.ddtw) put6(a.ddtw, 6 * (f + 1), jk);
+        if (a.ddtw_lin) put6(a.ddtw_lin, 6 * (f + 1), jL);
+        if (a.ddtw_nonlin) put6(a.ddtw_nonlin, 6 * (f + 1), jN);
+      }
+      else
+      {
+        // link f + 1: spatial inertia about its origin from the nominal parameters [m, m c, Io] (primitives_impl.h:399-417)
+        const double m = J.pi[0];
+        const V3 mc = mk(J.pi[1], J.pi[2], J.pi[3]);
+        auto Imul = [&](S6 x) -> S6 {  // [[m 1, m c^T],[m c^, Io]] x   (spacevect_algebra.h:232-239)
+          S6 r;
+          r.l = mk(m * x.l.x, m * x.l.y, m * x.l.z) - cross(mc, x.a);
+          r.a = cross(mc, x.l) + symv(J.pi + 4, x.a);
+          return r;
+        };
+        S6 al, vloc;
+        al.l = rotT(R, acc.l); al.a = rotT(R, acc.a);      // spatialRotation(m_Dtwists, R^T), :1242
+        vloc.l = rotT(R, v.l); vloc.a = rotT(R, v.a);      // :1245
+        const S6 Iv = Imul(vloc), Ia = Imul(al);
+        S6 wl;  // I a + v x* (I v), spatialDualCrossProduct spacevect_algebra.h:108-113
+        wl.l = Ia.l + cross(vloc.a, Iv.l);
+        wl.a = Ia.a + cross(vloc.a, Iv.a) + cross(vloc.l, Iv.l);
+        S6 own;
+        own.l = rot(R, wl.l);                              // :1248
+        own.a = rot(R, wl.a);
+        own.l = own.l - mk(m * grav.x, m * grav.y, m * grav.z);   // gravity wrench, :1249-1250
+        own.a = own.a - cross(rot(R, mc), grav);
+        const S6 e = ext_of(f + 1);                        // spatialTranformation(-ext, T_bl): twist form, :1255 / spacevect_algebra.h:193-197
+        const V3 Ra = rot(R, e.a);
+        own.l = own.l + rot(R, e.l) + cross(Ra, p);
+        own.a = own.a + Ra;
+        own.a = own.a + cross(p, own.l);  // referred to the base origin: sums need no per-pair translation
+        if (pass == 0)
+        {
+          total.l = total.l + own.l;
+          total.a = total.a + own.a;
+        }
+        else
+        {
+          // w[f + 1] = the links f + 1 .. tool, referred to link f + 1's origin (spatialDualTranslation: ang += lin x d, :1255);
+          // tau of joint f = w[f + 1] . the joint's screw at that origin (:1264-1272)
+          S6 w;
+          w.l = total.l - upstream.l;
+          w.a = (total.a - upstream.a) - cross(p, w.l);
+          if (a.wrench) put6(a.wrench, 6 * (f + 1), w);
+          if (tp && idx >= 0) tp[idx * a.tau_sj] = type == RDYN_REVOLUTE ? dot(zl, w.a) : (type == RDYN_PRISMATIC ? dot(zl, w.l) : 0.0);
+          upstream.l = upstream.l + own.l;
+          upstream.a = upstream.a + own.a;
+        }
       }
     }
   }
@@ -364,23 +362,14 @@ hipError_t rdyn_launch_long_base(const RdynKinArgs& a, hipStream_t st)
   return hipGetLastError();
 }
 
-hipError_t rdyn_launch_long_ext(int n_joints, const RdynKinExtArgs& a_in, hipStream_t st)
+hipError_t rdyn_launch_long_ext(int n_joints, const RdynKinExtArgs& a, hipStream_t st)
 {
-  if (a_in.n_samples <= 0) return hipSuccess;
-  RdynKinExtArgs a = a_in;
+  (void)n_joints;
+  if (a.n_samples <= 0) return hipSuccess;
+  const dim3 grid((unsigned)((a.n_samples + 255) / 256));
   if (a.wrench || a.tau)
-  {
-    const size_t per_lane = (size_t)(a.tau ? 12 : 9) * (n_joints + 1) * sizeof(double);
-    a.lanes = per_lane * 64 <= 160 * 1024 ? 64 : 32;
-    const size_t lds = per_lane * a.lanes;
-    if (lds > 64 * 1024)
-    {
-      hipError_t e = hipFuncSetAttribute((const void*)k_long_ext<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      if (e != hipSuccess) return e;
-    }
-    hipLaunchKernelGGL((k_long_ext<true>), dim3((unsigned)((a.n_samples + a.lanes - 1) / a.lanes)), dim3(64), lds, st, a);
-  }
+    hipLaunchKernelGGL((k_long_ext<true>), grid, dim3(256), 0, st, a);
   else
-    hipLaunchKernelGGL((k_long_ext<false>), dim3((unsigned)((a.n_samples + 255) / 256)), dim3(256), 0, st, a);
+    hipLaunchKernelGGL((k_long_ext<false>), grid, dim3(256), 0, st, a);
   return hipGetLastError();
 }
