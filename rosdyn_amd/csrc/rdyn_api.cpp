@@ -1273,6 +1273,7 @@ static const int kCholqrBlocks = 256;
 // rows say little about what a preconditioner built on them is worth, and there is nothing to win.
 static const int64_t kCholqrMinTiles = 256;        // fused routes: 4 096 samples
 static const int64_t kCholqrMinGroups = 2048;      // rdyn_tsqr: 32 768 rows
+static const int64_t kTsqrImageChunk = 16384;      // samples per chunk image of the 9 .. 10-joint factor route (132 MB at 10 joints)
 
 // offsets (doubles) of the regions every factor call carves out of its workspace.  Region 1: the Householder route's leaves + tree
 // levels (rdyn_tsqr.hip or rdyn_tsqr_wide.hip).  Region 2: the preconditioned route's slabs, W, the intermediate factors and the flags.
@@ -1508,7 +1509,6 @@ int rdyn_tsqr_rows_last_report(int n_cols_with_rhs, int64_t rows, const void* wo
 // the chain whose rows are swept: the reduced companion when the chain has non-input joints (component columns belong to input
 // joints, which the companion keeps in the same order: they ride along unchanged).  A companion of ONE joint is below what the
 // sweeping kernels are built for: such a chain is swept as it is.
-static const rdyn_chain* swept_chain(const rdyn_chain* c) { return ordered((c->reduced && c->reduced->n_joints() >= 2) ? c->reduced.get() : c); }
 
 // rectangular 16-sample tile of rdyn_tsqr_wide.hip: every column 16 n rows + 4 doubles, structural zeros stored
 static bool build_rect_tile(const rdyn_chain* c, int n_comp_cols, RdynLdsGramArgs* la)
@@ -1549,6 +1549,10 @@ struct TsqrPlan
   bool wide = false;          // the LDS-resident folds of rdyn_tsqr_wide.hip serve the shape
   int pairs = 0, nb = 0;      // preconditioned route: pass-B configuration (0: not served), 16-column blocks of its column space
   bool sub_compact = false;   // the subsample pass (four tiles per workgroup) needs the compact tile
+  // 9 .. 10 input joints (more rows per sample than the tile kernels' sweepers hold): the rows go through a chunk image in the
+  // workspace -- swept by the one-thread-per-sample kernel, factored by rdyn_tsqr's kernels, chunk after chunk
+  bool image = false;
+  size_t img_off = 0, rows_off = 0;  // doubles: the chunk image, rdyn_tsqr's own workspace
   RdynLdsGramArgs la, la_sub, la_wide;
   TsqrLayout L;
   const char* why = nullptr;  // when nothing serves the shape
@@ -1556,8 +1560,11 @@ struct TsqrPlan
 
 static bool tsqr_plan(const rdyn_chain* c, const rdyn_component* comps, int n_comps, TsqrPlan* p)
 {
-  p->cs = swept_chain(c);
-  p->expand = p->cs != ordered(c);
+  // the chain whose rows are swept: the reduced companion where the chain has joints that are not input joints; the tile kernels sweep
+  // its sorted view (input joints listed out of chain order)
+  const rdyn_chain* const raw = (c->reduced && c->reduced->n_joints() >= 2) ? c->reduced.get() : c;
+  p->cs = ordered(raw);
+  p->expand = raw != c;
   if (c->long_chain() && !p->expand)
   {
     p->why = "a chain of more than 10 joints needs 2 .. 10 input joints";
@@ -1579,9 +1586,20 @@ static bool tsqr_plan(const rdyn_chain* c, const rdyn_component* comps, int n_co
   memset(&p->la, 0, sizeof p->la);
   memset(&p->la_sub, 0, sizeof p->la_sub);
   memset(&p->la_wide, 0, sizeof p->la_wide);
+  if (p->n > 8 && p->n <= RDYN_MAX_SWEPT_JOINTS && p->n == p->nJ && p->n1s <= rdyn_tsqr_wide_max_cols() &&
+      !(p->expand && rdyn_cholqr_expand_lds_bytes(c->n_joints(), p->nJ, K) > 156 * 1024))
+  {
+    p->image = true;
+    p->cs = raw;  // (the image's rows are the caller's input indices: the one-thread-per-sample sweep and the component kernel agree on that)
+    p->L = tsqr_layout(0, p->n1s, 0, p->expand ? p->n1 : 0);
+    p->img_off = (p->L.total_doubles + 31) & ~(size_t)31;
+    p->rows_off = p->img_off + (size_t)kTsqrImageChunk * p->n * p->n1s;
+    p->L.total_doubles = p->rows_off + rdyn_tsqr_workspace_bytes(p->n1s) / sizeof(double);
+    return true;
+  }
   if (p->n < 1 || p->n > 8 || p->nJ < 1 || !build_rect_tile(cs, K, &p->la_wide))
   {
-    p->why = "chains of 1..8 input joints are supported";
+    p->why = "chains of 1..10 input joints whose factor (after the reduction) has at most 112 columns are supported";
     return false;
   }
   const bool tile_ok = build_lds_tile(cs, K, false, &p->la) && 4 * (size_t)p->la.tile_bytes <= 160 * 1024;
@@ -1685,6 +1703,78 @@ static int regressor_tsqr_run(const rdyn_chain* c, const rdyn_component* comps, 
   if (b->n_samples == 0)
   {
     if (!accumulate) RDYN_HIP_TRY(hipMemsetAsync(R, 0, sizeof(double) * (swept_only ? (size_t)n1s * n1s : (size_t)n1 * n1), stream));
+    return RDYN_OK;
+  }
+  if (p.image)
+  {
+    // ---- 9 .. 10 input joints: [Y | C | tau_meas] of a chunk as an element-major image (rows j * cnt + s), factored by rdyn_tsqr's
+    // kernels (matrix cores up to 96 columns, LDS-resident Householder folds beyond) and folded into the running factor
+    double* const ws = (double*)workspace;
+    double* const img = ws + p.img_off;
+    double* const R_swept = expand ? ws + L.r_swept : R;
+    const int cols = n1s - 1;  // columns in front of the right-hand side
+    const int64_t in_step = (b->layout == RDYN_LAYOUT_SAMPLE_MAJOR) ? n : 1;
+    int64_t prev_cnt = -1;
+    for (int64_t s0 = 0; s0 < b->n_samples; s0 += kTsqrImageChunk)
+    {
+      const int64_t cnt = (b->n_samples - s0 < kTsqrImageChunk) ? (b->n_samples - s0) : kTsqrImageChunk;
+      if (cnt != prev_cnt)
+      {
+        // the sweep does not store the structural zeros of the image: they must read as zeros
+        RDYN_HIP_TRY(hipMemsetAsync(img, 0, sizeof(double) * (size_t)cnt * n * n1s, stream));
+        prev_cnt = cnt;
+      }
+      RdynSweepArgs a;
+      memset(&a, 0, sizeof a);
+      a.chain = dc;
+      a.q = b->q + s0 * in_step;
+      a.dq = b->dq + s0 * in_step;
+      a.ddq = b->ddq + s0 * in_step;
+      a.bcol = tau_meas ? tau_meas + s0 * in_step : nullptr;
+      a.bcol_col = cols;
+      a.n_samples = cnt;
+      rec_strides(b, n, &a.in_ss, &a.in_sj);
+      a.Y = img;
+      a.y_ss = 1;
+      a.y_sr = cnt;
+      a.y_sc = (int64_t)n * cnt;
+      RDYN_HIP_TRY(rdyn_launch_local_sweep(nJ, RDYN_MODE_REGRESSOR_GRAM, a, stream));
+      if (K > 0)
+      {
+        RdynComponentArgs cc = ca;
+        cc.q = a.q;
+        cc.dq = a.dq;
+        cc.n_samples = cnt;
+        cc.in_ss = a.in_ss;
+        cc.in_sj = a.in_sj;
+        cc.n_active = n;
+        cc.n_comps = n_comps;
+        cc.C = img + (int64_t)10 * nJ * n * cnt;
+        cc.c_ss = 1;
+        cc.c_sr = cnt;
+        cc.c_sc = (int64_t)n * cnt;
+        cc.tau = nullptr;
+        RDYN_HIP_TRY(rdyn_launch_components(cc, stream));
+      }
+      // (without measured torques the image's last column stays zero: the factor of [A | 0])
+      st = rdyn_tsqr(img, (int64_t)n * cnt, (int64_t)n * cnt, cols, img + (int64_t)cols * n * cnt, R_swept, (s0 > 0 || (accumulate && !expand)) ? 1 : 0,
+                     ws + p.rows_off, rdyn_tsqr_workspace_bytes(n1s), -1, stream);
+      if (st != RDYN_OK) return st;
+    }
+    if (expand)
+    {
+      RdynGramExpandArgs ea;
+      memset(&ea, 0, sizeof ea);
+      st = device_expand(c, &ea.X);
+      if (st != RDYN_OK) return st;
+      for (int f = 0; f < c->n_joints(); ++f) ea.red_of[f] = c->red_of[f];
+      ea.n_joints = c->n_joints();
+      ea.n_red = nJ;
+      ea.n_comp_cols = K;
+      double* const R_exp = accumulate ? ws + L.r_full : R;
+      RDYN_HIP_TRY(rdyn_launch_cholqr_expand(ea, R_swept, R_exp, stream));
+      if (accumulate) RDYN_HIP_TRY(rdyn_launch_cholqr_fold(R_exp, R, n1, stream, n1s));
+    }
     return RDYN_OK;
   }
   auto bind = [&](RdynLdsGramArgs& la) {
@@ -1892,7 +1982,7 @@ int rdyn_tsqr_last_report(const rdyn_chain* c, const rdyn_component* comps, int 
     rdyn_set_error("rdyn_tsqr_last_report: the factor entry points do not serve this chain");
     return RDYN_ERR_UNSUPPORTED;
   }
-  if (p.pairs == 0 || (n_samples + 15) / 16 < kCholqrMinTiles) return RDYN_OK;  // route 0: the Householder folds, nothing to report
+  if (p.image || p.pairs == 0 || (n_samples + 15) / 16 < kCholqrMinTiles) return RDYN_OK;  // route 0: the Householder folds, nothing to report
   DeviceGuard g;
   int st = g.enter(device);
   if (st != RDYN_OK) return st;

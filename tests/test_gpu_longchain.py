@@ -164,3 +164,46 @@ def test_long_chain_normal_equations_and_r_factor(N):
     R3 = chain.getIdentificationTsqr(comps, *args2).cpu().numpy()
     assert R3.shape == (C + 1, C + 1) and np.allclose(np.tril(R3, -1), 0.0)
     assert np.abs(R3.T @ R3 - G2r).max() <= 1e-11 * np.abs(G2r).max()
+
+
+@pytest.mark.parametrize("nj,N,permute", [(9, 300, False), (10, 300, True), (9, 20000, True), (10, 20000, False)])
+def test_r_factor_with_nine_and_ten_input_joints(nj, N, permute):
+    """VERDICT r4 "next" 1(c): the R factor of [Y | C | tau] for 9 .. 10 input joints (91 .. 112 columns) -- more rows per sample than
+    the tile kernels' sweepers hold, so the rows go through a chunk image and rdyn_tsqr's kernels (two chunks at N = 20 000), in any
+    input order, with friction columns, accumulated."""
+    torch = pytest.importorskip("torch")
+    from oracle.oracle import OracleChain, components_regressor
+    from rosdyn_amd import Chain
+    from rosdyn_amd.components import ComponentSet
+    from rosdyn_amd.samples import trajectory_batch
+    xml = _chain_xml(nj, 300 + nj)
+    names = ["j%d" % i for i in range(nj)]
+    if permute:
+        names = names[3:] + names[:3][::-1]
+    chain, ref = Chain(xml, "l0", "l%d" % nj, GRAV), OracleChain(xml, "l0", "l%d" % nj, GRAV, input_joint_names=names)
+    assert chain.setInputJointsName(names)
+    n, P = ref.n, ref.P
+    q, dq, ddq = trajectory_batch(11 + nj, N, n)
+    rng = np.random.default_rng(N + nj)
+    tau = ref.joint_torque(q, dq, ddq) + 1e-3 * rng.normal(size=(N, n))
+    A = ref.regressor(q, dq, ddq).reshape(N * n, P)
+    M = np.column_stack([A, tau.reshape(-1)])
+    G = M.T @ M
+    args = [torch.from_numpy(x).cuda() for x in (q, dq, ddq, tau)]
+    R1 = chain.getRegressorTsqr(*args).cpu().numpy()
+    assert R1.shape == (P + 1, P + 1) and np.allclose(np.tril(R1, -1), 0.0)
+    assert np.abs(R1.T @ R1 - G).max() <= 1e-11 * np.abs(G).max()
+    R2 = chain.getRegressorTsqr(*args, out=torch.from_numpy(R1).cuda(), accumulate=True).cpu().numpy()
+    assert np.allclose(np.tril(R2, -1), 0.0) and np.abs(R2.T @ R2 - 2 * G).max() <= 1e-11 * np.abs(G).max()
+    # friction on five input joints: 10 more columns (10 joints: 111 + 1 = the widest factor the entry points hold)
+    specs = [(0, j, 1e-3, 5.0, [0.4 + 0.1 * j, 1.0]) for j in (0, 2, 4, 6, n - 1)]
+    comps = ComponentSet([dict(type=0, joint=sp[1], min_velocity=1e-3, max_velocity=5.0, parameters=sp[4]) for sp in specs], n)
+    Cm, tau_c = components_regressor(specs, n, q, dq)
+    tau2 = tau + tau_c
+    M2 = np.column_stack([A, Cm.reshape(N * n, comps.columns), tau2.reshape(-1)])
+    G2 = M2.T @ M2
+    R3 = chain.getIdentificationTsqr(comps, *(args[:3] + [torch.from_numpy(tau2).cuda()])).cpu().numpy()
+    assert np.allclose(np.tril(R3, -1), 0.0) and np.abs(R3.T @ R3 - G2).max() <= 1e-11 * np.abs(G2).max()
+    s_ref, s_gpu = np.linalg.svd(np.linalg.qr(M2, mode="r"), compute_uv=False), np.linalg.svd(R3, compute_uv=False)
+    keep = s_ref > 1e-9 * s_ref[0]
+    assert np.abs(s_gpu[keep] / s_ref[keep] - 1.0).max() <= 1e-8
