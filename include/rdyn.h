@@ -40,15 +40,16 @@ extern "C" {
 
 #define RDYN_VERSION 100
 /* Chain joints INCLUDING fixed ones (reference: m_joints_number, primitives_impl.h:638).  The reference's default build is
- * unbounded (rosdyn_core/CMakeLists.txt:12-16: MAX_NUM_AXES = -1); here a chain may have up to RDYN_MAX_JOINTS joints, of which the
- * kernels sweep at most RDYN_MAX_SWEPT_JOINTS (they are instantiated for 1..RDYN_MAX_SWEPT_JOINTS with every per-link quantity in
- * registers).  A chain with more joints than that is long because of FIXED frames (a tool changer, a camera mount, the flange /
- * tool0 frames of the public UR and Panda models): its input joints (at most RDYN_MAX_SWEPT_JOINTS, in chain order) define a reduced
- * companion chain -- the fixed frames folded into the neighbouring bodies, rdyn_chain_reduction -- which the kernels sweep, and the
- * columns of every folded link are restored exactly (Y_f = Y_body X_f).  Served that way: rdyn_regressor, rdyn_joint_torque,
- * rdyn_joint_torque_nonlinear, rdyn_joint_inertia, rdyn_nominal_parameters, the normal equations and the R factors
- * (rdyn_regressor_gram, rdyn_identification_gram, rdyn_regressor_tsqr, rdyn_identification_tsqr and their multi-GPU forms).
- * The by-link kinematic outputs (transformations, twists, wrenches of every link, the IK) answer RDYN_ERR_UNSUPPORTED for such a chain. */
+ * unbounded (rosdyn_core/CMakeLists.txt:12-16: MAX_NUM_AXES = -1); here a chain may have up to RDYN_MAX_JOINTS joints.
+ *  - Chains of up to RDYN_MAX_SWEPT_JOINTS joints: kernels instantiated per joint count, every per-link quantity in registers.
+ *  - Longer chains (long because of FIXED frames as a rule: a tool changer, a camera mount, the flange / tool0 frames of the public
+ *    UR and Panda models), input joints listed in ANY order (setInputJointsName, primitives_impl.h:705-737):
+ *      the by-link kinematic outputs -- rdyn_transformation, rdyn_jacobian(_link), rdyn_twist, rdyn_twist_parts, rdyn_jerk_parts,
+ *      rdyn_wrench, rdyn_joint_torque_ext -- run on kernels with a run-time link loop (rdyn_long_kin.hip), any number of input joints;
+ *      rdyn_regressor, rdyn_joint_torque(_nonlinear), rdyn_joint_inertia, rdyn_nominal_parameters, the normal equations, the R factors
+ *      and rdyn_local_ik sweep the REDUCED COMPANION -- the input joints (at most RDYN_MAX_SWEPT_JOINTS) with the fixed frames folded
+ *      into the neighbouring bodies, rdyn_chain_reduction -- and restore the columns of every folded link exactly (Y_f = Y_body X_f);
+ *      with more input joints than that only the kinematic outputs and the joint torques (read off the wrench recursion) are served. */
 #define RDYN_MAX_JOINTS 32
 #define RDYN_MAX_SWEPT_JOINTS 10
 
@@ -421,9 +422,12 @@ int rdyn_regressor_tsqr_multi(rdyn_multi_gpu* ctx, const rdyn_chain* chain, cons
  * the stack with rdyn_tsqr_combine_host.  Solve with rdyn_solve_r_factor(R1, n1, n_cols, n_cols, d = R1 + n_cols * n1, ...).
  * rdyn_tsqr: any column-major rows x n_cols device matrix, n1 <= 112 (what rdyn_gram takes: a materialised [Y | C | tau_meas] of a
  * chain with fixed frames and friction columns has 90 - 110 columns).  rdyn_regressor_tsqr: the stacked regressor of the batch and
- * tau_meas (layout of batch->q), rows generated in LDS by the regressor sweep, never stored: n1 = 10 joints_number + 1; chains of
- * 1..8 INPUT joints in chain order (else RDYN_ERR_UNSUPPORTED); joints that are not input joints are folded away (the reduced chain
- * of rdyn_chain_reduction is swept and the factor expanded by a small QR: up to RDYN_MAX_JOINTS chain joints).
+ * tau_meas (layout of batch->q), n1 = 10 joints_number + 1; chains of 1..10 INPUT joints in any order; joints that are not input
+ * joints are folded away (the reduced chain of rdyn_chain_reduction is swept and the factor expanded by a small QR: up to
+ * RDYN_MAX_JOINTS chain joints).  Up to 8 input joints the rows are generated in LDS by the regressor sweep and never stored (input
+ * joints listed out of chain order: the kernels sweep in chain order and read q, Dq, DDq, tau_meas of every row through an index map
+ * -- A'A, A'tau and R do not depend on the order of the rows inside a sample); 9..10 input joints: chunk images of 16 384 samples in
+ * the workspace (132 MB) factored by rdyn_tsqr's kernels.
  * rdyn_identification_tsqr: the same for the identification step's [Y | C | tau_meas] (C = the component columns of
  * rdyn_components_regressor -- friction_polynomial1.h:126, ideal_spring.h:64 -- K = rdyn_components_columns):
  * n1 = 10 joints_number + K + 1 <= 112 after the reduction, unknowns [inertial ; component] parameters.  The component columns

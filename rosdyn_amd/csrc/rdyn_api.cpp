@@ -332,27 +332,55 @@ int run_local(const rdyn_chain* c, const rdyn_batch* b, int mode, double* tau, d
 extern "C"
 {
 
+// a chain of more than RDYN_MAX_SWEPT_JOINTS joints whose input joints are too many for the companion: the joint torques read off the
+// wrench recursion of the run-time-length kernels (primitives_impl.h:1264-1272; use_ddq = false: DDq = 0)
+static int long_chain_torque(const rdyn_chain* c, const rdyn_batch* b, double* tau, bool use_ddq)
+{
+  if (b->n_samples == 0) return RDYN_OK;
+  DeviceGuard g;
+  int st = g.enter(b->device);
+  if (st != RDYN_OK) return st;
+  RdynKinExtArgs e;
+  memset(&e, 0, sizeof e);
+  st = device_const_long(c, &e.chain_long);
+  if (st != RDYN_OK) return st;
+  e.q = b->q;
+  e.dq = b->dq;
+  e.ddq = use_ddq ? b->ddq : nullptr;
+  e.n_samples = b->n_samples;
+  rec_strides(b, c->n_active(), &e.in_ss, &e.in_sj);
+  e.tau = tau;
+  e.tau_ss = e.in_ss;
+  e.tau_sj = e.in_sj;
+  RDYN_HIP_TRY(rdyn_launch_long_ext(c->n_joints(), e, (hipStream_t)b->stream));
+  return RDYN_OK;
+}
+
 int rdyn_joint_torque(const rdyn_chain* c, const rdyn_batch* b, double* tau)
 {
-  int st = check_batch(c, b, true, true, "rdyn_joint_torque", LONG_COMPANION);
+  const bool by_wrench = c && c->long_chain() && !c->reduced;
+  int st = check_batch(c, b, true, true, "rdyn_joint_torque", by_wrench ? LONG_KERNELS : LONG_COMPANION);
   if (st != RDYN_OK) return st;
   if (!tau && b->n_samples > 0)
   {
     rdyn_set_error("rdyn_joint_torque: null output");
     return RDYN_ERR_INVALID_ARGUMENT;
   }
+  if (by_wrench) return long_chain_torque(c, b, tau, true);
   return run_local(c, b, RDYN_MODE_TORQUE, tau, nullptr, nullptr, nullptr, true, true);
 }
 
 int rdyn_joint_torque_nonlinear(const rdyn_chain* c, const rdyn_batch* b, double* tau)
 {
-  int st = check_batch(c, b, true, false, "rdyn_joint_torque_nonlinear", LONG_COMPANION);
+  const bool by_wrench = c && c->long_chain() && !c->reduced;
+  int st = check_batch(c, b, true, false, "rdyn_joint_torque_nonlinear", by_wrench ? LONG_KERNELS : LONG_COMPANION);
   if (st != RDYN_OK) return st;
   if (!tau && b->n_samples > 0)
   {
     rdyn_set_error("rdyn_joint_torque_nonlinear: null output");
     return RDYN_ERR_INVALID_ARGUMENT;
   }
+  if (by_wrench) return long_chain_torque(c, b, tau, false);
   return run_local(c, b, RDYN_MODE_TORQUE, tau, nullptr, nullptr, nullptr, true, false);  // DDq = 0, primitives_impl.h:1287-1288
 }
 

@@ -166,6 +166,9 @@ def test_long_chain_more_than_ten_input_joints_is_kinematics_only():
     tq, tdq, tddq = (torch.from_numpy(x).cuda() for x in (q, dq, ddq))
     with pytest.raises(Exception, match="at most 10 input joints"):
         chain.getRegressor(tq, tdq, tddq)
+    # ... the joint torques are: read off the wrench recursion of the run-time-length kernels (primitives_impl.h:1264-1272)
+    _close(chain.getJointTorque(tq, tdq, tddq).cpu().numpy(), ref.joint_torque(q, dq, ddq), "tau, 14 input joints")
+    _close(chain.getJointTorqueNonLinearPart(tq, tdq).cpu().numpy(), ref.joint_torque(q, dq, 0 * ddq), "non-linear part, 14 input joints")
 
 
 @pytest.mark.parametrize("case", ["ur10_long", "gen20_permuted"])
