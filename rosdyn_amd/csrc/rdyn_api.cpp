@@ -1035,15 +1035,19 @@ static void fill_in_map(const rdyn_chain* c, RdynLdsGramArgs* la)
 {
   const int n = c->n_active();
   for (int r = 0; r < 8; ++r) la->in_map[r] = (r < n && r < (int)c->row_input.size()) ? c->row_input[r] : r;
-  // rows of the three row waves of the one-lane-per-sample sweepers (rdyn_duo_gram.hip, KIN): row l (input joints in chain order) is
-  // carried through n - l links; longest row first, each to the wave with the least work so far (three slots per wave: n <= 8)
-  for (int i = 0; i < 9; ++i) la->sw_rows[i] = 99;
-  int load[3] = {0, 0, 0}, used[3] = {0, 0, 0};
+  // rows of the seven row waves of the one-lane-per-sample sweepers (rdyn_duo_gram.hip, KIN): row l (input joints in chain order) is
+  // carried through n - l links; longest row first, each to the wave with the least work so far (two slots per wave)
+  for (int i = 0; i < 21; ++i) la->sw_rows[i] = 99;
+  int load[7] = {0, 0, 0, 0, 0, 0, 0}, used[7] = {0, 0, 0, 0, 0, 0, 0};
   for (int l = 0; l < n && l < 8; ++l)
   {
     int best = -1;
-    for (int w = 0; w < 3; ++w)
-      if (used[w] < 3 && (best < 0 || load[w] < load[best])) best = w;
+    for (int w = 0; w < 7; ++w)
+    {
+      // (row wave w = sweeper wave w + 1 sits on SIMD (w + 1) % 4: the one that shares the kinematics wave's SIMD takes rows last)
+      if (w == 3 && !probe_env("RDYN_KIN_ROW4") && n <= 6) continue;
+      if (used[w] < 2 && (best < 0 || load[w] < load[best])) best = w;
+    }
     la->sw_rows[3 * best + used[best]++] = l;
     load[best] += n - l;
   }

@@ -65,7 +65,7 @@ typedef double d4h __attribute__((ext_vector_type(4), aligned(16)));  // operand
 // KIN != 0: the one-lane-per-sample sweepers (DIRECT only; KIN = the padding of the tile columns in doubles, 4 or 2): sweeper wave 0
 // runs the link kinematics of the workgroup's 64 samples once, waves 1-3 the regressor rows -- the consumers do not see the difference
 template <int NJ, bool DIRECT, int XB, bool ALLREV, int KIN = 0>
-__global__ __launch_bounds__(512) void k_regressor_gram_duo(const RdynLdsGramArgs fa)
+__global__ __launch_bounds__(KIN ? 768 : 512) void k_regressor_gram_duo(const RdynLdsGramArgs fa)
 {
   constexpr int NB = (10 * NJ + 1 + 15) / 16 + XB;
   constexpr int NT = NB * (NB + 1) / 2;
@@ -73,8 +73,12 @@ __global__ __launch_bounds__(512) void k_regressor_gram_duo(const RdynLdsGramArg
   extern __shared__ __attribute__((aligned(32))) char lds_raw[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int pair = wave & 3;
-  const bool sweeper = wave < 4;
+  // KIN: TWELVE waves -- eight sweepers (wave 0 the kinematics, waves 1-7 the rows: the sweeper waves' own chain between two barriers
+  // is what a tile costs, so it is split over as many waves as the register file holds: three per SIMD, 168 registers each) and the
+  // four consumers behind them
+  constexpr int NSW = KIN ? 8 : 4;
+  const int pair = KIN ? (wave - NSW) & 3 : wave & 3;
+  const bool sweeper = wave < NSW;
   char* const tile = lds_raw + (size_t)pair * fa.tile_bytes;  // shared by the pair
   const int n = fa.n_active;
   // tile_stride > 1: only every tile_stride-th 16-sample tile (the subsample pass of the robust factor, rdyn_cholqr.hip)
@@ -203,24 +207,21 @@ __global__ __launch_bounds__(512) void k_regressor_gram_duo(const RdynLdsGramArg
     else
     {
       // ---- a row wave
-      const int ra = fa.sw_rows[3 * (wave - 1)], rb = fa.sw_rows[3 * (wave - 1) + 1], rc = fa.sw_rows[3 * (wave - 1) + 2];  // wave-uniform; RDYN_LANE_NO_ROW = none
-      const int64_t oba = ra < 8 ? (int64_t)fa.in_map[ra] * fa.in_sj : 0, obb = rb < 8 ? (int64_t)fa.in_map[rb] * fa.in_sj : 0,
-                    obc = rc < 8 ? (int64_t)fa.in_map[rc] * fa.in_sj : 0;
+      const int ra = fa.sw_rows[3 * (wave - 1)], rb = fa.sw_rows[3 * (wave - 1) + 1];  // wave-uniform; 99 = none (seven row waves: at most two rows each)
+      const int64_t oba = ra < 8 ? (int64_t)fa.in_map[ra] * fa.in_sj : 0, obb = rb < 8 ? (int64_t)fa.in_map[rb] * fa.in_sj : 0;
       // measured torque of my rows; position and velocity of their joints (component columns only): one tile ahead
-      double nba = 0.0, nbb = 0.0, nbc = 0.0, nqa = 0.0, nqb = 0.0, nqc = 0.0, nda = 0.0, ndb = 0.0, ndc = 0.0;
+      double nba = 0.0, nbb = 0.0, nqa = 0.0, nqb = 0.0, nda = 0.0, ndb = 0.0;
       auto fetch = [&](int64_t tile_index) {
         const int64_t o = sample_offset(tile_index);
         if (fa.bcol)
         {
           if (ra < 8) nba = fa.bcol[o + oba];
           if (rb < 8) nbb = fa.bcol[o + obb];
-          if (rc < 8) nbc = fa.bcol[o + obc];
         }
         if (XB > 0 || fa.n_comps > 0)
         {
           if (ra < 8) { nqa = fa.q[o + oba]; nda = fa.dq[o + oba]; }
           if (rb < 8) { nqb = fa.q[o + obb]; ndb = fa.dq[o + obb]; }
-          if (rc < 8) { nqc = fa.q[o + obc]; ndc = fa.dq[o + obc]; }
         }
       };
       fetch(t_mine);
@@ -230,30 +231,26 @@ __global__ __launch_bounds__(512) void k_regressor_gram_duo(const RdynLdsGramArg
         DUO_STAMP_TRIP(it);
         const int64_t tl = t_mine + it * t_step;
         const bool valid = tl < n_tiles && tl * t_mul * 16 + s_loc < fa.n_samples;
-        const double tba = valid ? nba : 0.0, tbb = valid ? nbb : 0.0, tbc = valid ? nbc : 0.0;
-        const double qra = nqa, qrb = nqb, qrc = nqc, dqra = nda, dqrb = ndb, dqrc = ndc;
+        const double tba = valid ? nba : 0.0, tbb = valid ? nbb : 0.0;
+        const double qra = nqa, qrb = nqb, dqra = nda, dqrb = ndb;
         fetch(tl + t_step);  // in flight during this tile's sweep
-        V3 La = mk(0, 0, 0), Aa = mk(0, 0, 0), Lb = mk(0, 0, 0), Ab = mk(0, 0, 0), Lc = mk(0, 0, 0), Ac = mk(0, 0, 0);
+        V3 La = mk(0, 0, 0), Aa = mk(0, 0, 0), Lb = mk(0, 0, 0), Ab = mk(0, 0, 0);
         int col_off = 0;  // byte offset of link f's first column in the sub-tile
         // (a ROLLED link loop: nothing in it depends on f at compile time, and the three roles share the instruction cache)
-        // what the kinematics wave published for the link: requested right behind the barrier that releases it, IN FRONT of the
-        // stores of the previous link (the LDS serves a wave's requests in order)
-        double xv[XV];
-#pragma unroll
-        for (int k = 0; k < XV; ++k) xv[k] = xch[k * 64];
 #pragma unroll 1
         for (int f = 0; f < NJ; ++f)
         {
+          const double* const xi = xch + (f & 1) * (XV * 64);  // what the kinematics wave published for the link
           double R[9], b00, b01, b02, b10, b11, b12, b20, b21, b22;
           V3 tt, w, al, d;
           if constexpr (XV == 12)
           {
             asm volatile("" : "+s"(c));
             JointRef J = c->j[f];
-            const double sn = xv[0], oc = xv[1], qp = xv[2];
-            w = mk(xv[3], xv[4], xv[5]);
-            al = mk(xv[6], xv[7], xv[8]);
-            d = mk(xv[9], xv[10], xv[11]);
+            const double sn = xi[0], oc = xi[64], qp = xi[128];
+            w = mk(xi[192], xi[256], xi[320]);
+            al = mk(xi[384], xi[448], xi[512]);
+            d = mk(xi[576], xi[640], xi[704]);
 #pragma unroll
             for (int i = 0; i < 9; ++i) R[i] = fma(sn, J.B[i], fma(oc, J.C[i], J.A[i]));
             tt = ALLREV ? ld3(J.t) : axpy(ld3(J.t), ld3(J.up), qp);
@@ -266,14 +263,14 @@ __global__ __launch_bounds__(512) void k_regressor_gram_duo(const RdynLdsGramArg
           else
           {
 #pragma unroll
-            for (int i = 0; i < 9; ++i) R[i] = xv[i];
-            tt = mk(xv[9], xv[10], xv[11]);
-            w = mk(xv[12], xv[13], xv[14]);
-            al = mk(xv[15], xv[16], xv[17]);
-            d = mk(xv[18], xv[19], xv[20]);
-            b00 = xv[21]; b01 = xv[22]; b02 = xv[23];
-            b10 = xv[24]; b11 = xv[25]; b12 = xv[26];
-            b20 = xv[27]; b21 = xv[28]; b22 = xv[29];
+            for (int i = 0; i < 9; ++i) R[i] = xi[i * 64];
+            tt = mk(xi[576], xi[640], xi[704]);
+            w = mk(xi[768], xi[832], xi[896]);
+            al = mk(xi[960], xi[1024], xi[1088]);
+            d = mk(xi[1152], xi[1216], xi[1280]);
+            b00 = xi[1344]; b01 = xi[1408]; b02 = xi[1472];
+            b10 = xi[1536]; b11 = xi[1600]; b12 = xi[1664];
+            b20 = xi[1728]; b21 = xi[1792]; b22 = xi[1856];
           }
           if (f > ra)  // (before its joint a row's unit twist is zero: nothing to carry)
           {
@@ -287,13 +284,7 @@ __global__ __launch_bounds__(512) void k_regressor_gram_duo(const RdynLdsGramArg
             Ab = rotT(R, Ab);
             Lb = nL;
           }
-          if (f > rc)
-          {
-            const V3 nL = rotT(R, Lc + cross(Ac, tt));
-            Ac = rotT(R, Ac);
-            Lc = nL;
-          }
-          if (f == ra || f == rb || f == rc)
+          if (f == ra || f == rb)
           {
             // the row of joint f starts here with the joint's own unit twist (zero for a sample beyond the batch: all its entries stay 0)
             asm volatile("" : "+s"(c));
@@ -304,8 +295,7 @@ __global__ __launch_bounds__(512) void k_regressor_gram_duo(const RdynLdsGramArg
             const V3 sl = mk((pri && valid) ? u.x : 0.0, (pri && valid) ? u.y : 0.0, (pri && valid) ? u.z : 0.0);
             const V3 sa = mk((rev && valid) ? u.x : 0.0, (rev && valid) ? u.y : 0.0, (rev && valid) ? u.z : 0.0);
             if (f == ra) { La = sl; Aa = sa; }
-            else if (f == rb) { Lb = sl; Ab = sa; }
-            else { Lc = sl; Ac = sa; }
+            else { Lb = sl; Ab = sa; }
           }
           auto row_y = [&](V3 L, V3 A, double (&y)[10]) {
             const V3 dxA = cross(d, A), x = cross(A, w);
@@ -320,19 +310,12 @@ __global__ __launch_bounds__(512) void k_regressor_gram_duo(const RdynLdsGramArg
             y[8] = fma(A.y, al.z, fma(A.z, al.y, fma(x.y, w.z, x.z * w.y)));
             y[9] = fma(A.z, al.z, x.z * w.z);
           };
-          double ya[10], yb[10], yc[10];
+          double ya[10], yb[10];
           if (f >= ra) row_y(La, Aa, ya);
           if (f >= rb) row_y(Lb, Ab, yb);
-          if (f >= rc) row_y(Lc, Ac, yc);
           // B_f: the consumers have read row group f of the previous tile -- the columns of link f may be overwritten now -- and link
           // f + 1 waits in the other exchange buffer (my reads of this one have returned: it is rewritten behind this barrier)
           DUO_BARRIER_LDS();
-          if (f + 1 < NJ)
-          {
-            const double* const xi = xch + ((f + 1) & 1) * (XV * 64);
-#pragma unroll
-            for (int k = 0; k < XV; ++k) xv[k] = xi[k * 64];
-          }
           const int stride = (16 * (f + 1) + KIN) * 8;
           char* const lf = tile + col_off + s_loc * 8;
           col_off += 10 * stride;
@@ -346,11 +329,6 @@ __global__ __launch_bounds__(512) void k_regressor_gram_duo(const RdynLdsGramArg
 #pragma unroll
             for (int p = 0; p < 10; ++p) *(double*)(lf + p * stride + rb * 128) = yb[p];
           }
-          if (f >= rc)
-          {
-#pragma unroll
-            for (int p = 0; p < 10; ++p) *(double*)(lf + p * stride + rc * 128) = yc[p];
-          }
           DUO_STAMP_HERE(0);  // (diagnostic builds) stores and exchange reads issued
           DUO_STAMP_HERE(1);  // ... and completed
         }
@@ -363,9 +341,9 @@ __global__ __launch_bounds__(512) void k_regressor_gram_duo(const RdynLdsGramArg
           {
             const int type = fa.comps[ci].type, jc = fa.comps[ci].joint;
             const int cols = type == RDYN_COMP_FRICTION2 ? 3 : 2;
-            if (jc == ra || jc == rb || jc == rc)
+            if (jc == ra || jc == rb)
             {
-              const double qv = jc == ra ? qra : (jc == rb ? qrb : qrc), dv = jc == ra ? dqra : (jc == rb ? dqrb : dqrc);
+              const double qv = jc == ra ? qra : qrb, dv = jc == ra ? dqra : dqrb;
               double row[3] = {0.0, 0.0, 0.0};
               if (type == RDYN_COMP_SPRING)
               {
@@ -395,7 +373,6 @@ __global__ __launch_bounds__(512) void k_regressor_gram_duo(const RdynLdsGramArg
           char* const lb = tile + fa.lds_off_b + s_loc * 8;
           if (ra < 8) *(double*)(lb + ra * 128) = tba;
           if (rb < 8) *(double*)(lb + rb * 128) = tbb;
-          if (rc < 8) *(double*)(lb + rc * 128) = tbc;
         }
         DUO_BARRIER_LDS();  // the tile is complete
       }
@@ -574,7 +551,7 @@ __global__ __launch_bounds__(512) void k_regressor_gram_duo(const RdynLdsGramArg
     };
     // 7 joints + component columns: 21 accumulator tiles (168 registers) + two operand sets (96) do not fit 256 registers (468 B of
     // scratch in the hot loop): ONE operand set there -- the next group's loads are issued behind this group's MFMAs instead of in front
-    constexpr bool ONEBUF = NJ >= 7 && XB > 0;
+    constexpr bool ONEBUF = (NJ >= 7 && XB > 0) || KIN != 0;  // (KIN: three waves per SIMD, 168 registers)
     d4 opa[NB], opb[ONEBUF ? 1 : NB];
     if (KIN) DUO_BARRIER();  // the prologue of the one-lane-per-sample sweepers (link 0 of the first tile is published)
     for (int64_t it = 0; it <= trips; ++it)
@@ -612,7 +589,7 @@ __global__ __launch_bounds__(512) void k_regressor_gram_duo(const RdynLdsGramArg
     // tiles: every consumer must be done with its own first.
     DUO_BARRIER_LDS();
     double* red = (double*)lds_raw;
-    const int cw = wave - 4;
+    const int cw = wave - NSW;
     for (int w = 0; w < 4; ++w)
     {
       if (cw == w)
@@ -640,7 +617,7 @@ __global__ __launch_bounds__(512) void k_regressor_gram_duo(const RdynLdsGramArg
   {
     const double* red = (const double*)lds_raw;
     double* slab = fa.slabs + (int64_t)blockIdx.x * (NT * 256);
-    for (int i = threadIdx.x; i < NT * 256; i += 512) slab[i] = red[i];
+    for (int i = threadIdx.x; i < NT * 256; i += (KIN ? 768 : 512)) slab[i] = red[i];
   }
 }
 
@@ -658,7 +635,7 @@ hipError_t launch_duo_nj2(const RdynLdsGramArgs& a, int blocks, size_t lds_bytes
     if (e != hipSuccess) return e;
     attr_set.fetch_or(bit, std::memory_order_release);
   }
-  hipLaunchKernelGGL((k_regressor_gram_duo<NJ, DIRECT, XB, ALLREV, KIN>), dim3(blocks), dim3(512), lds_bytes, st, a);
+  hipLaunchKernelGGL((k_regressor_gram_duo<NJ, DIRECT, XB, ALLREV, KIN>), dim3(blocks), dim3(KIN ? 768 : 512), lds_bytes, st, a);
   return hipGetLastError();
 }
 template <int NJ>

@@ -191,10 +191,10 @@ struct RdynLdsGramArgs
   // the identity for input joints in chain order
   int in_map[8];
   // one-lane-per-sample sweepers (rdyn_duo_gram.hip, KIN): sweep_lanes != 0 selects them (the host then sized the dynamic LDS for the
-  // exchange area behind the tiles, RDYN_KIN_XCH_BYTES); sw_rows[3 (w - 1) + slot] = the tile rows sweeper wave w = 1 .. 3 computes (99 =
+  // exchange area behind the tiles, RDYN_KIN_XCH_BYTES); sw_rows[3 (w - 1) + slot] = the tile rows sweeper wave w = 1 .. 7 computes (99 =
   // none), balanced over the waves by the cost of a row (a row of joint l is carried through the links l .. n - 1)
   int sweep_lanes;
-  int sw_rows[9];
+  int sw_rows[21];
   int all_revolute;                    // every chain joint is revolute (selects the sweeper without joint-kind selects)
   int first_col[RDYN_MAX_SWEPT_JOINTS];      // per input joint: 10 * chain index
   int lds_off[RDYN_MAX_SWEPT_JOINTS];        // per link: byte offset of its first column in the tile

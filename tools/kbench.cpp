@@ -221,13 +221,13 @@ int main(int argc, char** argv)
         std::printf("    stamps: sweeper cycles %.0f (in barriers %.0f = %.0f%%), consumer cycles %.0f (in barriers %.0f = %.0f%%)\n", tot[0][0] / 24, tot[0][1] / 24,
                     100 * tot[0][1] / tot[0][0], tot[1][0] / 24, tot[1][1] / 24, 100 * tot[1][1] / tot[1][0]);
         {
-          std::vector<double> tlv(8 * 32);
+          std::vector<double> tlv(12 * 32);
           CHECK(hipMemcpy(tlv.data(), (const double*)d_ws + (size_t)600 * 4096, sizeof(double) * tlv.size(), hipMemcpyDeviceToHost));
           std::printf("    timeline of workgroup 0 (clock at entry / exit of each barrier of one trip, per wave):\n");
-          for (int w = 0; w < 8; ++w)
+          for (int w = 0; w < 12; ++w)
           {
             std::printf("      w%d", w);
-            for (int k = 0; k < 30; ++k) std::printf(" %7.0f", tlv[w * 32 + k] - tlv[0]);
+            for (int k = 0; k < 16; ++k) std::printf(" %7.0f", tlv[w * 32 + k] - tlv[0]);
             std::printf("\n");
           }
         }
