@@ -57,6 +57,18 @@ namespace
 #define DUO_STAMP_OUT(NT_)
 #endif
 
+// ocml's sincos for angles beyond the range of rdyn_sincos_small, out of line: one copy of its Payne-Hanek path in the kernel, not one per joint
+struct DuoSinCos
+{
+  double sn, cs;
+};
+__device__ __attribute__((noinline)) DuoSinCos duo_sincos_cold(double x)
+{
+  DuoSinCos r;
+  sincos(x, &r.sn, &r.cs);
+  return r;
+}
+
 // XB: extra 16-column blocks for the component columns of rdyn_identification_gram (0: plain regressor Gram)
 typedef double d4h __attribute__((ext_vector_type(4), aligned(16)));  // operand quads: 16-byte aligned in the compact tile layout
 
@@ -106,7 +118,9 @@ __global__ __launch_bounds__(KIN ? 768 : 512) void k_regressor_gram_duo(const Rd
     const int sub = lane >> 4, s_loc = lane & 15;
     char* const tile = lds_raw + (size_t)sub * fa.tile_bytes;  // the 16-sample sub-tile of my sample
     // doubles per sample and exchange buffer: 30 (R, the joint offset, w, al, d, the b-matrix) where the LDS has room, 12 at 7 joints
-    constexpr int XV = NJ <= 6 ? 30 : 12;
+    // (without component columns the row waves have the slack to rebuild the b-matrix: 9 stores and ~18 instructions less on the
+    // kinematics wave, the longest chain of an interval: 515 -> 487 us at 6 joints; with them the row waves are the longer side)
+    constexpr int XV = NJ <= 6 ? (XB > 0 ? 30 : 21) : 12;
     double* const xch = (double*)(lds_raw + (size_t)4 * fa.tile_bytes) + lane;  // [2][XV][64]
     const int64_t t_mine = (int64_t)blockIdx.x * 4 + sub;
     // sub-tile p of the workgroup's trip `it` is the 16-sample tile (blockIdx.x * 4 + p) + it * t_step of the pair kernels' numbering
@@ -134,45 +148,27 @@ __global__ __launch_bounds__(KIN ? 768 : 512) void k_regressor_gram_duo(const Rd
       }
       V3 w = mk(0, 0, 0), vl = mk(0, 0, 0), al = mk(0, 0, 0), lin = mk(-c->g[0], -c->g[1], -c->g[2]);
       int64_t o_next = sample_offset(t_mine + t_step);
-      // sin and 1 - cos of all the tile's joint angles at once: NJ independent chains (one sincos per link leaves the wave waiting on
-      // its own results: measured 1 900 cycles per link against 600 of issue)
+      // sin and 1 - cos of all the tile's joint angles at once, a tile ahead: NJ independent chains (one sincos per link on demand leaves
+      // the wave waiting on its own results: 1 900 cycles per link against 600 of issue).  Code size matters (three roles share the
+      // instruction cache): the range-limited evaluation inline,
+      // ocml's for angles beyond 2^20 in ONE out-of-line function (duo_sincos_cold) -- same results as rdyn_sincos.
       double sn_[NJ], oc_[NJ];
-      // (code size matters: three roles share the instruction cache -- the range-limited evaluation inline, ocml's for angles
-      // beyond 2^20 ONCE, in a cold rolled loop: same results as rdyn_sincos)
-      auto all_sincos = [&]() {
-        bool big = false;
+#define RDYN_KIN_ONE_SINCOS(j_)                                                                     \
+  do                                                                                               \
+  {                                                                                                \
+    double sn1_, cs1_;                                                                             \
+    rdyn_sincos_small(q_[j_], &sn1_, &cs1_);                                                       \
+    if (__builtin_expect(!(fabs(q_[j_]) <= 1048576.0), 0))                                         \
+    {                                                                                              \
+      const DuoSinCos big_ = duo_sincos_cold(q_[j_]);                                              \
+      sn1_ = big_.sn;                                                                              \
+      cs1_ = big_.cs;                                                                              \
+    }                                                                                              \
+    sn_[j_] = sn1_;                                                                                \
+    oc_[j_] = 1.0 - cs1_;                                                                          \
+  } while (0)
 #pragma unroll
-        for (int j = 0; j < NJ; ++j)
-        {
-          double cs;
-          rdyn_sincos_small(q_[j], &sn_[j], &cs);
-          oc_[j] = 1.0 - cs;
-          big = big || !(fabs(q_[j]) <= 1048576.0);
-        }
-        if (__builtin_expect(big, 0))
-        {
-#pragma unroll 1
-          for (int j = 0; j < NJ; ++j)
-          {
-            double x = q_[0];
-#pragma unroll
-            for (int k = 1; k < NJ; ++k) x = (j == k) ? q_[k] : x;
-            if (!(fabs(x) <= 1048576.0))
-            {
-              double s1, c1;
-              sincos(x, &s1, &c1);
-#pragma unroll
-              for (int k = 0; k < NJ; ++k)
-                if (j == k)
-                {
-                  sn_[k] = s1;
-                  oc_[k] = 1.0 - c1;
-                }
-            }
-          }
-        }
-      };
-      all_sincos();
+      for (int j = 0; j < NJ; ++j) RDYN_KIN_ONE_SINCOS(j);  // the first tile's
       {
         constexpr int g = 0;
 #include "rdyn_kin_link_body.inc"
@@ -191,7 +187,12 @@ __global__ __launch_bounds__(KIN ? 768 : 512) void k_regressor_gram_duo(const Rd
 #include "rdyn_kin_link_body.inc"
           }
           else
-            all_sincos();  // the NEXT tile's (q_[] holds its angles: every link refilled its joint's registers) -- behind the row waves' longest step
+          {
+            // the NEXT tile's sin / 1 - cos (q_[] holds its angles: every link refilled its joint's registers), NJ independent chains,
+            // behind the row waves' longest step.  (One per interval beside every link: the same at 6 joints, 3 % slower at 7.)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) RDYN_KIN_ONE_SINCOS(j);
+          }
           DUO_BARRIER_LDS();  // B_f: link f + 1 is published; the rows of link f are computed (their stores follow)
         }
         // the next tile: fresh state, its link 0 (buffer 0: the last reads of it are behind B_{NJ-1})
@@ -268,9 +269,20 @@ __global__ __launch_bounds__(KIN ? 768 : 512) void k_regressor_gram_duo(const Rd
             w = mk(xi[768], xi[832], xi[896]);
             al = mk(xi[960], xi[1024], xi[1088]);
             d = mk(xi[1152], xi[1216], xi[1280]);
-            b00 = xi[1344]; b01 = xi[1408]; b02 = xi[1472];
-            b10 = xi[1536]; b11 = xi[1600]; b12 = xi[1664];
-            b20 = xi[1728]; b21 = xi[1792]; b22 = xi[1856];
+            if constexpr (XV == 30)
+            {
+              b00 = xi[1344]; b01 = xi[1408]; b02 = xi[1472];
+              b10 = xi[1536]; b11 = xi[1600]; b12 = xi[1664];
+              b20 = xi[1728]; b21 = xi[1792]; b22 = xi[1856];
+            }
+            else
+            {
+              const double wxy = w.x * w.y, wxz = w.x * w.z, wyz = w.y * w.z;
+              const double wxx = w.x * w.x, wyy = w.y * w.y, wzz = w.z * w.z;
+              b00 = -(wyy + wzz); b01 = wxy - al.z; b02 = wxz + al.y;
+              b10 = wxy + al.z; b11 = -(wxx + wzz); b12 = wyz - al.x;
+              b20 = wxz - al.y; b21 = wyz + al.x; b22 = -(wxx + wyy);
+            }
           }
           if (f > ra)  // (before its joint a row's unit twist is zero: nothing to carry)
           {

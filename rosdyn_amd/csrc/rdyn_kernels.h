@@ -223,6 +223,7 @@ bool rdyn_regressor_gram_pipe_supported(int n_cols);
 hipError_t rdyn_launch_regressor_gram_pipe(int n_cols, const RdynLdsGramArgs& a, int blocks, size_t lds_bytes, hipStream_t st);
 // the two streams on two co-resident waves (rdyn_duo_gram.hip): chains of 2..7 joints, 512-thread workgroups
 bool rdyn_regressor_gram_duo_supported(int n_cols);
+// doubles per sample and exchange buffer: up to 6 joints 30 (the b-matrix too; the kernel uses 21 of them without component columns), 12 at 7
 #define RDYN_KIN_XCH_BYTES(n_joints) (2 * ((n_joints) <= 6 ? 30 : 12) * 64 * 8)
 // the one-lane-per-sample sweepers exist for this shape: 0 no, 4 / 2 = with the standard / the compact tile layout (column padding in doubles)
 int rdyn_regressor_gram_duo_kin_pad(int n_joints, int n_comp_cols);
