@@ -1031,26 +1031,28 @@ static int gram_through_reduced(const rdyn_chain* c, const rdyn_component* comps
 
 // the chain the tile kernels sweep: the sorted view when the input joints were listed out of chain order (rdyn_chain.hpp)
 static const rdyn_chain* ordered(const rdyn_chain* c) { return c->sorted ? c->sorted.get() : c; }
-static void fill_in_map(const rdyn_chain* c, RdynLdsGramArgs* la)
+// rows of the row waves of the one-lane-per-sample sweepers (rdyn_kin_sweepers.inc): row l (input joints in chain order) is carried
+// through n - l links; longest row first, each to the wave with the least work so far.  The Gram kernel has seven row waves with two
+// slots (the one that shares the kinematics wave's SIMD, `skip`, stays empty up to 6 joints), pass B of the R factor three with three.
+static void fill_sw_rows(RdynLdsGramArgs* la, int n, int waves, int slots, int skip)
 {
-  const int n = c->n_active();
-  for (int r = 0; r < 8; ++r) la->in_map[r] = (r < n && r < (int)c->row_input.size()) ? c->row_input[r] : r;
-  // rows of the seven row waves of the one-lane-per-sample sweepers (rdyn_duo_gram.hip, KIN): row l (input joints in chain order) is
-  // carried through n - l links; longest row first, each to the wave with the least work so far (two slots per wave)
   for (int i = 0; i < 21; ++i) la->sw_rows[i] = 99;
   int load[7] = {0, 0, 0, 0, 0, 0, 0}, used[7] = {0, 0, 0, 0, 0, 0, 0};
   for (int l = 0; l < n && l < 8; ++l)
   {
     int best = -1;
-    for (int w = 0; w < 7; ++w)
-    {
-      // (row wave w = sweeper wave w + 1 sits on SIMD (w + 1) % 4: the one that shares the kinematics wave's SIMD takes rows last)
-      if (w == 3 && !probe_env("RDYN_KIN_ROW4") && n <= 6) continue;
-      if (used[w] < 2 && (best < 0 || load[w] < load[best])) best = w;
-    }
+    for (int w = 0; w < waves; ++w)
+      if (w != skip && used[w] < slots && (best < 0 || load[w] < load[best])) best = w;
+    if (best < 0) return;
     la->sw_rows[3 * best + used[best]++] = l;
     load[best] += n - l;
   }
+}
+static void fill_in_map(const rdyn_chain* c, RdynLdsGramArgs* la)
+{
+  const int n = c->n_active();
+  for (int r = 0; r < 8; ++r) la->in_map[r] = (r < n && r < (int)c->row_input.size()) ? c->row_input[r] : r;
+  fill_sw_rows(la, n, 7, 2, !probe_env("RDYN_KIN_ROW4") && n <= 6 ? 3 : -1);
   la->sweep_lanes = 0;
 }
 // the one-lane-per-sample sweepers of the wave-pair Gram kernel serve this chain (every joint an input joint): the tile padding they
@@ -1586,6 +1588,7 @@ struct TsqrPlan
   bool image = false;
   size_t img_off = 0, rows_off = 0;  // doubles: the chunk image, rdyn_tsqr's own workspace
   RdynLdsGramArgs la, la_sub, la_wide;
+  RdynLdsGramArgs la_b;       // pass B's tile: la, or the layout of the one-lane-per-sample sweepers (sweep_lanes set)
   TsqrLayout L;
   const char* why = nullptr;  // when nothing serves the shape
 };
@@ -1618,6 +1621,7 @@ static bool tsqr_plan(const rdyn_chain* c, const rdyn_component* comps, int n_co
   memset(&p->la, 0, sizeof p->la);
   memset(&p->la_sub, 0, sizeof p->la_sub);
   memset(&p->la_wide, 0, sizeof p->la_wide);
+  memset(&p->la_b, 0, sizeof p->la_b);
   if (p->n > 8 && p->n <= RDYN_MAX_SWEPT_JOINTS && p->n == p->nJ && p->n1s <= rdyn_tsqr_wide_max_cols() &&
       !(p->expand && rdyn_cholqr_expand_lds_bytes(c->n_joints(), p->nJ, K) > 156 * 1024))
   {
@@ -1656,6 +1660,22 @@ static bool tsqr_plan(const rdyn_chain* c, const rdyn_component* comps, int n_co
         p->la = compact;
       else
         p->pairs = rdyn_cholqr_pairs(p->nJ, -p->la.tile_bytes, p->xb);  // too many component columns: two pairs beside W, or nothing
+    }
+    p->la_b = p->la;
+    const int kin_pad = rdyn_cholqr_kin_pad(p->nJ, p->xb, p->pairs);
+    if (kin_pad && !(probe_env("RDYN_PGRAM_SWEEPER") && !strcmp(probe_env("RDYN_PGRAM_SWEEPER"), "pair")))
+    {
+      // one lane per sample: wave 0 the link kinematics, three row waves (7 joints: four compact tiles + the exchange area, W in global memory)
+      RdynLdsGramArgs kin;
+      memset(&kin, 0, sizeof kin);
+      build_lds_tile(cs, K, false, &kin, kin_pad == 2);
+      const size_t need = (p->pairs == 4 ? rdyn_cholqr_w_doubles(p->nJ, p->xb) * 8 : 0) + 4 * (size_t)kin.tile_bytes + RDYN_KIN_XCH_BYTES_XV(p->nJ <= 6 ? 21 : 12);
+      if (need <= 160 * 1024)
+      {
+        fill_sw_rows(&kin, p->n, 3, 3, -1);
+        kin.sweep_lanes = 1;
+        p->la_b = kin;
+      }
     }
     if (p->pairs != 0)
     {
@@ -1829,6 +1849,7 @@ static int regressor_tsqr_run(const rdyn_chain* c, const rdyn_component* comps, 
     }
   };
   bind(p.la);
+  bind(p.la_b);
   bind(p.la_sub);
   bind(p.la_wide);
   double* const ws = (double*)workspace;
@@ -1864,7 +1885,7 @@ static int regressor_tsqr_run(const rdyn_chain* c, const rdyn_component* comps, 
     // pass A: the Gram matrix of every S-th tile (about 1 024 tiles whatever the batch size: one tile per wave pair of the regressor ->
     // Gram kernel; 16 384 samples = 115 000 rows for <= 96 columns put the pivots of the second factorisation within a few % of 1).
     // A preconditioner does not have to be a backward-stable factor -- what it is worth is measured on all rows afterwards.
-    RdynLdsGramArgs& la = p.la;
+    RdynLdsGramArgs& la = p.la_b;
     RdynLdsGramArgs sub = p.la_sub;
     const int64_t kSubTiles = probe_env("RDYN_CHOLQR_SUBTILES") ? atoll(probe_env("RDYN_CHOLQR_SUBTILES")) : 1024;
     sub.tile_stride = (int)(tiles / kSubTiles > 1 ? tiles / kSubTiles : 1);

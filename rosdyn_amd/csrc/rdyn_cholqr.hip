@@ -47,6 +47,8 @@
 namespace
 {
 
+typedef const __attribute__((address_space(1))) double* GlobalD;
+
 // pass B.  NPAIR wave pairs per workgroup (4, or 3 when four LDS tiles do not fit beside W: 7 joints).  Waves are dealt to the four
 // SIMDs cyclically: with 8 waves pair p = (wave p, wave p + 4) shares SIMD p; with 6 waves the pairs are (0, 4), (1, 5) and (2, 3).
 // NPAIR = 2 (7 joints + component columns: 21 accumulator tiles + 6 product tiles do not fit the 256 registers of a wave that shares
@@ -58,7 +60,11 @@ namespace
 // then holds four tiles again where W + four tiles exceed 160 KB (7 joints).
 // XB = 1: the per-joint component columns of rdyn_identification_tsqr ride in the tile ([Y | C | tau_meas], one more 16-column block), as
 // in rdyn_duo_gram.hip: a component column is stored as ONE 16-row group, that of its own joint.
-template <int NJ, bool ALLREV, int NPAIR, bool WGLOBAL, int XB>
+// KIN != 0 (NPAIR = 4; KIN = the padding of the tile columns in doubles, 4 or 2): the one-lane-per-sample sweepers of rdyn_kin_sweepers.inc
+// instead of the four row-pair sweepers -- wave 0 the link kinematics of the workgroup's 64 samples, waves 1-3 the rows (three each at
+// most), waves 4-7 the consumers as before (same tiles bit for bit, same barriers + the sweepers' prologue).  The exchange area sits
+// behind the four tiles.
+template <int NJ, bool ALLREV, int NPAIR, bool WGLOBAL, int XB, int KIN = 0>
 __global__ __launch_bounds__(128 * NPAIR) void k_regressor_pgram(const RdynLdsGramArgs fa, const double* __restrict__ Wg, const int* __restrict__ run_flag)
 {
   constexpr bool DIRECT = true;
@@ -93,7 +99,30 @@ __global__ __launch_bounds__(128 * NPAIR) void k_regressor_pgram(const RdynLdsGr
   const int64_t trips_raw = (n_tiles - (int64_t)blockIdx.x * NPAIR + t_step - 1) / t_step;
   const int64_t trips = trips_raw > 0 ? trips_raw : 0;
 
-  if (sweeper)
+#ifndef RDYN_PGRAM_X_IDLE
+#define RDYN_PGRAM_X_IDLE(wave_) true
+#endif
+#ifdef RDYN_PGRAM_X_NOSWEEP  // timing experiment only (wrong numbers): the sweepers (those RDYN_PGRAM_X_IDLE names) keep the barriers and do nothing else
+  if (sweeper && RDYN_PGRAM_X_IDLE(wave))
+  {
+    if (KIN) DUO_BARRIER();
+    for (int64_t it = 0; it < trips; ++it)
+      for (int f = 0; f <= NJ; ++f) DUO_BARRIER_LDS();
+  }
+  else
+#endif
+  if (sweeper && KIN)
+  {
+    // ================================================================ one lane per sample (doubles per sample and exchange buffer: 21 = R, the
+    // joint offset, w, al, d; 12 at 7 joints: sin, 1 - cos, the displacement, w, al, d -- what the compact tiles leave of the LDS)
+    constexpr int XV = NJ <= 6 ? 21 : 12;
+    constexpr int KIN_SLOTS = 3;
+    const int KIN_SW = wave;
+    char* const kin_tiles = lds_raw + WB;
+    double* const kin_xch_base = (double*)(lds_raw + WB + (size_t)4 * fa.tile_bytes);
+#include "rdyn_kin_sweepers.inc"
+  }
+  else if (sweeper)
   {
     // ================================================================ sweeper: as in rdyn_duo_gram.hip (16 samples x 4 lanes)
     ChainPtr c = as_const(fa.chain);
@@ -199,7 +228,8 @@ __global__ __launch_bounds__(128 * NPAIR) void k_regressor_pgram(const RdynLdsGr
       {
         if (col < 0) return 0.0;
         const int f = (col * 205) >> 11;  // col / 10 for col < 1024
-        const int off = f * (640 * f + 960) + (col - 10 * f) * (128 * f + 160);
+        constexpr int PAD = KIN ? KIN : 4;  // doubles of column padding (stride 128 f + 128 + 8 PAD bytes)
+        const int off = f * (640 * f + 640 + 80 * PAD) + (col - 10 * f) * (128 * f + 128 + 8 * PAD);
         if (j <= f) a = *(const double*)(tile + off + cl * 8 + j * 128);
       }
       else
@@ -215,65 +245,57 @@ __global__ __launch_bounds__(128 * NPAIR) void k_regressor_pgram(const RdynLdsGr
     const char* const wl = lds_raw + lane * 8;   // W in LDS
     // W in global memory: uniform base (laundered per row group: hoisted out of the tile loop, the ~250 operand addresses of a tile
     // become 64-bit VGPR pairs and spill) + lane index
-    const double* wgp = Wg;
+    // (explicitly a GLOBAL pointer: the laundering below hides the kernel argument it came from, and a flat load -- which may address
+    // the LDS -- counts on both wait counters and returns out of order with LDS reads: every wait then becomes vmcnt(0) lgkmcnt(0),
+    // the rows requested ahead included)
+    GlobalD wgp = (GlobalD)Wg;
+#ifdef RDYN_PGRAM_X_NOW  // timing experiment only (wrong numbers): no loads of W
+    auto wglob = [&](int blk_kk) -> double { return (double)(blk_kk + lane); };
+#else
     auto wglob = [&](int blk_kk) -> double { return (wgp + blk_kk * 64)[lane]; };
+#endif
     d4 D[NB];
     // Q(rows of group j, :) = X(rows of group j, :) W;  D[cb2] register r of lane (cl, g) = Q[sample g + 4 r][16 cb2 + cl]
     auto stage1 = [&](int j, int band) {
 #pragma unroll
       for (int cb = 0; cb < NB; ++cb) D[cb] = (d4){0.0, 0.0, 0.0, 0.0};
-      if constexpr (!WGLOBAL)
-      {
+      // rows (cb1, kk) of W in the order they are used, from the first block row of the band, RDYN_CHOLQR_AHEAD rows in flight: the
+      // operands of row r + AHEAD -- the tile's own (an LDS read: ~130 cycles before a dependent MFMA may issue, 84 rows per tile at 7
+      // joints: a third of the consumer's time when it was read in front of its MFMAs) and the row of W (LDS, or global memory: L1 / L2
+      // resident) -- are requested before the MFMAs of row r are issued, and no further ahead (compiler barrier): left alone the
+      // scheduler hoists every load of the group and spills the accumulators
+      constexpr int AH = RDYN_CHOLQR_AHEAD;
+      double ring[AH + 1][NB], aring[AH + 1];
+      if constexpr (WGLOBAL) asm volatile("" : "+s"(wgp));
+      auto load_row = [&](int r, double (&dst)[NB], double& adst) {  // r = flat row index from the band's first row
+        const int c1 = band + (r >> 2), k4 = r & 3;
+        adst = c1 < NB ? a_operand(c1, k4, j) : 0.0;
 #pragma unroll
-        for (int cb1 = 0; cb1 < NB; ++cb1)
+        for (int cb2 = 0; cb2 < NB; ++cb2)
         {
-          if (cb1 < band) continue;
-#pragma unroll
-          for (int kk = 0; kk < 4; ++kk)
+          dst[cb2] = 0.0;
+          if (c1 < NB && cb2 >= c1)
           {
-            const double a = a_operand(cb1, kk, j);
-#pragma unroll
-            for (int cb2 = cb1; cb2 < NB; ++cb2)
-            {
-              const double b = *(const double*)(wl + ((cb2 * (cb2 + 1) / 2 + cb1) * 4 + kk) * 512);
-              D[cb2] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, D[cb2], 0, 0, 0);
-            }
+            if constexpr (WGLOBAL) dst[cb2] = wglob((cb2 * (cb2 + 1) / 2 + c1) * 4 + k4);
+            else dst[cb2] = *(const double*)(wl + ((cb2 * (cb2 + 1) / 2 + c1) * 4 + k4) * 512);
           }
         }
-      }
-      else
+      };
+#pragma unroll
+      for (int r = 0; r < AH; ++r) load_row(r, ring[r], aring[r]);
+#pragma unroll
+      for (int cb1 = 0; cb1 < NB; ++cb1)
       {
-        // W from global memory: the operands of row (cb1, kk + 1) are requested before the MFMAs of row (cb1, kk) are issued, and no
-        // further ahead (compiler barrier): left alone the scheduler hoists every load of the group and spills the accumulators
-        // rows (cb1, kk) of W in the order they are used, from the first block row of the band; RDYN_CHOLQR_AHEAD rows in flight
-        constexpr int AH = RDYN_CHOLQR_AHEAD;
-        double ring[AH + 1][NB];
-        asm volatile("" : "+s"(wgp));
-        auto load_row = [&](int r, double (&dst)[NB]) {  // r = flat row index from the band's first row
-          const int c1 = band + (r >> 2), k4 = r & 3;
+        if (cb1 < band) continue;
 #pragma unroll
-          for (int cb2 = 0; cb2 < NB; ++cb2)
-          {
-            dst[cb2] = 0.0;
-            if (c1 < NB && cb2 >= c1) dst[cb2] = wglob((cb2 * (cb2 + 1) / 2 + c1) * 4 + k4);
-          }
-        };
-#pragma unroll
-        for (int r = 0; r < AH; ++r) load_row(r, ring[r]);
-#pragma unroll
-        for (int cb1 = 0; cb1 < NB; ++cb1)
+        for (int kk = 0; kk < 4; ++kk)
         {
-          if (cb1 < band) continue;
+          const int r = (cb1 - band) * 4 + kk;
+          load_row(r + AH, ring[(r + AH) % (AH + 1)], aring[(r + AH) % (AH + 1)]);
+          asm volatile("" ::: "memory");
+          const double a = aring[r % (AH + 1)];
 #pragma unroll
-          for (int kk = 0; kk < 4; ++kk)
-          {
-            const int r = (cb1 - band) * 4 + kk;
-            load_row(r + AH, ring[(r + AH) % (AH + 1)]);
-            asm volatile("" ::: "memory");
-            const double a = a_operand(cb1, kk, j);
-#pragma unroll
-            for (int cb2 = cb1; cb2 < NB; ++cb2) D[cb2] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, ring[r % (AH + 1)][cb2], D[cb2], 0, 0, 0);
-          }
+          for (int cb2 = cb1; cb2 < NB; ++cb2) D[cb2] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, ring[r % (AH + 1)][cb2], D[cb2], 0, 0, 0);
         }
       }
     };
@@ -293,9 +315,14 @@ __global__ __launch_bounds__(128 * NPAIR) void k_regressor_pgram(const RdynLdsGr
           }
       }
     };
+    if (KIN) DUO_BARRIER();  // the prologue of the one-lane-per-sample sweepers (link 0 of the first tile is published)
     for (int64_t it = 0; it <= trips; ++it)
     {
+#ifdef RDYN_PGRAM_X_NOMFMA  // timing experiment only (wrong numbers): the consumers keep the barriers and do nothing else
+      const bool have = it > trips + 1;
+#else
       const bool have = it > 0;  // the tile in LDS is complete (nothing to consume while the first tile is being swept)
+#endif
 #pragma unroll
       for (int f = 0; f < NJ; ++f)
       {
@@ -442,7 +469,7 @@ __global__ __launch_bounds__(64 * NW) void k_regressor_pgram_solo(const RdynLdsG
   d4 acc[NT];
 #pragma unroll
   for (int t = 0; t < NT; ++t) acc[t] = (d4){0.0, 0.0, 0.0, 0.0};
-  const double* wgp = Wg;
+  GlobalD wgp = (GlobalD)Wg;  // (a global pointer by type: see k_regressor_pgram)
   auto wglob = [&](int blk_kk) -> double { return (wgp + blk_kk * 64)[lane]; };
   // one row group (the 16 samples of joint j) with the first BAND column blocks in its zero band: Q = X W, then acc += Q'Q
   auto row_group = [&](int j, auto band_tag) {
@@ -1566,16 +1593,17 @@ hipError_t opt_in_lds_once(K kernel, std::atomic<uint64_t>& done, int max_bytes 
   return hipSuccess;
 }
 
-template <int NJ, bool ALLREV, int NPAIR, bool WGLOBAL, int XB = 0>
+template <int NJ, bool ALLREV, int NPAIR, bool WGLOBAL, int XB = 0, int KIN = 0>
 hipError_t launch_pgram3(const RdynLdsGramArgs& a, const double* W, const int* run_flag, int blocks, hipStream_t st)
 {
   static std::atomic<uint64_t> attr{0};
-  hipError_t e = opt_in_lds_once(k_regressor_pgram<NJ, ALLREV, NPAIR, WGLOBAL, XB>, attr);
+  hipError_t e = opt_in_lds_once(k_regressor_pgram<NJ, ALLREV, NPAIR, WGLOBAL, XB, KIN>, attr);
   if (e != hipSuccess) return e;
   constexpr int NB = (10 * NJ + 1 + 15) / 16 + XB, NT = NB * (NB + 1) / 2;
-  size_t lds = (WGLOBAL ? 0 : (size_t)NT * 2048) + (size_t)NPAIR * a.tile_bytes;
+  size_t lds = (WGLOBAL ? 0 : (size_t)NT * 2048) + (size_t)NPAIR * a.tile_bytes + (KIN ? RDYN_KIN_XCH_BYTES_XV(NJ <= 6 ? 21 : 12) : 0);
   if (lds < (size_t)NT * 2048) lds = (size_t)NT * 2048;  // the final reduction area
-  hipLaunchKernelGGL((k_regressor_pgram<NJ, ALLREV, NPAIR, WGLOBAL, XB>), dim3(blocks), dim3(128 * NPAIR), lds, st, a, W, run_flag);
+  if (lds > 160 * 1024) return hipErrorInvalidValue;
+  hipLaunchKernelGGL((k_regressor_pgram<NJ, ALLREV, NPAIR, WGLOBAL, XB, KIN>), dim3(blocks), dim3(128 * NPAIR), lds, st, a, W, run_flag);
   return hipGetLastError();
 }
 template <int NJ, bool ALLREV, int NW, bool WGLOBAL>
@@ -1617,6 +1645,18 @@ hipError_t launch_pgram(const RdynLdsGramArgs& a, const double* W, const int* ru
       if (pairs == -4)
         return a.all_revolute ? launch_pgram3<NJ, true, 4, true, 1>(a, W, run_flag, blocks, st) : launch_pgram3<NJ, false, 4, true, 1>(a, W, run_flag, blocks, st);
     }
+    return hipErrorInvalidValue;
+  }
+  if (a.sweep_lanes)
+  {
+    // the one-lane-per-sample sweepers: the host built the tile with their padding (rdyn_cholqr_kin_pad) and filled sw_rows for three row waves
+    if constexpr (NJ <= 6)
+    {
+      if (pairs == 4)
+        return a.all_revolute ? launch_pgram3<NJ, true, 4, false, 0, 4>(a, W, run_flag, blocks, st) : launch_pgram3<NJ, false, 4, false, 0, 4>(a, W, run_flag, blocks, st);
+    }
+    else if (pairs == -4)
+      return a.all_revolute ? launch_pgram3<NJ, true, 4, true, 0, 2>(a, W, run_flag, blocks, st) : launch_pgram3<NJ, false, 4, true, 0, 2>(a, W, run_flag, blocks, st);
     return hipErrorInvalidValue;
   }
   if (pairs == 4)
@@ -1670,6 +1710,15 @@ int rdyn_cholqr_pairs(int n_joints, int tile_bytes, int xb)
   if (4 * (size_t)tile_bytes <= 160 * 1024) return -4;  // W from global memory (7 joints)
 #endif
   return 0;
+}
+
+// the one-lane-per-sample sweepers serve pass B of this shape (no component columns yet): the tile padding they use (4; 2 = the compact
+// layout at 7 joints), 0 = no.  pairs as returned by rdyn_cholqr_pairs for the PADDED (4) tile.
+int rdyn_cholqr_kin_pad(int n_joints, int xb, int pairs)
+{
+  if (xb) return 0;
+  if (n_joints >= 2 && n_joints <= 6) return pairs == 4 ? 4 : 0;
+  return (n_joints == 7 && pairs == -4) ? 2 : 0;
 }
 
 // nb = ceil(n1 / 16) <= 6 column blocks (n1 = n_cols + (b != null)); slabs: [blocks][nb (nb + 1) / 2 * 256]

@@ -38,5 +38,18 @@ __device__ __forceinline__ constexpr int duo_direct_off(int f, int pad = 4)
 #define RDYN_DUO_TILE_PAD 4  // (a kernel that sweeps into the compact tile redefines it around its include of rdyn_duo_link_body.inc)
 #endif
 
+// ocml's sincos for angles beyond the range of rdyn_sincos_small, out of line: one copy of its Payne-Hanek path in a kernel, not one per
+// joint (the one-lane-per-sample sweepers, rdyn_kin_sweepers.inc)
+struct DuoSinCos
+{
+  double sn, cs;
+};
+__device__ __attribute__((noinline)) inline DuoSinCos duo_sincos_cold(double x)
+{
+  DuoSinCos r;
+  sincos(x, &r.sn, &r.cs);
+  return r;
+}
+
 }  // namespace
 #endif

@@ -57,18 +57,6 @@ namespace
 #define DUO_STAMP_OUT(NT_)
 #endif
 
-// ocml's sincos for angles beyond the range of rdyn_sincos_small, out of line: one copy of its Payne-Hanek path in the kernel, not one per joint
-struct DuoSinCos
-{
-  double sn, cs;
-};
-__device__ __attribute__((noinline)) DuoSinCos duo_sincos_cold(double x)
-{
-  DuoSinCos r;
-  sincos(x, &r.sn, &r.cs);
-  return r;
-}
-
 // XB: extra 16-column blocks for the component columns of rdyn_identification_gram (0: plain regressor Gram)
 typedef double d4h __attribute__((ext_vector_type(4), aligned(16)));  // operand quads: 16-byte aligned in the compact tile layout
 
@@ -106,289 +94,16 @@ __global__ __launch_bounds__(KIN ? 768 : 512) void k_regressor_gram_duo(const Rd
   if (sweeper && KIN)
   {
     // ================================================================ one lane per sample: 64 samples, the link kinematics ONCE
-    // Sweeper wave 0 runs the link recursion of the workgroup's 64 samples (lane = sample: sincos, R, the four carried 3-vectors, the
-    // joint's motion, d) one link AHEAD and publishes what the rows of that link need -- R, the joint offset, w, al, d and the
-    // b-matrix: 30 doubles per sample (7 joints, where the tiles leave 12 KB of LDS: sin, 1 - cos, the prismatic displacement, w, al,
-    // d, and the row waves rebuild the rest) -- in a double-buffered exchange area behind the tiles.  Sweeper waves 1-3 own the
-    // regressor ROWS (fa.sw_rows: three slots each, balanced by the number of links a row is carried through): they carry their rows'
-    // unit twists into the link, form the ten-vectors and drop them into the 16-sample sub-tile of their lane.  The row-pair sweeper repeats the kinematics in the four lanes of every sample (2 113 VALU instructions per SIMD and
-    // 64 samples); here a SIMD pays ~130 (wave 0) or 36 + 69 per active row (waves 1-3) per link.  Same closed forms as
-    // rdyn_duo_link_body.inc, statement by statement: the tile is bit-identical, the consumers do not see the difference.
-    ChainPtr c = as_const(fa.chain);
-    const int sub = lane >> 4, s_loc = lane & 15;
-    char* const tile = lds_raw + (size_t)sub * fa.tile_bytes;  // the 16-sample sub-tile of my sample
-    // doubles per sample and exchange buffer: 30 (R, the joint offset, w, al, d, the b-matrix) where the LDS has room, 12 at 7 joints
-    // (without component columns the row waves have the slack to rebuild the b-matrix: 9 stores and ~18 instructions less on the
-    // kinematics wave, the longest chain of an interval: 515 -> 487 us at 6 joints; with them the row waves are the longer side)
+    // (rdyn_kin_sweepers.inc: wave 0 the kinematics, waves 1-7 the rows, at most two each).  Doubles per sample and exchange buffer:
+    // 30 (R, the joint offset, w, al, d, the b-matrix) with component columns, 21 without (the row waves have the slack to rebuild the
+    // b-matrix: 9 stores and ~18 instructions less on the kinematics wave, the longest chain of an interval: 515 -> 487 us at 6
+    // joints; with component columns the row waves are the longer side), 12 at 7 joints (what the compact tiles leave of the LDS).
     constexpr int XV = NJ <= 6 ? (XB > 0 ? 30 : 21) : 12;
-    double* const xch = (double*)(lds_raw + (size_t)4 * fa.tile_bytes) + lane;  // [2][XV][64]
-    const int64_t t_mine = (int64_t)blockIdx.x * 4 + sub;
-    // sub-tile p of the workgroup's trip `it` is the 16-sample tile (blockIdx.x * 4 + p) + it * t_step of the pair kernels' numbering
-    auto sample_offset = [&](int64_t tile_index) -> int64_t {
-      if (tile_index >= n_tiles) tile_index = n_tiles - 1;
-      int64_t sx = tile_index * t_mul * 16 + s_loc;
-      if (sx >= fa.n_samples) sx = fa.n_samples - 1;
-      return sx * fa.in_ss;
-    };
-    if (wave == 0)
-    {
-      // ---- the kinematics wave.  The inputs of joint j wait in q_[j], dq_[j], ddq_[j]; link j consumes them and refills the same
-      // registers with the NEXT tile's (a full tile period in flight, no second set of registers)
-      double q_[NJ], dq_[NJ], ddq_[NJ];
-      {
-        const int64_t o = sample_offset(t_mine);
-#pragma unroll
-        for (int j = 0; j < NJ; ++j)
-        {
-          const int64_t oj = o + (int64_t)fa.in_map[j] * fa.in_sj;
-          q_[j] = fa.q[oj];
-          dq_[j] = fa.dq[oj];
-          ddq_[j] = fa.ddq[oj];
-        }
-      }
-      V3 w = mk(0, 0, 0), vl = mk(0, 0, 0), al = mk(0, 0, 0), lin = mk(-c->g[0], -c->g[1], -c->g[2]);
-      int64_t o_next = sample_offset(t_mine + t_step);
-      // sin and 1 - cos of all the tile's joint angles at once, a tile ahead: NJ independent chains (one sincos per link on demand leaves
-      // the wave waiting on its own results: 1 900 cycles per link against 600 of issue).  Code size matters (three roles share the
-      // instruction cache): the range-limited evaluation inline,
-      // ocml's for angles beyond 2^20 in ONE out-of-line function (duo_sincos_cold) -- same results as rdyn_sincos.
-      double sn_[NJ], oc_[NJ];
-#define RDYN_KIN_ONE_SINCOS(j_)                                                                     \
-  do                                                                                               \
-  {                                                                                                \
-    double sn1_, cs1_;                                                                             \
-    rdyn_sincos_small(q_[j_], &sn1_, &cs1_);                                                       \
-    if (__builtin_expect(!(fabs(q_[j_]) <= 1048576.0), 0))                                         \
-    {                                                                                              \
-      const DuoSinCos big_ = duo_sincos_cold(q_[j_]);                                              \
-      sn1_ = big_.sn;                                                                              \
-      cs1_ = big_.cs;                                                                              \
-    }                                                                                              \
-    sn_[j_] = sn1_;                                                                                \
-    oc_[j_] = 1.0 - cs1_;                                                                          \
-  } while (0)
-#pragma unroll
-      for (int j = 0; j < NJ; ++j) RDYN_KIN_ONE_SINCOS(j);  // the first tile's
-      {
-        constexpr int g = 0;
-#include "rdyn_kin_link_body.inc"
-      }
-      DUO_BARRIER_LDS();  // prologue: link 0 of the first tile is published
-      for (int64_t it = 0; it < trips; ++it)
-      {
-        DUO_STAMP_TRIP(it);
-        // (o_next was the offset of THIS tile's successor while link 0 was consumed in the previous trip; links 1 .. NJ - 1 refill from it too)
-#pragma unroll
-        for (int f = 0; f < NJ; ++f)
-        {
-          if (f + 1 < NJ)
-          {
-            const int g = f + 1;
-#include "rdyn_kin_link_body.inc"
-          }
-          else
-          {
-            // the NEXT tile's sin / 1 - cos (q_[] holds its angles: every link refilled its joint's registers), NJ independent chains,
-            // behind the row waves' longest step.  (One per interval beside every link: the same at 6 joints, 3 % slower at 7.)
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) RDYN_KIN_ONE_SINCOS(j);
-          }
-          DUO_BARRIER_LDS();  // B_f: link f + 1 is published; the rows of link f are computed (their stores follow)
-        }
-        // the next tile: fresh state, its link 0 (buffer 0: the last reads of it are behind B_{NJ-1})
-        w = mk(0, 0, 0); vl = mk(0, 0, 0); al = mk(0, 0, 0); lin = mk(-c->g[0], -c->g[1], -c->g[2]);
-        o_next = sample_offset(t_mine + (it + 2) * t_step);
-        {
-          constexpr int g = 0;
-#include "rdyn_kin_link_body.inc"
-        }
-        DUO_BARRIER_LDS();  // the tile is complete
-      }
-    }
-    else
-    {
-      // ---- a row wave
-      const int ra = fa.sw_rows[3 * (wave - 1)], rb = fa.sw_rows[3 * (wave - 1) + 1];  // wave-uniform; 99 = none (seven row waves: at most two rows each)
-      const int64_t oba = ra < 8 ? (int64_t)fa.in_map[ra] * fa.in_sj : 0, obb = rb < 8 ? (int64_t)fa.in_map[rb] * fa.in_sj : 0;
-      // measured torque of my rows; position and velocity of their joints (component columns only): one tile ahead
-      double nba = 0.0, nbb = 0.0, nqa = 0.0, nqb = 0.0, nda = 0.0, ndb = 0.0;
-      auto fetch = [&](int64_t tile_index) {
-        const int64_t o = sample_offset(tile_index);
-        if (fa.bcol)
-        {
-          if (ra < 8) nba = fa.bcol[o + oba];
-          if (rb < 8) nbb = fa.bcol[o + obb];
-        }
-        if (XB > 0 || fa.n_comps > 0)
-        {
-          if (ra < 8) { nqa = fa.q[o + oba]; nda = fa.dq[o + oba]; }
-          if (rb < 8) { nqb = fa.q[o + obb]; ndb = fa.dq[o + obb]; }
-        }
-      };
-      fetch(t_mine);
-      DUO_BARRIER();  // prologue
-      for (int64_t it = 0; it < trips; ++it)
-      {
-        DUO_STAMP_TRIP(it);
-        const int64_t tl = t_mine + it * t_step;
-        const bool valid = tl < n_tiles && tl * t_mul * 16 + s_loc < fa.n_samples;
-        const double tba = valid ? nba : 0.0, tbb = valid ? nbb : 0.0;
-        const double qra = nqa, qrb = nqb, dqra = nda, dqrb = ndb;
-        fetch(tl + t_step);  // in flight during this tile's sweep
-        V3 La = mk(0, 0, 0), Aa = mk(0, 0, 0), Lb = mk(0, 0, 0), Ab = mk(0, 0, 0);
-        int col_off = 0;  // byte offset of link f's first column in the sub-tile
-        // (a ROLLED link loop: nothing in it depends on f at compile time, and the three roles share the instruction cache)
-#pragma unroll 1
-        for (int f = 0; f < NJ; ++f)
-        {
-          const double* const xi = xch + (f & 1) * (XV * 64);  // what the kinematics wave published for the link
-          double R[9], b00, b01, b02, b10, b11, b12, b20, b21, b22;
-          V3 tt, w, al, d;
-          if constexpr (XV == 12)
-          {
-            asm volatile("" : "+s"(c));
-            JointRef J = c->j[f];
-            const double sn = xi[0], oc = xi[64], qp = xi[128];
-            w = mk(xi[192], xi[256], xi[320]);
-            al = mk(xi[384], xi[448], xi[512]);
-            d = mk(xi[576], xi[640], xi[704]);
-#pragma unroll
-            for (int i = 0; i < 9; ++i) R[i] = fma(sn, J.B[i], fma(oc, J.C[i], J.A[i]));
-            tt = ALLREV ? ld3(J.t) : axpy(ld3(J.t), ld3(J.up), qp);
-            const double wxy = w.x * w.y, wxz = w.x * w.z, wyz = w.y * w.z;
-            const double wxx = w.x * w.x, wyy = w.y * w.y, wzz = w.z * w.z;
-            b00 = -(wyy + wzz); b01 = wxy - al.z; b02 = wxz + al.y;
-            b10 = wxy + al.z; b11 = -(wxx + wzz); b12 = wyz - al.x;
-            b20 = wxz - al.y; b21 = wyz + al.x; b22 = -(wxx + wyy);
-          }
-          else
-          {
-#pragma unroll
-            for (int i = 0; i < 9; ++i) R[i] = xi[i * 64];
-            tt = mk(xi[576], xi[640], xi[704]);
-            w = mk(xi[768], xi[832], xi[896]);
-            al = mk(xi[960], xi[1024], xi[1088]);
-            d = mk(xi[1152], xi[1216], xi[1280]);
-            if constexpr (XV == 30)
-            {
-              b00 = xi[1344]; b01 = xi[1408]; b02 = xi[1472];
-              b10 = xi[1536]; b11 = xi[1600]; b12 = xi[1664];
-              b20 = xi[1728]; b21 = xi[1792]; b22 = xi[1856];
-            }
-            else
-            {
-              const double wxy = w.x * w.y, wxz = w.x * w.z, wyz = w.y * w.z;
-              const double wxx = w.x * w.x, wyy = w.y * w.y, wzz = w.z * w.z;
-              b00 = -(wyy + wzz); b01 = wxy - al.z; b02 = wxz + al.y;
-              b10 = wxy + al.z; b11 = -(wxx + wzz); b12 = wyz - al.x;
-              b20 = wxz - al.y; b21 = wyz + al.x; b22 = -(wxx + wyy);
-            }
-          }
-          if (f > ra)  // (before its joint a row's unit twist is zero: nothing to carry)
-          {
-            const V3 nL = rotT(R, La + cross(Aa, tt));
-            Aa = rotT(R, Aa);
-            La = nL;
-          }
-          if (f > rb)
-          {
-            const V3 nL = rotT(R, Lb + cross(Ab, tt));
-            Ab = rotT(R, Ab);
-            Lb = nL;
-          }
-          if (f == ra || f == rb)
-          {
-            // the row of joint f starts here with the joint's own unit twist (zero for a sample beyond the batch: all its entries stay 0)
-            asm volatile("" : "+s"(c));
-            JointRef J = c->j[f];
-            const int type = J.type;
-            const bool rev = ALLREV || type == RDYN_REVOLUTE, pri = !ALLREV && type == RDYN_PRISMATIC;
-            const V3 u = ld3(J.u);
-            const V3 sl = mk((pri && valid) ? u.x : 0.0, (pri && valid) ? u.y : 0.0, (pri && valid) ? u.z : 0.0);
-            const V3 sa = mk((rev && valid) ? u.x : 0.0, (rev && valid) ? u.y : 0.0, (rev && valid) ? u.z : 0.0);
-            if (f == ra) { La = sl; Aa = sa; }
-            else { Lb = sl; Ab = sa; }
-          }
-          auto row_y = [&](V3 L, V3 A, double (&y)[10]) {
-            const V3 dxA = cross(d, A), x = cross(A, w);
-            y[0] = dot(L, d);
-            y[1] = fma(L.x, b00, fma(L.y, b10, fma(L.z, b20, dxA.x)));
-            y[2] = fma(L.x, b01, fma(L.y, b11, fma(L.z, b21, dxA.y)));
-            y[3] = fma(L.x, b02, fma(L.y, b12, fma(L.z, b22, dxA.z)));
-            y[4] = fma(A.x, al.x, x.x * w.x);
-            y[5] = fma(A.x, al.y, fma(A.y, al.x, fma(x.x, w.y, x.y * w.x)));
-            y[6] = fma(A.x, al.z, fma(A.z, al.x, fma(x.x, w.z, x.z * w.x)));
-            y[7] = fma(A.y, al.y, x.y * w.y);
-            y[8] = fma(A.y, al.z, fma(A.z, al.y, fma(x.y, w.z, x.z * w.y)));
-            y[9] = fma(A.z, al.z, x.z * w.z);
-          };
-          double ya[10], yb[10];
-          if (f >= ra) row_y(La, Aa, ya);
-          if (f >= rb) row_y(Lb, Ab, yb);
-          // B_f: the consumers have read row group f of the previous tile -- the columns of link f may be overwritten now -- and link
-          // f + 1 waits in the other exchange buffer (my reads of this one have returned: it is rewritten behind this barrier)
-          DUO_BARRIER_LDS();
-          const int stride = (16 * (f + 1) + KIN) * 8;
-          char* const lf = tile + col_off + s_loc * 8;
-          col_off += 10 * stride;
-          if (f >= ra)
-          {
-#pragma unroll
-            for (int p = 0; p < 10; ++p) *(double*)(lf + p * stride + ra * 128) = ya[p];
-          }
-          if (f >= rb)
-          {
-#pragma unroll
-            for (int p = 0; p < 10; ++p) *(double*)(lf + p * stride + rb * 128) = yb[p];
-          }
-          DUO_STAMP_HERE(0);  // (diagnostic builds) stores and exchange reads issued
-          DUO_STAMP_HERE(1);  // ... and completed
-        }
-        if (XB > 0 || fa.n_comps > 0)
-        {
-          // the consumers have read every row group of the previous tile by now (the last link's barrier is behind us): the component
-          // columns of my rows (friction_polynomial1.h:45-52, friction_polynomial2.h:42-58, ideal_spring.h:64-70)
-          int col = 0;
-          for (int ci = 0; ci < fa.n_comps; ++ci)
-          {
-            const int type = fa.comps[ci].type, jc = fa.comps[ci].joint;
-            const int cols = type == RDYN_COMP_FRICTION2 ? 3 : 2;
-            if (jc == ra || jc == rb)
-            {
-              const double qv = jc == ra ? qra : qrb, dv = jc == ra ? dqra : dqrb;
-              double row[3] = {0.0, 0.0, 0.0};
-              if (type == RDYN_COMP_SPRING)
-              {
-                row[0] = qv;
-                row[1] = 1.0;
-              }
-              else
-              {
-                const double vmax = fa.comps[ci].max_velocity, vmin = fa.comps[ci].min_velocity;
-                const double omega = fmin(fmax(dv, -vmax), vmax);
-                double sg;
-                if (type == RDYN_COMP_FRICTION1)
-                  sg = fmin(fmax(omega / vmin, -1.0), 1.0);
-                else
-                  sg = (omega == 0.0) ? 0.0 : (omega > vmin ? 1.0 : (omega < -vmin ? -1.0 : omega / vmin));
-                row[0] = sg;
-                row[1] = omega;
-                row[2] = omega * omega * sg;
-              }
-              char* const lc = tile + fa.lds_off_c + col * fa.comp_stride + jc * fa.comp_row_step + s_loc * 8;
-              for (int e = 0; e < cols; ++e) *(double*)(lc + e * fa.comp_stride) = valid ? row[e] : 0.0;
-            }
-            col += cols;
-          }
-        }
-        {
-          char* const lb = tile + fa.lds_off_b + s_loc * 8;
-          if (ra < 8) *(double*)(lb + ra * 128) = tba;
-          if (rb < 8) *(double*)(lb + rb * 128) = tbb;
-        }
-        DUO_BARRIER_LDS();  // the tile is complete
-      }
-    }
+    constexpr int KIN_SLOTS = 2;
+    const int KIN_SW = wave;
+    char* const kin_tiles = lds_raw;
+    double* const kin_xch_base = (double*)(lds_raw + (size_t)4 * fa.tile_bytes);
+#include "rdyn_kin_sweepers.inc"
   }
   else if (sweeper)
   {

@@ -225,6 +225,7 @@ hipError_t rdyn_launch_regressor_gram_pipe(int n_cols, const RdynLdsGramArgs& a,
 bool rdyn_regressor_gram_duo_supported(int n_cols);
 // doubles per sample and exchange buffer: up to 6 joints 30 (the b-matrix too; the kernel uses 21 of them without component columns), 12 at 7
 #define RDYN_KIN_XCH_BYTES(n_joints) (2 * ((n_joints) <= 6 ? 30 : 12) * 64 * 8)
+#define RDYN_KIN_XCH_BYTES_XV(xv) (2 * (xv) * 64 * 8)  // (pass B of the R factor: 21 doubles per sample up to 6 joints, 12 at 7)
 // the one-lane-per-sample sweepers exist for this shape: 0 no, 4 / 2 = with the standard / the compact tile layout (column padding in doubles)
 int rdyn_regressor_gram_duo_kin_pad(int n_joints, int n_comp_cols);
 // n_cols = 10 * chain joints; a.n_comp_cols extra component columns may add at most one 16-column block
@@ -234,6 +235,7 @@ hipError_t rdyn_launch_regressor_gram_duo(int n_cols, const RdynLdsGramArgs& a, 
 //   W = R1^-1 of a Householder factor R1 of a row SUBSAMPLE (rdyn_tsqr.hip);  G2 = (A W)'(A W) over ALL rows: sweep -> LDS tile -> the
 //   consumer wave multiplies every 16-row group by W (MFMA) and accumulates the Gram of the product (MFMA);  R = chol(G2) R1.
 // xb = 1: one more 16-column block for the component columns of rdyn_identification_tsqr (chains of <= 6 joints)
+int rdyn_cholqr_kin_pad(int n_joints, int xb, int pairs);  // pass B with the one-lane-per-sample sweepers: tile padding (4 / 2), 0 = not served
 int rdyn_cholqr_pairs(int n_joints, int tile_bytes, int xb);  // 4: W in LDS beside four tiles; -4: four tiles, W in global memory; 2: two pairs on four SIMDs, -1: four waves that sweep and consume their own compact tile (7 joints + components); 0: unsupported
 size_t rdyn_cholqr_w_doubles(int n_joints, int xb);           // W in MFMA operand order
 // R <- qr([R ; R_new]); rows_new > 0: R_new is zero below that many rows (an expanded factor); any n1 whose packed R_new fits 156 KB of LDS
