@@ -258,6 +258,7 @@ hipError_t rdyn_launch_cholqr_precond(const double* R1, const double* Gs, const 
                                       double* gamma_out, hipStream_t st);
 int rdyn_cholqr_max_cols();  // widest factor (right-hand side included) the dense steps of the preconditioned route hold in LDS
 int rdyn_cholqr_col_shift(int n_joints, int xb);
+hipError_t rdyn_launch_regressor_pgram_solo(const RdynLdsGramArgs& a, const double* W, const int* run_flag, int blocks, int pairs, hipStream_t st);  // rdyn_pgram_solo.hip
 int rdyn_cholqr_solo_col_shift(int n_joints, int n_comp_cols);  // pairs == -1 at 7 joints + components (k_regressor_pgram_solo: compact tile, every wave sweeps and consumes)
 // G2 = [G c; c' bb] -> R = chol(G2) T (n1 x n1 upper, column-major; zero rows at the confirmed null columns); flags[round] = 1 when the
 // round is not accepted (rho_out, may be null: [0] the conditioning measure of the equilibrated Q, [2] gamma on the norms of all rows);

@@ -2,7 +2,7 @@
 // side, interleaved rounds on the same box) and prints a checksum of the results so that variants can be compared bit for bit.
 //   g++ -O2 -std=c++17 -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -Iinclude tools/kbench.cpp -o tools/_build/kbench \
 //       -L/opt/rocm/lib -lamdhip64 -ldl -Wl,-rpath,/opt/rocm/lib
-//   tools/_build/kbench <what> <rounds> lib1.so [lib2.so ...]        what = gram2 | gram3 | persample | stacked | element | ident | ident3 | tsqr2 | tsqr3
+//   tools/_build/kbench <what> <rounds> lib1.so [lib2.so ...]        what = gram2 | gram3 | persample | stacked | element | ident | ident3 | tsqr2 | tsqr3 | itsqr2 | itsqr3 (identification R factor)
 #include <dlfcn.h>
 #include <hip/hip_runtime_api.h>
 #include <cmath>
@@ -30,6 +30,8 @@ struct Lib
   decltype(&rdyn_identification_gram_workspace_bytes) ident_ws;
   decltype(&rdyn_regressor_tsqr) tsqr;
   decltype(&rdyn_regressor_tsqr_workspace_bytes) tsqr_ws;
+  decltype(&rdyn_identification_tsqr) itsqr;
+  decltype(&rdyn_identification_tsqr_workspace_bytes) itsqr_ws;
   rdyn_chain* chain = nullptr;
 };
 
@@ -58,7 +60,7 @@ int main(int argc, char** argv)
   if (argc < 4) { std::printf("usage: kbench <gram2|gram3|persample|stacked|element|ident> <rounds> lib.so...\n"); return 2; }
   const std::string what = argv[1];
   const int rounds = std::atoi(argv[2]);
-  const bool cfg3 = what == "gram3" || what == "ident3" || what == "tsqr3";
+  const bool cfg3 = what == "gram3" || what == "ident3" || what == "tsqr3" || what == "itsqr3";
   // KB_URDF / KB_BASE / KB_TOOL: another chain (e.g. tests/fixtures/ur10_public.urdf base_link tool0: fixed head + two fixed tail joints)
   const char* urdf = getenv("KB_URDF") ? getenv("KB_URDF") : (cfg3 ? "tests/fixtures/panda_like.urdf" : "tests/fixtures/ur10_like.urdf");
   const char* base = getenv("KB_BASE") ? getenv("KB_BASE") : (cfg3 ? "link0" : "base_link");
@@ -95,6 +97,8 @@ int main(int argc, char** argv)
     SYM(ident_ws, rdyn_identification_gram_workspace_bytes)
     SYM(tsqr, rdyn_regressor_tsqr)
     SYM(tsqr_ws, rdyn_regressor_tsqr_workspace_bytes)
+    SYM(itsqr, rdyn_identification_tsqr)
+    SYM(itsqr_ws, rdyn_identification_tsqr_workspace_bytes)
     if (l.chain_from_urdf(xml.c_str(), base, tool, g, &l.chain) != RDYN_OK) { std::printf("chain: %s\n", l.last_error()); return 1; }
     libs.push_back(l);
   }
@@ -118,18 +122,19 @@ int main(int argc, char** argv)
   hipEvent_t e0, e1;
   CHECK(hipEventCreate(&e0));
   CHECK(hipEventCreate(&e1));
-  const bool gram = what.rfind("gram", 0) == 0, ident = what.rfind("ident", 0) == 0, tsqr = what.rfind("tsqr", 0) == 0;
+  const bool gram = what.rfind("gram", 0) == 0, ident = what.rfind("ident", 0) == 0, itsqr = what.rfind("itsqr", 0) == 0, tsqr = itsqr || what.rfind("tsqr", 0) == 0;
   rdyn_component comps[7];
   const int ncomp = cfg3 ? 7 : 6;
   for (int i = 0; i < 7; ++i)
   {
-    comps[i].type = RDYN_COMP_FRICTION1;
+    comps[i].type = getenv("KB_COMP2") ? RDYN_COMP_FRICTION2 : RDYN_COMP_FRICTION1;  // KB_COMP2: second-order friction (3 columns each)
     comps[i].joint = i;
     comps[i].min_velocity = 1e-3;
-    comps[i].max_velocity = 0;
+    comps[i].max_velocity = getenv("KB_COMP2") ? 10.0 : 0;
     comps[i].parameters[0] = comps[i].parameters[1] = comps[i].parameters[2] = 0.1;
   }
-  const int cols = ident ? P + 2 * ncomp : (tsqr ? P + 1 : P);
+  const int cw = getenv("KB_COMP2") ? 3 : 2;
+  const int cols = ident ? P + cw * ncomp : (itsqr ? P + cw * ncomp + 1 : (tsqr ? P + 1 : P));
   double *d_G = nullptr, *d_Y = nullptr, *d_tau = nullptr;
   void* d_ws = nullptr;
   size_t ws_bytes = 0;
@@ -138,7 +143,7 @@ int main(int argc, char** argv)
     CHECK(hipMalloc((void**)&d_G, sizeof(double) * (cols * cols + cols + 1)));
     for (auto& l : libs)
     {
-      const size_t w = ident ? l.ident_ws(l.chain, comps, ncomp) : (tsqr ? l.tsqr_ws(l.chain) : l.gram_ws(l.chain, 0));
+      const size_t w = ident ? l.ident_ws(l.chain, comps, ncomp) : itsqr ? l.itsqr_ws(l.chain, comps, ncomp) : (tsqr ? l.tsqr_ws(l.chain) : l.gram_ws(l.chain, 0));
       if (w > ws_bytes) ws_bytes = w;
     }
     CHECK(hipMalloc(&d_ws, ws_bytes));
@@ -169,6 +174,7 @@ int main(int argc, char** argv)
       explicit Env(const Lib& x) : l(x) { if (!l.env_key.empty()) setenv(l.env_key.c_str(), l.env_val.c_str(), 1); }
       ~Env() { if (!l.env_key.empty()) unsetenv(l.env_key.c_str()); }
     } env(l);
+    if (itsqr) return l.itsqr(l.chain, comps, ncomp, &b, tau_meas, d_G, 0, d_ws, ws_bytes);
     if (tsqr) return l.tsqr(l.chain, &b, tau_meas, d_G, 0, d_ws, ws_bytes);
     if (ident) return l.ident(l.chain, comps, ncomp, &b, tau_meas, d_G, d_G + cols * cols, d_G + cols * cols + cols, 0, d_ws, ws_bytes);
     if (gram) return l.regressor_gram(l.chain, &b, tau_meas, d_G, d_G + P * P, d_G + P * P + P, 0, 0, d_ws, ws_bytes);

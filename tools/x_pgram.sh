@@ -14,7 +14,7 @@ best = {}
 for f in glob.glob(sys.argv[1] + '/**/*kernel_trace.csv', recursive=True):
     for r in csv.DictReader(open(f)):
         n = r['Kernel_Name']
-        if 'pgram' in n or 'gram_duo' in n:
+        if "pgram" in n or "gram_duo" in n:
             k = n[:70]
             d = (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3
             best.setdefault(k, []).append(d)
