@@ -213,8 +213,9 @@ inline void rec_strides(const rdyn_batch* b, int64_t elems, int64_t* ss, int64_t
 // fixed-joint pattern (*fix_mask: bit f = chain joint f is not an input joint), and a 16-byte aligned Y: the copy-out moves 16-byte
 // chunks whose addresses are Y + a multiple of 16 (an 8-byte aligned base -- a view at an odd double offset -- would put the last
 // chunk of every image 8 bytes past its end); such calls keep the row-pair / strided kernels.
-int image_route(const rdyn_chain* c, const rdyn_regressor_layout* yl, int64_t n_samples, const double* Y, bool multi, unsigned* fix_mask)
+int image_route(const rdyn_chain* c, const rdyn_regressor_layout* yl, int64_t n_samples, const double* Y, bool multi, unsigned* fix_mask, bool* perm = nullptr)
 {
+  if (perm) *perm = false;
   const int n = c->n_active(), nJ = c->n_joints();
   const bool lay_image = yl->stride_row == 1 && yl->stride_col == n && yl->stride_sample >= (int64_t)n * 10 * nJ;
   const bool lay_stacked = yl->stride_row == 1 && yl->stride_sample == n && yl->stride_col >= n_samples * n && !probe_env("RDYN_NO_STACKED_LDS");
@@ -224,7 +225,15 @@ int image_route(const rdyn_chain* c, const rdyn_regressor_layout* yl, int64_t n_
   unsigned fix = (nJ >= 32) ? 0u : ((1u << nJ) - 1u);
   for (int j = 0; j < n; ++j)
   {
-    if (j > 0 && c->active[j] <= c->active[j - 1]) return 0;  // input joints in chain order
+    if (j > 0 && c->active[j] <= c->active[j - 1])
+    {
+      // input joints out of chain order: per-sample images of a chain without fixed joints sweep its sorted view and map the rows
+      // (k_image_sweep<.., PERM>); everything else keeps the row-pair / strided kernels
+      if (!perm || multi || !lay_image || lay_stacked || n != nJ || !c->sorted || !rdyn_image_supported(nJ, 0u, yl->stride_sample, false)) return 0;
+      *perm = true;
+      *fix_mask = 0u;
+      return 1;
+    }
     fix &= ~(1u << c->active[j]);
   }
   if (!rdyn_image_supported(nJ, fix, yl->stride_sample, multi)) return 0;
@@ -301,9 +310,19 @@ int run_local(const rdyn_chain* c, const rdyn_batch* b, int mode, double* tau, d
   // the drop-in per-sample image (either input layout): one thread per sample, link blocks staged through LDS (rdyn_image.hip)
   // and the stacked column-major (N n) x P matrix (stride_sample == n): same kernel, column-major staging tile per link
   unsigned fix_mask = 0;
-  const bool image = mode == RDYN_MODE_REGRESSOR && yl && image_route(c, yl, b->n_samples, Y, false, &fix_mask) != 0;
+  bool perm = false;
+  const bool image = mode == RDYN_MODE_REGRESSOR && yl && image_route(c, yl, b->n_samples, Y, false, &fix_mask, &perm) != 0;
   if (image)
-    RDYN_HIP_TRY(rdyn_launch_image_sweep(c->n_joints(), fix_mask, a, (hipStream_t)b->stream));
+  {
+    if (perm)
+    {
+      const rdyn_chain* const so = c->sorted.get();
+      st = device_const(so, &a.chain);
+      if (st != RDYN_OK) return st;
+      for (int l = 0; l < n; ++l) a.row_map[l] = so->row_input[l];
+    }
+    RDYN_HIP_TRY(rdyn_launch_image_sweep(c->n_joints(), fix_mask, a, (hipStream_t)b->stream, perm));
+  }
   else if (rowpair)
   {
     // the kernel addresses Y with a 32-bit per-lane byte offset: split so that every launch spans < 4 GB of Y

@@ -8,7 +8,7 @@
 #define RDYN_IMAGE_NA_LIST(X) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10)
 #define RDYN_IMAGE_MULTI_NA_LIST(X) X(2) X(3) X(4) X(5) X(6) X(7) X(8)
 
-#define DECL(NA_) hipError_t rdyn_image_launch_na##NA_(int n_joints, unsigned fix, bool stacked, const RdynSweepArgs* a, hipStream_t st);
+#define DECL(NA_) hipError_t rdyn_image_launch_na##NA_(int n_joints, unsigned fix, bool stacked, const RdynSweepArgs* a, hipStream_t st, bool perm);
 RDYN_IMAGE_NA_LIST(DECL)
 #undef DECL
 #define DECL(NA_) \
@@ -44,14 +44,16 @@ bool rdyn_image_supported(int n_joints, unsigned fix_mask, int64_t y_ss, bool mu
   return y_ss > 0 && (y_ss * 8) % 16 == 0 && 64 * y_ss * 8 < (int64_t)0xFFFFFFFFll;
 }
 
-hipError_t rdyn_launch_image_sweep(int n_joints, unsigned fix_mask, const RdynSweepArgs& a, hipStream_t st)
+// perm: a.chain is the sorted view of a chain whose input joints were listed out of chain order, a.row_map the caller's row of every
+// swept row (per-sample images of chains without fixed joints only)
+hipError_t rdyn_launch_image_sweep(int n_joints, unsigned fix_mask, const RdynSweepArgs& a, hipStream_t st, bool perm)
 {
   if (a.n_samples <= 0) return hipSuccess;
   const int n_active = n_joints - popcount_u(fix_mask);
   const bool stacked = a.y_ss == n_active;  // row = s n + j (stacked matrix) instead of one image per sample
   switch (n_active)
   {
-#define CASE(NA_) case NA_: return rdyn_image_launch_na##NA_(n_joints, fix_mask, stacked, &a, st);
+#define CASE(NA_) case NA_: return rdyn_image_launch_na##NA_(n_joints, fix_mask, stacked, &a, st, perm);
     RDYN_IMAGE_NA_LIST(CASE)
 #undef CASE
   default: return hipErrorInvalidValue;

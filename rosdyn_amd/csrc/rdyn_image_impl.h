@@ -71,9 +71,12 @@ constexpr int image_flushes(int na)
 #else
 #define RDYN_IMAGE_WG_WAVES(STACKED_) 1
 #endif
-template <int NJ, unsigned FIX, bool NT, bool STACKED>
+// PERM (per-sample images, every joint an input joint): the input joints were listed out of chain order -- the sweep runs over the
+// sorted view of the chain and row l of it is the caller's input joint a.row_map[l] (wave-uniform): inputs, torques and the image row.
+template <int NJ, unsigned FIX, bool NT, bool STACKED, bool PERM = false>
 __global__ __launch_bounds__(64 * RDYN_IMAGE_WG_WAVES(STACKED), RDYN_IMAGE_WG_WAVES(STACKED) > 1 ? 1 : RDYN_IMAGE_WAVES(STACKED, FIX, NJ)) void k_image_sweep(const RdynSweepArgs a)
 {
+  static_assert(!PERM || (FIX == 0 && !STACKED), "row maps: per-sample images of chains without fixed joints");
   constexpr int IMAGE_WAVES = RDYN_IMAGE_WG_WAVES(STACKED);
 #ifdef RDYN_STACKED_XCD_REMAP
   // A/B variant: workgroups are dealt to the 8 XCDs round-robin; give every XCD one contiguous eighth of the batch instead
@@ -96,11 +99,12 @@ __global__ __launch_bounds__(64, RDYN_IMAGE_WAVES(STACKED, FIX, NJ)) void k_imag
   const RDYN_CONST_AS RdynSweepArgs& a = *((const RDYN_CONST_AS RdynSweepArgs*)table + blockIdx.y);
 #pragma clang diagnostic pop
   constexpr int IMAGE_WAVES = 1;
+  constexpr bool PERM = false;
   const unsigned blk = blockIdx.x;
 #include "rdyn_image_body.inc"
 }
 
-template <int NJ, unsigned FIX, bool STACKED>
+template <int NJ, unsigned FIX, bool STACKED, bool PERM = false>
 hipError_t launch_image(const RdynSweepArgs& a, hipStream_t st)
 {
   constexpr int NA = NJ - __builtin_popcount(FIX);
@@ -125,12 +129,12 @@ hipError_t launch_image(const RdynSweepArgs& a, hipStream_t st)
     if (e != hipSuccess) return e;
     if (!(attr.load() & (1ull << (dev & 63))))
     {
-      e = hipFuncSetAttribute((const void*)k_image_sweep<NJ, FIX, kNT, STACKED>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      e = hipFuncSetAttribute((const void*)k_image_sweep<NJ, FIX, kNT, STACKED, PERM>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       if (e != hipSuccess) return e;
       attr.fetch_or(1ull << (dev & 63));
     }
   }
-  hipLaunchKernelGGL((k_image_sweep<NJ, FIX, kNT, STACKED>), grid, dim3(64 * WV), lds, st, a);
+  hipLaunchKernelGGL((k_image_sweep<NJ, FIX, kNT, STACKED, PERM>), grid, dim3(64 * WV), lds, st, a);
   return hipGetLastError();
 }
 template <int NJ, unsigned FIX, bool STACKED>
@@ -146,7 +150,7 @@ hipError_t launch_image_multi(const RdynSweepArgs* table, int n_items, int64_t m
 
 // one (input joints, fixed head joints, fixed tail joints) pattern; compiled only when the chain fits RDYN_MAX_SWEPT_JOINTS
 template <int NA, int H, int T, bool MULTI>
-hipError_t image_try(int n_joints, unsigned fix, bool stacked, const RdynSweepArgs* a, int n_items, int64_t max_samples, hipStream_t st, bool* hit)
+hipError_t image_try(int n_joints, unsigned fix, bool stacked, const RdynSweepArgs* a, int n_items, int64_t max_samples, hipStream_t st, bool* hit, bool perm)
 {
   if constexpr (NA + H + T <= RDYN_MAX_SWEPT_JOINTS)
   {
@@ -158,19 +162,24 @@ hipError_t image_try(int n_joints, unsigned fix, bool stacked, const RdynSweepAr
       if constexpr (MULTI)
         return stacked ? launch_image_multi<NJ, FIX, true>(a, n_items, max_samples, st) : launch_image_multi<NJ, FIX, false>(a, n_items, max_samples, st);
       else
+      {
+        if constexpr (H == 0 && T == 0)
+          if (perm) return stacked ? hipErrorInvalidValue : launch_image<NJ, FIX, false, true>(*a, st);
+        if (perm) return hipErrorInvalidValue;
         return stacked ? launch_image<NJ, FIX, true>(*a, st) : launch_image<NJ, FIX, false>(*a, st);
+      }
     }
   }
   return hipSuccess;
 }
 
 template <int NA, bool MULTI>
-hipError_t image_launch_na(int n_joints, unsigned fix, bool stacked, const RdynSweepArgs* a, int n_items, int64_t max_samples, hipStream_t st)
+hipError_t image_launch_na(int n_joints, unsigned fix, bool stacked, const RdynSweepArgs* a, int n_items, int64_t max_samples, hipStream_t st, bool perm = false)
 {
   bool hit = false;
   hipError_t e = hipSuccess;
 #define RDYN_IMG_TRY(H_, T_) \
-  if (!hit) e = image_try<NA, H_, T_, MULTI>(n_joints, fix, stacked, a, n_items, max_samples, st, &hit);
+  if (!hit) e = image_try<NA, H_, T_, MULTI>(n_joints, fix, stacked, a, n_items, max_samples, st, &hit, perm);
   RDYN_IMAGE_PATTERNS(RDYN_IMG_TRY)
 #undef RDYN_IMG_TRY
   return hit ? e : hipErrorInvalidValue;

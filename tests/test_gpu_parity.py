@@ -134,6 +134,37 @@ def test_regressor_layouts_agree(torch_cuda):
         assert np.all(a[:, j, :10 * j] == 0.0)
 
 
+@pytest.mark.parametrize("urdf,base,tool,order", [("ur10_like.urdf", "base_link", "wrist_3_link", [2, 0, 5, 1, 4, 3]),
+                                                  ("panda_like.urdf", "link0", "link7", [6, 5, 4, 3, 2, 1, 0]),
+                                                  ("ur10_like.urdf", "base_link", "forearm_link", [2, 0, 1])])
+def test_permuted_input_joints_per_sample_images(torch_cuda, urdf, base, tool, order):
+    """setInputJointsName in any order (primitives_impl.h:705-829): the per-sample image of the permuted chain is the chain-order image
+    with its rows permuted, bit for bit (k_image_sweep<.., PERM>: the sorted view swept, inputs / torques / image rows through the row
+    map) -- ragged batch, and against the oracle."""
+    torch = torch_cuda
+    from oracle.oracle import OracleChain
+    from rosdyn_amd import Chain
+    path = os.path.join(FIXTURES, urdf)
+    chain, perm = Chain(path, base, tool, GRAV), Chain(path, base, tool, GRAV)
+    names = chain.getActiveJointsName()
+    n = len(names)
+    assert sorted(order) == list(range(n))
+    assert perm.setInputJointsName([names[i] for i in order])
+    N = 4099
+    rng = np.random.default_rng(77)
+    q, dq, ddq = (rng.uniform(-1, 1, (N, n)) for _ in range(3))
+    t = [torch.from_numpy(x).cuda() for x in (q, dq, ddq)]
+    Y0, tau0 = chain.getRegressor(*t, with_torque=True)
+    tp = [torch.from_numpy(np.ascontiguousarray(x[:, order])).cuda() for x in (q, dq, ddq)]
+    Yp, taup = perm.getRegressor(*tp, with_torque=True)
+    Y0, Yp = Y0.cpu().numpy().reshape(N, -1, n), Yp.cpu().numpy().reshape(N, -1, n)
+    assert np.array_equal(Yp, Y0[:, :, order]) and np.array_equal(taup.cpu().numpy(), tau0.cpu().numpy()[:, order])
+    ref = OracleChain(path, base, tool, GRAV)
+    Yr = ref.regressor(q[:64], dq[:64], ddq[:64])   # (64, n, P)
+    got = np.transpose(Yp[:64], (0, 2, 1))           # image = column-major n x P
+    assert np.abs(got - Yr[:, order, :]).max() <= 1e-11 * max(1.0, np.abs(Yr).max())
+
+
 def test_full_size_properties(torch_cuda):
     """BASELINE config 2 size (N = 1e6, 6-DOF, P = 60): Y pi = tau and tau - tau_nl = M ddq on the whole batch,
     plus oracle parity on a 4 096-sample prefix."""

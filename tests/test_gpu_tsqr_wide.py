@@ -127,6 +127,26 @@ def test_identification_factor_preconditioned_route(case, N):
     assert np.array_equal(R1, chain.getIdentificationTsqr(comps, *args).cpu().numpy())
 
 
+@pytest.mark.parametrize("kinds,K_expected", [([FRICTION2], 21), ([FRICTION2, FRICTION1, FRICTION1], 17), ([SPRING, FRICTION1], 14)])
+def test_seven_joint_identification_factor_at_every_column_shift(kinds, K_expected):
+    """k_regressor_pgram_solo is instantiated per quantised column shift (rdyn_pgram_solo.hip: 11 up to 14 component columns, 4 up to 21):
+    second-order friction on every joint (K = 21, shift 4), a mix (K = 17: room for 8, quantised to 4), springs + friction (K = 14, shift
+    11) -- R'R = M'M against the oracle's rows on the preconditioned route, accepted in round 0, reproducible bit for bit."""
+    torch = pytest.importorskip("torch")
+    from rosdyn_amd._lib import lib
+    import ctypes as C
+    N = 20000
+    chain, M, args, comps, specs, P, K = _ident_case("panda_like.urdf", "link0", "link7", N, kinds, seed=11)
+    assert K == K_expected
+    nbytes = lib().rdyn_identification_tsqr_workspace_bytes(chain._h, C.cast(comps._arr, C.c_void_p), comps.n_comps)
+    ws = torch.empty((nbytes,), dtype=torch.uint8, device="cuda")
+    R1 = chain.getIdentificationTsqr(comps, *args, workspace=ws).cpu().numpy()
+    rep = chain.lastTsqrReport(N, ws, components=comps)
+    assert rep["route"] == 1 and rep["stage"] == 0, rep
+    _check_factor(R1, M)
+    assert np.array_equal(R1, chain.getIdentificationTsqr(comps, *args).cpu().numpy())
+
+
 @pytest.mark.parametrize("tool,N", [("link3", 4096), ("link4", 5000), ("link2", 4500)])
 def test_identification_factor_short_chains_above_the_threshold(tool, N):
     """chains of 2..4 joints with component columns and >= 4 096 samples took the preconditioned route, whose
