@@ -229,7 +229,7 @@ int image_route(const rdyn_chain* c, const rdyn_regressor_layout* yl, int64_t n_
     {
       // input joints out of chain order: per-sample images of a chain without fixed joints sweep its sorted view and map the rows
       // (k_image_sweep<.., PERM>); everything else keeps the row-pair / strided kernels
-      if (!perm || multi || !lay_image || lay_stacked || n != nJ || !c->sorted || !rdyn_image_supported(nJ, 0u, yl->stride_sample, false)) return 0;
+      if (!perm || multi || !lay_image || lay_stacked || n != nJ || n > 8 || !c->sorted || !rdyn_image_supported(nJ, 0u, yl->stride_sample, false)) return 0;
       *perm = true;
       *fix_mask = 0u;
       return 1;

@@ -163,7 +163,7 @@ hipError_t image_try(int n_joints, unsigned fix, bool stacked, const RdynSweepAr
         return stacked ? launch_image_multi<NJ, FIX, true>(a, n_items, max_samples, st) : launch_image_multi<NJ, FIX, false>(a, n_items, max_samples, st);
       else
       {
-        if constexpr (H == 0 && T == 0)
+        if constexpr (H == 0 && T == 0 && NA <= 8)  // (9 .. 10 input joints out of chain order keep the row-pair kernel: build time)
           if (perm) return stacked ? hipErrorInvalidValue : launch_image<NJ, FIX, false, true>(*a, st);
         if (perm) return hipErrorInvalidValue;
         return stacked ? launch_image<NJ, FIX, true>(*a, st) : launch_image<NJ, FIX, false>(*a, st);
