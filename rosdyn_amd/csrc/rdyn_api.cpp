@@ -213,9 +213,9 @@ inline void rec_strides(const rdyn_batch* b, int64_t elems, int64_t* ss, int64_t
 // fixed-joint pattern (*fix_mask: bit f = chain joint f is not an input joint), and a 16-byte aligned Y: the copy-out moves 16-byte
 // chunks whose addresses are Y + a multiple of 16 (an 8-byte aligned base -- a view at an odd double offset -- would put the last
 // chunk of every image 8 bytes past its end); such calls keep the row-pair / strided kernels.
-int image_route(const rdyn_chain* c, const rdyn_regressor_layout* yl, int64_t n_samples, const double* Y, bool multi, unsigned* fix_mask, bool* perm = nullptr)
+int image_route(const rdyn_chain* c, const rdyn_regressor_layout* yl, int64_t n_samples, const double* Y, bool multi, unsigned* fix_mask, bool* mapped = nullptr)
 {
-  if (perm) *perm = false;
+  if (mapped) *mapped = false;
   const int n = c->n_active(), nJ = c->n_joints();
   const bool lay_image = yl->stride_row == 1 && yl->stride_col == n && yl->stride_sample >= (int64_t)n * 10 * nJ;
   const bool lay_stacked = yl->stride_row == 1 && yl->stride_sample == n && yl->stride_col >= n_samples * n && !probe_env("RDYN_NO_STACKED_LDS");
@@ -223,22 +223,23 @@ int image_route(const rdyn_chain* c, const rdyn_regressor_layout* yl, int64_t n_
   if (((uintptr_t)Y & 15u) != 0) return 0;
   if (lay_stacked && (yl->stride_col * 8) % 16 != 0) return 0;  // every column must start 16-byte aligned too
   unsigned fix = (nJ >= 32) ? 0u : ((1u << nJ) - 1u);
+  bool ordered_inputs = true;
   for (int j = 0; j < n; ++j)
   {
-    if (j > 0 && c->active[j] <= c->active[j - 1])
-    {
-      // input joints out of chain order: per-sample images of a chain without fixed joints sweep its sorted view and map the rows
-      // (k_image_sweep<.., PERM>); everything else keeps the row-pair / strided kernels
-      if (!perm || multi || !lay_image || lay_stacked || n != nJ || n > 8 || !c->sorted || !rdyn_image_supported(nJ, 0u, yl->stride_sample, false)) return 0;
-      *perm = true;
-      *fix_mask = 0u;
-      return 1;
-    }
+    if (j > 0 && c->active[j] <= c->active[j - 1]) ordered_inputs = false;
     fix &= ~(1u << c->active[j]);
   }
-  if (!rdyn_image_supported(nJ, fix, yl->stride_sample, multi)) return 0;
   *fix_mask = fix;
-  return lay_stacked ? 2 : 1;
+  if (ordered_inputs && rdyn_image_supported(nJ, fix, yl->stride_sample, multi)) return lay_stacked ? 2 : 1;
+  // input joints out of chain order, or joints that are not input joints somewhere else than the compiled head / tail patterns:
+  // per-sample images go through the run-time row map (k_image_sweep<.., MAP>); everything else keeps the row-pair / strided kernels
+  if (mapped && !multi && lay_image && !lay_stacked && (ordered_inputs || c->sorted) && rdyn_image_map_supported(nJ, fix, yl->stride_sample) &&
+      !probe_env("RDYN_NO_IMAGE_MAP"))
+  {
+    *mapped = true;
+    return 1;
+  }
+  return 0;
 }
 
 int run_local(const rdyn_chain* c, const rdyn_batch* b, int mode, double* tau, double* Y, const rdyn_regressor_layout* yl, double* M,
@@ -310,18 +311,20 @@ int run_local(const rdyn_chain* c, const rdyn_batch* b, int mode, double* tau, d
   // the drop-in per-sample image (either input layout): one thread per sample, link blocks staged through LDS (rdyn_image.hip)
   // and the stacked column-major (N n) x P matrix (stride_sample == n): same kernel, column-major staging tile per link
   unsigned fix_mask = 0;
-  bool perm = false;
-  const bool image = mode == RDYN_MODE_REGRESSOR && yl && image_route(c, yl, b->n_samples, Y, false, &fix_mask, &perm) != 0;
+  bool mapped = false;
+  const bool image = mode == RDYN_MODE_REGRESSOR && yl && image_route(c, yl, b->n_samples, Y, false, &fix_mask, &mapped) != 0;
   if (image)
   {
-    if (perm)
+    if (mapped)
     {
-      const rdyn_chain* const so = c->sorted.get();
+      // the swept chain: the sorted view when the input joints were listed out of chain order (same joints, rows in chain order)
+      const rdyn_chain* const so = c->sorted ? c->sorted.get() : c;
       st = device_const(so, &a.chain);
       if (st != RDYN_OK) return st;
-      for (int l = 0; l < n; ++l) a.row_map[l] = so->row_input[l];
+      for (int f = 0; f < RDYN_MAX_SWEPT_JOINTS; ++f) a.row_map[f] = -1;
+      for (int r = 0; r < n; ++r) a.row_map[so->active[r]] = r < (int)so->row_input.size() ? so->row_input[r] : r;
     }
-    RDYN_HIP_TRY(rdyn_launch_image_sweep(c->n_joints(), fix_mask, a, (hipStream_t)b->stream, perm));
+    RDYN_HIP_TRY(rdyn_launch_image_sweep(c->n_joints(), fix_mask, a, (hipStream_t)b->stream, mapped));
   }
   else if (rowpair)
   {

@@ -44,16 +44,25 @@ bool rdyn_image_supported(int n_joints, unsigned fix_mask, int64_t y_ss, bool mu
   return y_ss > 0 && (y_ss * 8) % 16 == 0 && 64 * y_ss * 8 < (int64_t)0xFFFFFFFFll;
 }
 
-// perm: a.chain is the sorted view of a chain whose input joints were listed out of chain order, a.row_map the caller's row of every
-// swept row (per-sample images of chains without fixed joints only)
-hipError_t rdyn_launch_image_sweep(int n_joints, unsigned fix_mask, const RdynSweepArgs& a, hipStream_t st, bool perm)
+// run-time row map (per-sample images only): NA = n_joints - popcount(fix_mask) input joints in any order, the joints of fix_mask anywhere
+bool rdyn_image_map_supported(int n_joints, unsigned fix_mask, int64_t y_ss)
+{
+  if (n_joints < 2 || n_joints > RDYN_MAX_SWEPT_JOINTS || (fix_mask >> n_joints)) return false;
+  const int nfx = popcount_u(fix_mask), na = n_joints - nfx;
+  if (na < 2 || na > RDYN_IMAGE_MAP_MAX_NA || nfx > RDYN_IMAGE_MAP_MAX_FIXED) return false;
+  return y_ss >= (int64_t)na * 10 * n_joints && (y_ss * 8) % 16 == 0 && 64 * y_ss * 8 < (int64_t)0xFFFFFFFFll;
+}
+
+// mapped: a.row_map[f] = the caller's row of chain joint f, -1 for the joints of fix_mask (k_image_sweep<.., MAP>); a.chain is the
+// sorted view when the input joints were listed out of chain order
+hipError_t rdyn_launch_image_sweep(int n_joints, unsigned fix_mask, const RdynSweepArgs& a, hipStream_t st, bool mapped)
 {
   if (a.n_samples <= 0) return hipSuccess;
   const int n_active = n_joints - popcount_u(fix_mask);
   const bool stacked = a.y_ss == n_active;  // row = s n + j (stacked matrix) instead of one image per sample
   switch (n_active)
   {
-#define CASE(NA_) case NA_: return rdyn_image_launch_na##NA_(n_joints, fix_mask, stacked, &a, st, perm);
+#define CASE(NA_) case NA_: return rdyn_image_launch_na##NA_(n_joints, mapped ? 0u : fix_mask, stacked, &a, st, mapped);
     RDYN_IMAGE_NA_LIST(CASE)
 #undef CASE
   default: return hipErrorInvalidValue;

@@ -71,12 +71,16 @@ constexpr int image_flushes(int na)
 #else
 #define RDYN_IMAGE_WG_WAVES(STACKED_) 1
 #endif
-// PERM (per-sample images, every joint an input joint): the input joints were listed out of chain order -- the sweep runs over the
-// sorted view of the chain and row l of it is the caller's input joint a.row_map[l] (wave-uniform): inputs, torques and the image row.
-template <int NJ, unsigned FIX, bool NT, bool STACKED, bool PERM = false>
-__global__ __launch_bounds__(64 * RDYN_IMAGE_WG_WAVES(STACKED), RDYN_IMAGE_WG_WAVES(STACKED) > 1 ? 1 : RDYN_IMAGE_WAVES(STACKED, FIX, NJ)) void k_image_sweep(const RdynSweepArgs a)
+// MAP >= 0 (per-sample images; FIX == 0): the input joints of the chain are described at RUN time -- a.row_map[f] = the caller's row of
+// chain joint f (where its q / Dq / DDq are read, its torque is written, and the row of the image its values land in), -1 for the MAP
+// joints that are not input joints (fixed joints, moving joints left out of setInputJointsName).  Serves input joints listed in any
+// order and fixed joints ANYWHERE in the chain (the compiled FIX patterns are heads and tails only); the chain passed is the sorted
+// view when there is one (same joints, rows in chain order).
+template <int NJ, unsigned FIX, bool NT, bool STACKED, int MAP = -1>
+// (the row-mapped 7-joint chain does not fit the 256 registers of two waves per SIMD: 444 B of scratch, 868 us per 1e6 at 7 joints)
+__global__ __launch_bounds__(64 * RDYN_IMAGE_WG_WAVES(STACKED), (RDYN_IMAGE_WG_WAVES(STACKED) > 1 || (MAP == 0 && NJ == 7)) ? 1 : RDYN_IMAGE_WAVES(STACKED, FIX, NJ)) void k_image_sweep(const RdynSweepArgs a)
 {
-  static_assert(!PERM || (FIX == 0 && !STACKED), "row maps: per-sample images of chains without fixed joints");
+  static_assert(MAP < 0 || (FIX == 0 && !STACKED && MAP < NJ), "row maps: per-sample images, the fixed joints in the map");
   constexpr int IMAGE_WAVES = RDYN_IMAGE_WG_WAVES(STACKED);
 #ifdef RDYN_STACKED_XCD_REMAP
   // A/B variant: workgroups are dealt to the 8 XCDs round-robin; give every XCD one contiguous eighth of the batch instead
@@ -99,15 +103,15 @@ __global__ __launch_bounds__(64, RDYN_IMAGE_WAVES(STACKED, FIX, NJ)) void k_imag
   const RDYN_CONST_AS RdynSweepArgs& a = *((const RDYN_CONST_AS RdynSweepArgs*)table + blockIdx.y);
 #pragma clang diagnostic pop
   constexpr int IMAGE_WAVES = 1;
-  constexpr bool PERM = false;
+  constexpr int MAP = -1;
   const unsigned blk = blockIdx.x;
 #include "rdyn_image_body.inc"
 }
 
-template <int NJ, unsigned FIX, bool STACKED, bool PERM = false>
+template <int NJ, unsigned FIX, bool STACKED, int MAP = -1>
 hipError_t launch_image(const RdynSweepArgs& a, hipStream_t st)
 {
-  constexpr int NA = NJ - __builtin_popcount(FIX);
+  constexpr int NA = MAP >= 0 ? NJ - MAP : NJ - __builtin_popcount(FIX);
   constexpr int WV = RDYN_IMAGE_WG_WAVES(STACKED);
   const dim3 grid((unsigned)((a.n_samples + 64 * WV - 1) / (64 * WV)));
   constexpr int runf = (10 / image_flushes(NA)) * NA * 8, w = ((runf + 15) / 16) * 16 + 128, pitch = w + ((w / 16) % 2 ? 32 : 16);
@@ -129,12 +133,12 @@ hipError_t launch_image(const RdynSweepArgs& a, hipStream_t st)
     if (e != hipSuccess) return e;
     if (!(attr.load() & (1ull << (dev & 63))))
     {
-      e = hipFuncSetAttribute((const void*)k_image_sweep<NJ, FIX, kNT, STACKED, PERM>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      e = hipFuncSetAttribute((const void*)k_image_sweep<NJ, FIX, kNT, STACKED, MAP>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       if (e != hipSuccess) return e;
       attr.fetch_or(1ull << (dev & 63));
     }
   }
-  hipLaunchKernelGGL((k_image_sweep<NJ, FIX, kNT, STACKED, PERM>), grid, dim3(64 * WV), lds, st, a);
+  hipLaunchKernelGGL((k_image_sweep<NJ, FIX, kNT, STACKED, MAP>), grid, dim3(64 * WV), lds, st, a);
   return hipGetLastError();
 }
 template <int NJ, unsigned FIX, bool STACKED>
@@ -163,9 +167,7 @@ hipError_t image_try(int n_joints, unsigned fix, bool stacked, const RdynSweepAr
         return stacked ? launch_image_multi<NJ, FIX, true>(a, n_items, max_samples, st) : launch_image_multi<NJ, FIX, false>(a, n_items, max_samples, st);
       else
       {
-        if constexpr (H == 0 && T == 0 && NA <= 8)  // (9 .. 10 input joints out of chain order keep the row-pair kernel: build time)
-          if (perm) return stacked ? hipErrorInvalidValue : launch_image<NJ, FIX, false, true>(*a, st);
-        if (perm) return hipErrorInvalidValue;
+        if (perm) return hipErrorInvalidValue;  // (row-mapped chains: image_launch_na dispatches them)
         return stacked ? launch_image<NJ, FIX, true>(*a, st) : launch_image<NJ, FIX, false>(*a, st);
       }
     }
@@ -174,12 +176,28 @@ hipError_t image_try(int n_joints, unsigned fix, bool stacked, const RdynSweepAr
 }
 
 template <int NA, bool MULTI>
-hipError_t image_launch_na(int n_joints, unsigned fix, bool stacked, const RdynSweepArgs* a, int n_items, int64_t max_samples, hipStream_t st, bool perm = false)
+hipError_t image_launch_na(int n_joints, unsigned fix, bool stacked, const RdynSweepArgs* a, int n_items, int64_t max_samples, hipStream_t st, bool mapped = false)
 {
+  if constexpr (!MULTI && NA <= RDYN_IMAGE_MAP_MAX_NA)
+  {
+    // run-time row map: NA input joints among n_joints chain joints (up to RDYN_IMAGE_MAP_MAX_FIXED joints that are not)
+    if (mapped)
+    {
+      if (stacked || fix != 0u) return hipErrorInvalidValue;
+      if (n_joints == NA) return launch_image<NA, 0u, false, 0>(*a, st);
+      if constexpr (NA + 1 <= RDYN_MAX_SWEPT_JOINTS)
+        if (n_joints == NA + 1) return launch_image<NA + 1, 0u, false, 1>(*a, st);
+      if constexpr (NA + 2 <= RDYN_MAX_SWEPT_JOINTS)
+        if (n_joints == NA + 2) return launch_image<NA + 2, 0u, false, 2>(*a, st);
+      return hipErrorInvalidValue;
+    }
+  }
+  else if (mapped)
+    return hipErrorInvalidValue;
   bool hit = false;
   hipError_t e = hipSuccess;
 #define RDYN_IMG_TRY(H_, T_) \
-  if (!hit) e = image_try<NA, H_, T_, MULTI>(n_joints, fix, stacked, a, n_items, max_samples, st, &hit, perm);
+  if (!hit) e = image_try<NA, H_, T_, MULTI>(n_joints, fix, stacked, a, n_items, max_samples, st, &hit, false);
   RDYN_IMAGE_PATTERNS(RDYN_IMG_TRY)
 #undef RDYN_IMG_TRY
   return hit ? e : hipErrorInvalidValue;

@@ -36,9 +36,9 @@ struct RdynSweepArgs
   // (stride_col == rows, a link's block is one run of 10 rows doubles per sample), 2: stacked matrix (stride_sample == rows, a column is
   // one run of 64 rows doubles per wave)
   int expand_stage;
-  // per-sample images of a chain whose input joints were listed out of chain order (k_image_sweep<.., PERM>: `chain` is the sorted view,
-  // rdyn_chain.hpp): row l of the sweep is the caller's input joint row_map[l] -- where q / Dq / DDq are read, tau is written, and the
-  // row of the image the values land in
+  // per-sample images through a run-time row map (k_image_sweep<.., MAP>: input joints in any order -- `chain` is then the sorted view,
+  // rdyn_chain.hpp -- and joints that are not input joints anywhere in the chain): row_map[f] = the caller's input index of chain joint
+  // f -- where q / Dq / DDq are read, tau is written, and the row of the image its values land in --, -1 for a joint that is none
   int row_map[RDYN_MAX_SWEPT_JOINTS];
 };
 
@@ -337,7 +337,8 @@ hipError_t rdyn_launch_rowpair_sweep(int n_joints, int n_active, const RdynSweep
 // through LDS and written in whole lines (rdyn_image.hip / rdyn_image_impl.h).  fix_mask: bit f set = chain joint f is not an input
 // joint; the input joints are the others, in chain order.  Compiled patterns: <= 1 fixed head joint, <= 3 fixed tail joints.
 bool rdyn_image_supported(int n_joints, unsigned fix_mask, int64_t y_ss, bool multi);
-hipError_t rdyn_launch_image_sweep(int n_joints, unsigned fix_mask, const RdynSweepArgs& a, hipStream_t st, bool perm = false);
+hipError_t rdyn_launch_image_sweep(int n_joints, unsigned fix_mask, const RdynSweepArgs& a, hipStream_t st, bool mapped = false);
+bool rdyn_image_map_supported(int n_joints, unsigned fix_mask, int64_t y_ss);  // per-sample images through a run-time row map (any input order, fixed joints anywhere)
 hipError_t rdyn_launch_image_sweep_multi(int n_joints, unsigned fix_mask, bool stacked, const RdynSweepArgs* table, int n_items, int64_t max_samples,
                                          hipStream_t st);  // 2..8 input joints
 hipError_t rdyn_launch_local_sweep_multi(int n_joints, int mode, const RdynSweepArgs* table, int n_items, int64_t max_samples, hipStream_t st);

@@ -134,6 +134,36 @@ def test_regressor_layouts_agree(torch_cuda):
         assert np.all(a[:, j, :10 * j] == 0.0)
 
 
+def test_fixed_joints_anywhere_per_sample_images(torch_cuda):
+    """Per-sample images through the run-time row map (k_image_sweep<.., MAP>): a fixed frame in the MIDDLE of the chain (not one of the
+    compiled head / tail patterns), a moving joint left out of setInputJointsName mid-chain, and that one with the rest permuted --
+    against the oracle, ragged batch."""
+    torch = torch_cuda
+    from oracle.oracle import OracleChain
+    from rosdyn_amd import Chain
+    cases = [("ur10_public_long.urdf", "base_link", "wrist_3_link", None),
+             ("panda_like.urdf", "link0", "link7", [0, 1, 2, 4, 5, 6]),
+             ("panda_like.urdf", "link0", "hand", [5, 0, 6, 2, 1])]
+    for urdf, base, tool, keep in cases:
+        path = os.path.join(FIXTURES, urdf)
+        chain = Chain(path, base, tool, GRAV)
+        sel = None
+        if keep is not None:
+            names = chain.getActiveJointsName()
+            sel = [names[i] for i in keep]
+            assert chain.setInputJointsName(sel)
+        ref = OracleChain(path, base, tool, GRAV, input_joint_names=sel)
+        n, P = ref.n, ref.P
+        N = 1031
+        rng = np.random.default_rng(5)
+        q, dq, ddq = (rng.uniform(-1, 1, (N, n)) for _ in range(3))
+        Y, tau = chain.getRegressor(*(torch.from_numpy(x).cuda() for x in (q, dq, ddq)), with_torque=True)
+        Y = np.transpose(Y.cpu().numpy().reshape(N, P, n), (0, 2, 1))
+        Yr, tr = ref.regressor(q, dq, ddq), ref.joint_torque(q, dq, ddq)
+        assert np.abs(Y - Yr).max() <= 1e-11 * max(1.0, np.abs(Yr).max()), (urdf, tool)
+        assert np.abs(tau.cpu().numpy() - tr).max() <= 1e-11 * max(1.0, np.abs(tr).max()), (urdf, tool)
+
+
 @pytest.mark.parametrize("urdf,base,tool,order", [("ur10_like.urdf", "base_link", "wrist_3_link", [2, 0, 5, 1, 4, 3]),
                                                   ("panda_like.urdf", "link0", "link7", [6, 5, 4, 3, 2, 1, 0]),
                                                   ("ur10_like.urdf", "base_link", "forearm_link", [2, 0, 1])])
