@@ -291,6 +291,27 @@ int run_local(const rdyn_chain* c, const rdyn_batch* b, int mode, double* tau, d
     else if (yl->stride_sample == n && yl->stride_col % 2 == 0) a.expand_stage = 2;   // stacked (N n) x P matrix
     if (a.expand_stage) mode = RDYN_MODE_REGRESSOR_EXPAND_STAGED;
   }
+  // per-sample images of a long chain whose companion has up to 6 joints: the image kernel (whole-line copy-out through the per-sample
+  // ring) forms the blocks of the riding links one at a time (k_image_sweep<.., EXPAND>)
+  bool expand_image = false;
+  if (mode == RDYN_MODE_REGRESSOR_EXPAND_STAGED && a.expand_stage == 1 && c->n_active() == c->n_joints() && !probe_env("RDYN_NO_EXPAND_IMAGE") &&
+      rdyn_image_expand_supported(c->n_joints(), full->n_joints(), yl->stride_sample))
+  {
+    const int nr = c->n_joints(), nf = full->n_joints();
+    bool mono = true;
+    for (int g = 1; g < nf; ++g) mono = mono && full->red_of[g] >= full->red_of[g - 1];
+    if (mono)
+    {
+      for (int f = 0; f <= nr; ++f)
+      {
+        int g = 0;
+        while (g < nf && full->red_of[g] < f) ++g;
+        a.expand_first[f] = g;   // (f = nr: nf)
+      }
+      for (int i = 0; i < n; ++i) a.row_map[c->active[i]] = i;  // reduced joint -> the caller's input index
+      expand_image = true;
+    }
+  }
   if (yl && (mode == RDYN_MODE_REGRESSOR || mode == RDYN_MODE_REGRESSOR_EXPAND || mode == RDYN_MODE_REGRESSOR_EXPAND_STAGED))
   {
     // the one-thread-per-sample kernel addresses a workgroup's 256 samples with 32-bit lane offsets: free strides must be
@@ -313,7 +334,9 @@ int run_local(const rdyn_chain* c, const rdyn_batch* b, int mode, double* tau, d
   unsigned fix_mask = 0;
   bool mapped = false;
   const bool image = mode == RDYN_MODE_REGRESSOR && yl && image_route(c, yl, b->n_samples, Y, false, &fix_mask, &mapped) != 0;
-  if (image)
+  if (expand_image)
+    RDYN_HIP_TRY(rdyn_launch_image_sweep(c->n_joints(), 0u, a, (hipStream_t)b->stream, 2));
+  else if (image)
   {
     if (mapped)
     {

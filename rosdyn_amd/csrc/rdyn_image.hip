@@ -8,7 +8,7 @@
 #define RDYN_IMAGE_NA_LIST(X) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10)
 #define RDYN_IMAGE_MULTI_NA_LIST(X) X(2) X(3) X(4) X(5) X(6) X(7) X(8)
 
-#define DECL(NA_) hipError_t rdyn_image_launch_na##NA_(int n_joints, unsigned fix, bool stacked, const RdynSweepArgs* a, hipStream_t st, bool perm);
+#define DECL(NA_) hipError_t rdyn_image_launch_na##NA_(int n_joints, unsigned fix, bool stacked, const RdynSweepArgs* a, hipStream_t st, int mapped);
 RDYN_IMAGE_NA_LIST(DECL)
 #undef DECL
 #define DECL(NA_) \
@@ -45,6 +45,13 @@ bool rdyn_image_supported(int n_joints, unsigned fix_mask, int64_t y_ss, bool mu
 }
 
 // run-time row map (per-sample images only): NA = n_joints - popcount(fix_mask) input joints in any order, the joints of fix_mask anywhere
+// the expanded images of a long chain: its reduced companion has 2 .. 6 joints (one flush per link block)
+bool rdyn_image_expand_supported(int n_red, int n_full, int64_t y_ss)
+{
+  return n_red >= 2 && n_red <= 6 && n_full > n_red && n_full <= RDYN_MAX_JOINTS && y_ss >= (int64_t)n_red * 10 * n_full && (y_ss * 8) % 16 == 0 &&
+         64 * y_ss * 8 < (int64_t)0xFFFFFFFFll;
+}
+
 bool rdyn_image_map_supported(int n_joints, unsigned fix_mask, int64_t y_ss)
 {
   if (n_joints < 2 || n_joints > RDYN_MAX_SWEPT_JOINTS || (fix_mask >> n_joints)) return false;
@@ -53,9 +60,10 @@ bool rdyn_image_map_supported(int n_joints, unsigned fix_mask, int64_t y_ss)
   return y_ss >= (int64_t)na * 10 * n_joints && (y_ss * 8) % 16 == 0 && 64 * y_ss * 8 < (int64_t)0xFFFFFFFFll;
 }
 
-// mapped: a.row_map[f] = the caller's row of chain joint f, -1 for the joints of fix_mask (k_image_sweep<.., MAP>); a.chain is the
-// sorted view when the input joints were listed out of chain order
-hipError_t rdyn_launch_image_sweep(int n_joints, unsigned fix_mask, const RdynSweepArgs& a, hipStream_t st, bool mapped)
+// mapped = 1: a.row_map[f] = the caller's row of chain joint f, -1 for the joints of fix_mask (k_image_sweep<.., MAP>); a.chain is the
+// sorted view when the input joints were listed out of chain order.  mapped = 2: the same map (every joint an input joint) + the blocks
+// of a longer chain's links (a.expand_*; k_image_sweep<.., 0, EXPAND>: 2 .. 6 joints); the image stride is the full chain's
+hipError_t rdyn_launch_image_sweep(int n_joints, unsigned fix_mask, const RdynSweepArgs& a, hipStream_t st, int mapped)
 {
   if (a.n_samples <= 0) return hipSuccess;
   const int n_active = n_joints - popcount_u(fix_mask);

@@ -76,7 +76,9 @@ constexpr int image_flushes(int na)
 // joints that are not input joints (fixed joints, moving joints left out of setInputJointsName).  Serves input joints listed in any
 // order and fixed joints ANYWHERE in the chain (the compiled FIX patterns are heads and tails only); the chain passed is the sorted
 // view when there is one (same joints, rows in chain order).
-template <int NJ, unsigned FIX, bool NT, bool STACKED, int MAP = -1>
+// EXPAND (with MAP = 0): per-sample images of a chain LONGER than the sweep -- `a.chain` is the reduced companion (every joint an input
+// joint), the image holds the blocks of all a.expand_n links of the full chain: see rdyn_image_body.inc.
+template <int NJ, unsigned FIX, bool NT, bool STACKED, int MAP = -1, bool EXPAND = false>
 // (the row-mapped 7-joint chain does not fit the 256 registers of two waves per SIMD: 444 B of scratch, 868 us per 1e6 at 7 joints)
 __global__ __launch_bounds__(64 * RDYN_IMAGE_WG_WAVES(STACKED), (RDYN_IMAGE_WG_WAVES(STACKED) > 1 || (MAP == 0 && NJ == 7)) ? 1 : RDYN_IMAGE_WAVES(STACKED, FIX, NJ)) void k_image_sweep(const RdynSweepArgs a)
 {
@@ -104,11 +106,12 @@ __global__ __launch_bounds__(64, RDYN_IMAGE_WAVES(STACKED, FIX, NJ)) void k_imag
 #pragma clang diagnostic pop
   constexpr int IMAGE_WAVES = 1;
   constexpr int MAP = -1;
+  constexpr bool EXPAND = false;
   const unsigned blk = blockIdx.x;
 #include "rdyn_image_body.inc"
 }
 
-template <int NJ, unsigned FIX, bool STACKED, int MAP = -1>
+template <int NJ, unsigned FIX, bool STACKED, int MAP = -1, bool EXPAND = false>
 hipError_t launch_image(const RdynSweepArgs& a, hipStream_t st)
 {
   constexpr int NA = MAP >= 0 ? NJ - MAP : NJ - __builtin_popcount(FIX);
@@ -133,12 +136,12 @@ hipError_t launch_image(const RdynSweepArgs& a, hipStream_t st)
     if (e != hipSuccess) return e;
     if (!(attr.load() & (1ull << (dev & 63))))
     {
-      e = hipFuncSetAttribute((const void*)k_image_sweep<NJ, FIX, kNT, STACKED, MAP>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      e = hipFuncSetAttribute((const void*)k_image_sweep<NJ, FIX, kNT, STACKED, MAP, EXPAND>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       if (e != hipSuccess) return e;
       attr.fetch_or(1ull << (dev & 63));
     }
   }
-  hipLaunchKernelGGL((k_image_sweep<NJ, FIX, kNT, STACKED, MAP>), grid, dim3(64 * WV), lds, st, a);
+  hipLaunchKernelGGL((k_image_sweep<NJ, FIX, kNT, STACKED, MAP, EXPAND>), grid, dim3(64 * WV), lds, st, a);
   return hipGetLastError();
 }
 template <int NJ, unsigned FIX, bool STACKED>
@@ -176,8 +179,12 @@ hipError_t image_try(int n_joints, unsigned fix, bool stacked, const RdynSweepAr
 }
 
 template <int NA, bool MULTI>
-hipError_t image_launch_na(int n_joints, unsigned fix, bool stacked, const RdynSweepArgs* a, int n_items, int64_t max_samples, hipStream_t st, bool mapped = false)
+hipError_t image_launch_na(int n_joints, unsigned fix, bool stacked, const RdynSweepArgs* a, int n_items, int64_t max_samples, hipStream_t st, int mapped = 0)
 {
+  // mapped: 0 = a compiled fixed-joint pattern, 1 = the run-time row map, 2 = the row map + the expansion to a longer chain's links
+  if constexpr (!MULTI && image_flushes(NA) == 1)
+    if (mapped == 2) return (stacked || fix != 0u || n_joints != NA) ? hipErrorInvalidValue : launch_image<NA, 0u, false, 0, true>(*a, st);
+  if (mapped == 2) return hipErrorInvalidValue;
   if constexpr (!MULTI && NA <= RDYN_IMAGE_MAP_MAX_NA)
   {
     // run-time row map: NA input joints among n_joints chain joints (up to RDYN_IMAGE_MAP_MAX_FIXED joints that are not)

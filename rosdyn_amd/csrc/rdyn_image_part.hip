@@ -16,8 +16,8 @@ hipError_t RDYN_CAT(rdyn_image_launch_multi_na, RDYN_IMAGE_NA)(int n_joints, uns
   return image_launch_na<RDYN_IMAGE_NA, true>(n_joints, fix, stacked, table, n_items, max_samples, st);
 }
 #else
-hipError_t RDYN_CAT(rdyn_image_launch_na, RDYN_IMAGE_NA)(int n_joints, unsigned fix, bool stacked, const RdynSweepArgs* a, hipStream_t st, bool perm)
+hipError_t RDYN_CAT(rdyn_image_launch_na, RDYN_IMAGE_NA)(int n_joints, unsigned fix, bool stacked, const RdynSweepArgs* a, hipStream_t st, int mapped)
 {
-  return image_launch_na<RDYN_IMAGE_NA, false>(n_joints, fix, stacked, a, 1, a->n_samples, st, perm);
+  return image_launch_na<RDYN_IMAGE_NA, false>(n_joints, fix, stacked, a, 1, a->n_samples, st, mapped);
 }
 #endif

@@ -40,6 +40,9 @@ struct RdynSweepArgs
   // rdyn_chain.hpp -- and joints that are not input joints anywhere in the chain): row_map[f] = the caller's input index of chain joint
   // f -- where q / Dq / DDq are read, tau is written, and the row of the image its values land in --, -1 for a joint that is none
   int row_map[RDYN_MAX_SWEPT_JOINTS];
+  // k_image_sweep<.., EXPAND>: the links of the full chain that ride on body f are expand_first[f] .. expand_first[f + 1] - 1 (chain order;
+  // the links below expand_first[0] sit upstream of the first input joint: zero blocks)
+  int expand_first[RDYN_MAX_SWEPT_JOINTS + 1];
 };
 
 // split / jerk sweeps (rdyn_kin_ext.hip); every output record is links x 6
@@ -337,7 +340,8 @@ hipError_t rdyn_launch_rowpair_sweep(int n_joints, int n_active, const RdynSweep
 // through LDS and written in whole lines (rdyn_image.hip / rdyn_image_impl.h).  fix_mask: bit f set = chain joint f is not an input
 // joint; the input joints are the others, in chain order.  Compiled patterns: <= 1 fixed head joint, <= 3 fixed tail joints.
 bool rdyn_image_supported(int n_joints, unsigned fix_mask, int64_t y_ss, bool multi);
-hipError_t rdyn_launch_image_sweep(int n_joints, unsigned fix_mask, const RdynSweepArgs& a, hipStream_t st, bool mapped = false);
+hipError_t rdyn_launch_image_sweep(int n_joints, unsigned fix_mask, const RdynSweepArgs& a, hipStream_t st, int mapped = 0);  // mapped: 1 = run-time row map, 2 = + expansion to a longer chain
+bool rdyn_image_expand_supported(int n_red, int n_full, int64_t y_ss);
 bool rdyn_image_map_supported(int n_joints, unsigned fix_mask, int64_t y_ss);  // per-sample images through a run-time row map (any input order, fixed joints anywhere)
 hipError_t rdyn_launch_image_sweep_multi(int n_joints, unsigned fix_mask, bool stacked, const RdynSweepArgs* table, int n_items, int64_t max_samples,
                                          hipStream_t st);  // 2..8 input joints

@@ -24,7 +24,8 @@ skip.setInputJointsName([pn[i] for i in (0, 1, 2, 4, 5, 6)])   # a moving joint 
 p7 = Chain(os.path.join(ROOT, "tests/fixtures/panda_like.urdf"), "link0", "link7", (0, 0, -9.806))
 p7.setInputJointsName(list(reversed(pn)))
 q7, dq7, ddq7 = (torch.rand((N, 7), dtype=torch.float64, device="cuda") * 2 - 1 for _ in range(3))
-for name, c, args in (("6 joints, chain order", chain, (qs, dqs, ddqs)), ("6 joints, permuted", perm, (qs, dqs, ddqs)),
+longc = Chain(os.path.join(ROOT, "tests/fixtures/ur10_public_long.urdf"), "base_link", "tcp", (0, 0, -9.806))   # 14 joints, 6 inputs: expanded images
+for name, c, args in (("14 joints, 6 inputs (P = 140): expanded images", longc, (qs, dqs, ddqs)), ("6 joints, chain order", chain, (qs, dqs, ddqs)), ("6 joints, permuted", perm, (qs, dqs, ddqs)),
                       ("8 joints, fixed head + fixed middle (P = 80)", midc, (qs, dqs, ddqs)),
                       ("7 joints, one left out mid-chain (6 x 70)", skip, (qs, dqs, ddqs)),
                       ("7 joints, reversed", p7, (q7, dq7, ddq7))):
