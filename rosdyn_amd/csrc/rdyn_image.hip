@@ -54,7 +54,7 @@ bool rdyn_image_expand_supported(int n_red, int n_full, int64_t y_ss)
 
 bool rdyn_image_map_supported(int n_joints, unsigned fix_mask, int64_t y_ss)
 {
-  if (n_joints < 2 || n_joints > RDYN_MAX_SWEPT_JOINTS || (fix_mask >> n_joints)) return false;
+  if (n_joints < 2 || n_joints > RDYN_IMAGE_MAP_MAX_NJ || (fix_mask >> n_joints)) return false;
   const int nfx = popcount_u(fix_mask), na = n_joints - nfx;
   if (na < 2 || na > RDYN_IMAGE_MAP_MAX_NA || nfx > RDYN_IMAGE_MAP_MAX_FIXED) return false;
   return y_ss >= (int64_t)na * 10 * n_joints && (y_ss * 8) % 16 == 0 && 64 * y_ss * 8 < (int64_t)0xFFFFFFFFll;

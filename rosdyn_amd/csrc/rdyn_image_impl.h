@@ -192,9 +192,9 @@ hipError_t image_launch_na(int n_joints, unsigned fix, bool stacked, const RdynS
     {
       if (stacked || fix != 0u) return hipErrorInvalidValue;
       if (n_joints == NA) return launch_image<NA, 0u, false, 0>(*a, st);
-      if constexpr (NA + 1 <= RDYN_MAX_SWEPT_JOINTS)
+      if constexpr (NA + 1 <= RDYN_IMAGE_MAP_MAX_NJ)
         if (n_joints == NA + 1) return launch_image<NA + 1, 0u, false, 1>(*a, st);
-      if constexpr (NA + 2 <= RDYN_MAX_SWEPT_JOINTS)
+      if constexpr (NA + 2 <= RDYN_IMAGE_MAP_MAX_NJ)
         if (n_joints == NA + 2) return launch_image<NA + 2, 0u, false, 2>(*a, st);
       return hipErrorInvalidValue;
     }

@@ -15,9 +15,10 @@ constexpr unsigned rdyn_image_pattern_mask(int na, int h, int t)
   return ((1u << h) - 1u) | (((1u << t) - 1u) << (h + na));
 }
 
-// run-time row maps (k_image_sweep<.., MAP>): per-sample images of chains with up to MAX_NA input joints in any order and up to MAX_FIXED
-// joints that are not input joints anywhere in the chain
+// run-time row maps (k_image_sweep<.., MAP>): per-sample images of chains of up to MAX_NJ joints with up to MAX_NA input joints in any
+// order and up to MAX_FIXED joints that are not input joints anywhere in the chain
 #define RDYN_IMAGE_MAP_MAX_NA 8
 #define RDYN_IMAGE_MAP_MAX_FIXED 2
+#define RDYN_IMAGE_MAP_MAX_NJ 8  // chain joints (the row-mapped sweep carries one row per chain joint: 9+ joints cost minutes of build time each)
 
 #endif

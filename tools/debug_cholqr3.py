@@ -15,9 +15,14 @@ def layout(nJ, workspace_bytes=None):
     """offsets (doubles) of the preconditioned route's regions in the factor workspace: a copy of tsqr_layout() in rdyn_api.cpp for chains
     without component columns (the supported way to read the outcome is rdyn_tsqr_last_report); checked against the library's size"""
     n1 = 10 * nJ + 1; nb = (n1 + 15) // 16; nt = nb * (nb + 1) // 2
-    off = ((256 + 128 + 2) * n1 * n1 + 31) & ~31
+    regions = (("slabs", 256 * nt * 256), ("w", nt * 256), ("r1p", n1 * n1), ("g2", n1 * n1 + 1), ("r_swept", n1 * n1), ("v", n1 * n1), ("r_full", 0), ("flag", 96))
+    tail = sum((d + 31) & ~31 for _, d in regions)
+    # the regions sit behind the Householder folds' own workspace (whichever of the register / LDS-resident folds needs more: its size is
+    # the library's business): counted back from the end of the workspace the library asks for
+    off = ((256 + 128 + 2) * n1 * n1 + 31) & ~31 if workspace_bytes is None else workspace_bytes // 8 - tail
+    assert off >= 0 and off % 32 == 0, "tools/debug_cholqr3.py: layout() is out of step with rdyn_api.cpp"
     L = {}
-    for name, d in (("slabs", 256 * nt * 256), ("w", nt * 256), ("r1p", n1 * n1), ("g2", n1 * n1 + 1), ("r_swept", n1 * n1), ("v", n1 * n1), ("flag", 96)):
+    for name, d in regions:
         L[name] = off; off = (off + d + 31) & ~31
     assert workspace_bytes is None or workspace_bytes == off * 8, "tools/debug_cholqr3.py: layout() is out of step with rdyn_api.cpp"
     return L, n1
