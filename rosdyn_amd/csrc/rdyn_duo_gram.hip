@@ -204,11 +204,7 @@ __global__ __launch_bounds__(KIN ? 768 : 512) void k_regressor_gram_duo(const Rd
     // per column block: LDS offset of MY column (for row group 0) and the row groups [collo, colm) it stores
     int colbase[NB], colm[NB], collo[NB];
     const int K = XB > 0 ? fa.n_comp_cols : 0;  // component columns: in FRONT of the accumulation order (a constant 0 without them)
-#ifdef RDYN_DUO_X_KF  // timing experiment (valid for K == RDYN_DUO_X_KF only): the zero bands with component columns at compile time
-    const int KF = XB > 0 ? RDYN_DUO_X_KF : K;
-#else
     const int KF = K;
-#endif
 #pragma unroll
     for (int cb = 0; cb < NB; ++cb)
     {
