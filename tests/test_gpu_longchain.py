@@ -1,5 +1,7 @@
 """GPU parity on generated chains at the ends of the supported range (1, 2, 3, 9 and 10 chain joints): exercises every
 kernel instantiation boundary (NJ = 10 regressor spills to scratch, 7 Gram column blocks) against the CPU oracle."""
+import os
+
 import numpy as np
 import pytest
 
@@ -207,3 +209,39 @@ def test_r_factor_with_nine_and_ten_input_joints(nj, N, permute):
     s_ref, s_gpu = np.linalg.svd(np.linalg.qr(M2, mode="r"), compute_uv=False), np.linalg.svd(R3, compute_uv=False)
     keep = s_ref > 1e-9 * s_ref[0]
     assert np.abs(s_gpu[keep] / s_ref[keep] - 1.0).max() <= 1e-8
+
+
+@pytest.mark.parametrize("pick", [[0, 1, 3, 4, 6, 7], [7, 0, 4, 12, 1, 9], [3, 10], [13, 11, 9, 6, 1]])
+def test_long_chain_per_sample_images_expanded_in_the_image_kernel(pick):
+    """k_image_sweep<.., EXPAND> (companions of 2..6 joints): a generated 20-joint chain (fixed, prismatic and revolute joints, links
+    without inertial data), a subset of its moving joints as input joints in chain order and out of it, ragged batch -- the per-sample
+    image and the fused torque against the oracle; the same numbers as the element-major layout, bit for bit."""
+    torch = pytest.importorskip("torch")
+    import tempfile
+    from oracle.oracle import OracleChain
+    from rosdyn_amd import Chain
+    from test_gpu_longkin import generated_long_chain
+    xml = generated_long_chain(20, 2020)
+    with tempfile.NamedTemporaryFile("w", suffix=".urdf", delete=False) as f:
+        f.write(xml)
+        path = f.name
+    try:
+        chain = Chain(path, "l0", "l20", GRAV)
+        moving = chain.getActiveJointsName()
+        sel = [moving[i] for i in pick]
+        assert chain.setInputJointsName(sel)
+        ref = OracleChain(path, "l0", "l20", GRAV, input_joint_names=sel)
+    finally:
+        os.unlink(path)
+    n, P, N = ref.n, ref.P, 1000 + 37
+    assert n == len(pick) and P == 200
+    rng = np.random.default_rng(len(pick))
+    q, dq, ddq = (rng.uniform(-1, 1, (N, n)) for _ in range(3))
+    t = [torch.from_numpy(x).cuda() for x in (q, dq, ddq)]
+    Y, tau = chain.getRegressor(*t, with_torque=True)
+    Yr, tr = ref.regressor(q, dq, ddq), ref.joint_torque(q, dq, ddq)
+    Yi = Y.cpu().numpy().reshape(N, P, n).transpose(0, 2, 1)
+    assert np.abs(Yi - Yr).max() <= 1e-11 * max(1.0, np.abs(Yr).max())
+    assert np.abs(tau.cpu().numpy() - tr).max() <= 1e-11 * max(1.0, np.abs(tr).max())
+    Ye = chain.getRegressor(*(x.t().contiguous() for x in t), layout="element")
+    assert np.array_equal(Ye.cpu().numpy().transpose(2, 1, 0), Yi)
