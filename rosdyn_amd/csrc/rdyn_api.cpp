@@ -1359,7 +1359,7 @@ static const int64_t kTsqrImageChunk = 16384;      // samples per chunk image of
 struct TsqrLayout
 {
   size_t householder_doubles = 0;
-  size_t slabs = 0, w = 0, v = 0, r1p = 0, g2 = 0, r_swept = 0, r_full = 0, flag = 0, total_doubles = 0;
+  size_t slabs = 0, w = 0, v = 0, r1p = 0, g2 = 0, r_swept = 0, r_full = 0, flag = 0, wide = 0, wide_doubles = 0, total_doubles = 0;
 };
 // n1: width of the factor that is computed (padded width where the kernels pad); nb: 16-column blocks of the preconditioned route's
 // column space (0: that route does not serve the shape); n1_full: width of the expanded factor (0: nothing is expanded)
@@ -1381,9 +1381,11 @@ static TsqrLayout tsqr_layout(size_t householder_doubles, int n1, int nb, int n1
   L.r_swept = take((size_t)n1 * n1);
   L.v = take((size_t)n1 * n1);
   L.r_full = take((size_t)n1_full * n1_full);  // the expanded factor of a call that accumulates (folded into the caller's afterwards)
-  L.flag = take(96);  // ints: [0] run round 1, [1] run the stand-by (Householder) call, [2] run round 0, [16 .. 111] the deferred columns;
-                      // doubles [56 .. 61]: gamma (preconditioner), rho, gamma (factor kernel) of the two rounds (diagnostics) -- behind
-                      // the 96 column flags (until round 4 they sat at [50 .. 55], on top of the flags of columns 84 .. 95)
+  L.flag = take(96);  // ints: [0] run round 1, [1] run the stand-by (Householder) call, [2] run round 0, [16 .. 127] the deferred columns;
+                      // doubles [64 .. 69]: gamma (preconditioner), rho, gamma (factor kernel) of the two rounds (diagnostics) -- behind
+                      // the 112 column flags (until round 5 at [56 .. 61], on top of the flags of columns 96 .. 107)
+  L.wide_doubles = (nb > 0 && n1 > rdyn_cholqr_max_cols_lds()) ? (size_t)2 * n1 * n1 : 0;
+  L.wide = take(L.wide_doubles);  // the dense kernels' two n1 x n1 squares where they do not fit the LDS (97 .. 112 columns)
   L.total_doubles = off;
   return L;
 }
@@ -1406,6 +1408,7 @@ static int cholqr_rounds(double* ws, const TsqrLayout& L, int n1, int col_shift,
   ga.col_shift = col_shift;
   ga.slab_nb = slab_nb;
   const int n_rounds = probe_env("RDYN_CHOLQR_ROUNDS") ? atoi(probe_env("RDYN_CHOLQR_ROUNDS")) : 2;  // A/B builds only
+  double* const wide_sq = L.wide_doubles ? ws + L.wide : nullptr;  // factors beyond 96 columns: the dense kernels' two squares
   for (int round = 0; round < n_rounds; ++round)
   {
     // round 0: W from the subsample's Gram matrix.  Round 1 (CholeskyQR2 on top): W from round 0's factor; its kernels leave at once
@@ -1413,16 +1416,16 @@ static int cholqr_rounds(double* ws, const TsqrLayout& L, int n1, int col_shift,
     const int* const run = round == 0 ? flag + 2 : flag;
     if (round == 0)
       RDYN_HIP_TRY(rdyn_launch_cholqr_precond(nullptr, ga.G, ga.c, ga.bb, n1, col_shift, nb, row_scale, ws + L.r1p, ws + L.w, ws + L.v, flag + 16, flag, 0,
-                                              nullptr, ws + L.flag + 56, stream));
+                                              nullptr, ws + L.flag + 64, stream, wide_sq));
     else
       RDYN_HIP_TRY(rdyn_launch_cholqr_precond(R_out, nullptr, nullptr, nullptr, n1, col_shift, nb, 1.0, ws + L.r1p, ws + L.w, ws + L.v, flag + 16, flag, 1,
-                                              flag, ws + L.flag + 57, stream));
+                                              flag, ws + L.flag + 65, stream, wide_sq));
     int st = run_pass_b(ws + L.w, run, ws + L.slabs);
     if (st != RDYN_OK) return st;
     ga.run_flag = run;
     RDYN_HIP_TRY(rdyn_launch_gram_finish(ga, blocks, stream));
-    RDYN_HIP_TRY(rdyn_launch_cholqr_factor(ga.G, ga.c, ga.bb, n1, has_b, ws + L.r1p, ws + L.v, flag + 16, R_out, flag, round, run, ws + L.flag + 58 + round,
-                                           stream));
+    RDYN_HIP_TRY(rdyn_launch_cholqr_factor(ga.G, ga.c, ga.bb, n1, has_b, ws + L.r1p, ws + L.v, flag + 16, R_out, flag, round, run, ws + L.flag + 66 + round,
+                                           stream, wide_sq));
   }
   return RDYN_OK;
 }
@@ -1437,13 +1440,13 @@ static void read_report(const double* raw, int n1, rdyn_tsqr_report* out)
   for (int k = 0; k < n1 && 16 + k < 128; ++k) out->n_deferred += flags[16 + k] ? 1 : 0;
   if (round0)
   {
-    out->gamma[0] = raw[60];
-    out->rho[0] = raw[58];
+    out->gamma[0] = raw[68];
+    out->rho[0] = raw[66];
   }
   if (round1)
   {
-    out->gamma[1] = raw[61];
-    out->rho[1] = raw[59];
+    out->gamma[1] = raw[69];
+    out->rho[1] = raw[67];
   }
 }
 
@@ -1691,7 +1694,7 @@ static bool tsqr_plan(const rdyn_chain* c, const rdyn_component* comps, int n_co
   // preconditioned route: every joint of the swept chain an input joint, the factor within the dense kernels' LDS, the component
   // columns within the one extra column block, and a subsample kernel for the shape
   p->nb = (10 * p->nJ + 1 + 15) / 16 + p->xb;
-  if (p->n == p->nJ && p->nJ >= 2 && p->nJ <= 7 && p->n1s <= rdyn_cholqr_max_cols() && p->n1s <= 16 * p->nb &&
+  if (p->n == p->nJ && p->nJ >= 2 && p->nJ <= 7 && p->n1s <= rdyn_cholqr_max_cols_lds() && p->n1s <= 16 * p->nb &&
       (K == 0 || rdyn_regressor_gram_duo_supports_components(10 * p->nJ, K)) && build_lds_tile(cs, K, false, &p->la))
   {
     p->pairs = rdyn_cholqr_pairs(p->nJ, p->la.tile_bytes, p->xb);

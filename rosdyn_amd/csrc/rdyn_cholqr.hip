@@ -415,14 +415,17 @@ __global__ __launch_bounds__(256) void k_pgram_rows(const double* __restrict__ A
   while (r0 < rows)
   {
     const int64_t rn = r0 + gstride;
-    if (rn < rows) load(rn, nxt);
+    // seven column blocks: 28 accumulator tiles + this group's operands + the products + the ring leave no room for the next group's
+    // operands (268 B of scratch in the loop, 3x the time per row): they are requested behind stage 1, under the 112 MFMAs of stage 2
+    constexpr bool LATE = NB >= 7;
+    if (!LATE && rn < rows) load(rn, nxt);
     d4 D[NB];
 #pragma unroll
     for (int cb = 0; cb < NB; ++cb) D[cb] = (d4){0.0, 0.0, 0.0, 0.0};
     {
       // rows (cb1, kk) of W from LDS, two rows ahead of their MFMAs and no further (compiler barrier): left alone the scheduler hoists
       // every operand of the group and spills the accumulators at six column blocks
-      constexpr int AH = 2;
+      constexpr int AH = LATE ? 1 : 2;
       double ring[AH + 1][NB];
       auto load_row = [&](int r, double (&dst)[NB]) {
         const int c1 = r >> 2, k4 = r & 3;
@@ -448,6 +451,11 @@ __global__ __launch_bounds__(256) void k_pgram_rows(const double* __restrict__ A
           for (int cb2 = cb1; cb2 < NB; ++cb2) D[cb2] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, ring[r % (AH + 1)][cb2], D[cb2], 0, 0, 0);
         }
     }
+    if (LATE)
+    {
+      asm volatile("" ::: "memory");
+      if (rn < rows) load(rn, nxt);
+    }
 #pragma unroll
     for (int t = 0; t < 4; ++t)
     {
@@ -470,7 +478,8 @@ __global__ __launch_bounds__(256) void k_pgram_rows(const double* __restrict__ A
 }
 
 // ---------------------------------------------------------------- the small dense steps (one workgroup each, n1 <= 81)
-constexpr int kMaxN1 = 96;  // 2 n1^2 doubles of LDS per dense kernel: 147 KB
+constexpr int kMaxN1 = 112;    // widest factor of the dense kernels
+constexpr int kMaxN1Lds = 96;  // ... with their two n1 x n1 squares in LDS (147 KB); wider: the squares live in the workspace (WIDE)
 constexpr int kMaxFoldN1 = 136;  // k_cholqr_fold: two packed triangles in LDS (136 * 137 * 8 = 149 KB)
 #ifndef RDYN_CHOLQR_DENSE_THREADS
 #define RDYN_CHOLQR_DENSE_THREADS 1024
@@ -597,7 +606,7 @@ struct PivotAct
   int elim;
   double diag;
 };
-template <class Decide, class Diag, class Idle>
+template <int MAXNB = 6, class Decide, class Diag, class Idle>
 __device__ __forceinline__ void chol_with_inverse_lds(double* M, double* E, int n, int tid, double* fdiag, double* xdiag, Decide decide, Diag diagf, Idle idle_work)
 {
   const int tx = tid & 31, ty = tid >> 5;
@@ -659,7 +668,7 @@ __device__ __forceinline__ void chol_with_inverse_lds(double* M, double* E, int 
 // not (uniform; its side effects are thread 0's), diagf(k, d, elim) -> the diagonal of row k of the factor (pure); idle_work(): run by
 // the waves that only keep the barrier count (threads 384 ..) before they do -- their barriers carry no fence, so global loads issued
 // there stay in flight through the whole factorisation.
-constexpr int kCholRS = 96;  // row buffer: rM | rE | d
+constexpr int kCholRS = 112;  // row buffer: rM | rE | d
 template <int NB, class Decide>
 __device__ __forceinline__ void chol_compute_waves(const double* M, const double* E, int n, int tid, double* fdiag, double* xdiag, double (*s_row)[2 * kCholRS + 2],
                                                    Decide decide)
@@ -752,18 +761,22 @@ __device__ __forceinline__ void chol_compute_waves(const double* M, const double
   if constexpr (NB > 3) block_row(std::integral_constant<int, 3>());
   if constexpr (NB > 4) block_row(std::integral_constant<int, 4>());
   if constexpr (NB > 5) block_row(std::integral_constant<int, 5>());
+  if constexpr (NB > 6) block_row(std::integral_constant<int, 6>());
 }
-template <class Decide, class Diag, class Idle>
+// MAXNB: the widest instantiation compiled in (6: n <= 96; 7: n <= 112 -- 98 working values per thread beside the row buffers: the kernels of
+// 1 024 threads spill some of them, the WIDE kernels only).
+template <int MAXNB = 6, class Decide, class Diag, class Idle>
 __device__ __forceinline__ void chol_with_inverse_regs(double* M, double* E, int n, int tid, double* fdiag, double* xdiag, Decide decide, Diag diagf, Idle idle_work)
 {
-  static_assert(NTD >= 384 && NTD % 128 == 0 && kMaxN1 <= 96, "four computing waves, two parking waves; six 16-wide blocks per side");
+  static_assert(NTD >= 384 && NTD % 128 == 0 && kMaxN1Lds <= 96 && kMaxN1 <= 112 && MAXNB >= 6 && MAXNB <= 7, "four computing waves, two parking waves; six (seven) 16-wide blocks per side");
   constexpr int RS = kCholRS;
   __shared__ double s_row[2][2 * RS + 2], s_scm[kMaxN1], s_sce[kMaxN1];
   if (tid < 256)
   {
     if (n <= 64) chol_compute_waves<4>(M, E, n, tid, fdiag, xdiag, s_row, decide);
     else if (n <= 80) chol_compute_waves<5>(M, E, n, tid, fdiag, xdiag, s_row, decide);
-    else chol_compute_waves<6>(M, E, n, tid, fdiag, xdiag, s_row, decide);
+    else if (n <= 96 || MAXNB < 7) chol_compute_waves<6>(M, E, n, tid, fdiag, xdiag, s_row, decide);
+    else if constexpr (MAXNB >= 7) chol_compute_waves<7>(M, E, n, tid, fdiag, xdiag, s_row, decide);
   }
   else if (tid < 384)
   {
@@ -829,16 +842,20 @@ __device__ __forceinline__ void chol_with_inverse_regs(double* M, double* E, int
 // flags: [0] run round 1, [1] run the stand-by, [2] run round 0 (written here in round 0).  zmask <- Z (for the factor kernel).
 // W is written in the MFMA operand order of k_regressor_pgram.
 constexpr double kCholqrGammaMax = 1e4;
+// WIDE (97 .. 112 columns): the two squares do not fit the LDS -- they live in `wide_sq` (2 n1^2 doubles of the workspace: L1 / L2
+// resident; one workgroup, so its barriers order the accesses).  The factorisation itself works in registers as before (the squares are
+// only where it starts from and where it parks its rows); the element-wise passes around it run at global-memory latency.
+template <bool WIDE>
 __global__ __launch_bounds__(NTD) void k_cholqr_precond(const double* __restrict__ R1, const double* __restrict__ Gs, const double* __restrict__ cs,
                                                         const double* __restrict__ bbs, int n1, int col_shift, int nb_w, double row_scale,
                                                         double* __restrict__ Tout, double* __restrict__ W, double* __restrict__ Vout, int* __restrict__ zmask,
                                                         int* __restrict__ flags, int round, const int* __restrict__ run_flag,
-                                                        double* __restrict__ gamma_out)
+                                                        double* __restrict__ gamma_out, double* __restrict__ wide_sq)
 {
   if (run_flag && *run_flag == 0) return;
   extern __shared__ __attribute__((aligned(16))) double sh[];
-  double* const A0 = sh;                // [n1][n1] column-major: R1, then T
-  double* const B = sh + n1 * n1;       // [nc][n1]: the kept columns (or the Gram matrix being factorised), then V = T^-1
+  double* const A0 = WIDE ? wide_sq : sh;  // [n1][n1] column-major: R1, then T
+  double* const B = A0 + n1 * n1;          // [nc][n1]: the kept columns (or the Gram matrix being factorised), then V = T^-1
   __shared__ double s_part[kMaxN1], s_norm[kMaxN1], s_lift[kMaxN1], s_g[kMaxN1];
   __shared__ int s_z[kMaxN1], s_cmap[kMaxN1], s_rend[kMaxN1], s_nc;
   const int tid = threadIdx.x;
@@ -872,7 +889,11 @@ __global__ __launch_bounds__(NTD) void k_cholqr_precond(const double* __restrict
     }
     __syncthreads();
     STAMP_P(1);
-    RDYN_CHOL_WITH_INVERSE(B, A0, n1, tid, s_part, s_g, [&](int k, double d) {
+    auto chol = [&](auto... args) {
+      if constexpr (WIDE) RDYN_CHOL_WITH_INVERSE<7>(args...);
+      else RDYN_CHOL_WITH_INVERSE<6>(args...);
+    };
+    chol(B, A0, n1, tid, s_part, s_g, [&](int k, double d) {
       // the squared sine of the angle to the columns on the left: a Gram matrix resolves it down to ~1e-14; below 1e-10 (sine 1e-5, the
       // own-norm rule of the other branch) or below the residue floor the column is deferred.  The last column eliminates nothing.
       const double g0 = s_norm[k] * s_norm[k];  // d / g0 = the squared sine
@@ -1029,16 +1050,17 @@ __global__ __launch_bounds__(NTD) void k_cholqr_precond(const double* __restrict
 //   Re of the equilibrated Gram of the k pivoted columns (1 for orthogonal columns; |Re^-1|_2 <= rho sqrt(k)); rho > 4, or a kept
 //   column that turns out dependent on its left neighbours, and the round is not accepted: flags[round] = 1 (flags[0] starts round 1,
 //   flags[1] starts the stand-by Householder factorisation).  Round 0 also clears flags[1].
+template <bool WIDE>
 __global__ __launch_bounds__(NTD) void k_cholqr_factor(const double* __restrict__ G, const double* __restrict__ cvec, const double* __restrict__ bb, int n1,
                                                        int has_b, const double* __restrict__ T_in, const double* __restrict__ V, const int* __restrict__ zmask,
                                                        double* __restrict__ Rout, int* __restrict__ flags, int round, const int* __restrict__ run_flag,
-                                                       double* __restrict__ rho_out)
+                                                       double* __restrict__ rho_out, double* __restrict__ wide_sq)
 {
   if (run_flag && *run_flag == 0) return;
   extern __shared__ __attribute__((aligned(16))) double sh[];
-  double* const M = sh;             // [n1][n1] column-major, upper triangle = the running Cholesky factor
+  double* const M = WIDE ? wide_sq : sh;  // [n1][n1] column-major, upper triangle = the running Cholesky factor
   STAMP(0);
-  double* const T = sh + n1 * n1;   // the identity that becomes the inverse of the Cholesky factor, then T
+  double* const T = M + n1 * n1;          // the identity that becomes the inverse of the Cholesky factor, then T
   __shared__ double s_g0[kMaxN1], s_sc[kMaxN1], s_xd[kMaxN1], s_part[kMaxN1], s_gam[kMaxN1], s_wave[NTD / 64];
   __shared__ int s_flag, s_z[kMaxN1], s_skip[kMaxN1];
   const int tid = threadIdx.x, P = n1 - 1;
@@ -1059,11 +1081,16 @@ __global__ __launch_bounds__(NTD) void k_cholqr_factor(const double* __restrict_
   // T (global, written by the preconditioner kernel) is needed after the factorisation: the waves that only keep the barrier count
   // during it fetch their share then and hold it in registers (loaded afterwards, the dependent misses cost 8 us)
   static_assert(NTD > 384, "the waves behind the four computing and two parking ones prefetch T");
-  constexpr int kTPre = (kMaxN1 * kMaxN1 + (NTD - 384) - 1) / (NTD - 384);
+  constexpr int kWidth = WIDE ? kMaxN1 : kMaxN1Lds;
+  constexpr int kTPre = (kWidth * kWidth + (NTD - 384) - 1) / (NTD - 384);
   double tpre[kTPre];
   __syncthreads();
   STAMP(1);
-  RDYN_CHOL_WITH_INVERSE(M, T, n1, tid, s_sc, s_xd, [&](int k, double d) {
+  auto chol = [&](auto... args) {
+    if constexpr (WIDE) RDYN_CHOL_WITH_INVERSE<7>(args...);
+    else RDYN_CHOL_WITH_INVERSE<6>(args...);
+  };
+  chol(M, T, n1, tid, s_sc, s_xd, [&](int k, double d) {
     // d / g0 = the squared sine of the angle between Q(:, k) and the columns to its left; "resolved": >= 1e-12
     const bool resolved = d >= 1e-12 * s_g0[k] && s_g0[k] > 0.0;
     const bool large = d >= 0.01;  // the pivot sqrt(d) against the 1/10 mark (in units of the lift for a deferred column)
@@ -1168,7 +1195,7 @@ __global__ __launch_bounds__(NTD) void k_cholqr_factor(const double* __restrict_
     {
       double sum = 0.0;
 #pragma unroll
-      for (int m = 0; m < kMaxN1 / 16; ++m)
+      for (int m = 0; m < kWidth / 16; ++m)
       {
         const int i = (tid & 15) + 16 * m;
         sum += term(i <= j ? i : j, j, i <= j);
@@ -1469,6 +1496,7 @@ hipError_t rdyn_launch_pgram_rows(const double* A, const double* b, int64_t rows
   case 4: return launch_pgram_rows<4>(A, b, rows, lda, n_cols, W, slabs, run_flag, blocks, st);
   case 5: return launch_pgram_rows<5>(A, b, rows, lda, n_cols, W, slabs, run_flag, blocks, st);
   case 6: return launch_pgram_rows<6>(A, b, rows, lda, n_cols, W, slabs, run_flag, blocks, st);
+  case 7: return launch_pgram_rows<7>(A, b, rows, lda, n_cols, W, slabs, run_flag, blocks, st);
   default: return hipErrorInvalidValue;
   }
 }
@@ -1487,29 +1515,42 @@ hipError_t rdyn_launch_regressor_pgram(int n_joints, const RdynLdsGramArgs& a, c
   }
 }
 
-int rdyn_cholqr_max_cols() { return kMaxN1; }
+int rdyn_cholqr_max_cols() { return kMaxN1; }          // rdyn_tsqr on a materialised matrix (the squares of the dense steps in the workspace beyond 96)
+int rdyn_cholqr_max_cols_lds() { return kMaxN1Lds; }  // the fused regressor routes (pass B holds six column blocks)
 
 hipError_t rdyn_launch_cholqr_precond(const double* R1, const double* Gs, const double* cs, const double* bbs, int n1, int col_shift, int nb_w,
                                       double row_scale, double* T, double* W, double* V, int* zmask, int* flags, int round, const int* run_flag,
-                                      double* gamma_out, hipStream_t st)
+                                      double* gamma_out, hipStream_t st, double* wide_sq)
 {
   if (n1 < 1 || n1 > kMaxN1 || 16 * nb_w < n1 + col_shift) return hipErrorInvalidValue;
+  if (n1 > kMaxN1Lds)
+  {
+    if (!wide_sq) return hipErrorInvalidValue;  // (2 n1^2 doubles of the caller's workspace)
+    hipLaunchKernelGGL(k_cholqr_precond<true>, dim3(1), dim3(NTD), 0, st, R1, Gs, cs, bbs, n1, col_shift, nb_w, row_scale, T, W, V, zmask, flags, round, run_flag, gamma_out, wide_sq);
+    return hipGetLastError();
+  }
   static std::atomic<uint64_t> attr{0};
-  hipError_t e = opt_in_lds_once(k_cholqr_precond, attr, 146 * 1024);
+  hipError_t e = opt_in_lds_once(k_cholqr_precond<false>, attr, 146 * 1024);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(k_cholqr_precond, dim3(1), dim3(NTD), ((size_t)2 * n1 * n1 + n1) * sizeof(double), st, R1, Gs, cs, bbs, n1, col_shift, nb_w, row_scale, T, W, V, zmask, flags, round, run_flag,
-                     gamma_out);
+  hipLaunchKernelGGL(k_cholqr_precond<false>, dim3(1), dim3(NTD), ((size_t)2 * n1 * n1 + n1) * sizeof(double), st, R1, Gs, cs, bbs, n1, col_shift, nb_w, row_scale, T, W, V, zmask, flags, round, run_flag,
+                     gamma_out, nullptr);
   return hipGetLastError();
 }
 
 hipError_t rdyn_launch_cholqr_factor(const double* G, const double* c, const double* bb, int n1, int has_b, const double* T, const double* V, const int* zmask,
-                                     double* R, int* flags, int round, const int* run_flag, double* rho_out, hipStream_t st)
+                                     double* R, int* flags, int round, const int* run_flag, double* rho_out, hipStream_t st, double* wide_sq)
 {
   if (n1 < 2 || n1 > kMaxN1 || round < 0 || round > 1) return hipErrorInvalidValue;
+  if (n1 > kMaxN1Lds)
+  {
+    if (!wide_sq) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_cholqr_factor<true>, dim3(1), dim3(NTD), 0, st, G, c, bb, n1, has_b, T, V, zmask, R, flags, round, run_flag, rho_out, wide_sq);
+    return hipGetLastError();
+  }
   static std::atomic<uint64_t> attr{0};
-  hipError_t e = opt_in_lds_once(k_cholqr_factor, attr, 146 * 1024);
+  hipError_t e = opt_in_lds_once(k_cholqr_factor<false>, attr, 146 * 1024);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(k_cholqr_factor, dim3(1), dim3(NTD), (size_t)2 * n1 * n1 * sizeof(double), st, G, c, bb, n1, has_b, T, V, zmask, R, flags, round, run_flag, rho_out);
+  hipLaunchKernelGGL(k_cholqr_factor<false>, dim3(1), dim3(NTD), (size_t)2 * n1 * n1 * sizeof(double), st, G, c, bb, n1, has_b, T, V, zmask, R, flags, round, run_flag, rho_out, nullptr);
   return hipGetLastError();
 }
 

@@ -262,8 +262,9 @@ hipError_t rdyn_launch_pgram_rows(const double* A, const double* b, int64_t rows
 // nb_w: 16-column blocks of the consumer's column space (W is written, zero-padded, for all nb_w (nb_w + 1) / 2 operand blocks)
 hipError_t rdyn_launch_cholqr_precond(const double* R1, const double* Gs, const double* cs, const double* bbs, int n1, int col_shift, int nb_w,
                                       double row_scale, double* T, double* W, double* V, int* zmask, int* flags, int round, const int* run_flag,
-                                      double* gamma_out, hipStream_t st);
-int rdyn_cholqr_max_cols();  // widest factor (right-hand side included) the dense steps of the preconditioned route hold in LDS
+                                      double* gamma_out, hipStream_t st, double* wide_sq = nullptr);  // wide_sq: 2 n1^2 doubles of workspace for n1 > rdyn_cholqr_max_cols_lds()
+int rdyn_cholqr_max_cols();      // widest factor (right-hand side included) of the dense steps of the preconditioned route (112)
+int rdyn_cholqr_max_cols_lds();  // ... with their two squares in LDS (96): what the fused regressor routes take
 int rdyn_cholqr_col_shift(int n_joints, int xb);
 hipError_t rdyn_launch_regressor_pgram_solo(const RdynLdsGramArgs& a, const double* W, const int* run_flag, int blocks, int pairs, hipStream_t st);  // rdyn_pgram_solo.hip
 int rdyn_cholqr_solo_col_shift(int n_joints, int n_comp_cols);  // pairs == -1 at 7 joints + components (k_regressor_pgram_solo: compact tile, every wave sweeps and consumes)
@@ -271,7 +272,7 @@ int rdyn_cholqr_solo_col_shift(int n_joints, int n_comp_cols);  // pairs == -1 a
 // round is not accepted (rho_out, may be null: [0] the conditioning measure of the equilibrated Q, [2] gamma on the norms of all rows);
 // round 0 clears flags[1]
 hipError_t rdyn_launch_cholqr_factor(const double* G, const double* c, const double* bb, int n1, int has_b, const double* T, const double* V, const int* zmask,
-                                     double* R, int* flags, int round, const int* run_flag, double* rho_out, hipStream_t st);
+                                     double* R, int* flags, int round, const int* run_flag, double* rho_out, hipStream_t st, double* wide_sq = nullptr);
 // factor of the reduced chain -> factor of the chain: R = qr(R_red diag(E, I_K, 1)) (a.X, a.red_of, a.n_joints, a.n_red, a.n_comp_cols used)
 hipError_t rdyn_launch_cholqr_expand(const RdynGramExpandArgs& a, const double* R_red, double* R, hipStream_t st);
 size_t rdyn_cholqr_expand_lds_bytes(int n_joints, int n_red, int n_comp_cols);  // dynamic LDS of that launch (limit: 156 KB)

@@ -235,9 +235,11 @@ def test_wide_matrix_householder_matches_numpy_qr(rows, n, with_b):
     assert np.allclose(np.tril(R2, -1), 0.0) and np.abs(R2.T @ R2 - 2 * G).max() <= 1e-12 * np.abs(G).max()
 
 
-@pytest.mark.parametrize("rows,n,with_b", [(40000, 30, True), (33000, 64, False), (70000, 90, True), (100000, 95, True), (50000, 16, False)])
+@pytest.mark.parametrize("rows,n,with_b", [(40000, 30, True), (33000, 64, False), (70000, 90, True), (100000, 95, True), (50000, 16, False),
+                                           (60000, 96, True), (70000, 104, True), (90000, 111, True), (40000, 112, False), (50000, 100, False)])
 def test_matrix_tsqr_on_the_matrix_cores(rows, n, with_b):
-    """rdyn_tsqr from 32 768 rows on, factors of <= 96 columns: the preconditioned CholeskyQR route fed from memory (k_pgram_rows).
+    """rdyn_tsqr from 32 768 rows on, factors of <= 112 columns: the preconditioned CholeskyQR route fed from memory (k_pgram_rows; the
+    dense steps keep their two squares in LDS up to 96 columns, in the workspace beyond).
     Columns spread over six orders of magnitude, two exactly dependent columns: the factor reproduces the Gram matrix and numpy's
     singular values; the device's acceptance is read back."""
     torch = pytest.importorskip("torch")
@@ -292,7 +294,8 @@ def test_wide_factor_defers_nothing_on_a_well_conditioned_matrix():
 
 
 def test_matrix_tsqr_beyond_the_dense_kernels_width():
-    """97..112 columns with many rows: the dense steps of the preconditioned route do not hold the factor; the LDS-resident folds do."""
+    """97..112 columns with many rows: the dense steps of the preconditioned route keep their squares in the workspace (round 5: until
+    then the LDS-resident folds took these shapes) -- route 1, accepted in round 0 on a well-conditioned matrix, nothing deferred."""
     torch = pytest.importorskip("torch")
     from rosdyn_amd._lib import lib
     from rosdyn_amd.gram import tsqr, tsqr_last_report
@@ -302,10 +305,53 @@ def test_matrix_tsqr_beyond_the_dense_kernels_width():
     b = rng.normal(size=rows)
     ws = torch.empty((lib().rdyn_tsqr_workspace_bytes(n + 1),), dtype=torch.uint8, device="cuda")
     R1 = tsqr(torch.from_numpy(np.ascontiguousarray(A.T)).cuda(), torch.from_numpy(b).cuda(), workspace=ws).cpu().numpy()
-    assert tsqr_last_report(n + 1, rows, ws)["route"] == 0
+    rep = tsqr_last_report(n + 1, rows, ws)
+    assert rep["route"] == 1 and rep["stage"] == 0 and rep["n_deferred"] == 0, rep
+    assert 0.0 < rep["gamma"][0] < 100.0 and 0.0 < rep["rho"][0] <= 4.0, rep
     M = np.column_stack([A, b])
     G = M.T @ M
     assert np.allclose(np.tril(R1, -1), 0.0) and np.abs(R1.T @ R1 - G).max() <= 1e-12 * np.abs(G).max()
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_doctored_wide_matrices_on_the_matrix_cores(seed):
+    """97..112 columns, doctored: column scales over eight orders of magnitude, exactly dependent and null columns, a subsample (every
+    S-th 16-row group) that sees some columns at a vanishing scale -- whatever path the device takes (round 0, round 1, the stand-by),
+    R'R = M'M to 1e-14 of the columns' own scales and numpy's singular values."""
+    torch = pytest.importorskip("torch")
+    from rosdyn_amd._lib import lib
+    from rosdyn_amd.gram import tsqr, tsqr_last_report
+    rng = np.random.default_rng(1000 + seed)
+    n = int(rng.integers(97, 112))
+    rows = int(rng.integers(140000, 200000))
+    A = rng.normal(size=(rows, n)) * np.logspace(0, -8 * rng.random(), n)[rng.permutation(n)][None, :]
+    dep = rng.choice(n, size=4, replace=False)
+    A[:, dep[0]] = A[:, dep[1]] - 0.5 * A[:, dep[2]]
+    if seed % 2:
+        A[:, dep[3]] = 0.0
+    # the rows the subsample sees: every gs-th 16-row group (rdyn_api.cpp: 8 192 groups, odd stride)
+    groups = (rows + 15) // 16
+    gs = max(1, groups // 8192)
+    gs += 1 if (gs > 1 and gs % 2 == 0) else 0
+    sub = (np.arange(rows) // 16) % gs == 0
+    if seed >= 3:
+        cols = rng.choice(n, size=int(rng.integers(1, 6)), replace=False)
+        A[np.ix_(sub, cols)] *= 10.0 ** (-rng.integers(3, 12))
+    b = A @ rng.normal(size=n) + 1e-3 * rng.normal(size=rows)
+    ws = torch.empty((lib().rdyn_tsqr_workspace_bytes(n + 1),), dtype=torch.uint8, device="cuda")
+    R1 = tsqr(torch.from_numpy(np.ascontiguousarray(A.T)).cuda(), torch.from_numpy(b).cuda(), workspace=ws).cpu().numpy()
+    rep = tsqr_last_report(n + 1, rows, ws)
+    assert rep["route"] == 1, rep
+    M = np.column_stack([A, b])
+    G = M.T @ M
+    d = np.sqrt(np.diag(G))
+    d[d == 0] = 1.0
+    assert np.allclose(np.tril(R1, -1), 0.0)
+    assert np.abs((R1.T @ R1 - G) / np.outer(d, d)).max() <= 1e-14 * n, rep
+    s_ref = np.linalg.svd(np.linalg.qr(M / d, mode="r"), compute_uv=False)
+    s_gpu = np.linalg.svd(R1 / d, compute_uv=False)
+    keep = s_ref > 1e-9 * s_ref[0]
+    assert np.abs(s_gpu[keep] / s_ref[keep] - 1.0).max() <= 1e-9, rep
 
 
 def test_matrix_tsqr_solves_what_the_normal_equations_cannot_at_scale():

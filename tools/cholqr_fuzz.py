@@ -64,7 +64,7 @@ def main(n_cases=24, N=66000, seed0=0, only=None):
         e3 = (s[~keep].max() / s_ref[0]) if (~keep).any() else 0.0
         path_taken = "stand-by" if ints[1] else ("round 1" if ints[0] else ("round 0" if ints[2] else "stand-by (round 0 called off)"))
         worst = max(worst, e1, e2 * 1e-3)
-        dg = ws[L["flag"] + 56:L["flag"] + 62].cpu().numpy()
+        dg = ws[L["flag"] + 64:L["flag"] + 70].cpu().numpy()
         print(f"{case:3d} n={n} {what:55s} {path_taken:10s} R'R-G {e1:.1e}  sv {e2:.1e}  null {e3:.1e}   "
               f"gamma {dg[0]:.0e}/{dg[4]:.0e} rho {dg[2]:.3g} | gamma {dg[1]:.0e}/{dg[5]:.0e} rho {dg[3]:.3g}", flush=True)
     print("worst", worst)

@@ -15,7 +15,7 @@ def layout(nJ, workspace_bytes=None):
     """offsets (doubles) of the preconditioned route's regions in the factor workspace: a copy of tsqr_layout() in rdyn_api.cpp for chains
     without component columns (the supported way to read the outcome is rdyn_tsqr_last_report); checked against the library's size"""
     n1 = 10 * nJ + 1; nb = (n1 + 15) // 16; nt = nb * (nb + 1) // 2
-    regions = (("slabs", 256 * nt * 256), ("w", nt * 256), ("r1p", n1 * n1), ("g2", n1 * n1 + 1), ("r_swept", n1 * n1), ("v", n1 * n1), ("r_full", 0), ("flag", 96))
+    regions = (("slabs", 256 * nt * 256), ("w", nt * 256), ("r1p", n1 * n1), ("g2", n1 * n1 + 1), ("r_swept", n1 * n1), ("v", n1 * n1), ("r_full", 0), ("flag", 96), ("wide", 0))
     tail = sum((d + 31) & ~31 for _, d in regions)
     # the regions sit behind the Householder folds' own workspace (whichever of the register / LDS-resident folds needs more: its size is
     # the library's business): counted back from the end of the workspace the library asks for
@@ -55,7 +55,7 @@ def main():
         ev[1].record()
         torch.cuda.synchronize()
         ints = ws[L["flag"]:L["flag"] + 96].cpu().numpy().view(np.int32)
-        gam = ws[L["flag"] + 56:L["flag"] + 62].cpu().numpy()
+        gam = ws[L["flag"] + 64:L["flag"] + 70].cpu().numpy()
         R = R.cpu().numpy()
         G = M.T @ M
         s_ref = np.linalg.svd(np.linalg.qr(M, mode="r"), compute_uv=False)
