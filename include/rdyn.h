@@ -437,7 +437,7 @@ int rdyn_regressor_tsqr_multi(rdyn_multi_gpu* ctx, const rdyn_chain* chain, cons
  *   Householder folds on the vector units -- in the registers of one wave where the factor fits them (rdyn_tsqr.hip: <= 64 columns of a
  *     matrix; swept chains of 2..7 joints, 2..6 with component columns; ~5x the time of rdyn_regressor_gram), with the factor packed in
  *     LDS beyond (rdyn_tsqr_wide.hip: up to 112 columns; a 7-joint arm with friction columns; slower, a dependent chain per column);
- *   from 4 096 samples (32 768 rows of a matrix) on, factors of <= 96 columns: preconditioned CholeskyQR with the heavy pass on the
+ *   from 4 096 samples (32 768 rows of a matrix) on, factors of <= 96 columns (rdyn_tsqr on a matrix: <= 112): preconditioned CholeskyQR with the heavy pass on the
  *     fp64 matrix cores (rdyn_cholqr.hip: a triangular T from the Gram matrix of a row subsample, W = T^-1 with nearly dependent
  *     pivots deferred, G2 = (A W)'(A W) over all rows by MFMA, R = chol(G2) T; the device accepts the result only if the measured
  *     error growth of A W and the conditioning of the equilibrated A W are small, runs a second round from R otherwise, and falls

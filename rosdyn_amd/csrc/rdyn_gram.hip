@@ -30,7 +30,11 @@
 namespace
 {
 
-template <int NB>
+// BANDS: the rows come in blocks with a leading zero band (a.row_block > 0: the chunk images of a regressor) -- one straight-line MFMA
+// block per possible band behind a wave-uniform switch.  A plain matrix (rdyn_gram, the subsample of rdyn_tsqr) takes the instantiation
+// without the switch: where its branches meet the compiler copies accumulators (504 B of scratch and 152 us for the subsample pass at
+// seven column blocks).
+template <int NB, bool BANDS>
 __global__ __launch_bounds__(256) void k_gram(const RdynGramArgs a)
 {
   constexpr int NT = NB * (NB + 1) / 2;
@@ -61,7 +65,7 @@ __global__ __launch_bounds__(256) void k_gram(const RdynGramArgs a)
   int jb = 0;
   int64_t bound = a.row_block;  // rows < bound belong to row block jb
   auto cb_min_of = [&](int64_t r) -> int {
-    if (a.row_block <= 0) return 0;
+    if (!BANDS || a.row_block <= 0) return 0;
     while (r >= bound)
     {
       ++jb;
@@ -113,7 +117,7 @@ __global__ __launch_bounds__(256) void k_gram(const RdynGramArgs a)
       load(rn, cbm_n, nxt);  // prefetch the next 16-row group behind this group's MFMAs
     }
     // one straight-line MFMA block per possible zero band (wave-uniform switch, no per-tile branches)
-    switch (NB > 1 ? cbm : 0)
+    switch ((BANDS && NB > 1) ? cbm : 0)
     {
     case 0: mfma_group<NB, 0>(cur, acc); break;
     case 1: mfma_group<NB, 1>(cur, acc); break;
@@ -252,7 +256,10 @@ __global__ void k_set_double(double* p, double v) { *p = v; }
 template <int NB>
 hipError_t launch_gram_nb(const RdynGramArgs& a, int blocks, hipStream_t st)
 {
-  hipLaunchKernelGGL((k_gram<NB>), dim3(blocks), dim3(256), 0, st, a);
+  if (a.row_block > 0)
+    hipLaunchKernelGGL((k_gram<NB, true>), dim3(blocks), dim3(256), 0, st, a);
+  else
+    hipLaunchKernelGGL((k_gram<NB, false>), dim3(blocks), dim3(256), 0, st, a);
   return hipGetLastError();
 }
 
