@@ -426,7 +426,7 @@ int rdyn_regressor_tsqr_multi(rdyn_multi_gpu* ctx, const rdyn_chain* chain, cons
  * joints are folded away (the reduced chain of rdyn_chain_reduction is swept and the factor expanded by a small QR: up to
  * RDYN_MAX_JOINTS chain joints).  Up to 8 input joints the rows are generated in LDS by the regressor sweep and never stored (input
  * joints listed out of chain order: the kernels sweep in chain order and read q, Dq, DDq, tau_meas of every row through an index map
- * -- A'A, A'tau and R do not depend on the order of the rows inside a sample); 9..10 input joints: chunk images of 16 384 samples in
+ * -- A'A, A'tau and R do not depend on the order of the rows inside a sample); 9..10 input joints: chunk images of 65 536 samples in
  * the workspace (132 MB) factored by rdyn_tsqr's kernels.
  * rdyn_identification_tsqr: the same for the identification step's [Y | C | tau_meas] (C = the component columns of
  * rdyn_components_regressor -- friction_polynomial1.h:126, ideal_spring.h:64 -- K = rdyn_components_columns):

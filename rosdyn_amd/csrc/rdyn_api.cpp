@@ -1352,7 +1352,7 @@ static const int kCholqrBlocks = 256;
 // rows say little about what a preconditioner built on them is worth, and there is nothing to win.
 static const int64_t kCholqrMinTiles = 256;        // fused routes: 4 096 samples
 static const int64_t kCholqrMinGroups = 2048;      // rdyn_tsqr: 32 768 rows
-static const int64_t kTsqrImageChunk = 16384;      // samples per chunk image of the 9 .. 10-joint factor route (132 MB at 10 joints)
+static const int64_t kTsqrImageChunk = 65536;      // samples per chunk image of the 9 .. 10-joint factor route (0.53 GB at 10 joints; 16 384: 3x the time per sample -- every chunk pays the fixed cost of a factor call)
 
 // offsets (doubles) of the regions every factor call carves out of its workspace.  Region 1: the Householder route's leaves + tree
 // levels (rdyn_tsqr.hip or rdyn_tsqr_wide.hip).  Region 2: the preconditioned route's slabs, W, the intermediate factors and the flags.
