@@ -357,6 +357,12 @@ hipError_t launch_base_nj(const RdynKinArgs& a, hipStream_t st)
   default: return hipErrorInvalidValue;            \
   }
 
+// The file is compiled in slices (Makefile: -DRDYN_KERNELS_PART=0..3, like rdyn_image_part.hip) so that the instantiations build in
+// parallel: 0 the single-chain sweeps, 1 every getter of a sample in one launch, 2 the base sweeps, 3 the mixed-chain plans.
+#ifndef RDYN_KERNELS_PART
+#error "compile with -DRDYN_KERNELS_PART=<0..3>"
+#endif
+#if RDYN_KERNELS_PART == 0
 hipError_t rdyn_launch_local_sweep(int n_joints, int mode, const RdynSweepArgs& a, hipStream_t st)
 {
   if (a.n_samples <= 0) return hipSuccess;
@@ -364,7 +370,9 @@ hipError_t rdyn_launch_local_sweep(int n_joints, int mode, const RdynSweepArgs& 
   RDYN_DISPATCH_NJ(n_joints, CALL)
 #undef CALL
 }
+#endif
 
+#if RDYN_KERNELS_PART == 1
 namespace
 {
 template <int NJ>
@@ -381,7 +389,9 @@ hipError_t rdyn_launch_sample_all(int n_joints, const RdynAllArgs& a, hipStream_
   RDYN_DISPATCH_NJ(n_joints, CALL)
 #undef CALL
 }
+#endif
 
+#if RDYN_KERNELS_PART == 2
 hipError_t rdyn_launch_base_sweep(int n_joints, const RdynKinArgs& a, hipStream_t st)
 {
   if (a.n_samples <= 0) return hipSuccess;
@@ -389,7 +399,9 @@ hipError_t rdyn_launch_base_sweep(int n_joints, const RdynKinArgs& a, hipStream_
   RDYN_DISPATCH_NJ(n_joints, CALL)
 #undef CALL
 }
+#endif
 
+#if RDYN_KERNELS_PART == 3
 namespace
 {
 template <int NJ>
@@ -414,4 +426,4 @@ hipError_t rdyn_launch_local_sweep_multi(int n_joints, int mode, const RdynSweep
   RDYN_DISPATCH_NJ(n_joints, CALL)
 #undef CALL
 }
-
+#endif

@@ -14,7 +14,8 @@ else
   if [[ $SRC == rdyn_image_part.hip || $SRC == rdyn_kernels.hip ]]; then EXTRA="-mllvm -pragma-unroll-threshold=1000000"; fi
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wextra -Wno-unused-parameter -Wno-cuda-compat -ffp-contract=on $EXTRA "$@" -c $SRC -o $OBJ
 fi
-# STOCK_OBJ=<object the variant replaces> when it is not _obj/<stem>.o (the slices of rdyn_image_part.hip: _obj/rdyn_image_na6.o ...)
+# STOCK_OBJ=<object the variant replaces> when it is not _obj/<stem>.o (the slices of rdyn_image_part.hip: _obj/rdyn_image_na6.o ...;
+# of rdyn_kernels.hip: STOCK_OBJ=_obj/rdyn_kernels_part0.o with -DRDYN_KERNELS_PART=0, ...)
 OTHERS=$(ls _obj/*.o | grep -v "${STOCK_OBJ:-_obj/${STEM}.o}")
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -o ../variants/librdyn_${NAME}.so $OBJ $OTHERS
 echo built ../variants/librdyn_${NAME}.so

@@ -7,7 +7,7 @@
   ident     round 4: the identification R factor [Y | C | tau] -- panda link0 -> link7 + 7 friction components at N = 4e6 (k_regressor_pgram_solo),
             ur10_public base_link -> tool0 + 6 mixed components at N = 1e6 (reduced chain, k_regressor_pgram<6, XB>, k_cholqr_expand)
   long      round 4: the 14-joint fixture (ur10_public_long base_link -> tcp): element-major / per-sample regressor, Gram, R factor at N = 1e6
-  tsqr_rows round 4: rdyn_tsqr on materialised matrices: 6e6 x 86 (k_pgram_rows) and 1e6 x 112 (k_tsqr_wide_rows)"""
+  tsqr_rows rdyn_tsqr on materialised matrices: 6e6 x 86 (k_pgram_rows<6>) and 1e6 x 112 (k_pgram_rows<7>, the dense steps in the workspace)"""
 import os
 import sys
 
