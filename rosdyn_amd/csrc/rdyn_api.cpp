@@ -193,6 +193,13 @@ int check_batch(const rdyn_chain* c, const rdyn_batch* b, bool need_dq, bool nee
   return RDYN_OK;
 }
 
+// every non-null pointer starts on a 128-byte line (the staged copy-out of the sample-major records writes whole lines)
+template <class... P>
+inline bool lines_aligned(P... p)
+{
+  return (((uintptr_t)p | ...) & 127u) == 0;
+}
+
 // per-sample / per-element strides of a record of `elems` doubles
 inline void rec_strides(const rdyn_batch* b, int64_t elems, int64_t* ss, int64_t* se)
 {
@@ -324,6 +331,10 @@ int run_local(const rdyn_chain* c, const rdyn_batch* b, int mode, double* tau, d
   }
   a.M = M;
   rec_strides(b, (int64_t)n * n, &a.m_ss, &a.m_se);
+  // torque / inertia records in the drop-in layout: through the wave's LDS tile, whole lines (rdyn_record_stage.h)
+  if ((mode == RDYN_MODE_TORQUE || mode == RDYN_MODE_INERTIA) && b->layout == RDYN_LAYOUT_SAMPLE_MAJOR && lines_aligned(tau, M) &&
+      !probe_env("RDYN_NO_RECORD_STAGING"))
+    a.staged = mode == RDYN_MODE_INERTIA ? n * n : n;
   // Row-contiguous regressor layouts (stacked column-major, per-sample Eigen image) with sample-major inputs:
   // ceil(n/2) lanes per sample, 16-byte row-pair stores (k_rowpair_sweep) instead of 8-byte strided stores.
   const bool rowpair = mode == RDYN_MODE_REGRESSOR && yl && yl->stride_row == 1 && n >= 2 && n <= 10 &&
@@ -397,6 +408,7 @@ static int long_chain_torque(const rdyn_chain* c, const rdyn_batch* b, double* t
   e.tau = tau;
   e.tau_ss = e.in_ss;
   e.tau_sj = e.in_sj;
+  e.staged = b->layout == RDYN_LAYOUT_SAMPLE_MAJOR && lines_aligned(tau) && !probe_env("RDYN_NO_RECORD_STAGING");
   RDYN_HIP_TRY(rdyn_launch_long_ext(c->n_joints(), e, (hipStream_t)b->stream));
   return RDYN_OK;
 }
@@ -482,6 +494,9 @@ static int run_base(const rdyn_chain* c, const rdyn_batch* b, double* T_bt, doub
   a.dtwists = dtw;
   rec_strides(b, 6 * (int64_t)L, &a.tw_ss, &se);
   a.out_se = se;
+  a.n_active = n;
+  // the drop-in layout: records leave through wave-private LDS in whole lines (rdyn_record_stage.h) when every output starts on a line
+  a.staged = b->layout == RDYN_LAYOUT_SAMPLE_MAJOR && lines_aligned(T_bt, T_links, J, tw, dtw) && !probe_env("RDYN_NO_RECORD_STAGING");
   if (c->long_chain())
   {
     for (int l = 0; l < a.j_link; ++l) a.j_up += c->host_joints[l].in_idx >= 0 ? 1 : 0;
@@ -634,6 +649,7 @@ int rdyn_twist_parts(const rdyn_chain* c, const rdyn_batch* b, const double* ddd
   a.dtw_lin = dtw_lin;
   a.dtw_nonlin = dtw_nonlin;
   a.ddtw = ddtw;
+  a.staged = b->layout == RDYN_LAYOUT_SAMPLE_MAJOR && lines_aligned(dtw_lin, dtw_nonlin, ddtw) && !probe_env("RDYN_NO_RECORD_STAGING");
   if (c->long_chain())
     RDYN_HIP_TRY(rdyn_launch_long_ext(c->n_joints(), a, (hipStream_t)b->stream));
   else
@@ -667,6 +683,7 @@ int rdyn_jerk_parts(const rdyn_chain* c, const rdyn_batch* b, const double* dddq
   rec_strides(b, 6 * (int64_t)(c->n_joints() + 1), &a.out_ss, &a.out_se);
   a.ddtw_lin = ddtw_lin;
   a.ddtw_nonlin = ddtw_nonlin;
+  a.staged = b->layout == RDYN_LAYOUT_SAMPLE_MAJOR && lines_aligned(ddtw_lin, ddtw_nonlin) && !probe_env("RDYN_NO_RECORD_STAGING");
   if (c->long_chain())
     RDYN_HIP_TRY(rdyn_launch_long_ext(c->n_joints(), a, (hipStream_t)b->stream));
   else
@@ -701,6 +718,7 @@ int rdyn_wrench(const rdyn_chain* c, const rdyn_batch* b, const double* ext, dou
   a.ext = ext;
   a.ext_ss = a.out_ss;
   a.ext_se = a.out_se;
+  a.staged = b->layout == RDYN_LAYOUT_SAMPLE_MAJOR && lines_aligned(wrenches) && !probe_env("RDYN_NO_RECORD_STAGING");
   if (c->long_chain())
     RDYN_HIP_TRY(rdyn_launch_long_ext(c->n_joints(), a, (hipStream_t)b->stream));
   else
@@ -738,6 +756,7 @@ int rdyn_joint_torque_ext(const rdyn_chain* c, const rdyn_batch* b, const double
     e.tau_sj = e.in_sj;
     e.ext = ext;
     rec_strides(b, 6 * (int64_t)(c->n_joints() + 1), &e.ext_ss, &e.ext_se);
+    e.staged = b->layout == RDYN_LAYOUT_SAMPLE_MAJOR && lines_aligned(tau) && !probe_env("RDYN_NO_RECORD_STAGING");
     RDYN_HIP_TRY(rdyn_launch_long_ext(c->n_joints(), e, (hipStream_t)b->stream));
     return RDYN_OK;
   }

@@ -24,6 +24,7 @@
 #include "rdyn_device.h"
 #include "rdyn_devmath.h"
 #include "rdyn_kernels.h"
+#include "rdyn_record_stage.h"
 #include "rdyn_gram_common.h"
 
 namespace

@@ -43,6 +43,9 @@ struct RdynSweepArgs
   // k_image_sweep<.., EXPAND>: the links of the full chain that ride on body f are expand_first[f] .. expand_first[f + 1] - 1 (chain order;
   // the links below expand_first[0] sit upstream of the first input joint: zero blocks)
   int expand_first[RDYN_MAX_SWEPT_JOINTS + 1];
+  // torque / inertia launches: the sample-major records (tau: n, M: n x n doubles per sample) through the wave's LDS tile, written in whole
+  // lines (rdyn_record_stage.h); decided by the host: natural strides, 128-byte aligned output
+  int staged;
 };
 
 // split / jerk sweeps (rdyn_kin_ext.hip); every output record is links x 6
@@ -65,6 +68,7 @@ struct RdynKinExtArgs
   const RdynLongChainConst* chain_long;
   double* tau;
   int64_t tau_ss, tau_sj;
+  int staged;  // sample-major records through wave-private LDS, whole lines (rdyn_record_stage.h); decided by the host: natural strides, line-aligned outputs
 };
 hipError_t rdyn_launch_base_ext(int n_joints, const RdynKinExtArgs& a, hipStream_t st);
 hipError_t rdyn_launch_long_ext(int n_joints, const RdynKinExtArgs& a, hipStream_t st);  // a.chain_long; any chain length
@@ -125,6 +129,10 @@ struct RdynKinArgs
   // j_link (the first j_up input columns of the Jacobian are filled, primitives_impl.h:965-972)
   const RdynLongChainConst* chain_long;
   int j_up;
+  // sample-major records through wave-private LDS, written in whole lines (rdyn_record_stage.h): natural record strides (out_se == 1,
+  // X_ss = the record length) and every output pointer 128-byte aligned -- decided by the host; n_active sizes the Jacobian's tile
+  int staged;
+  int n_active;
 };
 hipError_t rdyn_launch_long_base(const RdynKinArgs& a, hipStream_t st);
 

@@ -35,6 +35,7 @@
 #include "rdyn_device.h"
 #include "rdyn_devmath.h"
 #include "rdyn_kernels.h"
+#include "rdyn_record_stage.h"
 
 namespace
 {
@@ -71,6 +72,16 @@ __global__ __launch_bounds__(256) RDYN_LOCAL_ATTR void k_local_sweep(const RdynS
   constexpr double* expand_tile = nullptr;  // (the staged expanding sweep's LDS tile: k_expand_staged)
 #include "rdyn_local_sweep_body.inc"
 }
+// torque / inertia in the sample-major layout (a.staged = doubles per record): one wave per workgroup, the wave's 64 records through its
+// LDS tile (64 (rec | 1) doubles of dynamic LDS), written in whole lines
+template <int NJ, int MODE>
+__global__ __launch_bounds__(64) RDYN_LOCAL_ATTR void k_local_sweep_rec(const RdynSweepArgs a)
+{
+  const unsigned blk = blockIdx.x;
+  constexpr double* expand_tile = nullptr;
+#define RDYN_LOCAL_WGS 64
+#include "rdyn_local_sweep_body.inc"
+}
 // the staged expanding sweep: one wave per workgroup, its tile in dynamic LDS (64 x (CG NJ + 2) doubles, CG columns of a link at a time)
 // and behind it the lanes' inputs (64 x (3 NJ + 1) doubles)
 #ifndef RDYN_EXPAND_WAVES
@@ -105,10 +116,42 @@ __global__ __launch_bounds__(256) void k_local_sweep_multi(const RdynSweepArgs* 
 // LEVEL: what the caller asked for -- 0 frames only (getTransformation(s)), 1 + the Jacobian (screws and origins kept), 2 + twists,
 // 3 + spatial accelerations.  One instantiation per level: a getTransformation call does not pay for the velocity / acceleration
 // recursions of getDTwist (750 -> 420 fp64 instructions per sample at 6 joints).
-template <int NJ, int LEVEL, class Args>
-__device__ __forceinline__ void base_sweep_body(const Args& a, const int64_t s)
+// STAGED (k_base_sweep_staged: 64-thread workgroups, `lds` = the wave's staging area): the sample-major records of a FULL wave leave
+// through wave-private LDS in whole lines (rdyn_record_stage.h); a partial last wave keeps the 8-byte stores below.
+template <int NJ, int LEVEL, bool STAGED, class Args>
+__device__ __forceinline__ void base_sweep_body(const Args& a, const int64_t s, char* lds = nullptr)
 {
   ChainPtr c = as_const(a.chain);
+  const int lane = threadIdx.x & 63;
+  bool stg = false;  // wave-uniform
+  RecordRing<96> ringT;
+  RecordRing<48> ringV, ringA;
+  char* small_area = nullptr;
+  if constexpr (STAGED)
+  {
+    const int64_t s_wave = s - lane;
+    stg = a.n_samples - s_wave >= 64;
+    if (stg)
+    {
+      char* p = lds;
+      if (a.T_links)
+      {
+        ringT.init(p, a.T_links + s_wave * a.tl_ss, 96u * (NJ + 1), lane);
+        p += RecordRing<96>::BYTES;
+      }
+      if (LEVEL >= 2 && a.twists)
+      {
+        ringV.init(p, a.twists + s_wave * a.tw_ss, 48u * (NJ + 1), lane);
+        p += RecordRing<48>::BYTES;
+      }
+      if (LEVEL >= 3 && a.dtwists)
+      {
+        ringA.init(p, a.dtwists + s_wave * a.tw_ss, 48u * (NJ + 1), lane);
+        p += RecordRing<48>::BYTES;
+      }
+      small_area = p;
+    }
+  }
   if (s >= a.n_samples) return;
   const double* __restrict__ qp = a.q + s * a.in_ss;
   const double* __restrict__ dqp = (LEVEL >= 2 && a.dq) ? a.dq + s * a.in_ss : nullptr;
@@ -134,9 +177,40 @@ __device__ __forceinline__ void base_sweep_body(const Args& a, const int64_t s)
     o[0] = l.x; o[es] = l.y; o[2 * es] = l.z; o[3 * es] = g.x; o[4 * es] = g.y; o[5 * es] = g.z;
   };
 
-  if (a.T_links) put3x4(a.T_links + s * a.tl_ss);
-  if (LEVEL >= 2 && a.twists) put6(a.twists + s * a.tw_ss, vlin, vang);
-  if (LEVEL >= 3 && a.dtwists) put6(a.dtwists + s * a.tw_ss, alin, aang);
+  // the records that grow link by link: frame / twist / spatial acceleration of link `link` (0 = the base link)
+  auto frame_out = [&](const int link) {
+    if (!a.T_links) return;
+    if (STAGED && stg)
+    {
+#pragma unroll
+      for (int cc = 0; cc < 3; ++cc)
+#pragma unroll
+        for (int r = 0; r < 3; ++r) ringT.put((uint32_t)(96 * link + 8 * (cc * 3 + r)), R[r * 3 + cc]);
+      ringT.put((uint32_t)(96 * link + 72), p.x);
+      ringT.put((uint32_t)(96 * link + 80), p.y);
+      ringT.put((uint32_t)(96 * link + 88), p.z);
+      ringT.flush(96 * link, 96 * (link + 1));
+    }
+    else
+      put3x4(a.T_links + s * a.tl_ss + (int64_t)(12 * link) * es);
+  };
+  auto six_out = [&](const RecordRing<48>& ring, double* base, const int link, V3 l, V3 g) {
+    if (STAGED && stg)
+    {
+      ring.put((uint32_t)(48 * link), l.x);
+      ring.put((uint32_t)(48 * link + 8), l.y);
+      ring.put((uint32_t)(48 * link + 16), l.z);
+      ring.put((uint32_t)(48 * link + 24), g.x);
+      ring.put((uint32_t)(48 * link + 32), g.y);
+      ring.put((uint32_t)(48 * link + 40), g.z);
+      ring.flush(48 * link, 48 * (link + 1));
+    }
+    else
+      put6(base + s * a.tw_ss + (int64_t)(6 * link) * es, l, g);
+  };
+  frame_out(0);
+  if (LEVEL >= 2 && a.twists) six_out(ringV, a.twists, 0, vlin, vang);
+  if (LEVEL >= 3 && a.dtwists) six_out(ringA, a.dtwists, 0, alin, aang);
 
 #pragma unroll
   for (int f = 0; f < NJ; ++f)
@@ -204,13 +278,38 @@ __device__ __forceinline__ void base_sweep_body(const Args& a, const int64_t s)
       vlin = nvl;
       vang = nva;
     }
-    if (a.T_links) put3x4(a.T_links + s * a.tl_ss + (int64_t)(12 * (f + 1)) * es);
-    if (LEVEL >= 2 && a.twists) put6(a.twists + s * a.tw_ss + (int64_t)(6 * (f + 1)) * es, vlin, vang);
-    if (LEVEL >= 3 && a.dtwists) put6(a.dtwists + s * a.tw_ss + (int64_t)(6 * (f + 1)) * es, alin, aang);
+    frame_out(f + 1);
+    if (LEVEL >= 2 && a.twists) six_out(ringV, a.twists, f + 1, vlin, vang);
+    if (LEVEL >= 3 && a.dtwists) six_out(ringA, a.dtwists, f + 1, alin, aang);
   }
-  if (a.T_bt) put3x4(a.T_bt + s * a.tb_ss);
+  if (STAGED && stg)
+  {
+    if (a.T_links) ringT.finish();
+    if (LEVEL >= 2 && a.twists) ringV.finish();
+    if (LEVEL >= 3 && a.dtwists) ringA.finish();
+  }
+  SmallRecords sm;
+  if (a.T_bt)
+  {
+    if (STAGED && stg)
+    {
+      sm.init(small_area, 12, lane);
+#pragma unroll
+      for (int cc = 0; cc < 3; ++cc)
+#pragma unroll
+        for (int r = 0; r < 3; ++r) sm.put(cc * 3 + r, R[r * 3 + cc]);
+      sm.put(9, p.x);
+      sm.put(10, p.y);
+      sm.put(11, p.z);
+      sm.copy_out(a.T_bt + (s - lane) * a.tb_ss, lane);
+    }
+    else
+      put3x4(a.T_bt + s * a.tb_ss);
+  }
   if (LEVEL >= 1 && a.J)
   {
+    const bool jst = STAGED && stg;
+    if (jst) sm.init(small_area, 6 * c->n_active, lane);
     // getJacobian, primitives_impl.h:939-945: column k = spatialTranslation(S_l, p_tool - p_l);
     // getJacobianLink, primitives_impl.h:951-979: the same referred to the origin of link j_link; only the FIRST
     // `up` input columns are filled, up = number of input joints upstream of the link (the reference's loop runs over
@@ -243,15 +342,29 @@ __device__ __forceinline__ void base_sweep_body(const Args& a, const int64_t s)
         else if (type == RDYN_PRISMATIC)
           jlin = z[l];
       }
-      put6(jp + (int64_t)(6 * k) * es, jlin, jang);
+      if (jst)
+      {
+        sm.put(6 * k, jlin.x); sm.put(6 * k + 1, jlin.y); sm.put(6 * k + 2, jlin.z);
+        sm.put(6 * k + 3, jang.x); sm.put(6 * k + 4, jang.y); sm.put(6 * k + 5, jang.z);
+      }
+      else
+        put6(jp + (int64_t)(6 * k) * es, jlin, jang);
     }
+    if (jst) sm.copy_out(a.J + (s - lane) * a.j_ss, lane);
   }
 }
 
 template <int NJ, int LEVEL>
 __global__ __launch_bounds__(256) void k_base_sweep(const RdynKinArgs a)
 {
-  base_sweep_body<NJ, LEVEL>(a, (int64_t)blockIdx.x * 256 + threadIdx.x);
+  base_sweep_body<NJ, LEVEL, false>(a, (int64_t)blockIdx.x * 256 + threadIdx.x);
+}
+// the sample-major records in whole lines: one wave per workgroup, its staging area in dynamic LDS (base_stage_lds_bytes)
+template <int NJ, int LEVEL>
+__global__ __launch_bounds__(64) void k_base_sweep_staged(const RdynKinArgs a)
+{
+  extern __shared__ __attribute__((aligned(16))) char stage_lds[];
+  base_sweep_body<NJ, LEVEL, true>(a, (int64_t)blockIdx.x * 64 + threadIdx.x, stage_lds);
 }
 
 // Every getter of a sample in ONE launch (rdyn_evaluate_all): blockIdx.y picks a role -- frames of all links, the tool Jacobian, twists +
@@ -266,14 +379,14 @@ __global__ __launch_bounds__(256) void k_sample_all(const RdynAllArgs all)
   switch (blockIdx.y)
   {
   case 0:
-    if (all.frames.T_bt || all.frames.T_links) base_sweep_body<NJ, 0>(all.frames, (int64_t)blk * 256 + threadIdx.x);
+    if (all.frames.T_bt || all.frames.T_links) base_sweep_body<NJ, 0, false>(all.frames, (int64_t)blk * 256 + threadIdx.x);
     return;
   case 1:
-    if (all.jacobian.J) base_sweep_body<NJ, 1>(all.jacobian, (int64_t)blk * 256 + threadIdx.x);
+    if (all.jacobian.J) base_sweep_body<NJ, 1, false>(all.jacobian, (int64_t)blk * 256 + threadIdx.x);
     return;
   case 2:
-    if (all.twists.dtwists) base_sweep_body<NJ, 3>(all.twists, (int64_t)blk * 256 + threadIdx.x);
-    else if (all.twists.twists) base_sweep_body<NJ, 2>(all.twists, (int64_t)blk * 256 + threadIdx.x);
+    if (all.twists.dtwists) base_sweep_body<NJ, 3, false>(all.twists, (int64_t)blk * 256 + threadIdx.x);
+    else if (all.twists.twists) base_sweep_body<NJ, 2, false>(all.twists, (int64_t)blk * 256 + threadIdx.x);
     return;
   case 3:
   {
@@ -322,14 +435,38 @@ hipError_t launch_local_nj(int mode, const RdynSweepArgs& a, hipStream_t st)
   case MODE_REGRESSOR: hipLaunchKernelGGL((k_local_sweep<NJ, MODE_REGRESSOR>), dim3(grid), dim3(256), 0, st, a); break;
   case MODE_REGRESSOR_GRAM: hipLaunchKernelGGL((k_local_sweep<NJ, MODE_REGRESSOR_GRAM>), dim3(grid), dim3(256), 0, st, a); break;
   case MODE_REGRESSOR_EXPAND: hipLaunchKernelGGL((k_local_sweep<NJ, MODE_REGRESSOR_EXPAND>), dim3(grid), dim3(256), 0, st, a); break;
-  case MODE_TORQUE: hipLaunchKernelGGL((k_local_sweep<NJ, MODE_TORQUE>), dim3(grid), dim3(256), 0, st, a); break;
-  default: hipLaunchKernelGGL((k_local_sweep<NJ, MODE_INERTIA>), dim3(grid), dim3(256), 0, st, a); break;
+  // (a.staged = doubles per record: the sample-major records through one LDS tile per wave, 64 (rec | 1) doubles)
+  case MODE_TORQUE:
+    if (a.staged) hipLaunchKernelGGL((k_local_sweep_rec<NJ, MODE_TORQUE>), dim3((unsigned)((a.n_samples + 63) / 64)), dim3(64), (size_t)64 * (a.staged | 1) * 8, st, a);
+    else hipLaunchKernelGGL((k_local_sweep<NJ, MODE_TORQUE>), dim3(grid), dim3(256), 0, st, a);
+    break;
+  default:
+    if (a.staged) hipLaunchKernelGGL((k_local_sweep_rec<NJ, MODE_INERTIA>), dim3((unsigned)((a.n_samples + 63) / 64)), dim3(64), (size_t)64 * (a.staged | 1) * 8, st, a);
+    else hipLaunchKernelGGL((k_local_sweep<NJ, MODE_INERTIA>), dim3(grid), dim3(256), 0, st, a);
+    break;
   }
   return hipGetLastError();
 }
 template <int NJ>
 hipError_t launch_base_nj(const RdynKinArgs& a, hipStream_t st)
 {
+  if (a.staged)
+  {
+    // rings in the order the kernel lays them out, then the tile of the records that are complete at the end of the sweep
+    size_t lds = 0, small = 0;
+    if (a.T_links) lds += RecordRing<96>::BYTES;
+    if (a.twists) lds += RecordRing<48>::BYTES;
+    if (a.dtwists) lds += RecordRing<48>::BYTES;
+    if (a.T_bt) small = (size_t)64 * 13 * 8;
+    if (a.J && (size_t)64 * (size_t)((6 * a.n_active) | 1) * 8 > small) small = (size_t)64 * (size_t)((6 * a.n_active) | 1) * 8;
+    lds += small;
+    const unsigned g64 = (unsigned)((a.n_samples + 63) / 64);
+    if (a.dtwists) hipLaunchKernelGGL((k_base_sweep_staged<NJ, 3>), dim3(g64), dim3(64), lds, st, a);
+    else if (a.twists) hipLaunchKernelGGL((k_base_sweep_staged<NJ, 2>), dim3(g64), dim3(64), lds, st, a);
+    else if (a.J) hipLaunchKernelGGL((k_base_sweep_staged<NJ, 1>), dim3(g64), dim3(64), lds, st, a);
+    else hipLaunchKernelGGL((k_base_sweep_staged<NJ, 0>), dim3(g64), dim3(64), lds, st, a);
+    return hipGetLastError();
+  }
   const unsigned grid = (unsigned)((a.n_samples + 255) / 256);
   // the cheapest instantiation that produces everything asked for
   if (a.dtwists) hipLaunchKernelGGL((k_base_sweep<NJ, 3>), dim3(grid), dim3(256), 0, st, a);

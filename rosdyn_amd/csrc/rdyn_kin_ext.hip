@@ -14,6 +14,7 @@
 #include "rdyn_device.h"
 #include "rdyn_devmath.h"
 #include "rdyn_kernels.h"
+#include "rdyn_record_stage.h"
 
 namespace
 {
@@ -47,13 +48,39 @@ __device__ __forceinline__ S6 axpy6(S6 a, S6 b, double s)
 #define RDYN_KIN_EXT_WAVES 1  // minimum waves per SIMD asked of the register allocator.  3 and 4 were measured: hipcc then spills (60-404 B of scratch) and getWrench / getDDTwist slow down 1.15-5x (profiles/r2/perf_sheet.txt)
 #endif
 // WRENCH: 64-thread workgroups (the wave parks every link's own wrench in LDS, 48 (NJ + 1) bytes per thread; no barrier)
-template <int NJ, bool WRENCH>
-__global__ __launch_bounds__(WRENCH ? 64 : 256, RDYN_KIN_EXT_WAVES) void k_base_ext(const RdynKinExtArgs a)
+// STAGED (a.staged: sample-major records at their natural stride, line-aligned outputs): 64-thread workgroups; the records of a FULL
+// wave leave through wave-private LDS in whole lines (rdyn_record_stage.h) -- one ring per requested split / jerk output, the wrench
+// records from the tile they are parked in anyway (then laid out [sample][6 (NJ + 1) | 1])
+template <int NJ, bool WRENCH, bool STAGED>
+__global__ __launch_bounds__((WRENCH || STAGED) ? 64 : 256, RDYN_KIN_EXT_WAVES) void k_base_ext(const RdynKinExtArgs a)
 {
-  constexpr int BS = WRENCH ? 64 : 256;
-  extern __shared__ __attribute__((aligned(16))) double own_lds[];  // WRENCH: [6 (NJ + 1)][64]
+  constexpr int BS = (WRENCH || STAGED) ? 64 : 256;
+  extern __shared__ __attribute__((aligned(16))) double own_lds[];  // WRENCH: [6 (NJ + 1)][64]; STAGED: the rings / the record tile
   ChainPtr c = as_const(a.chain);
   const int64_t s = (int64_t)blockIdx.x * BS + threadIdx.x;
+  const bool stg = STAGED && a.n_samples - (int64_t)blockIdx.x * BS >= 64;  // wave-uniform
+  RecordRing<48> rings[(STAGED && !WRENCH) ? 5 : 1];
+  SmallRecords wtile;
+  if constexpr (STAGED)
+  {
+    if (stg)
+    {
+      if constexpr (WRENCH)
+        wtile.init((char*)own_lds, 6 * (NJ + 1), threadIdx.x);
+      else
+      {
+        char* lp = (char*)own_lds;
+        double* const outs[5] = {a.dtw_lin, a.dtw_nonlin, a.ddtw, a.ddtw_lin, a.ddtw_nonlin};
+#pragma unroll
+        for (int k = 0; k < 5; ++k)
+          if (outs[k])
+          {
+            rings[k].init(lp, outs[k] + (int64_t)blockIdx.x * BS * a.out_ss, 48u * (NJ + 1), threadIdx.x);
+            lp += RecordRing<48>::BYTES;
+          }
+      }
+    }
+  }
   if (s >= a.n_samples) return;
   const double* __restrict__ qp = a.q + s * a.in_ss;
   const double* __restrict__ dqp = a.dq ? a.dq + s * a.in_ss : nullptr;
@@ -77,24 +104,59 @@ __global__ __launch_bounds__(WRENCH ? 64 : 256, RDYN_KIN_EXT_WAVES) void k_base_
   const S6 zero = {mk(0, 0, 0), mk(0, 0, 0)};
   double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
   S6 v = zero, acc = zero, aL = zero, aN = zero, jk = zero, jL = zero, jN = zero;
-  if (a.dtw_lin) put6(a.dtw_lin, 0, zero);
-  if (a.dtw_nonlin) put6(a.dtw_nonlin, 0, zero);
-  if (a.ddtw) put6(a.ddtw, 0, zero);
-  if (a.ddtw_lin) put6(a.ddtw_lin, 0, zero);
-  if (a.ddtw_nonlin) put6(a.ddtw_nonlin, 0, zero);
+  // link `link` of split / jerk output k
+  auto out6 = [&](const int k, double* base, const int link, S6 x) {
+    if (!base) return;
+    if (STAGED && stg)
+    {
+      const RecordRing<48>& ring = rings[(STAGED && !WRENCH) ? k : 0];
+      ring.put((uint32_t)(48 * link), x.l.x);
+      ring.put((uint32_t)(48 * link + 8), x.l.y);
+      ring.put((uint32_t)(48 * link + 16), x.l.z);
+      ring.put((uint32_t)(48 * link + 24), x.a.x);
+      ring.put((uint32_t)(48 * link + 32), x.a.y);
+      ring.put((uint32_t)(48 * link + 40), x.a.z);
+      ring.flush(48 * link, 48 * (link + 1));
+    }
+    else
+      put6(base, 6 * link, x);
+  };
+  if (!WRENCH)
+  {
+    out6(0, a.dtw_lin, 0, zero);
+    out6(1, a.dtw_nonlin, 0, zero);
+    out6(2, a.ddtw, 0, zero);
+    out6(3, a.ddtw_lin, 0, zero);
+    out6(4, a.ddtw_nonlin, 0, zero);
+  }
   // WRENCH: origins of links 0 .. NJ.  The per-link wrench accumulators do NOT live in registers (6 (NJ + 1) doubles pushed the
   // kernel to 200 VGPRs = 2 waves per SIMD on a streaming kernel): every link's OWN wrench is parked in LDS referred to the base
   // origin (moment + p x force), and a short backward pass over the thread's own records forms the suffix sums and refers each
   // one back to its link's origin.  (Round 2's first version parked them in the output records: the store -> load round trip
   // through L2 / HBM, at two waves per SIMD, left the kernel waiting on memory for two thirds of its cycles.)
   V3 po[WRENCH ? NJ + 1 : 1];
+  // (staged: the tile the records are copied out of -- [sample][6 (NJ + 1) | 1], an odd pitch: conflict-free for the lanes' own records
+  // and for the copy-out, which walks along a record)
   auto park6 = [&](int link, S6 x) {
+    if (STAGED && stg)
+    {
+      double* const o = wtile.mine + 6 * link;
+      o[0] = x.l.x; o[1] = x.l.y; o[2] = x.l.z; o[3] = x.a.x; o[4] = x.a.y; o[5] = x.a.z;
+      return;
+    }
     double* const o = own_lds + (6 * link) * 64 + threadIdx.x;
     o[0] = x.l.x; o[64] = x.l.y; o[128] = x.l.z; o[192] = x.a.x; o[256] = x.a.y; o[320] = x.a.z;
   };
   auto parked6 = [&](int link) -> S6 {
-    const double* const o = own_lds + (6 * link) * 64 + threadIdx.x;
     S6 x;
+    if (STAGED && stg)
+    {
+      const double* const o = wtile.mine + 6 * link;
+      x.l = mk(o[0], o[1], o[2]);
+      x.a = mk(o[3], o[4], o[5]);
+      return x;
+    }
+    const double* const o = own_lds + (6 * link) * 64 + threadIdx.x;
     x.l = mk(o[0], o[64], o[128]);
     x.a = mk(o[192], o[256], o[320]);
     return x;
@@ -176,11 +238,11 @@ __global__ __launch_bounds__(WRENCH ? 64 : 256, RDYN_KIN_EXT_WAVES) void k_base_
       jk = axpy6(axpy6(axpy6(shift(jk, d), S, dddqf), vxs, ddqf), cq, dqf);
       jL = axpy6(shift(jL, d), S, dddqf);
       jN = axpy6(axpy6(shift(jN, d), vxs, ddqf), cq, dqf);
-      if (a.dtw_lin) put6(a.dtw_lin, 6 * (f + 1), aL);
-      if (a.dtw_nonlin) put6(a.dtw_nonlin, 6 * (f + 1), aN);
-      if (a.ddtw) put6(a.ddtw, 6 * (f + 1), jk);
-      if (a.ddtw_lin) put6(a.ddtw_lin, 6 * (f + 1), jL);
-      if (a.ddtw_nonlin) put6(a.ddtw_nonlin, 6 * (f + 1), jN);
+      out6(0, a.dtw_lin, f + 1, aL);
+      out6(1, a.dtw_nonlin, f + 1, aN);
+      out6(2, a.ddtw, f + 1, jk);
+      out6(3, a.ddtw_lin, f + 1, jL);
+      out6(4, a.ddtw_nonlin, f + 1, jN);
     }
     if (WRENCH)
     {
@@ -228,19 +290,36 @@ __global__ __launch_bounds__(WRENCH ? 64 : 256, RDYN_KIN_EXT_WAVES) void k_base_
       S6 w;
       w.l = run.l;
       w.a = run.a - cross(po[l], run.l);
-      put6(a.wrench, 6 * l, w);
+      if (STAGED && stg) park6(l, w);  // (the lane's own slot: read above, never again)
+      else put6(a.wrench, 6 * l, w);
     }
+    if (STAGED && stg) wtile.copy_out(a.wrench + (int64_t)blockIdx.x * BS * a.out_ss, threadIdx.x);
+  }
+  else if (STAGED && stg)
+  {
+    double* const outs[5] = {a.dtw_lin, a.dtw_nonlin, a.ddtw, a.ddtw_lin, a.ddtw_nonlin};
+#pragma unroll
+    for (int k = 0; k < 5; ++k)
+      if (outs[k]) rings[(STAGED && !WRENCH) ? k : 0].finish();
   }
 }
 
 template <int NJ>
 hipError_t launch_ext_nj(const RdynKinExtArgs& a, hipStream_t st)
 {
-  const dim3 grid((unsigned)((a.n_samples + 255) / 256));
+  const dim3 grid((unsigned)((a.n_samples + 255) / 256)), grid64((unsigned)((a.n_samples + 63) / 64));
   if (a.wrench)
-    hipLaunchKernelGGL((k_base_ext<NJ, true>), dim3((unsigned)((a.n_samples + 63) / 64)), dim3(64), (size_t)6 * (NJ + 1) * 64 * sizeof(double), st, a);
+  {
+    if (a.staged) hipLaunchKernelGGL((k_base_ext<NJ, true, true>), grid64, dim3(64), (size_t)((6 * (NJ + 1)) | 1) * 64 * sizeof(double), st, a);
+    else hipLaunchKernelGGL((k_base_ext<NJ, true, false>), grid64, dim3(64), (size_t)6 * (NJ + 1) * 64 * sizeof(double), st, a);
+  }
+  else if (a.staged)
+  {
+    const int rings = (a.dtw_lin ? 1 : 0) + (a.dtw_nonlin ? 1 : 0) + (a.ddtw ? 1 : 0) + (a.ddtw_lin ? 1 : 0) + (a.ddtw_nonlin ? 1 : 0);
+    hipLaunchKernelGGL((k_base_ext<NJ, false, true>), grid64, dim3(64), (size_t)rings * RecordRing<48>::BYTES, st, a);
+  }
   else
-    hipLaunchKernelGGL((k_base_ext<NJ, false>), grid, dim3(256), 0, st, a);
+    hipLaunchKernelGGL((k_base_ext<NJ, false, false>), grid, dim3(256), 0, st, a);
   return hipGetLastError();
 }
 }  // namespace

@@ -18,6 +18,7 @@
 #include "rdyn_device.h"
 #include "rdyn_devmath.h"
 #include "rdyn_kernels.h"
+#include "rdyn_record_stage.h"
 
 namespace
 {
@@ -90,12 +91,47 @@ __device__ __forceinline__ void frame_step(JointRef J, double qf, double (&R)[9]
 }
 
 // LEVEL as in k_base_sweep: 0 frames only, 1 + the Jacobian, 2 + twists, 3 + spatial accelerations
-template <int LEVEL>
-__global__ __launch_bounds__(256) void k_long_base(const RdynKinArgs a)
+// STAGED (a.staged: sample-major records at their natural stride, line-aligned outputs): 64-thread workgroups; the records of a FULL wave
+// leave through wave-private LDS in whole lines (rdyn_record_stage.h: one ring per by-link output, a tile for the tool frame / Jacobian)
+template <int LEVEL, bool STAGED>
+__global__ __launch_bounds__(STAGED ? 64 : 256) void k_long_base(const RdynKinArgs a)
 {
+  constexpr int BS = STAGED ? 64 : 256;
+  extern __shared__ __attribute__((aligned(16))) char stage_lds[];
   LongChainPtr c = as_const_long(a.chain_long);
   const int nj = c->n_joints;
-  const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t s = (int64_t)blockIdx.x * BS + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  const bool stg = STAGED && a.n_samples - (int64_t)blockIdx.x * BS >= 64;  // wave-uniform
+  RecordRing<96> ringT;
+  RecordRing<48> ringV, ringA;
+  SmallRecords smJ;
+  char* small_area = nullptr;
+  if constexpr (STAGED)
+  {
+    if (stg)
+    {
+      const int64_t s_wave = (int64_t)blockIdx.x * BS;
+      char* lp = stage_lds;
+      if (a.T_links)
+      {
+        ringT.init(lp, a.T_links + s_wave * a.tl_ss, 96u * (uint32_t)(nj + 1), lane);
+        lp += RecordRing<96>::BYTES;
+      }
+      if (LEVEL >= 2 && a.twists)
+      {
+        ringV.init(lp, a.twists + s_wave * a.tw_ss, 48u * (uint32_t)(nj + 1), lane);
+        lp += RecordRing<48>::BYTES;
+      }
+      if (LEVEL >= 3 && a.dtwists)
+      {
+        ringA.init(lp, a.dtwists + s_wave * a.tw_ss, 48u * (uint32_t)(nj + 1), lane);
+        lp += RecordRing<48>::BYTES;
+      }
+      small_area = lp;
+      if (LEVEL >= 1 && a.J) smJ.init(small_area, 6 * a.n_active, lane);
+    }
+  }
   if (s >= a.n_samples) return;
   const double* __restrict__ qp = a.q + s * a.in_ss;
   const double* __restrict__ dqp = (LEVEL >= 2 && a.dq) ? a.dq + s * a.in_ss : nullptr;
@@ -136,9 +172,41 @@ __global__ __launch_bounds__(256) void k_long_base(const RdynKinArgs a)
   }
 
   V3 vlin = mk(0, 0, 0), vang = mk(0, 0, 0), alin = mk(0, 0, 0), aang = mk(0, 0, 0);
-  if (a.T_links) put3x4(a.T_links + s * a.tl_ss);
-  if (LEVEL >= 2 && a.twists) put6(a.twists + s * a.tw_ss, vlin, vang);
-  if (LEVEL >= 3 && a.dtwists) put6(a.dtwists + s * a.tw_ss, alin, aang);
+  auto frame_out = [&](const int link) {
+    if (!a.T_links) return;
+    if (STAGED && stg)
+    {
+      const uint32_t x0 = 96u * (uint32_t)link;
+#pragma unroll
+      for (int cc = 0; cc < 3; ++cc)
+#pragma unroll
+        for (int r = 0; r < 3; ++r) ringT.put(x0 + 8u * (cc * 3 + r), R[r * 3 + cc]);
+      ringT.put(x0 + 72u, p.x);
+      ringT.put(x0 + 80u, p.y);
+      ringT.put(x0 + 88u, p.z);
+      ringT.flush(96 * link, 96 * (link + 1));
+    }
+    else
+      put3x4(a.T_links + s * a.tl_ss + (int64_t)(12 * link) * es);
+  };
+  auto six_out = [&](const RecordRing<48>& ring, double* base, const int link, V3 l, V3 g) {
+    if (STAGED && stg)
+    {
+      const uint32_t x0 = 48u * (uint32_t)link;
+      ring.put(x0, l.x);
+      ring.put(x0 + 8u, l.y);
+      ring.put(x0 + 16u, l.z);
+      ring.put(x0 + 24u, g.x);
+      ring.put(x0 + 32u, g.y);
+      ring.put(x0 + 40u, g.z);
+      ring.flush(48 * link, 48 * (link + 1));
+    }
+    else
+      put6(base + s * a.tw_ss + (int64_t)(6 * link) * es, l, g);
+  };
+  frame_out(0);
+  if (LEVEL >= 2 && a.twists) six_out(ringV, a.twists, 0, vlin, vang);
+  if (LEVEL >= 3 && a.dtwists) six_out(ringA, a.dtwists, 0, alin, aang);
 #pragma unroll 1
   for (int f = 0; f < nj; ++f)
   {
@@ -173,9 +241,9 @@ __global__ __launch_bounds__(256) void k_long_base(const RdynKinArgs a)
       vlin = nvl;
       vang = nva;
     }
-    if (a.T_links) put3x4(a.T_links + s * a.tl_ss + (int64_t)(12 * (f + 1)) * es);
-    if (LEVEL >= 2 && a.twists) put6(a.twists + s * a.tw_ss + (int64_t)(6 * (f + 1)) * es, vlin, vang);
-    if (LEVEL >= 3 && a.dtwists) put6(a.dtwists + s * a.tw_ss + (int64_t)(6 * (f + 1)) * es, alin, aang);
+    frame_out(f + 1);
+    if (LEVEL >= 2 && a.twists) six_out(ringV, a.twists, f + 1, vlin, vang);
+    if (LEVEL >= 3 && a.dtwists) six_out(ringA, a.dtwists, f + 1, alin, aang);
     if (LEVEL >= 1 && a.J && idx >= 0)
     {
       // getJacobian :939-945 / getJacobianLink :951-979: column k = spatialTranslation(S_l, p_ref - p_l) for the FIRST j_up input
@@ -191,10 +259,40 @@ __global__ __launch_bounds__(256) void k_long_base(const RdynKinArgs a)
         else if (type == RDYN_PRISMATIC)
           jlin = zl;
       }
-      put6(a.J + s * a.j_ss + (int64_t)(6 * idx) * es, jlin, jang);
+      if (STAGED && stg)
+      {
+        smJ.put(6 * idx, jlin.x); smJ.put(6 * idx + 1, jlin.y); smJ.put(6 * idx + 2, jlin.z);
+        smJ.put(6 * idx + 3, jang.x); smJ.put(6 * idx + 4, jang.y); smJ.put(6 * idx + 5, jang.z);
+      }
+      else
+        put6(a.J + s * a.j_ss + (int64_t)(6 * idx) * es, jlin, jang);
     }
   }
-  if (a.T_bt) put3x4(a.T_bt + s * a.tb_ss);
+  if (STAGED && stg)
+  {
+    if (a.T_links) ringT.finish();
+    if (LEVEL >= 2 && a.twists) ringV.finish();
+    if (LEVEL >= 3 && a.dtwists) ringA.finish();
+    if (LEVEL >= 1 && a.J) smJ.copy_out(a.J + (s - lane) * a.j_ss, lane);
+  }
+  if (a.T_bt)
+  {
+    if (STAGED && stg)
+    {
+      SmallRecords sm;
+      sm.init(small_area, 12, lane);
+#pragma unroll
+      for (int cc = 0; cc < 3; ++cc)
+#pragma unroll
+        for (int r = 0; r < 3; ++r) sm.put(cc * 3 + r, R[r * 3 + cc]);
+      sm.put(9, p.x);
+      sm.put(10, p.y);
+      sm.put(11, p.z);
+      sm.copy_out(a.T_bt + (s - lane) * a.tb_ss, lane);
+    }
+    else
+      put3x4(a.T_bt + s * a.tb_ss);
+  }
 }
 
 // The split / jerk recursions (WRENCH = false) and the wrench recursion (true).  The reference sums the link wrenches tool -> base
@@ -203,12 +301,54 @@ __global__ __launch_bounds__(256) void k_long_base(const RdynKinArgs a)
 // up every link's own wrench about the base origin, the second forms w[l] = total - (the links upstream of l) as it goes, refers it to
 // the link's origin, and reads the joint torque off it -- no per-link storage, full occupancy; the arithmetic differs from the suffix
 // sums by the rounding of one subtraction (1e-16 of the chain's total wrench).
-template <bool WRENCH>
-__global__ __launch_bounds__(256) void k_long_ext(const RdynKinExtArgs a)
+// STAGED: as k_long_base -- one ring per requested record (the link wrenches leave in link order in the second pass), the joint torques
+// through a tile.
+template <bool WRENCH, bool STAGED>
+__global__ __launch_bounds__(STAGED ? 64 : 256) void k_long_ext(const RdynKinExtArgs a)
 {
+  constexpr int BS = STAGED ? 64 : 256;
+  extern __shared__ __attribute__((aligned(16))) char stage_lds[];
   LongChainPtr c = as_const_long(a.chain_long);
   const int nj = c->n_joints;
-  const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t s = (int64_t)blockIdx.x * BS + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  const bool stg = STAGED && a.n_samples - (int64_t)blockIdx.x * BS >= 64;  // wave-uniform
+  // rings: WRENCH -- [0] the link wrenches; otherwise one per requested split / jerk output
+  RecordRing<48> rings[STAGED ? (WRENCH ? 1 : 5) : 1];
+  SmallRecords smT;
+  bool tau_staged = false;
+  if constexpr (STAGED)
+  {
+    if (stg)
+    {
+      const int64_t s_wave = (int64_t)blockIdx.x * BS;
+      char* lp = stage_lds;
+      if constexpr (WRENCH)
+      {
+        if (a.wrench)
+        {
+          rings[0].init(lp, a.wrench + s_wave * a.out_ss, 48u * (uint32_t)(nj + 1), lane);
+          lp += RecordRing<48>::BYTES;
+        }
+        if (a.tau && a.tau_sj == 1 && a.tau_ss == c->n_active && (((uintptr_t)a.tau) & 127u) == 0)
+        {
+          smT.init(lp, c->n_active, lane);
+          tau_staged = true;
+        }
+      }
+      else
+      {
+        double* const outs[5] = {a.dtw_lin, a.dtw_nonlin, a.ddtw, a.ddtw_lin, a.ddtw_nonlin};
+#pragma unroll
+        for (int k = 0; k < 5; ++k)
+          if (outs[k])
+          {
+            rings[(STAGED && !WRENCH) ? k : 0].init(lp, outs[k] + s_wave * a.out_ss, 48u * (uint32_t)(nj + 1), lane);
+            lp += RecordRing<48>::BYTES;
+          }
+      }
+    }
+  }
   if (s >= a.n_samples) return;
   const double* __restrict__ qp = a.q + s * a.in_ss;
   const double* __restrict__ dqp = a.dq ? a.dq + s * a.in_ss : nullptr;
@@ -231,13 +371,31 @@ __global__ __launch_bounds__(256) void k_long_ext(const RdynKinExtArgs a)
     }
     return e;
   };
+  // link `link` of output k (WRENCH: k = 0, the link wrenches)
+  auto out6 = [&](const int k, double* base, const int link, S6 x) {
+    if (!base) return;
+    if (STAGED && stg)
+    {
+      const RecordRing<48>& ring = rings[(STAGED && !WRENCH) ? k : 0];
+      const uint32_t x0 = 48u * (uint32_t)link;
+      ring.put(x0, x.l.x);
+      ring.put(x0 + 8u, x.l.y);
+      ring.put(x0 + 16u, x.l.z);
+      ring.put(x0 + 24u, x.a.x);
+      ring.put(x0 + 32u, x.a.y);
+      ring.put(x0 + 40u, x.a.z);
+      ring.flush(48 * link, 48 * (link + 1));
+    }
+    else
+      put6(base, 6 * link, x);
+  };
   if (!WRENCH)
   {
-    if (a.dtw_lin) put6(a.dtw_lin, 0, zero);
-    if (a.dtw_nonlin) put6(a.dtw_nonlin, 0, zero);
-    if (a.ddtw) put6(a.ddtw, 0, zero);
-    if (a.ddtw_lin) put6(a.ddtw_lin, 0, zero);
-    if (a.ddtw_nonlin) put6(a.ddtw_nonlin, 0, zero);
+    out6(0, a.dtw_lin, 0, zero);
+    out6(1, a.dtw_nonlin, 0, zero);
+    out6(2, a.ddtw, 0, zero);
+    out6(3, a.ddtw_lin, 0, zero);
+    out6(4, a.ddtw_nonlin, 0, zero);
   }
   S6 total = zero;
   double* __restrict__ tp = (WRENCH && a.tau) ? a.tau + s * a.tau_ss : nullptr;
@@ -255,7 +413,7 @@ __global__ __launch_bounds__(256) void k_long_ext(const RdynKinExtArgs a)
         total = own0;
       else
       {
-        if (a.wrench) put6(a.wrench, 0, total);  // the base link carries the whole chain; its origin IS the base origin
+        out6(0, a.wrench, 0, total);  // the base link carries the whole chain; its origin IS the base origin
         upstream = own0;
       }
     }
@@ -293,11 +451,11 @@ __global__ __launch_bounds__(256) void k_long_ext(const RdynKinExtArgs a)
         jk = axpy6(axpy6(axpy6(shift(jk, d), S, dddqf), vxs, ddqf), cq, dqf);
         jL = axpy6(shift(jL, d), S, dddqf);
         jN = axpy6(axpy6(shift(jN, d), vxs, ddqf), cq, dqf);
-        if (a.dtw_lin) put6(a.dtw_lin, 6 * (f + 1), aL);
-        if (a.dtw_nonlin) put6(a.dtw_nonlin, 6 * (f + 1), aN);
-        if (a.ddtw) put6(a.ddtw, 6 * (f + 1), jk);
-        if (a.ddtw_lin) put6(a.ddtw_lin, 6 * (f + 1), jL);
-        if (a.ddtw_nonlin) put6(a.ddtw_nonlin, 6 * (f + 1), jN);
+        out6(0, a.dtw_lin, f + 1, aL);
+        out6(1, a.dtw_nonlin, f + 1, aN);
+        out6(2, a.ddtw, f + 1, jk);
+        out6(3, a.ddtw_lin, f + 1, jL);
+        out6(4, a.ddtw_nonlin, f + 1, jN);
       }
       else
       {
@@ -339,12 +497,32 @@ __global__ __launch_bounds__(256) void k_long_ext(const RdynKinExtArgs a)
           S6 w;
           w.l = total.l - upstream.l;
           w.a = (total.a - upstream.a) - cross(p, w.l);
-          if (a.wrench) put6(a.wrench, 6 * (f + 1), w);
-          if (tp && idx >= 0) tp[idx * a.tau_sj] = type == RDYN_REVOLUTE ? dot(zl, w.a) : (type == RDYN_PRISMATIC ? dot(zl, w.l) : 0.0);
+          out6(0, a.wrench, f + 1, w);
+          if (tp && idx >= 0)
+          {
+            const double tq = type == RDYN_REVOLUTE ? dot(zl, w.a) : (type == RDYN_PRISMATIC ? dot(zl, w.l) : 0.0);
+            if (STAGED && tau_staged) smT.put(idx, tq);
+            else tp[idx * a.tau_sj] = tq;
+          }
           upstream.l = upstream.l + own.l;
           upstream.a = upstream.a + own.a;
         }
       }
+    }
+  }
+  if (STAGED && stg)
+  {
+    if constexpr (WRENCH)
+    {
+      if (a.wrench) rings[0].finish();
+      if (tau_staged) smT.copy_out(a.tau + (s - lane) * a.tau_ss, lane);
+    }
+    else
+    {
+      double* const outs[5] = {a.dtw_lin, a.dtw_nonlin, a.ddtw, a.ddtw_lin, a.ddtw_nonlin};
+#pragma unroll
+      for (int k = 0; k < 5; ++k)
+        if (outs[k]) rings[(STAGED && !WRENCH) ? k : 0].finish();
     }
   }
 }
@@ -354,11 +532,30 @@ __global__ __launch_bounds__(256) void k_long_ext(const RdynKinExtArgs a)
 hipError_t rdyn_launch_long_base(const RdynKinArgs& a, hipStream_t st)
 {
   if (a.n_samples <= 0) return hipSuccess;
+  if (a.staged)
+  {
+    size_t lds = 0, small = 0;
+    if (a.T_links) lds += RecordRing<96>::BYTES;
+    if (a.twists) lds += RecordRing<48>::BYTES;
+    if (a.dtwists) lds += RecordRing<48>::BYTES;
+    if (a.T_bt) small = (size_t)64 * 13 * 8;
+    if (a.J && (size_t)64 * (size_t)((6 * a.n_active) | 1) * 8 > small) small = (size_t)64 * (size_t)((6 * a.n_active) | 1) * 8;
+    lds += small;
+    if (lds <= 64 * 1024)
+    {
+      const unsigned g64 = (unsigned)((a.n_samples + 63) / 64);
+      if (a.dtwists) hipLaunchKernelGGL((k_long_base<3, true>), dim3(g64), dim3(64), lds, st, a);
+      else if (a.twists) hipLaunchKernelGGL((k_long_base<2, true>), dim3(g64), dim3(64), lds, st, a);
+      else if (a.J) hipLaunchKernelGGL((k_long_base<1, true>), dim3(g64), dim3(64), lds, st, a);
+      else hipLaunchKernelGGL((k_long_base<0, true>), dim3(g64), dim3(64), lds, st, a);
+      return hipGetLastError();
+    }
+  }
   const unsigned grid = (unsigned)((a.n_samples + 255) / 256);
-  if (a.dtwists) hipLaunchKernelGGL((k_long_base<3>), dim3(grid), dim3(256), 0, st, a);
-  else if (a.twists) hipLaunchKernelGGL((k_long_base<2>), dim3(grid), dim3(256), 0, st, a);
-  else if (a.J) hipLaunchKernelGGL((k_long_base<1>), dim3(grid), dim3(256), 0, st, a);
-  else hipLaunchKernelGGL((k_long_base<0>), dim3(grid), dim3(256), 0, st, a);
+  if (a.dtwists) hipLaunchKernelGGL((k_long_base<3, false>), dim3(grid), dim3(256), 0, st, a);
+  else if (a.twists) hipLaunchKernelGGL((k_long_base<2, false>), dim3(grid), dim3(256), 0, st, a);
+  else if (a.J) hipLaunchKernelGGL((k_long_base<1, false>), dim3(grid), dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((k_long_base<0, false>), dim3(grid), dim3(256), 0, st, a);
   return hipGetLastError();
 }
 
@@ -366,10 +563,19 @@ hipError_t rdyn_launch_long_ext(int n_joints, const RdynKinExtArgs& a, hipStream
 {
   (void)n_joints;
   if (a.n_samples <= 0) return hipSuccess;
-  const dim3 grid((unsigned)((a.n_samples + 255) / 256));
+  const dim3 grid((unsigned)((a.n_samples + 255) / 256)), grid64((unsigned)((a.n_samples + 63) / 64));
   if (a.wrench || a.tau)
-    hipLaunchKernelGGL((k_long_ext<true>), grid, dim3(256), 0, st, a);
+  {
+    // (the joint torques' tile behind the wrench ring: at most 64 (RDYN_MAX_JOINTS | 1) doubles)
+    if (a.staged) hipLaunchKernelGGL((k_long_ext<true, true>), grid64, dim3(64), (size_t)RecordRing<48>::BYTES + (size_t)64 * (RDYN_MAX_JOINTS | 1) * 8, st, a);
+    else hipLaunchKernelGGL((k_long_ext<true, false>), grid, dim3(256), 0, st, a);
+  }
+  else if (a.staged)
+  {
+    const int rings = (a.dtw_lin ? 1 : 0) + (a.dtw_nonlin ? 1 : 0) + (a.ddtw ? 1 : 0) + (a.ddtw_lin ? 1 : 0) + (a.ddtw_nonlin ? 1 : 0);
+    hipLaunchKernelGGL((k_long_ext<false, true>), grid64, dim3(64), (size_t)rings * RecordRing<48>::BYTES, st, a);
+  }
   else
-    hipLaunchKernelGGL((k_long_ext<false>), grid, dim3(256), 0, st, a);
+    hipLaunchKernelGGL((k_long_ext<false, false>), grid, dim3(256), 0, st, a);
   return hipGetLastError();
 }
