@@ -376,7 +376,8 @@ int rdyn_regressor_gram(const rdyn_chain* chain, const rdyn_batch* batch, const 
 /* ---- BASELINE.json configs[3] inside the library (rdyn_multi_gpu.cpp): one process, the trajectory batch
  * sharded over the GPUs of a node, every GPU the fused regressor -> Gram of its shard, then ONE
  * ncclAllReduce(P*P + P + 2 doubles, ncclDouble, ncclSum) over RCCL / xGMI.  rdyn_multi_gpu_create initialises one communicator
- * (ncclCommInitAll) and one stream per device; RCCL is resolved at run time (librccl.so.1) -> RDYN_ERR_UNSUPPORTED if absent.
+ * (ncclCommInitAll) and one stream per device; RCCL is resolved at run time (the library named by RDYN_RCCL_PATH if that variable is
+ * set, else librccl.so.1) -> RDYN_ERR_UNSUPPORTED if absent.
  * rdyn_regressor_gram_multi: batches[i] (device pointers on devices[i]; batch.device = devices[i] or -1), tau_meas[i] (may be NULL
  * as a whole or per shard), acc[i] = a device buffer of P*P + P + 2 doubles on devices[i].  The work runs on the CONTEXT's stream of
  * each device, ordered BEHIND everything already queued on batches[i].stream (NULL = that device's default stream) by an event, so
@@ -394,7 +395,12 @@ int rdyn_regressor_gram_multi(rdyn_multi_gpu* ctx, const rdyn_chain* chain, cons
                               double* const* acc);
 /* The same with accumulate != 0: acc[i] <- acc[i] + the sums over all shards of THIS call (a batch streamed through the devices in
  * pieces: the first piece with accumulate = 0, the others with 1; the accumulators hold the same totals on every device before and
- * after).  One ncclAllReduce per call either way.  The per-device part of both calls is issued by one host thread per device. */
+ * after).  One ncclAllReduce per call either way.  The per-device part of both calls is issued by one host thread per device.
+ * Failures: everything that can be refused (null pointers, devices, the chain's width) is checked BEFORE anything is queued; if a
+ * device fails later (a launch or allocation error on one shard) the call returns that device's error WITHOUT issuing the collective,
+ * and the other devices have already queued kernels that overwrite their outputs with their OWN shard's sums / factor: treat every
+ * acc[i] / R1[i] of a failed call as undefined.  A collective that fails half-way aborts the communicators (and closes the RCCL group
+ * it was issued in): the context then only accepts rdyn_multi_gpu_destroy; a new context can be created from the same thread. */
 int rdyn_regressor_gram_multi_accumulate(rdyn_multi_gpu* ctx, const rdyn_chain* chain, const rdyn_batch* batches, const double* const* tau_meas,
                                          double* const* acc, int accumulate);
 /* The R factor WITHOUT the normal equations over the devices of the context (the TSQR alternative):
@@ -427,7 +433,8 @@ int rdyn_regressor_tsqr_multi(rdyn_multi_gpu* ctx, const rdyn_chain* chain, cons
  * RDYN_MAX_JOINTS chain joints).  Up to 8 input joints the rows are generated in LDS by the regressor sweep and never stored (input
  * joints listed out of chain order: the kernels sweep in chain order and read q, Dq, DDq, tau_meas of every row through an index map
  * -- A'A, A'tau and R do not depend on the order of the rows inside a sample); 9..10 input joints: chunk images of 65 536 samples in
- * the workspace (132 MB) factored by rdyn_tsqr's kernels.
+ * the workspace (65 536 x n x (10 n + 1) doubles: 0.43 GB at 9, 0.53 GB at 10 input joints -- per device in the multi-device form;
+ * size buffers with rdyn_regressor_tsqr_workspace_bytes, never from a figure in a comment) factored by rdyn_tsqr's kernels.
  * rdyn_identification_tsqr: the same for the identification step's [Y | C | tau_meas] (C = the component columns of
  * rdyn_components_regressor -- friction_polynomial1.h:126, ideal_spring.h:64 -- K = rdyn_components_columns):
  * n1 = 10 joints_number + K + 1 <= 112 after the reduction, unknowns [inertial ; component] parameters.  The component columns

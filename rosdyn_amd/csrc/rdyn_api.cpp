@@ -2314,7 +2314,9 @@ int rdyn_identification_gram(const rdyn_chain* c, const rdyn_component* comps, i
 
 int rdyn_evaluate_all(const rdyn_chain* c, const rdyn_batch* b, const rdyn_all_outputs* o)
 {
-  int st = check_batch(c, b, true, true, "rdyn_evaluate_all", LONG_COMPANION);
+  // (a long chain goes through the single-purpose calls below: each one decides for itself what it serves, so that a request for
+  // frames / Jacobian / twists / torques of a chain whose inertia and regressor are not served is answered, not refused as a whole)
+  int st = check_batch(c, b, true, true, "rdyn_evaluate_all", LONG_KERNELS);
   if (st != RDYN_OK) return st;
   if (!o)
   {

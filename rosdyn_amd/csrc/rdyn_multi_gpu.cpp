@@ -16,6 +16,7 @@
 // Both calls end by ordering the CALLER's stream (batches[i].stream) behind the collective with an event: work queued there
 // afterwards sees the results, without a host synchronisation.
 #include <dlfcn.h>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <functional>
@@ -55,7 +56,18 @@ int load_rccl()
 {
   std::lock_guard<std::mutex> lk(g_rccl_mu);
   if (g_rccl.handle) return RDYN_OK;
-  void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+  // RDYN_RCCL_PATH: an explicit library (a site's own RCCL build; tests/cpp/rccl_stub.hip for logical ranks on one GPU)
+  void* h = nullptr;
+  if (const char* path = getenv("RDYN_RCCL_PATH"))
+  {
+    h = dlopen(path, RTLD_NOW | RTLD_LOCAL);
+    if (!h)
+    {
+      rdyn_set_error("RDYN_RCCL_PATH=%s cannot be loaded: %s", path, dlerror());
+      return RDYN_ERR_UNSUPPORTED;
+    }
+  }
+  if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
   if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
   if (!h) h = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
   if (!h)
@@ -163,9 +175,23 @@ static int for_each_device(rdyn_multi_gpu* ctx, const std::function<int(int)>& f
     status[i] = fn(i);
     if (status[i] != RDYN_OK) message[i] = rdyn_last_error();
   };
+  // (a thread that cannot be started -- std::system_error -- must not take the process down through the destructors of the joinable
+  // ones, nor cross the extern "C" boundary: its shard runs on the caller's thread instead)
   std::vector<std::thread> workers;
-  for (int i = 1; i < n_dev; ++i) workers.emplace_back(body, i);
+  std::vector<int> inline_shards;
+  for (int i = 1; i < n_dev; ++i)
+  {
+    try
+    {
+      workers.emplace_back(body, i);
+    }
+    catch (...)
+    {
+      inline_shards.push_back(i);
+    }
+  }
   body(0);
+  for (int i : inline_shards) body(i);
   for (auto& t : workers) t.join();
   for (int i = 0; i < n_dev; ++i)
     if (status[i] != RDYN_OK)
@@ -176,11 +202,28 @@ static int for_each_device(rdyn_multi_gpu* ctx, const std::function<int(int)>& f
   return RDYN_OK;
 }
 
-// a collective that failed inside a group: closing the group could wait for ever for the calls that were never made -- the
-// communicators are aborted instead and the context refuses further work
+// a collective that failed inside a group: closing the group as it stands could wait for ever for the calls that were never made --
+// the communicators are aborted FIRST, then the group is closed (with aborted communicators ncclGroupEnd returns instead of waiting;
+// its result is of no interest): the calling thread's group depth is back at zero, so whatever RCCL call it makes next -- a replacement
+// context's ncclCommInitAll, another context's collective -- is not captured into a group that nobody will ever close.  The context
+// then refuses further work.
 static int abort_collective(rdyn_multi_gpu* ctx, ncclResult_t r, const char* what, int device)
 {
+  // (message first: ncclGroupEnd below may overwrite RCCL's own last-error state)
   rdyn_set_error("RCCL error: %s (%s on device %d); the communicators were aborted: destroy the context", g_rccl.GetErrorString(r), what, device);
+  if (g_rccl.CommAbort)
+    for (auto& cm : ctx->comms)
+      if (cm) (void)g_rccl.CommAbort(cm);
+  (void)g_rccl.GroupEnd();
+  ctx->broken = true;
+  return RDYN_ERR_HIP;
+}
+// ncclGroupEnd itself failed: the collective may have been issued on some devices only -- same consequence
+static int group_end(rdyn_multi_gpu* ctx)
+{
+  const ncclResult_t r = g_rccl.GroupEnd();
+  if (r == kNcclSuccess) return RDYN_OK;
+  rdyn_set_error("RCCL error: %s (ncclGroupEnd); the communicators were aborted: destroy the context", g_rccl.GetErrorString(r));
   if (g_rccl.CommAbort)
     for (auto& cm : ctx->comms)
       if (cm) (void)g_rccl.CommAbort(cm);
@@ -212,10 +255,16 @@ int rdyn_multi_gpu_create(const int* devices, int n_devices, rdyn_multi_gpu** ou
     return RDYN_ERR_INVALID_ARGUMENT;
   }
   *out = nullptr;
+  // RDYN_TEST_ALIAS_DEVICES=1 (test infrastructure, tests/test_multi_gpu_alias.py): repeated ordinals are accepted -- n LOGICAL devices
+  // with their own streams, events and workspaces on one physical GPU, so that the n_dev > 1 code paths (one host thread per device,
+  // the grouped collective, the event ordering) run on a one-GPU machine; needs a collective library that serves such a clique
+  // (RDYN_RCCL_PATH = tests/cpp/rccl_stub.hip's .so: real RCCL refuses repeated ordinals)
+  const char* const alias_env = getenv("RDYN_TEST_ALIAS_DEVICES");
+  const bool alias = alias_env && alias_env[0] == '1';
   for (int i = 0; i < n_devices; ++i)
   {
     bool bad = devices[i] < 0;
-    for (int j = 0; j < i; ++j) bad = bad || devices[i] == devices[j];
+    for (int j = 0; j < i && !alias; ++j) bad = bad || devices[i] == devices[j];
     if (bad)
     {
       rdyn_set_error("rdyn_multi_gpu_create: device ordinals must be distinct and non-negative");
@@ -357,7 +406,7 @@ int rdyn_regressor_gram_multi_accumulate(rdyn_multi_gpu* ctx, const rdyn_chain* 
     ncclResult_t r = g_rccl.AllReduce(a, a, count, kNcclDouble, kNcclSum, ctx->comms[i], ctx->streams[i]);
     if (r != kNcclSuccess) return abort_collective(ctx, r, "ncclAllReduce", ctx->devices[i]);
   }
-  RDYN_NCCL_TRY(g_rccl.GroupEnd());
+  if (group_end(ctx) != RDYN_OK) return RDYN_ERR_HIP;
   if (accumulate)
     for (int i = 0; i < n_dev; ++i)
     {
@@ -440,7 +489,7 @@ int rdyn_identification_tsqr_multi(rdyn_multi_gpu* ctx, const rdyn_chain* chain,
     ncclResult_t r = g_rccl.AllGather(ws + off_own, ws + off_gather, f_bytes / sizeof(double), kNcclDouble, ctx->comms[i], ctx->streams[i]);
     if (r != kNcclSuccess) return abort_collective(ctx, r, "ncclAllGather", ctx->devices[i]);
   }
-  RDYN_NCCL_TRY(g_rccl.GroupEnd());
+  if (group_end(ctx) != RDYN_OK) return RDYN_ERR_HIP;
   // ---- every device folds the same stack in the same order, then expands: identical bits everywhere
   st = for_each_device(ctx, [&](int i) -> int {
     char* const ws = (char*)ctx->workspaces[i];

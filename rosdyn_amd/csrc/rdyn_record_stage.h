@@ -8,7 +8,12 @@
 // re-read) -- the copy-out of the regressor image kernel (rdyn_image_impl.h) for records that are produced
 //   * link by link (frames, twists, acceleration / jerk twists: PIECE bytes per link)  -> RecordRing<PIECE>
 //   * at once at the end of the sweep (tool frame, Jacobian, joint torque, inertia)     -> stage_small_records
-// Only wave-local ordering is needed (no barrier).  Preconditions, checked by the host (rdyn_api.cpp: natural strides, base pointer
+// Only wave-local ordering is needed (no barrier).  The INPUTS keep their per-lane loads: reading a wave's 64 input records as whole
+// lines into an LDS tile was built and measured (profiles/r6/sweep_sheet_input_tile.txt) -- every kernel the same or slower (getTwist
+// 91 -> 101 us, getWrench with its external wrenches through the record tile 234 -> 262 us): these kernels move 0.3-0.8 KB per sample
+// and are bound by the LIFETIME of a wave, not by the address unit; one more LDS hop in front of the first sincos costs more than the
+// strided loads do (and a load loop that waits per trip costs a whole memory round trip per trip: +27 us on a 129 us kernel).
+// Preconditions, checked by the host (rdyn_api.cpp: natural strides, base pointer
 // 128-byte aligned) and by the kernel (a full wave): everything else keeps the 8-byte stores.
 #ifndef RDYN_RECORD_STAGE_H
 #define RDYN_RECORD_STAGE_H
@@ -136,6 +141,7 @@ struct SmallRecords
     int e0 = 2 * lane - s0 * rec;
     const int ds = 128 / rec, de = 128 - ds * rec;  // wave-uniform
     char* dst = (char*)wave_records + lane * 16;
+#pragma unroll 4
     for (int it = 0; it < (rec + 1) / 2; ++it)
     {
       if (2 * (it * 64 + lane) < 64 * rec)
