@@ -111,6 +111,23 @@ def committed_traffic(kernel_tag):
         return None
 
 
+def committed_counter(tag, key):
+    """A counter-derived figure of profiles/pmc_latest.json (written from separate rocprofv3 --pmc passes on the builder's box)."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_latest.json")) as f:
+            e = json.load(f).get(tag)
+        return float(e[key]) if e and key in e else None
+    except (OSError, ValueError, KeyError):
+        return None
+
+
+# v_mfma_f64_16x16x4_f64 instructions per 16-sample tile: the fused regressor -> Gram kernel (rdyn_duo_gram.hip: descending column order,
+# zero bands on 16-column boundaries) and pass B of the preconditioned R factor (rdyn_cholqr.hip: product + Gram of the product)
+# (checked against SQ_INSTS_VALU_MFMA_MOPS_F64 / 4 of the committed counter passes: 8.25e6 per 1e6 samples at 6 joints, 4.8e7 per 4e6 at 7)
+GRAM_MFMA_PER_TILE = {6: 132, 7: 192}
+PASS_B_MFMA_PER_TILE = {7: 384}
+
+
 def algorithmic_bytes_per_eval(n, P):
     """3 n doubles read (q, Dq, DDq) + n written (tau) + n P written (dense Y)  -- SURVEY section 8(d)."""
     return 3 * n * 8 + n * 8 + n * P * 8
@@ -474,17 +491,40 @@ def extras_config3(dev, steps=5):
     report = chain.lastTsqrReport(N, ws_qr)   # which stage of the factorisation vouched for the result (decided on the device)
     f_eval = gram_flop_per_eval(n, P)
     tf = f_eval * N / (ms * 1e-3) / 1e12
-    # dense Householder convention for the factor of the (n N) x (P + 1) matrix [A | tau]: 2 rows cols^2
+    # dense Householder convention for the factor of the (n N) x (P + 1) matrix [A | tau]: 2 rows cols^2 -- a CONVENTION (the
+    # preconditioned CholeskyQR that runs does far fewer flops): kept as a labelled side value.  The utilisation figure is the MFMA-issue
+    # fraction: the v_mfma_f64_16x16x4_f64 instructions the call issues (pass A over the subsample + pass B over all rows: 384 per
+    # 16-sample tile at 7 joints, rdyn_cholqr.hip) x 64 issue cycles each, over the 1 024 SIMDs, against the time of the whole call
     qr_flop = 2.0 * n * N * (P + 1) ** 2
     qr_tf = qr_flop / (tsqr_ms * 1e-3) / 1e12
+    mfma_pass_b = (N / 16.0) * PASS_B_MFMA_PER_TILE.get(n, 0)
+    mfma_issue_ms = mfma_pass_b * 64.0 / (1024 * 2.4e9) * 1e3
+    gram_mfma = (N / 16.0) * GRAM_MFMA_PER_TILE.get(n, 0)
+    gram_issue_ms = gram_mfma * 64.0 / (1024 * 2.4e9) * 1e3
+    busy = committed_counter("gram_duo_n%d" % n, "mfma_busy")
+    busy_b = committed_counter("pgram_n%d" % n, "mfma_busy")
     return {"workload": "configs[2]: 7-DOF panda_like link0->link7 (n=7, P=70), N=%d, getRegressor -> Gram" % N,
             "value": N / (ms * 1e-3), "unit": "evals/s", "ms_per_step": ms, "tsqr_ms_per_step": tsqr_ms,
             "roofline": {"bound": "fp64-matrix", "achieved": tf, "peak": FP64_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": tf / FP64_MATRIX_PEAK_TFLOPS, "flop_per_eval_dense_syrk": f_eval, "kernel_ms": ms},
-            "tsqr_roofline": {"bound": "fp64-matrix", "achieved": qr_tf, "peak": FP64_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
-                              "frac": qr_tf / FP64_MATRIX_PEAK_TFLOPS, "flop_dense_householder": qr_flop, "ms": tsqr_ms,
+                         "frac": tf / FP64_MATRIX_PEAK_TFLOPS, "flop_per_eval_dense_syrk": f_eval, "kernel_ms": ms,
+                         # what the kernel really issues: MFMAs x 64 cycles over 1 024 SIMDs / launch time (zero bands skipped: fewer
+                         # flops than the dense-syrk convention credits), and the committed SQ_VALU_MFMA_BUSY_CYCLES fraction
+                         "mfma_issue_frac": gram_issue_ms / ms if gram_mfma else None, "mfma_per_launch": gram_mfma or None,
+                         "mfma_busy": busy, "mfma_busy_source": "committed counter pass (profiles/pmc_latest.json), not measured in this run" if busy else None},
+            "tsqr_roofline": {"bound": "fp64-matrix", "unit": "fraction of the fp64 MFMA issue rate",
+                              "frac": mfma_issue_ms / tsqr_ms if mfma_pass_b else None, "mfma_pass_b": mfma_pass_b or None, "ms": tsqr_ms,
+                              "mfma_busy_pass_b": busy_b,
+                              "dense_householder_convention": {"achieved_tflops": qr_tf, "frac": qr_tf / FP64_MATRIX_PEAK_TFLOPS, "flop": qr_flop,
+                                                               "note": "2 rows cols^2 credited to a route that does fewer flops: a convention, not a utilisation"},
                               "route": "rdyn_regressor_tsqr (R factor of [A | tau] without the normal equations)",
                               "report": report}}
+
+
+def extras_sweeps():
+    """tools/sweep_sheet.py: every getter of the reference's harness at N = 1e6 in the sample-major (drop-in) and the element-major layout:
+    ms per launch, the roofline that bounds it ("hbm" | "fp64-issue") and the fraction of it."""
+    from tools.sweep_sheet import measure_sweeps
+    return measure_sweeps()
 
 
 def extras_real_chains(dev, steps=5, N=1000000):
@@ -761,7 +801,11 @@ def main():
     b_eval = algorithmic_bytes_per_eval(n, P)
     kernel_ms = dev_ms / args.steps                       # one launch per step, back to back on one stream
     achieved = b_eval * N / (kernel_ms * 1e-3) / 1e9      # GB/s, algorithmic bytes per launch / launch duration
-    kernel = {"element": "k_local_sweep<6, REGRESSOR>", "stacked": "k_image_sweep<6, 0u, true, true> (NJ = 6, no fixed joints, nontemporal, stacked)", "per_sample": "k_image_sweep<6, 0u, true, false> (NJ = 6, no fixed joints, nontemporal, per-sample image)"}[args.y_layout]
+    # the names rocprofv3 --kernel-trace reports (profiles/r6/bench_default_summary.txt); template arguments of k_image_sweep: NJ, FIX
+    # (mask of joints that are not input joints), NT (nontemporal copy-out), STACKED, MAP (run-time row map, -1 = none), EXPAND
+    kernel = {"element": "void (anonymous namespace)::k_local_sweep<6, 0>(RdynSweepArgs)",
+              "stacked": "void (anonymous namespace)::k_image_sweep<6, 0u, true, true, -1, false>(RdynSweepArgs)",
+              "per_sample": "void (anonymous namespace)::k_image_sweep<6, 0u, true, false, -1, false>(RdynSweepArgs)"}[args.y_layout]
     traffic = committed_traffic("regressor_%s_n%d_P%d_N%d" % (args.y_layout, n, P, N))
 
     out = {
@@ -830,7 +874,9 @@ def main():
     torch.cuda.empty_cache()
     if not args.no_extras:
         out["extras"] = {"config3": guarded(extras_config3, dev), "config5": guarded(extras_config5, dev),
-                         "real_chains": guarded(extras_real_chains, dev)}
+                         "real_chains": guarded(extras_real_chains, dev),
+                         # the sweep kernels behind the reference's own timed calls (rosdyn_speed_test.cpp:109-192), both layouts, N = 1e6
+                         "sweeps": guarded(extras_sweeps)}
         torch.cuda.empty_cache()
     if not args.no_config4 and not args.no_library_config4:
         # the child owns ALL devices with its own communicator: it starts only once the other ranks' processes are gone (a process that

@@ -478,7 +478,7 @@ public:
     if ((size_t)DDDq.rows() != n) throw std::invalid_argument("Input data dimensions mismatch");
     // DDDq travels behind the output area of the staging buffer (the jerk record is 6 L doubles)
     double* d_dddq = out(6 * (size_t)m_links_number);
-    hip(hipMemcpyAsync(d_dddq, DDDq.data(), n * sizeof(double), hipMemcpyHostToDevice, nullptr));
+    std::memcpy(hout(6 * (size_t)m_links_number), DDDq.data(), n * sizeof(double));  // (mapped pinned memory: the kernel reads it in place)
     run(rdyn_twist_parts(m_h, &m_b, d_dddq, nullptr, nullptr, out(0)), 6 * m_links_number);
     return fill6(m_DDtwists);
   }
@@ -488,8 +488,7 @@ public:
     stage(&q, nullptr, nullptr);
     if ((size_t)DDDq.rows() != m_active_joints_number) throw std::invalid_argument("Input data dimensions mismatch");
     double* d_dddq = out(6 * (size_t)m_links_number);
-    hip(hipMemcpyAsync(d_dddq, DDDq.data(), m_active_joints_number * sizeof(double), hipMemcpyHostToDevice, nullptr));
-    hip(hipStreamSynchronize(nullptr));  // DDDq may be pageable caller memory
+    std::memcpy(hout(6 * (size_t)m_links_number), DDDq.data(), m_active_joints_number * sizeof(double));
     run(rdyn_jerk_parts(m_h, &m_b, d_dddq, out(0), nullptr), 6 * m_links_number);
     return fill6(m_DDtwists_linear_part);
   }
@@ -509,12 +508,10 @@ public:
   {
     if (ext_wrenches_in_link_frame.size() != m_links_number) throw std::invalid_argument("Input data dimensions mismatch");
     stage(&q, &Dq, &DDq);
-    std::vector<double> e(6 * (size_t)m_links_number);
+    double* const e = hout(6 * (size_t)m_links_number);  // behind the wrench record, in the mapped staging buffer
     for (unsigned l = 0; l < m_links_number; ++l)
       for (int i = 0; i < 6; ++i) e[6 * l + i] = ext_wrenches_in_link_frame[l](i);
     double* d_ext = out(6 * (size_t)m_links_number);
-    hip(hipMemcpyAsync(d_ext, e.data(), e.size() * sizeof(double), hipMemcpyHostToDevice, nullptr));
-    hip(hipStreamSynchronize(nullptr));  // `e` is pageable stack-owned memory
     run(rdyn_wrench(m_h, &m_b, d_ext, out(0)), 6 * m_links_number);
     return fill6(m_wrenches);
   }
@@ -546,12 +543,10 @@ public:
   {
     if (ext_wrenches_in_link_frame.size() != m_links_number) throw std::invalid_argument("Input data dimensions mismatch");
     stage(&q, &Dq, &DDq);
-    std::vector<double> e(6 * (size_t)m_links_number);
+    double* const e = hout(m_active_joints_number);  // behind the torque record, in the mapped staging buffer
     for (unsigned l = 0; l < m_links_number; ++l)
       for (int i = 0; i < 6; ++i) e[6 * l + i] = ext_wrenches_in_link_frame[l](i);
     double* d_ext = out(m_active_joints_number);
-    hip(hipMemcpyAsync(d_ext, e.data(), e.size() * sizeof(double), hipMemcpyHostToDevice, nullptr));
-    hip(hipStreamSynchronize(nullptr));  // `e` is pageable stack-owned memory
     run(rdyn_joint_torque_ext(m_h, &m_b, d_ext, out(0)), m_active_joints_number);
     return fillv(m_active_joint_torques);
   }
@@ -766,7 +761,9 @@ private:
   Matrix6Xd m_all_jacobian;
   VectorOfVector6d m_all_twists, m_all_Dtwists;
   MatrixXd m_all_inertia, m_all_regressor;
-  // staging: pinned host + device buffers for ONE sample
+  // staging for ONE sample: MAPPED pinned host memory (m_dev = the device's address of m_pin) -- the kernels read their inputs from and
+  // write their records to host memory directly, a call is one launch and one synchronisation (round 5 paid two hipMemcpyAsync on top:
+  // 20-35 us per getter against 10 us for the launch itself)
   double* m_dev = nullptr;
   double* m_pin = nullptr;
   size_t m_dev_doubles = 0, m_need_doubles = 0;
@@ -842,7 +839,6 @@ private:
   void release()
   {
     release_all();
-    if (m_dev) (void)hipFree(m_dev);
     if (m_pin) (void)hipHostFree(m_pin);
     m_dev = m_pin = nullptr;
     m_dev_doubles = 0;  // refresh() must allocate again (copy-assignment: release, clone, refresh)
@@ -903,16 +899,22 @@ private:
     m_b.device = -1;
     m_b.stream = nullptr;
   }
-  double* out(size_t off) { return m_dev + 3 * (size_t)m_active_joints_number + off; }
+  double* out(size_t off) { return m_dev + 3 * (size_t)m_active_joints_number + off; }   // device address ...
+  double* hout(size_t off) { return m_pin + 3 * (size_t)m_active_joints_number + off; }  // ... and host address of the same doubles
   void ensure_stage()
   {
     if (m_need_doubles <= m_dev_doubles) return;
-    if (m_dev) (void)hipFree(m_dev);
     if (m_pin) (void)hipHostFree(m_pin);
     m_dev = m_pin = nullptr;
     m_dev_doubles = 0;
-    hip(hipMalloc((void**)&m_dev, m_need_doubles * sizeof(double)));
-    hip(hipHostMalloc((void**)&m_pin, m_need_doubles * sizeof(double), hipHostMallocDefault));
+    hip(hipHostMalloc((void**)&m_pin, m_need_doubles * sizeof(double), hipHostMallocMapped));
+    std::memset(m_pin, 0, m_need_doubles * sizeof(double));
+    if (hipHostGetDevicePointer((void**)&m_dev, m_pin, 0) != hipSuccess)
+    {
+      (void)hipHostFree(m_pin);
+      m_dev = m_pin = nullptr;
+      throw std::runtime_error("HIP: pinned host memory is not addressable by the device");
+    }
     m_dev_doubles = m_need_doubles;
   }
   void stage(const VectorXd* q, const VectorXd* dq, const VectorXd* ddq)
@@ -926,7 +928,6 @@ private:
       if ((size_t)src[k]->rows() != n) throw std::invalid_argument("Input data dimensions mismatch");
       std::memcpy(m_pin + k * n, src[k]->data(), n * sizeof(double));
     }
-    hip(hipMemcpyAsync(m_dev, m_pin, 3 * n * sizeof(double), hipMemcpyHostToDevice, nullptr));
     m_b.q = m_dev;
     m_b.dq = dq ? m_dev + n : nullptr;
     m_b.ddq = ddq ? m_dev + 2 * n : nullptr;
@@ -934,8 +935,7 @@ private:
   void run(int status, size_t n_out)
   {
     chk(status);
-    hip(hipMemcpyAsync(m_pin + 3 * (size_t)m_active_joints_number, out(0), n_out * sizeof(double), hipMemcpyDeviceToHost, nullptr));
-    hip(hipStreamSynchronize(nullptr));
+    hip(hipStreamSynchronize(nullptr));  // the record is in m_pin: the kernel wrote host memory
     std::memcpy(m_host.data(), m_pin + 3 * (size_t)m_active_joints_number, n_out * sizeof(double));
   }
   bool localIk(VectorXd& sol, const Affine3d& T_b_t, const double* weight, const VectorXd& seed, double toll, int max_iterations)
@@ -951,10 +951,8 @@ private:
 #else
         pin[c * 3 + r] = T_b_t(r, c);
 #endif
-    hip(hipMemcpyAsync(out(0), pin, 12 * sizeof(double), hipMemcpyHostToDevice, nullptr));
     int32_t* flags = reinterpret_cast<int32_t*>(out(12 + n));
     chk(rdyn_local_ik(m_h, &m_b, out(0), weight, toll, max_iterations, out(12), flags, flags + 1));
-    hip(hipMemcpyAsync(pin + 12, out(12), (n + 1) * sizeof(double), hipMemcpyDeviceToHost, nullptr));
     hip(hipStreamSynchronize(nullptr));
     sol.resize((int)n);
     for (size_t i = 0; i < n; ++i) sol((int)i) = pin[12 + i];
