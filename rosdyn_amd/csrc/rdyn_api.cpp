@@ -383,6 +383,45 @@ int run_local(const rdyn_chain* c, const rdyn_batch* b, int mode, double* tau, d
   return RDYN_OK;
 }
 
+// regressor / inertia of a chain with more input joints than the unrolled kernels sweep (no reduced companion): the run-time-length
+// kernels of rdyn_long_local.hip -- rolled link and row loops, per-joint state in wave-private LDS
+int run_long_local(const rdyn_chain* c, const rdyn_batch* b, int mode, double* tau, double* Y, const rdyn_regressor_layout* yl, double* M)
+{
+  if (b->n_samples == 0) return RDYN_OK;
+  DeviceGuard g;
+  int st = g.enter(b->device);
+  if (st != RDYN_OK) return st;
+  RdynLongLocalArgs a;
+  memset(&a, 0, sizeof a);
+  st = device_const_long(c, &a.chain_long);
+  if (st != RDYN_OK) return st;
+  const int n = c->n_active();
+  a.q = b->q;
+  a.dq = b->dq;
+  a.ddq = b->ddq;
+  a.n_samples = b->n_samples;
+  rec_strides(b, n, &a.in_ss, &a.in_sj);
+  a.tau = tau;
+  a.tau_ss = a.in_ss;
+  a.tau_sj = a.in_sj;
+  a.Y = Y;
+  if (yl)
+  {
+    if (yl->stride_sample < 1 || yl->stride_row < 1 || yl->stride_col < 1)
+    {
+      rdyn_set_error("rdyn_regressor: strides must be positive");
+      return RDYN_ERR_INVALID_ARGUMENT;
+    }
+    a.y_ss = yl->stride_sample;
+    a.y_sr = yl->stride_row;
+    a.y_sc = yl->stride_col;
+  }
+  a.M = M;
+  rec_strides(b, (int64_t)n * n, &a.m_ss, &a.m_se);
+  RDYN_HIP_TRY(rdyn_launch_long_local(mode, c->n_joints(), a, (hipStream_t)b->stream));
+  return RDYN_OK;
+}
+
 }  // namespace
 
 extern "C"
@@ -443,25 +482,27 @@ int rdyn_joint_torque_nonlinear(const rdyn_chain* c, const rdyn_batch* b, double
 
 int rdyn_regressor(const rdyn_chain* c, const rdyn_batch* b, double* tau, double* Y, const rdyn_regressor_layout* yl)
 {
-  int st = check_batch(c, b, true, true, "rdyn_regressor", LONG_COMPANION);
+  int st = check_batch(c, b, true, true, "rdyn_regressor", LONG_KERNELS);
   if (st != RDYN_OK) return st;
   if (b->n_samples > 0 && (!Y || !yl))
   {
     rdyn_set_error("rdyn_regressor: null output or layout");
     return RDYN_ERR_INVALID_ARGUMENT;
   }
+  if (c->long_chain() && !c->reduced) return run_long_local(c, b, RDYN_MODE_REGRESSOR, tau, Y, yl, nullptr);
   return run_local(c, b, RDYN_MODE_REGRESSOR, tau, Y, yl, nullptr, true, true);
 }
 
 int rdyn_joint_inertia(const rdyn_chain* c, const rdyn_batch* b, double* M)
 {
-  int st = check_batch(c, b, false, false, "rdyn_joint_inertia", LONG_COMPANION);
+  int st = check_batch(c, b, false, false, "rdyn_joint_inertia", LONG_KERNELS);
   if (st != RDYN_OK) return st;
   if (!M && b->n_samples > 0)
   {
     rdyn_set_error("rdyn_joint_inertia: null output");
     return RDYN_ERR_INVALID_ARGUMENT;
   }
+  if (c->long_chain() && !c->reduced) return run_long_local(c, b, RDYN_MODE_INERTIA, nullptr, nullptr, nullptr, M);
   return run_local(c, b, RDYN_MODE_INERTIA, nullptr, nullptr, nullptr, M, false, false);
 }
 

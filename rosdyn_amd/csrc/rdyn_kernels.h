@@ -136,6 +136,22 @@ struct RdynKinArgs
 };
 hipError_t rdyn_launch_long_base(const RdynKinArgs& a, hipStream_t st);
 
+// regressor (+ fused torque) / joint inertia of a chain with more input joints than the unrolled kernels sweep (rdyn_long_local.hip)
+struct RdynLongLocalArgs
+{
+  const RdynLongChainConst* chain_long;
+  const double *q, *dq, *ddq;   // dq / ddq may be null (zero)
+  int64_t n_samples, in_ss, in_sj;
+  double* tau;                  // regressor mode, may be null
+  int64_t tau_ss, tau_sj;
+  double* Y;
+  int64_t y_ss, y_sr, y_sc;
+  double* M;
+  int64_t m_ss, m_se;
+};
+size_t rdyn_long_local_lds_bytes(int mode, int n_joints);
+hipError_t rdyn_launch_long_local(int mode, int n_joints, const RdynLongLocalArgs& a, hipStream_t st);  // mode: RDYN_MODE_REGRESSOR / RDYN_MODE_INERTIA
+
 // Gram / normal equations of a column-major rows x P matrix (rdyn_gram.hip)
 struct RdynGramArgs
 {

@@ -1,0 +1,363 @@
+// rdyn_long_local.hip -- getRegressor / getJointInertia of chains with MORE INPUT JOINTS than the unrolled kernels sweep (11 ..
+// RDYN_MAX_JOINTS input joints; chains of more than RDYN_MAX_SWEPT_JOINTS joints that have no reduced companion).
+//
+// The reference's default build has no bound on the number of joints (rosdyn_core/CMakeLists.txt:12-16); the kernels of
+// rdyn_kernels.hip keep one unit twist per upstream joint in registers (instantiated per joint count, every link unrolled), which ends
+// at ten.  Here the link loop AND the row loop are rolled (run-time trip counts, joint constants by scalar loads at wave-uniform
+// offsets into RdynLongChainConst) and the per-joint state lives in wave-private LDS, element-major ([value][joint][lane]: a lane
+// reads and writes its own column, conflict-free):
+//
+//   k_long_regressor   getRegressor (+ the fused joint torque tau = Y pi), primitives_impl.h:1295-1355.
+//     One forward sweep in base-frame coordinates exactly as getTwist / getDTwist state it (:1007-1008, :1116-1117); joint l parks its
+//     axis z_l and origin p_l (6 doubles) when the sweep passes it.  At link f the kinematic quantities are rotated into the link's own
+//     frame (w, al, d = R'(a + w x v - g)) and row l <= f of the link's 10 columns is j_l' W'_f with the closed form of the reference's
+//     ten basis-matrix products (:1324-1339, the same expression as rdyn_local_sweep_body.inc),
+//         W'_f = [ d | [al]x + [w]x[w]x | 0 ;  0 | -[d]x | L(al) + [w]x L(w) ],
+//     j_l = the unit twist of joint l at link f's origin in link f's axes: revolute (R' (z_l x (p_f - p_l)), R' z_l), prismatic
+//     (R' z_l, 0) -- the transposed operator of :1341-1347.  Rows l > f are the structural zeros of :690-691, written explicitly.
+//     ~70 fp64 fma per (row, link) and 10 stores; the output (n x 10 nJ doubles per sample: 32 KB at 20 joints) bounds the kernel.
+//   k_long_inertia     getJointInertia, :1357-1379: M = sum_f J_f' I_f J_f evaluated by composite bodies -- M(l1, l2) = s_l1' Ic_l2 s_l2
+//     for l1 <= l2, Ic_l = the spatial inertia of everything downstream of joint l.  A spatial inertia referred to the BASE origin and
+//     axes is ten numbers (m, h = m c, I_O) that simply add, so Ic_l = total - (the links upstream of joint l): two forward passes,
+//     no per-link storage (the device of rdyn_long_kin.hip's wrench recursion); the subtraction costs ~1e-16 of the chain's total
+//     inertia, far inside the parity tolerance.  O(n^2) instead of the reference's O(n^3).
+// Joint torques of such chains: the wrench recursion of rdyn_long_kin.hip (k_long_ext).
+#include <hip/hip_runtime.h>
+#include <atomic>
+#include "rdyn_device.h"
+#include "rdyn_devmath.h"
+#include "rdyn_kernels.h"
+
+namespace
+{
+typedef const RDYN_CONST_AS RdynLongChainConst* LongChainPtr;
+__device__ __forceinline__ LongChainPtr as_const_long(const RdynLongChainConst* p)
+{
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wold-style-cast"
+  return (LongChainPtr)p;
+#pragma clang diagnostic pop
+}
+
+// One step of computeFrames / computeScrews (primitives_impl.h:863-882): on entry R, p = frame of the parent link; on exit of the
+// child.  zl = the joint axis in the base frame (rotated by the PARENT frame, :879), d = p_child - p_parent.
+__device__ __forceinline__ void frame_step(JointRef J, double qf, double (&R)[9], V3& p, V3& zl, V3& d)
+{
+  const int type = J.type;
+  double Rpc[9];
+  V3 t = ld3(J.t);
+  if (type == RDYN_REVOLUTE)
+  {
+    double sn, cs;
+    rdyn_sincos(qf, &sn, &cs);
+    const double oc = 1.0 - cs;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) Rpc[i] = fma(sn, J.B[i], fma(oc, J.C[i], J.A[i]));
+  }
+  else
+  {
+#pragma unroll
+    for (int i = 0; i < 9; ++i) Rpc[i] = J.A[i];
+    if (type == RDYN_PRISMATIC) t = axpy(t, ld3(J.up), qf);
+  }
+  zl = rot(R, ld3(J.up));
+  d = rot(R, t);
+  double Rn[9];
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int cc = 0; cc < 3; ++cc) Rn[r * 3 + cc] = fma(R[r * 3 + 0], Rpc[cc], fma(R[r * 3 + 1], Rpc[3 + cc], R[r * 3 + 2] * Rpc[6 + cc]));
+#pragma unroll
+  for (int i = 0; i < 9; ++i) R[i] = Rn[i];
+  p = p + d;
+}
+
+// wave-private per-joint state: value v of joint j of the lane's sample at st[(v * nj + j) * 64 + lane]
+struct JointState
+{
+  double* st;
+  int nj;
+  __device__ __forceinline__ double& at(int v, int j) const { return st[(v * nj + j) * 64]; }
+  __device__ __forceinline__ void put3(int v0, int j, V3 x) const
+  {
+    at(v0, j) = x.x;
+    at(v0 + 1, j) = x.y;
+    at(v0 + 2, j) = x.z;
+  }
+  __device__ __forceinline__ V3 get3(int v0, int j) const { return mk(at(v0, j), at(v0 + 1, j), at(v0 + 2, j)); }
+};
+
+__global__ __launch_bounds__(64) void k_long_regressor(const RdynLongLocalArgs a)
+{
+  extern __shared__ __attribute__((aligned(16))) double joint_lds[];  // [7][nj][64]: z (3), p (3), tau (1)
+  LongChainPtr c = as_const_long(a.chain_long);
+  const int nj = c->n_joints;
+  const int lane = threadIdx.x;
+  const int64_t s = (int64_t)blockIdx.x * 64 + lane;
+  if (s >= a.n_samples) return;
+  const JointState js = {joint_lds + lane, nj};
+  const double* __restrict__ qp = a.q + s * a.in_ss;
+  const double* __restrict__ dqp = a.dq ? a.dq + s * a.in_ss : nullptr;
+  const double* __restrict__ ddqp = a.ddq ? a.ddq + s * a.in_ss : nullptr;
+  double* const ys = a.Y + s * a.y_ss;
+  const bool nt = a.y_ss == 1;  // element-major: every store instruction of the wave is 512 contiguous bytes, written once
+  const V3 g = mk(c->g[0], c->g[1], c->g[2]);
+
+  double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+  V3 p = mk(0, 0, 0);
+  V3 vlin = mk(0, 0, 0), vang = mk(0, 0, 0), alin = mk(0, 0, 0), aang = mk(0, 0, 0);
+#pragma unroll 1
+  for (int f = 0; f < nj; ++f)
+  {
+    JointRef J = c->j[f];
+    const int type = J.type;
+    const int idx = J.in_idx;
+    double qf = 0.0, dqf = 0.0, ddqf = 0.0;
+    if (idx >= 0)
+    {
+      const int64_t o = idx * a.in_sj;
+      qf = qp[o];
+      if (dqp) dqf = dqp[o];
+      if (ddqp) ddqf = ddqp[o];
+    }
+    V3 zl, d;
+    frame_step(J, qf, R, p, zl, d);
+    {
+      // twists (getTwist, :1007-1008) and spatial accelerations (getDTwist, :1116-1117), base frame, at the link's origin
+      V3 Sl = mk(0, 0, 0), Sa = mk(0, 0, 0);
+      if (type == RDYN_REVOLUTE) Sa = zl;
+      else if (type == RDYN_PRISMATIC) Sl = zl;
+      const V3 nvl = axpy(vlin + cross(vang, d), Sl, dqf);
+      const V3 nva = axpy(vang, Sa, dqf);
+      const V3 cl = cross(nva, Sl) + cross(nvl, Sa);  // spatialCrossProduct(v, S), sva.h:88-93
+      const V3 ca = cross(nva, Sa);
+      alin = axpy(axpy(alin + cross(aang, d), cl, dqf), Sl, ddqf);
+      aang = axpy(axpy(aang, ca, dqf), Sa, ddqf);
+      vlin = nvl;
+      vang = nva;
+    }
+    js.put3(0, f, zl);
+    js.put3(3, f, p);
+    js.at(6, f) = 0.0;
+    // ---- link f + 1 in its own frame: closed-form wrench regressor (rdyn_local_sweep_body.inc)
+    const V3 w = rotT(R, vang), vl = rotT(R, vlin), al = rotT(R, aang);
+    const V3 dd = rotT(R, alin - g) + cross(w, vl);
+    const double wxy = w.x * w.y, wxz = w.x * w.z, wyz = w.y * w.z;
+    const double wxx = w.x * w.x, wyy = w.y * w.y, wzz = w.z * w.z;
+    const double b00 = -(wyy + wzz), b01 = wxy - al.z, b02 = wxz + al.y;
+    const double b10 = wxy + al.z, b11 = -(wxx + wzz), b12 = wyz - al.x;
+    const double b20 = wxz - al.y, b21 = wyz + al.x, b22 = -(wxx + wyy);
+    const RDYN_CONST_AS double* pi = J.pi;
+    double* const yf = ys + (int64_t)(10 * f) * a.y_sc;
+#pragma unroll 1
+    for (int l = 0; l < nj; ++l)
+    {
+      JointRef Jl = c->j[l];
+      const int row = Jl.in_idx;
+      if (row < 0) continue;
+      double* const yr = yf + row * a.y_sr;
+      double y[10];
+      if (l <= f)
+      {
+        const V3 z = js.get3(0, l);
+        V3 L, A;
+        if (Jl.type == RDYN_REVOLUTE)
+        {
+          A = rotT(R, z);
+          L = rotT(R, cross(z, p - js.get3(3, l)));
+        }
+        else
+        {
+          A = mk(0, 0, 0);
+          L = Jl.type == RDYN_PRISMATIC ? rotT(R, z) : mk(0, 0, 0);
+        }
+        const V3 dxA = cross(dd, A);
+        const V3 x = cross(A, w);
+        y[0] = dot(L, dd);
+        y[1] = fma(L.x, b00, fma(L.y, b10, fma(L.z, b20, dxA.x)));
+        y[2] = fma(L.x, b01, fma(L.y, b11, fma(L.z, b21, dxA.y)));
+        y[3] = fma(L.x, b02, fma(L.y, b12, fma(L.z, b22, dxA.z)));
+        y[4] = fma(A.x, al.x, x.x * w.x);
+        y[5] = fma(A.x, al.y, fma(A.y, al.x, fma(x.x, w.y, x.y * w.x)));
+        y[6] = fma(A.x, al.z, fma(A.z, al.x, fma(x.x, w.z, x.z * w.x)));
+        y[7] = fma(A.y, al.y, x.y * w.y);
+        y[8] = fma(A.y, al.z, fma(A.z, al.y, fma(x.y, w.z, x.z * w.y)));
+        y[9] = fma(A.z, al.z, x.z * w.z);
+        double tl = js.at(6, l);
+#pragma unroll
+        for (int k = 0; k < 10; ++k) tl = fma(y[k], pi[k], tl);
+        js.at(6, l) = tl;
+      }
+      else
+      {
+#pragma unroll
+        for (int k = 0; k < 10; ++k) y[k] = 0.0;  // row of a joint downstream of this link (:690-691)
+      }
+      if (nt)
+      {
+#pragma unroll
+        for (int k = 0; k < 10; ++k) __builtin_nontemporal_store(y[k], yr + k * a.y_sc);
+      }
+      else
+      {
+        // row-contiguous layouts: a lane's stores of one link cover ONE run of 80 n bytes; default policy, so that the 8-byte pieces
+        // of a line meet in L2
+#pragma unroll
+        for (int k = 0; k < 10; ++k) yr[k * a.y_sc] = y[k];
+      }
+    }
+  }
+  if (a.tau)
+  {
+    double* __restrict__ tp = a.tau + s * a.tau_ss;
+#pragma unroll 1
+    for (int l = 0; l < nj; ++l)
+    {
+      const int row = c->j[l].in_idx;
+      if (row >= 0) tp[row * a.tau_sj] = js.at(6, l);
+    }
+  }
+}
+
+// ten numbers of a spatial inertia about the BASE origin, base axes: m, h = m c, I_O (xx xy xz yy yz zz)
+struct Inertia10
+{
+  double m;
+  V3 h;
+  double I[6];
+};
+__device__ __forceinline__ Inertia10 zero10()
+{
+  Inertia10 r;
+  r.m = 0.0;
+  r.h = mk(0, 0, 0);
+#pragma unroll
+  for (int i = 0; i < 6; ++i) r.I[i] = 0.0;
+  return r;
+}
+// the link's [m, m c, Io] (its own frame, about its own origin: primitives_impl.h:399-417) referred to the base origin and axes:
+//   h_b = m p + R h,   I_O = R Io R' + (m |p|^2 + 2 p.hb) 1 - (m p p' + p hb' + hb p'),   hb = R h
+template <class Ptr>
+__device__ __forceinline__ Inertia10 to_base(Ptr pi, const double (&R)[9], V3 p)
+{
+  Inertia10 r;
+  const double m = pi[0];
+  const V3 hb = rot(R, mk(pi[1], pi[2], pi[3]));
+  r.m = m;
+  r.h = axpy(hb, p, m);
+  // R Io R': columns of Io R' first
+  const V3 c0 = symv(pi + 4, mk(R[0], R[1], R[2])), c1 = symv(pi + 4, mk(R[3], R[4], R[5])), c2 = symv(pi + 4, mk(R[6], R[7], R[8]));  // Io r_i (r_i = row i of R)
+  const V3 r0 = mk(R[0], R[1], R[2]), r1 = mk(R[3], R[4], R[5]), r2 = mk(R[6], R[7], R[8]);
+  const double tr = m * dot(p, p) + 2.0 * dot(p, hb);
+  r.I[0] = dot(r0, c0) + tr - (m * p.x * p.x + 2.0 * p.x * hb.x);
+  r.I[1] = dot(r0, c1) - (m * p.x * p.y + p.x * hb.y + hb.x * p.y);
+  r.I[2] = dot(r0, c2) - (m * p.x * p.z + p.x * hb.z + hb.x * p.z);
+  r.I[3] = dot(r1, c1) + tr - (m * p.y * p.y + 2.0 * p.y * hb.y);
+  r.I[4] = dot(r1, c2) - (m * p.y * p.z + p.y * hb.z + hb.y * p.z);
+  r.I[5] = dot(r2, c2) + tr - (m * p.z * p.z + 2.0 * p.z * hb.z);
+  return r;
+}
+
+__global__ __launch_bounds__(64) void k_long_inertia(const RdynLongLocalArgs a)
+{
+  extern __shared__ __attribute__((aligned(16))) double joint_lds[];  // [6][nj][64]: the unit twist of joint j about the base origin (lin, ang)
+  LongChainPtr c = as_const_long(a.chain_long);
+  const int nj = c->n_joints, n = c->n_active;
+  const int lane = threadIdx.x;
+  const int64_t s = (int64_t)blockIdx.x * 64 + lane;
+  if (s >= a.n_samples) return;
+  const JointState js = {joint_lds + lane, nj};
+  const double* __restrict__ qp = a.q + s * a.in_ss;
+  double* __restrict__ mp = a.M + s * a.m_ss;
+  Inertia10 total = zero10(), upstream = zero10();
+#pragma unroll 1
+  for (int pass = 0; pass < 2; ++pass)
+  {
+    double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    V3 p = mk(0, 0, 0);
+#pragma unroll 1
+    for (int f = 0; f < nj; ++f)
+    {
+      JointRef J = c->j[f];
+      const int idx = J.in_idx;
+      V3 zl, d;
+      frame_step(J, idx >= 0 ? qp[idx * a.in_sj] : 0.0, R, p, zl, d);
+      const Inertia10 own = to_base(J.pi, R, p);
+      if (pass == 0)
+      {
+        total.m += own.m;
+        total.h = total.h + own.h;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) total.I[i] += own.I[i];
+        // unit twist of joint f referred to the base origin: revolute (p x z, z), prismatic (z, 0)
+        V3 sl = mk(0, 0, 0), sa = mk(0, 0, 0);
+        if (J.type == RDYN_REVOLUTE)
+        {
+          sl = cross(p, zl);
+          sa = zl;
+        }
+        else if (J.type == RDYN_PRISMATIC)
+          sl = zl;
+        js.put3(0, f, sl);
+        js.put3(3, f, sa);
+        continue;
+      }
+      if (idx >= 0)
+      {
+        // composite body downstream of joint f: everything but the links upstream of it
+        const double m = total.m - upstream.m;
+        const V3 h = total.h - upstream.h;
+        double I[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) I[i] = total.I[i] - upstream.I[i];
+        const V3 sl = js.get3(0, f), sa = js.get3(3, f);
+        // momentum of the composite body under the joint's unit twist: F = m v + w x h, N = h x v + I_O w
+        const V3 F = axpy(cross(sa, h), sl, m);
+        const V3 N = cross(h, sl) + symv(I, sa);
+#pragma unroll 1
+        for (int l = 0; l <= f; ++l)
+        {
+          const int r1 = c->j[l].in_idx;
+          if (r1 < 0) continue;
+          const double v = dot(js.get3(0, l), F) + dot(js.get3(3, l), N);
+          mp[(int64_t)(idx * n + r1) * a.m_se] = v;
+          mp[(int64_t)(r1 * n + idx) * a.m_se] = v;
+        }
+      }
+      upstream.m += own.m;
+      upstream.h = upstream.h + own.h;
+#pragma unroll
+      for (int i = 0; i < 6; ++i) upstream.I[i] += own.I[i];
+    }
+  }
+}
+
+hipError_t allow_big_lds(const void* fn, size_t bytes)
+{
+  if (bytes <= 64 * 1024) return hipSuccess;
+  return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+}
+}  // namespace
+
+size_t rdyn_long_local_lds_bytes(int mode, int n_joints) { return (size_t)(mode == RDYN_MODE_INERTIA ? 6 : 7) * n_joints * 64 * sizeof(double); }
+
+hipError_t rdyn_launch_long_local(int mode, int n_joints, const RdynLongLocalArgs& a, hipStream_t st)
+{
+  if (a.n_samples <= 0) return hipSuccess;
+  const size_t lds = rdyn_long_local_lds_bytes(mode, n_joints);
+  if (lds > 160 * 1024) return hipErrorInvalidValue;
+  const dim3 grid((unsigned)((a.n_samples + 63) / 64));
+  if (mode == RDYN_MODE_INERTIA)
+  {
+    hipError_t e = allow_big_lds((const void*)k_long_inertia, lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_long_inertia, grid, dim3(64), lds, st, a);
+  }
+  else
+  {
+    hipError_t e = allow_big_lds((const void*)k_long_regressor, lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_long_regressor, grid, dim3(64), lds, st, a);
+  }
+  return hipGetLastError();
+}

@@ -55,7 +55,7 @@ def _cases():
     return {
         "ur10_long": (ur, "base_link", "tcp", None),                                        # 14 joints, 6 input joints
         "ur10_long_permuted": (ur, "base_link", "tcp", ["wrist_2_joint", "shoulder_pan_joint", "elbow_joint", "wrist_3_joint"]),
-        "gen20_all": (g20, "l0", "l20", None),                                              # 14 input joints (> 10: kinematics only)
+        "gen20_all": (g20, "l0", "l20", None),                                              # 14 input joints (> 10: rdyn_long_local.hip serves regressor / inertia)
         "gen20_permuted": (g20, "l0", "l20", ["j13", "j0", "j9", "j4", "j16", "j1", "j7"]),
         "gen32_all": (g32, "l0", "l32", None),                                              # the longest chain a build holds
     }
@@ -158,17 +158,76 @@ def test_long_chain_permuted_inputs_regressor_torque_inertia(case):
     _close(chain.getJointInertia(eq, layout="element").cpu().numpy().transpose(2, 1, 0), ref.joint_inertia(q), "M")
 
 
-def test_long_chain_more_than_ten_input_joints_is_kinematics_only():
+def generated_revolute_chain(nj, seed):
+    """nj REVOLUTE joints, every one an input joint, every link with inertial data."""
+    from rosdyn_amd.samples import uniform_pm1
+    r = uniform_pm1(seed, (nj + 1, 16))
+    links, joints = ["<link name='l0'/>"], []
+    for i in range(nj):
+        k = r[i]
+        joints.append(
+            "<joint name='j%d' type='revolute'><parent link='l%d'/><child link='l%d'/>"
+            "<origin xyz='%.17g %.17g %.17g' rpy='%.17g %.17g %.17g'/><axis xyz='%.17g %.17g %.17g'/>"
+            "<limit lower='-3' upper='3' effort='10' velocity='2'/></joint>"
+            % (i, i, i + 1, 0.1 * k[0], 0.1 * k[1], 0.08 + 0.05 * k[2], k[3], k[4], k[5], k[6], k[7], 1.0 + 0.5 * k[8]))
+        links.append(
+            "<link name='l%d'><inertial><origin xyz='%.17g %.17g %.17g' rpy='%.17g %.17g 0'/><mass value='%.17g'/>"
+            "<inertia ixx='%.17g' ixy='%.17g' ixz='%.17g' iyy='%.17g' iyz='%.17g' izz='%.17g'/></inertial></link>"
+            % (i + 1, 0.05 * k[9], 0.05 * k[10], 0.05 * k[11], 0.3 * k[12], 0.3 * k[13], 1.2 + k[14],
+               0.02, 0.002 * k[15], -0.001, 0.03, 0.0015, 0.025))
+    return "<robot name='rev%d'>%s%s</robot>" % (nj, "".join(links), "".join(joints))
+
+
+@pytest.mark.parametrize("case", ["rev14", "rev20", "rev32", "gen20_all", "gen32_all", "gen20_twelve_permuted"])
+def test_long_chain_more_than_ten_input_joints_regressor_torque_inertia(case):
+    """Round 6: regressor (+ fused torque) and joint inertia of chains with MORE than ten input joints -- the run-time-length kernels of
+    rdyn_long_local.hip (rolled link and row loops, per-joint state in wave-private LDS) -- against the C oracle, all three regressor
+    layouts, both input layouts; N = 200 leaves a ragged wave.  Round 5 answered RDYN_ERR_UNSUPPORTED here.  The reference's default
+    build has no bound on the number of joints (rosdyn_core/CMakeLists.txt:12-16, primitives_impl.h:1295-1379)."""
     torch = pytest.importorskip("torch")
+    from oracle.oracle import OracleChain
+    from rosdyn_amd import Chain
     from rosdyn_amd.samples import trajectory_batch
-    chain, ref = _pair("gen20_all")
-    q, dq, ddq = trajectory_batch(3, 64, ref.n)
+    inputs = None
+    if case.startswith("rev"):
+        nj = int(case[3:])
+        xml, base, tool = generated_revolute_chain(nj, 1000 + nj), "l0", "l%d" % nj
+    elif case == "gen20_twelve_permuted":
+        xml, base, tool = generated_long_chain(20, 2020), "l0", "l20"
+        inputs = ["j13", "j0", "j9", "j4", "j16", "j1", "j7", "j19", "j3", "j10", "j6", "j12"]   # 12 of the 14 moving joints, out of chain order
+    else:
+        xml, base, tool, inputs = _cases()[case]
+    chain, ref = Chain(xml, base, tool, GRAV), OracleChain(xml, base, tool, GRAV, input_joint_names=inputs)
+    if inputs:
+        assert chain.setInputJointsName(inputs)
+    n, P = ref.n, ref.P
+    assert n > 10 and chain.getActiveJointsNumber() == n
+    N = 200
+    q, dq, ddq = trajectory_batch(61, N, n)
+    Yr, tr, Mr = ref.regressor(q, dq, ddq), ref.joint_torque(q, dq, ddq), ref.joint_inertia(q)
     tq, tdq, tddq = (torch.from_numpy(x).cuda() for x in (q, dq, ddq))
-    with pytest.raises(Exception, match="at most 10 input joints"):
-        chain.getRegressor(tq, tdq, tddq)
-    # ... the joint torques are: read off the wrench recursion of the run-time-length kernels (primitives_impl.h:1264-1272)
-    _close(chain.getJointTorque(tq, tdq, tddq).cpu().numpy(), ref.joint_torque(q, dq, ddq), "tau, 14 input joints")
-    _close(chain.getJointTorqueNonLinearPart(tq, tdq).cpu().numpy(), ref.joint_torque(q, dq, 0 * ddq), "non-linear part, 14 input joints")
+    eq, edq, eddq = (torch.from_numpy(np.ascontiguousarray(x.T)).cuda() for x in (q, dq, ddq))
+    Y, tau = chain.getRegressor(eq, edq, eddq, layout="element", with_torque=True)
+    _close(Y.cpu().numpy().transpose(2, 1, 0), Yr, "Y element")
+    _close(tau.cpu().numpy().T, tr, "tau fused (element)")
+    Y, tau = chain.getRegressor(tq, tdq, tddq, with_torque=True)
+    _close(Y.cpu().numpy().transpose(0, 2, 1), Yr, "Y per-sample")
+    _close(tau.cpu().numpy(), tr, "tau fused")
+    Ys = chain.getRegressor(tq, tdq, tddq, y_layout="stacked")
+    _close(Ys.cpu().numpy().reshape(P, N, n).transpose(1, 2, 0), Yr, "Y stacked")
+    # Y pi = tau with the chain's own nominal parameters (the identity of SURVEY.md section 4)
+    _close(np.einsum("snp,p->sn", Y.cpu().numpy().transpose(0, 2, 1), chain.getNominalParameters()), tr, "Y pi")
+    _close(chain.getJointInertia(eq, layout="element").cpu().numpy().transpose(2, 1, 0), Mr, "M element")
+    _close(chain.getJointInertia(tq).cpu().numpy().transpose(0, 2, 1), Mr, "M sample")
+    # the joint torques of such chains: the wrench recursion of the run-time-length kernels (primitives_impl.h:1264-1272)
+    _close(chain.getJointTorque(tq, tdq, tddq).cpu().numpy(), tr, "getJointTorque")
+    _close(chain.getJointTorqueNonLinearPart(tq, tdq).cpu().numpy(), ref.joint_torque(q, dq, 0 * ddq), "non-linear part")
+    # every getter of the samples through the one entry point (rdyn_evaluate_all serves long chains by the single-purpose launches)
+    o = chain.evaluateAll(tq, tdq, tddq)
+    _close(o["Y"].cpu().numpy().transpose(0, 2, 1), Yr, "evaluateAll Y")
+    _close(o["M"].cpu().numpy().transpose(0, 2, 1), Mr, "evaluateAll M")
+    _close(o["tau"].cpu().numpy(), tr, "evaluateAll tau")
+    _close(o["T_links"].cpu().numpy().transpose(0, 1, 3, 2), ref.fk(q), "evaluateAll T")
 
 
 @pytest.mark.parametrize("case", ["ur10_long", "gen20_permuted"])
