@@ -415,7 +415,14 @@ int run_long_local(const rdyn_chain* c, const rdyn_batch* b, int mode, double* t
     a.y_ss = yl->stride_sample;
     a.y_sr = yl->stride_row;
     a.y_sc = yl->stride_col;
+    // row-contiguous layouts: every link's block through the wave's LDS tile, copied out 16 bytes per lane
+    if (yl->stride_row == 1 && ((uintptr_t)Y & 15) == 0 && !probe_env("RDYN_NO_EXPAND_STAGING"))
+    {
+      if (yl->stride_col == n && yl->stride_sample % 2 == 0 && yl->stride_sample >= (int64_t)n * 10 * c->n_joints()) a.stage = 1;
+      else if (yl->stride_sample == n && yl->stride_col % 2 == 0 && yl->stride_col >= b->n_samples * n) a.stage = 2;
+    }
   }
+  a.n_active = n;
   a.M = M;
   rec_strides(b, (int64_t)n * n, &a.m_ss, &a.m_se);
   RDYN_HIP_TRY(rdyn_launch_long_local(mode, c->n_joints(), a, (hipStream_t)b->stream));
@@ -1083,9 +1090,18 @@ static bool gram_only_through_reduced(const rdyn_chain* c, int n_comp_cols)
   return c->long_chain() || (c->reduced && rdyn_gram_blocks_for(10 * c->n_joints() + n_comp_cols) > 7);
 }
 
+// a chain with more input joints than the unrolled kernels sweep (no companion) whose own columns still fit the Gram kernel: 11 input
+// joints (110 columns + tau_meas = 111) -- chunk images by rdyn_long_local.hip, contracted by k_gram
+static bool gram_by_long_images(const rdyn_chain* c) { return c->long_chain() && !c->reduced && rdyn_gram_blocks_for(10 * c->n_joints()) <= 7; }
+
 size_t rdyn_regressor_gram_workspace_bytes(const rdyn_chain* c, int64_t chunk_samples)
 {
   if (!c) return 0;
+  if (gram_by_long_images(c))
+  {
+    const int P = 10 * c->n_joints();
+    return (gram_slab_bytes(P) + (size_t)default_chunk(chunk_samples) * c->n_active() * (P + 1) * sizeof(double) + 255) & ~(size_t)255;
+  }
   if (gram_only_through_reduced(c, 0))
   {
     // only the reduced companion is swept: its workspace + its normal equations behind it
@@ -1210,7 +1226,8 @@ static bool build_lds_tile(const rdyn_chain* c, int n_comp_cols, bool dummy_slot
 int rdyn_regressor_gram(const rdyn_chain* c, const rdyn_batch* b, const double* tau_meas, double* G, double* cvec, double* bb,
                         int accumulate, int64_t chunk_samples, void* workspace, size_t workspace_bytes)
 {
-  int st = check_batch(c, b, true, true, "rdyn_regressor_gram", LONG_COMPANION);
+  const bool long_images = c && gram_by_long_images(c);
+  int st = check_batch(c, b, true, true, "rdyn_regressor_gram", long_images ? LONG_KERNELS : LONG_COMPANION);
   if (st != RDYN_OK) return st;
   if (!G || !workspace)
   {
@@ -1218,6 +1235,56 @@ int rdyn_regressor_gram(const rdyn_chain* c, const rdyn_batch* b, const double* 
     return RDYN_ERR_INVALID_ARGUMENT;
   }
   const int n = c->n_active(), P = 10 * c->n_joints();
+  if (long_images)
+  {
+    const int64_t chunk = default_chunk(chunk_samples), N = b->n_samples;
+    if (workspace_bytes < rdyn_regressor_gram_workspace_bytes(c, chunk))
+    {
+      rdyn_set_error("rdyn_regressor_gram: workspace too small");
+      return RDYN_ERR_INVALID_ARGUMENT;
+    }
+    DeviceGuard g;
+    st = g.enter(b->device);
+    if (st != RDYN_OK) return st;
+    hipStream_t stream = (hipStream_t)b->stream;
+    if (N == 0)
+    {
+      if (!accumulate)
+      {
+        RDYN_HIP_TRY(hipMemsetAsync(G, 0, sizeof(double) * P * P, stream));
+        if (cvec) RDYN_HIP_TRY(hipMemsetAsync(cvec, 0, sizeof(double) * P, stream));
+        if (bb) RDYN_HIP_TRY(hipMemsetAsync(bb, 0, sizeof(double), stream));
+      }
+      return RDYN_OK;
+    }
+    double* const slabs = (double*)workspace;
+    double* const image = (double*)((char*)workspace + gram_slab_bytes(P));
+    const int64_t in_step = (b->layout == RDYN_LAYOUT_SAMPLE_MAJOR) ? n : 1;
+    for (int64_t s0 = 0; s0 < N; s0 += chunk)
+    {
+      const int64_t cnt = (N - s0 < chunk) ? (N - s0) : chunk;
+      RdynLongLocalArgs a;
+      memset(&a, 0, sizeof a);
+      st = device_const_long(c, &a.chain_long);
+      if (st != RDYN_OK) return st;
+      a.q = b->q + s0 * in_step;
+      a.dq = b->dq + s0 * in_step;
+      a.ddq = b->ddq + s0 * in_step;
+      a.bcol = tau_meas ? tau_meas + s0 * in_step : nullptr;
+      a.bcol_col = P;
+      a.n_samples = cnt;
+      rec_strides(b, n, &a.in_ss, &a.in_sj);  // element-major: the joint stride stays the FULL batch's N
+      a.Y = image;                             // dense element-major image of this chunk: rows j * cnt + s, lda = n * cnt
+      a.y_ss = 1;
+      a.y_sr = cnt;
+      a.y_sc = (int64_t)n * cnt;
+      RDYN_HIP_TRY(rdyn_launch_long_local(RDYN_MODE_REGRESSOR, c->n_joints(), a, stream));
+      st = gram_launch(image, (int64_t)n * cnt, (int64_t)n * cnt, P, tau_meas ? image + (int64_t)P * n * cnt : nullptr, G, cvec, bb, s0 > 0 ? 1 : 0,
+                       s0 + cnt >= N, accumulate ? 1 : 0, slabs, stream);
+      if (st != RDYN_OK) return st;
+    }
+    return RDYN_OK;
+  }
   if (gram_only_through_reduced(c, 0))
   {
     const size_t need = rdyn_regressor_gram_workspace_bytes(c, 0);

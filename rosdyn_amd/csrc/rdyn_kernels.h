@@ -148,6 +148,14 @@ struct RdynLongLocalArgs
   int64_t y_ss, y_sr, y_sc;
   double* M;
   int64_t m_ss, m_se;
+  // regressor mode, may be null: the measured torque (layout of q), copied into regressor column bcol_col with the Y addressing -- the
+  // "b" column of the chunk images rdyn_regressor_gram hands to k_gram
+  const double* bcol;
+  int bcol_col;
+  // regressor mode: 1 = per-sample images (stride_row 1, stride_col n_active), 2 = the stacked matrix (stride_sample n_active) -- a link's
+  // block through a wave-private LDS tile two columns at a time, copied out 16 bytes per lane; 0 = stores from the computing lane
+  int stage;
+  int n_active;
 };
 size_t rdyn_long_local_lds_bytes(int mode, int n_joints);
 hipError_t rdyn_launch_long_local(int mode, int n_joints, const RdynLongLocalArgs& a, hipStream_t st);  // mode: RDYN_MODE_REGRESSOR / RDYN_MODE_INERTIA

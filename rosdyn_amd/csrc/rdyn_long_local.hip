@@ -24,6 +24,7 @@
 // Joint torques of such chains: the wrench recursion of rdyn_long_kin.hip (k_long_ext).
 #include <hip/hip_runtime.h>
 #include <atomic>
+#include <type_traits>
 #include "rdyn_device.h"
 #include "rdyn_devmath.h"
 #include "rdyn_kernels.h"
@@ -87,19 +88,88 @@ struct JointState
   __device__ __forceinline__ V3 get3(int v0, int j) const { return mk(at(v0, j), at(v0 + 1, j), at(v0 + 2, j)); }
 };
 
+// columns 2 G, 2 G + 1 of one row of a link's block (the closed form above, one column group at a time: the staged kernel forms a link's
+// block in five passes of two columns, see below)
+struct RowCtx
+{
+  V3 w, al, dd;
+  double b00, b01, b02, b10, b11, b12, b20, b21, b22;
+};
+template <int G>
+__device__ __forceinline__ void y_pair(const RowCtx& k, V3 L, V3 A, double& ya, double& yb)
+{
+  if constexpr (G == 0)
+  {
+    const V3 dxA = cross(k.dd, A);
+    ya = dot(L, k.dd);
+    yb = fma(L.x, k.b00, fma(L.y, k.b10, fma(L.z, k.b20, dxA.x)));
+  }
+  else if constexpr (G == 1)
+  {
+    const V3 dxA = cross(k.dd, A);
+    ya = fma(L.x, k.b01, fma(L.y, k.b11, fma(L.z, k.b21, dxA.y)));
+    yb = fma(L.x, k.b02, fma(L.y, k.b12, fma(L.z, k.b22, dxA.z)));
+  }
+  else
+  {
+    const V3 x = cross(A, k.w);
+    if constexpr (G == 2)
+    {
+      ya = fma(A.x, k.al.x, x.x * k.w.x);
+      yb = fma(A.x, k.al.y, fma(A.y, k.al.x, fma(x.x, k.w.y, x.y * k.w.x)));
+    }
+    else if constexpr (G == 3)
+    {
+      ya = fma(A.x, k.al.z, fma(A.z, k.al.x, fma(x.x, k.w.z, x.z * k.w.x)));
+      yb = fma(A.y, k.al.y, x.y * k.w.y);
+    }
+    else
+    {
+      ya = fma(A.y, k.al.z, fma(A.z, k.al.y, fma(x.y, k.w.z, x.z * k.w.y)));
+      yb = fma(A.z, k.al.z, x.z * k.w.z);
+    }
+  }
+}
+
+typedef double ll_d2u __attribute__((ext_vector_type(2), aligned(8)));
+typedef double ll_d2a __attribute__((ext_vector_type(2), aligned(16)));
+__device__ __forceinline__ void ll_wave_fence()
+{
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// STAGE 0: every value stored from the lane that computed it (element-major / free strides: 512 contiguous bytes per store instruction).
+// STAGE 1 / 2: the ROW-CONTIGUOUS layouts -- per-sample images (stride_row 1, stride_col n: what a rosdyn::Chain caller receives,
+// primitives_impl.h:1350-1354) and the stacked (N n) x P matrix (stride_sample n).  Stored from the computing lane these are 8-byte
+// pieces on 64 different lines per store instruction (0.65 TB/s measured, profiles/r6/long_regressor.txt); here a link's block goes
+// through a wave-private LDS tile two columns at a time and leaves 16 bytes per lane:
+//   images   tile [sample][2 n + 1]: a sample's piece is ONE run of 16 n bytes of its image
+//   stacked  tile [column][64 n + 2]: a column's 64 n values are ONE run of 512 n bytes of the matrix
+// The row loop runs once per column group (the unit twist of a row is rebuilt from the parked axis and origin: ~24 fma -- cheaper
+// than parking ten values per row and link), default-policy stores (the pieces of neighbouring column groups complete each other's
+// lines in L2).
+template <int STAGE>
 __global__ __launch_bounds__(64) void k_long_regressor(const RdynLongLocalArgs a)
 {
-  extern __shared__ __attribute__((aligned(16))) double joint_lds[];  // [7][nj][64]: z (3), p (3), tau (1)
+  extern __shared__ __attribute__((aligned(16))) double joint_lds[];  // [7][nj][64]: z (3), p (3), tau (1); STAGE: + the tile
   LongChainPtr c = as_const_long(a.chain_long);
-  const int nj = c->n_joints;
+  const int nj = c->n_joints, n = c->n_active;
   const int lane = threadIdx.x;
-  const int64_t s = (int64_t)blockIdx.x * 64 + lane;
-  if (s >= a.n_samples) return;
+  const int64_t s_wave = (int64_t)blockIdx.x * 64;
+  const int64_t left = a.n_samples - s_wave;
+  const int valid = left < 64 ? (int)left : 64;
+  const bool live = lane < valid;
+  if (STAGE == 0 && !live) return;
+  const int64_t s = s_wave + (live ? lane : valid - 1);  // (staged: lanes past the batch repeat the last sample and take part in the copy-out)
   const JointState js = {joint_lds + lane, nj};
+  double* const tile = joint_lds + 7 * nj * 64;
   const double* __restrict__ qp = a.q + s * a.in_ss;
   const double* __restrict__ dqp = a.dq ? a.dq + s * a.in_ss : nullptr;
   const double* __restrict__ ddqp = a.ddq ? a.ddq + s * a.in_ss : nullptr;
   double* const ys = a.Y + s * a.y_ss;
+  double* const ywave = a.Y + s_wave * a.y_ss;
   const bool nt = a.y_ss == 1;  // element-major: every store instruction of the wave is 512 contiguous bytes, written once
   const V3 g = mk(c->g[0], c->g[1], c->g[2]);
 
@@ -140,74 +210,155 @@ __global__ __launch_bounds__(64) void k_long_regressor(const RdynLongLocalArgs a
     js.put3(3, f, p);
     js.at(6, f) = 0.0;
     // ---- link f + 1 in its own frame: closed-form wrench regressor (rdyn_local_sweep_body.inc)
-    const V3 w = rotT(R, vang), vl = rotT(R, vlin), al = rotT(R, aang);
-    const V3 dd = rotT(R, alin - g) + cross(w, vl);
-    const double wxy = w.x * w.y, wxz = w.x * w.z, wyz = w.y * w.z;
-    const double wxx = w.x * w.x, wyy = w.y * w.y, wzz = w.z * w.z;
-    const double b00 = -(wyy + wzz), b01 = wxy - al.z, b02 = wxz + al.y;
-    const double b10 = wxy + al.z, b11 = -(wxx + wzz), b12 = wyz - al.x;
-    const double b20 = wxz - al.y, b21 = wyz + al.x, b22 = -(wxx + wyy);
-    const RDYN_CONST_AS double* pi = J.pi;
-    double* const yf = ys + (int64_t)(10 * f) * a.y_sc;
-#pragma unroll 1
-    for (int l = 0; l < nj; ++l)
+    RowCtx k;
+    k.w = rotT(R, vang);
+    k.al = rotT(R, aang);
+    k.dd = rotT(R, alin - g) + cross(k.w, rotT(R, vlin));
     {
-      JointRef Jl = c->j[l];
-      const int row = Jl.in_idx;
-      if (row < 0) continue;
-      double* const yr = yf + row * a.y_sr;
-      double y[10];
-      if (l <= f)
+      const V3 w = k.w, al = k.al;
+      const double wxy = w.x * w.y, wxz = w.x * w.z, wyz = w.y * w.z;
+      const double wxx = w.x * w.x, wyy = w.y * w.y, wzz = w.z * w.z;
+      k.b00 = -(wyy + wzz); k.b01 = wxy - al.z; k.b02 = wxz + al.y;
+      k.b10 = wxy + al.z; k.b11 = -(wxx + wzz); k.b12 = wyz - al.x;
+      k.b20 = wxz - al.y; k.b21 = wyz + al.x; k.b22 = -(wxx + wyy);
+    }
+    const RDYN_CONST_AS double* pi = J.pi;
+    // the unit twist of joint l at this link's origin, this link's axes
+    auto unit_twist = [&](JointRef Jl, int l, V3& L, V3& A) {
+      const V3 z = js.get3(0, l);
+      if (Jl.type == RDYN_REVOLUTE)
       {
-        const V3 z = js.get3(0, l);
-        V3 L, A;
-        if (Jl.type == RDYN_REVOLUTE)
+        A = rotT(R, z);
+        L = rotT(R, cross(z, p - js.get3(3, l)));
+      }
+      else
+      {
+        A = mk(0, 0, 0);
+        L = Jl.type == RDYN_PRISMATIC ? rotT(R, z) : mk(0, 0, 0);
+      }
+    };
+    if constexpr (STAGE == 0)
+    {
+      double* const yf = ys + (int64_t)(10 * f) * a.y_sc;
+#pragma unroll 1
+      for (int l = 0; l < nj; ++l)
+      {
+        JointRef Jl = c->j[l];
+        const int row = Jl.in_idx;
+        if (row < 0) continue;
+        double* const yr = yf + row * a.y_sr;
+        double y[10];
+        if (l <= f)
         {
-          A = rotT(R, z);
-          L = rotT(R, cross(z, p - js.get3(3, l)));
+          V3 L, A;
+          unit_twist(Jl, l, L, A);
+          y_pair<0>(k, L, A, y[0], y[1]);
+          y_pair<1>(k, L, A, y[2], y[3]);
+          y_pair<2>(k, L, A, y[4], y[5]);
+          y_pair<3>(k, L, A, y[6], y[7]);
+          y_pair<4>(k, L, A, y[8], y[9]);
+          double tl = js.at(6, l);
+#pragma unroll
+          for (int e = 0; e < 10; ++e) tl = fma(y[e], pi[e], tl);
+          js.at(6, l) = tl;
         }
         else
         {
-          A = mk(0, 0, 0);
-          L = Jl.type == RDYN_PRISMATIC ? rotT(R, z) : mk(0, 0, 0);
+#pragma unroll
+          for (int e = 0; e < 10; ++e) y[e] = 0.0;  // row of a joint downstream of this link (:690-691)
         }
-        const V3 dxA = cross(dd, A);
-        const V3 x = cross(A, w);
-        y[0] = dot(L, dd);
-        y[1] = fma(L.x, b00, fma(L.y, b10, fma(L.z, b20, dxA.x)));
-        y[2] = fma(L.x, b01, fma(L.y, b11, fma(L.z, b21, dxA.y)));
-        y[3] = fma(L.x, b02, fma(L.y, b12, fma(L.z, b22, dxA.z)));
-        y[4] = fma(A.x, al.x, x.x * w.x);
-        y[5] = fma(A.x, al.y, fma(A.y, al.x, fma(x.x, w.y, x.y * w.x)));
-        y[6] = fma(A.x, al.z, fma(A.z, al.x, fma(x.x, w.z, x.z * w.x)));
-        y[7] = fma(A.y, al.y, x.y * w.y);
-        y[8] = fma(A.y, al.z, fma(A.z, al.y, fma(x.y, w.z, x.z * w.y)));
-        y[9] = fma(A.z, al.z, x.z * w.z);
-        double tl = js.at(6, l);
+        if (nt)
+        {
 #pragma unroll
-        for (int k = 0; k < 10; ++k) tl = fma(y[k], pi[k], tl);
-        js.at(6, l) = tl;
-      }
-      else
-      {
+          for (int e = 0; e < 10; ++e) __builtin_nontemporal_store(y[e], yr + e * a.y_sc);
+        }
+        else
+        {
 #pragma unroll
-        for (int k = 0; k < 10; ++k) y[k] = 0.0;  // row of a joint downstream of this link (:690-691)
-      }
-      if (nt)
-      {
-#pragma unroll
-        for (int k = 0; k < 10; ++k) __builtin_nontemporal_store(y[k], yr + k * a.y_sc);
-      }
-      else
-      {
-        // row-contiguous layouts: a lane's stores of one link cover ONE run of 80 n bytes; default policy, so that the 8-byte pieces
-        // of a line meet in L2
-#pragma unroll
-        for (int k = 0; k < 10; ++k) yr[k * a.y_sc] = y[k];
+          for (int e = 0; e < 10; ++e) yr[e * a.y_sc] = y[e];
+        }
       }
     }
+    else
+    {
+      const int run = 2 * n, runp = run + 1, colp = 64 * n + 2;
+      double* const mine = STAGE == 1 ? tile + lane * runp : tile + lane * n;
+      const int pstep = STAGE == 1 ? n : colp;
+      auto group = [&](auto gtag) {
+        constexpr int G = decltype(gtag)::value;
+#pragma unroll 1
+        for (int l = 0; l < nj; ++l)
+        {
+          JointRef Jl = c->j[l];
+          const int row = Jl.in_idx;
+          if (row < 0) continue;
+          double ya = 0.0, yb = 0.0;  // (l > f: row of a joint downstream of this link, :690-691)
+          if (l <= f)
+          {
+            V3 L, A;
+            unit_twist(Jl, l, L, A);
+            y_pair<G>(k, L, A, ya, yb);
+            js.at(6, l) = fma(yb, pi[2 * G + 1], fma(ya, pi[2 * G], js.at(6, l)));
+          }
+          mine[row] = ya;
+          mine[pstep + row] = yb;
+        }
+        ll_wave_fence();
+        if (STAGE == 1)
+        {
+          // lps lanes per sample (a power of two >= the piece's n 16-byte chunks), 64 / lps samples per store instruction
+          const int lps = n <= 16 ? 16 : 32, spi = 64 / lps;
+          const int wch = lane & (lps - 1), sl = lane / lps;
+          const double* src = tile + sl * runp + 2 * wch;
+          double* dst = ywave + (int64_t)sl * a.y_ss + (int64_t)(10 * f + 2 * G) * a.y_sc + 2 * wch;
+#pragma unroll 4
+          for (int it = 0; it < lps; ++it)
+          {
+            if (wch < n && it * spi + sl < valid) *(ll_d2a*)dst = (ll_d2a)(*(const ll_d2u*)src);
+            src += spi * runp;
+            dst += (int64_t)spi * a.y_ss;
+          }
+        }
+        else
+        {
+#pragma unroll
+          for (int pp = 0; pp < 2; ++pp)
+          {
+            double* const yc = ywave + (int64_t)(10 * f + 2 * G + pp) * a.y_sc;
+#pragma unroll 2
+            for (int it = 0; it < (n + 1) / 2; ++it)
+            {
+              const int ch = it * 64 + lane;  // 16-byte piece of the column's run: values 2 ch, 2 ch + 1 of 64 n
+              if (ch < 32 * n)
+              {
+                const ll_d2a v = *(const ll_d2a*)(tile + pp * colp + 2 * ch);
+                if (2 * ch + 1 < valid * n) *(ll_d2a*)(yc + 2 * ch) = v;
+                else if (2 * ch < valid * n) yc[2 * ch] = v.x;
+              }
+            }
+          }
+        }
+        ll_wave_fence();
+      };
+      group(std::integral_constant<int, 0>());
+      group(std::integral_constant<int, 1>());
+      group(std::integral_constant<int, 2>());
+      group(std::integral_constant<int, 3>());
+      group(std::integral_constant<int, 4>());
+    }
   }
-  if (a.tau)
+  if (a.bcol && live)
+  {
+    const double* __restrict__ bp = a.bcol + s * a.in_ss;
+    double* const yb = ys + (int64_t)a.bcol_col * a.y_sc;
+#pragma unroll 1
+    for (int l = 0; l < nj; ++l)
+    {
+      const int row = c->j[l].in_idx;
+      if (row >= 0) yb[row * a.y_sr] = bp[row * a.in_sj];
+    }
+  }
+  if (a.tau && live)
   {
     double* __restrict__ tp = a.tau + s * a.tau_ss;
 #pragma unroll 1
@@ -344,20 +495,26 @@ size_t rdyn_long_local_lds_bytes(int mode, int n_joints) { return (size_t)(mode 
 hipError_t rdyn_launch_long_local(int mode, int n_joints, const RdynLongLocalArgs& a, hipStream_t st)
 {
   if (a.n_samples <= 0) return hipSuccess;
-  const size_t lds = rdyn_long_local_lds_bytes(mode, n_joints);
-  if (lds > 160 * 1024) return hipErrorInvalidValue;
+  size_t lds = rdyn_long_local_lds_bytes(mode, n_joints);
   const dim3 grid((unsigned)((a.n_samples + 63) / 64));
   if (mode == RDYN_MODE_INERTIA)
   {
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
     hipError_t e = allow_big_lds((const void*)k_long_inertia, lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_long_inertia, grid, dim3(64), lds, st, a);
+    return hipGetLastError();
   }
-  else
-  {
-    hipError_t e = allow_big_lds((const void*)k_long_regressor, lds);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_long_regressor, grid, dim3(64), lds, st, a);
-  }
+  // a.stage (decided by the host: a row-contiguous layout, 16-byte aligned Y, even strides): the tile behind the joint state
+  const size_t tile = a.stage == 1 ? (size_t)64 * (2 * a.n_active + 1) * 8 : (a.stage == 2 ? (size_t)2 * (64 * a.n_active + 2) * 8 : 0);
+  const int stage = (a.stage && lds + tile <= 160 * 1024) ? a.stage : 0;
+  if (stage) lds += tile;
+  if (lds > 160 * 1024) return hipErrorInvalidValue;
+  const void* fn = stage == 1 ? (const void*)k_long_regressor<1> : (stage == 2 ? (const void*)k_long_regressor<2> : (const void*)k_long_regressor<0>);
+  hipError_t e = allow_big_lds(fn, lds);
+  if (e != hipSuccess) return e;
+  if (stage == 1) hipLaunchKernelGGL(k_long_regressor<1>, grid, dim3(64), lds, st, a);
+  else if (stage == 2) hipLaunchKernelGGL(k_long_regressor<2>, grid, dim3(64), lds, st, a);
+  else hipLaunchKernelGGL(k_long_regressor<0>, grid, dim3(64), lds, st, a);
   return hipGetLastError();
 }

@@ -230,6 +230,35 @@ def test_long_chain_more_than_ten_input_joints_regressor_torque_inertia(case):
     _close(o["T_links"].cpu().numpy().transpose(0, 1, 3, 2), ref.fk(q), "evaluateAll T")
 
 
+def test_eleven_input_joints_normal_equations():
+    """rdyn_regressor_gram of a chain with ELEVEN input joints (110 columns + tau_meas = the 111 the Gram kernel holds): chunk images by
+    rdyn_long_local.hip contracted by k_gram, several chunks with a ragged last one, accumulation; 12 input joints (121 columns) are
+    refused before anything touches the device (the documented limit)."""
+    torch = pytest.importorskip("torch")
+    from oracle.oracle import OracleChain
+    from rosdyn_amd import Chain
+    from rosdyn_amd._lib import lib
+    from rosdyn_amd.samples import trajectory_batch
+    xml = generated_revolute_chain(11, 1111)
+    chain, ref = Chain(xml, "l0", "l11", GRAV), OracleChain(xml, "l0", "l11", GRAV)
+    n, P, N = 11, 110, 3000
+    q, dq, ddq = trajectory_batch(71, N, n)
+    tau = ref.joint_torque(q, dq, ddq) + 1e-3 * np.random.default_rng(2).normal(size=(N, n))
+    A = ref.regressor(q, dq, ddq).reshape(N * n, P)
+    Gr, cr, bbr = A.T @ A, A.T @ tau.reshape(-1), float(tau.reshape(-1) @ tau.reshape(-1))
+    tq, tdq, tddq, tt = (torch.from_numpy(x).cuda() for x in (q, dq, ddq, tau))
+    for chunk in (0, 1024):   # one chunk / three chunks with a ragged last one
+        G, c, bb = chain.getRegressorGram(tq, tdq, tddq, tt, chunk_samples=chunk)
+        assert np.linalg.norm(G.cpu().numpy() - Gr) <= 1e-10 * np.linalg.norm(Gr)
+        assert np.linalg.norm(c.cpu().numpy() - cr) <= 1e-10 * np.linalg.norm(cr)
+        assert abs(float(bb.cpu()[0]) - bbr) <= 1e-10 * bbr
+    eq, edq, eddq, et = (torch.from_numpy(np.ascontiguousarray(x.T)).cuda() for x in (q, dq, ddq, tau))
+    G, c, bb = chain.getRegressorGram(eq, edq, eddq, et, layout="element", chunk_samples=1000)
+    assert np.linalg.norm(G.cpu().numpy() - Gr) <= 1e-10 * np.linalg.norm(Gr) and np.linalg.norm(c.cpu().numpy() - cr) <= 1e-10 * np.linalg.norm(cr)
+    twelve = Chain(generated_revolute_chain(12, 1212), "l0", "l12", GRAV)
+    assert lib().rdyn_regressor_gram_workspace_bytes(twelve._h, 0) == 0
+
+
 @pytest.mark.parametrize("case", ["ur10_long", "gen20_permuted"])
 def test_long_chain_local_ik(case):
     """computeLocalIk on the companion + the constant frames behind the last input joint, against the oracle iterating the whole chain."""
