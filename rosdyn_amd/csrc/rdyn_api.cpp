@@ -346,7 +346,15 @@ int run_local(const rdyn_chain* c, const rdyn_batch* b, int mode, double* tau, d
   bool mapped = false;
   const bool image = mode == RDYN_MODE_REGRESSOR && yl && image_route(c, yl, b->n_samples, Y, false, &fix_mask, &mapped) != 0;
   if (expand_image)
+  {
+    // (the chunk permutation of the per-sample images, see below)
+    const unsigned grid = (unsigned)((b->n_samples + 63) / 64);
+    auto gcd = [](unsigned x, unsigned y) { while (y) { const unsigned t = x % y; x = y; y = t; } return x; };
+    unsigned m = 257;
+    while (gcd(m, grid) != 1) ++m;
+    a.blk_mul = (grid > 4 * m && !probe_env("RDYN_NO_IMAGE_SCATTER")) ? m : 0;
     RDYN_HIP_TRY(rdyn_launch_image_sweep(c->n_joints(), 0u, a, (hipStream_t)b->stream, 2));
+  }
   else if (image)
   {
     if (mapped)
@@ -357,6 +365,19 @@ int run_local(const rdyn_chain* c, const rdyn_batch* b, int mode, double* tau, d
       if (st != RDYN_OK) return st;
       for (int f = 0; f < RDYN_MAX_SWEPT_JOINTS; ++f) a.row_map[f] = -1;
       for (int r = 0; r < n; ++r) a.row_map[so->active[r]] = r < (int)so->row_input.size() ? so->row_input[r] : r;
+    }
+    // per-sample images: the workgroups visit the 64-sample chunks of the batch in a PERMUTED order (chunk = b * 257 mod grid), so that
+    // the ~2 000 waves resident at a time write all over the output instead of one contiguous ~370 MB window of it.  Measured (round 6,
+    // tools/probe_scatter.py, profiles/r6/probe_scatter.txt: ten 2.88 GB output allocations per process): 516-523 -> 450-455 us per 1e6
+    // evaluations in half of the allocations, 537-547 -> 508-520 in most others, never slower; multipliers 17 .. 4097 alike.  The stacked
+    // matrix (60 column fronts already) loses 2-5 % with it and keeps the workgroups in order.
+    if (image_route(c, yl, b->n_samples, Y, false, &fix_mask, &mapped) == 1 && !probe_env("RDYN_NO_IMAGE_SCATTER"))
+    {
+      const unsigned grid = (unsigned)((b->n_samples + 63) / 64);
+      auto gcd = [](unsigned x, unsigned y) { while (y) { const unsigned t = x % y; x = y; y = t; } return x; };
+      unsigned m = 257;
+      while (gcd(m, grid) != 1) ++m;
+      a.blk_mul = grid > 4 * m ? m : 0;
     }
     RDYN_HIP_TRY(rdyn_launch_image_sweep(c->n_joints(), fix_mask, a, (hipStream_t)b->stream, mapped));
   }

@@ -89,7 +89,9 @@ __global__ __launch_bounds__(64 * RDYN_IMAGE_WG_WAVES(STACKED), (RDYN_IMAGE_WG_W
   const unsigned per = (gridDim.x + 7u) / 8u;
   const unsigned bx = (blockIdx.x & 7u) * per + (blockIdx.x >> 3);
 #else
-  const unsigned bx = blockIdx.x;
+  // a.blk_mul != 0: workgroup b sweeps the 64 samples of chunk (b * blk_mul) mod grid (blk_mul coprime to the grid: a bijection) -- the
+  // waves that run at the same time are then spread over the whole batch instead of one narrow window of it
+  const unsigned bx = a.blk_mul ? (unsigned)(((uint64_t)blockIdx.x * (uint64_t)a.blk_mul) % (uint64_t)gridDim.x) : blockIdx.x;
 #endif
   const unsigned blk = bx * IMAGE_WAVES + (IMAGE_WAVES > 1 ? (threadIdx.x >> 6) : 0);
 #include "rdyn_image_body.inc"

@@ -46,6 +46,8 @@ struct RdynSweepArgs
   // torque / inertia launches: the sample-major records (tau: n, M: n x n doubles per sample) through the wave's LDS tile, written in whole
   // lines (rdyn_record_stage.h); decided by the host: natural strides, 128-byte aligned output
   int staged;
+  // k_image_sweep: chunk permutation of the workgroups (0 = none), see rdyn_image_impl.h
+  unsigned blk_mul;
 };
 
 // split / jerk sweeps (rdyn_kin_ext.hip); every output record is links x 6
