@@ -13,6 +13,9 @@
 // 91 -> 101 us, getWrench with its external wrenches through the record tile 234 -> 262 us): these kernels move 0.3-0.8 KB per sample
 // and are bound by the LIFETIME of a wave, not by the address unit; one more LDS hop in front of the first sincos costs more than the
 // strided loads do (and a load loop that waits per trip costs a whole memory round trip per trip: +27 us on a 129 us kernel).
+// PERSISTENT waves (a few workgroups per CU walking the batch in strides of the grid, the next tile's inputs requested while the current
+// one is swept; profiles/r6/sweep_sheet_persistent.txt) were built and measured too: slower everywhere (getTwist 91 -> 129 us,
+// getTransformations 129 -> 166 us) -- the hardware's own dispatch keeps more waves in flight than a fixed grid does.
 // Preconditions, checked by the host (rdyn_api.cpp: natural strides, base pointer
 // 128-byte aligned) and by the kernel (a full wave): everything else keeps the 8-byte stores.
 #ifndef RDYN_RECORD_STAGE_H
