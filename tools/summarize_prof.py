@@ -81,6 +81,7 @@ if len(sys.argv) > 2:
         except (OSError, ValueError):
             d = {}
         d[key] = {"kernel": k, "FETCH_SIZE_KB": fetch[k], "WRITE_SIZE_KB": write[k], "traffic_bytes_per_launch": traffic,
+                  "round": os.environ.get("PROF_ROUND", "6"),
                   "correction": "traffic = 2 * FETCH_SIZE * 1024 + WRITE_SIZE * 1024 (gfx950 FETCH_SIZE halving)"}
         json.dump(d, open(path, "w"), indent=1, sort_keys=True)
         print("wrote", path, key, traffic)
