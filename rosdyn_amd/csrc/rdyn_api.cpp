@@ -227,6 +227,9 @@ int image_route(const rdyn_chain* c, const rdyn_regressor_layout* yl, int64_t n_
   const bool lay_image = yl->stride_row == 1 && yl->stride_col == n && yl->stride_sample >= (int64_t)n * 10 * nJ;
   const bool lay_stacked = yl->stride_row == 1 && yl->stride_sample == n && yl->stride_col >= n_samples * n && !probe_env("RDYN_NO_STACKED_LDS");
   if (!(lay_image || lay_stacked) || probe_env("RDYN_NO_IMAGE")) return 0;
+  // less than one wave of samples (the facade's single-sample getRegressor): the staging machinery costs more than it saves (19.5 us per
+  // call at N = 1 against 11 for the kernels that store from the computing lane, profiles/r6/perf_sheet.txt) -- the row-pair / strided kernels
+  if (n_samples < 64 && !multi) return 0;
   if (((uintptr_t)Y & 15u) != 0) return 0;
   if (lay_stacked && (yl->stride_col * 8) % 16 != 0) return 0;  // every column must start 16-byte aligned too
   unsigned fix = (nJ >= 32) ? 0u : ((1u << nJ) - 1u);
