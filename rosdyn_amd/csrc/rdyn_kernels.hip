@@ -113,8 +113,9 @@ __global__ __launch_bounds__(256) void k_local_sweep_multi(const RdynSweepArgs* 
 
 // ---------------------------------------------------------------------------------------------------
 // Base-frame kinematics, stated as the reference states them.
-// LEVEL: what the caller asked for -- 0 frames only (getTransformation(s)), 1 + the Jacobian (screws and origins kept), 2 + twists,
-// 3 + spatial accelerations.  One instantiation per level: a getTransformation call does not pay for the velocity / acceleration
+// LEVEL: what the caller asked for -- 0 frames only (getTransformation(s)), 1 frames + the Jacobian (screws and origins kept), 2 frames +
+// twists, 3 + spatial accelerations (round 6: the Jacobian belongs to level 1 alone -- carried through levels 2 and 3 its 12 NJ registers
+// were dead weight in every getTwist / getDTwist call).  One instantiation per level: a getTransformation call does not pay for the velocity / acceleration
 // recursions of getDTwist (750 -> 420 fp64 instructions per sample at 6 joints).
 // STAGED (k_base_sweep_staged: 64-thread workgroups, `lds` = the wave's staging area): the sample-major records of a FULL wave leave
 // through wave-private LDS in whole lines (rdyn_record_stage.h); a partial last wave keeps the 8-byte stores below.
@@ -161,7 +162,6 @@ __device__ __forceinline__ void base_sweep_body(const Args& a, const int64_t s, 
   double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
   V3 p = mk(0, 0, 0);
   V3 vlin = mk(0, 0, 0), vang = mk(0, 0, 0), alin = mk(0, 0, 0), aang = mk(0, 0, 0);
-  V3 z[NJ], po[NJ];
 
   auto put3x4 = [&](double* __restrict__ o) {
     // column-major 3x4 [R | p]
@@ -208,6 +208,60 @@ __device__ __forceinline__ void base_sweep_body(const Args& a, const int64_t s, 
     else
       put6(base + s * a.tw_ss + (int64_t)(6 * link) * es, l, g);
   };
+  // getJacobian, primitives_impl.h:939-945: column k = spatialTranslation(S_l, p_tool - p_l);
+  // getJacobianLink, primitives_impl.h:951-979: the same referred to the origin of link j_link; only the FIRST
+  // `up` input columns are filled, up = number of input joints upstream of the link (the reference's loop runs over
+  // idx < joints.size() and reads m_active_joints.at(idx), :970-972) -- for the default, chain-ordered input list
+  // these are exactly the link's parent joints.  j_link == NJ is the tool (up = n_active: plain getJacobian).
+  // The reference point (origin of link j_link) is known only once the recursion has reached it: a FIRST PASS over the frames runs
+  // up to that link (one sincos and ~70 fma per joint) and the sweep below forms every column as it passes its joint -- no axis and
+  // origin kept per joint (12 NJ registers: 163 at 6 joints, round 5), the device of rdyn_long_kin.hip's Jacobian.
+  V3 pref = mk(0, 0, 0);
+  int j_up = 0;
+  const bool jst = LEVEL == 1 && STAGED && stg && a.J;
+  SmallRecords smJ;
+  V3 zs[(LEVEL == 1 && STAGED) ? NJ : 1], pos[(LEVEL == 1 && STAGED) ? NJ : 1];
+  if (LEVEL == 1 && !STAGED && a.J)
+  {
+    double R1[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    V3 p1 = mk(0, 0, 0);
+#pragma unroll
+    for (int l = 0; l < NJ; ++l)
+    {
+      JointRef J = c->j[l];
+      if (l < a.j_link)
+      {
+        if (J.in_idx >= 0) ++j_up;
+        const double ql = J.in_idx >= 0 ? qp[J.in_idx * a.in_sj] : 0.0;
+        double Rpc[9];
+        V3 t = ld3(J.t);
+        if (J.type == RDYN_REVOLUTE)
+        {
+          double sn, cs;
+          rdyn_sincos(ql, &sn, &cs);
+          const double oc = 1.0 - cs;
+#pragma unroll
+          for (int i = 0; i < 9; ++i) Rpc[i] = fma(sn, J.B[i], fma(oc, J.C[i], J.A[i]));
+        }
+        else
+        {
+#pragma unroll
+          for (int i = 0; i < 9; ++i) Rpc[i] = J.A[i];
+          if (J.type == RDYN_PRISMATIC) t = axpy(t, ld3(J.up), ql);
+        }
+        p1 = p1 + rot(R1, t);
+        double Rn[9];
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+          for (int cc = 0; cc < 3; ++cc)
+            Rn[r * 3 + cc] = fma(R1[r * 3 + 0], Rpc[cc], fma(R1[r * 3 + 1], Rpc[3 + cc], R1[r * 3 + 2] * Rpc[6 + cc]));
+#pragma unroll
+        for (int i = 0; i < 9; ++i) R1[i] = Rn[i];
+      }
+    }
+    pref = p1;
+  }
   frame_out(0);
   if (LEVEL >= 2 && a.twists) six_out(ringV, a.twists, 0, vlin, vang);
   if (LEVEL >= 3 && a.dtwists) six_out(ringA, a.dtwists, 0, alin, aang);
@@ -255,10 +309,26 @@ __device__ __forceinline__ void base_sweep_body(const Args& a, const int64_t s, 
 #pragma unroll
     for (int i = 0; i < 9; ++i) R[i] = Rn[i];
     p = p + d;
-    if (LEVEL >= 1)
+    if (LEVEL == 1 && STAGED)
     {
-      z[f] = zl;
-      po[f] = p;
+      zs[(LEVEL == 1 && STAGED) ? f : 0] = zl;
+      pos[(LEVEL == 1 && STAGED) ? f : 0] = p;
+    }
+    if (LEVEL == 1 && !STAGED && a.J && idx >= 0)
+    {
+      // column idx of the Jacobian, as soon as its joint's axis and origin are known (the reference point came from the first pass)
+      V3 jlin = mk(0, 0, 0), jang = mk(0, 0, 0);
+      if (idx < j_up)
+      {
+        if (type == RDYN_REVOLUTE)
+        {
+          jlin = cross(zl, pref - p);
+          jang = zl;
+        }
+        else if (type == RDYN_PRISMATIC)
+          jlin = zl;
+      }
+      put6(a.J + s * a.j_ss + (int64_t)(6 * idx) * es, jlin, jang);
     }
     if (LEVEL >= 2)
     {
@@ -306,51 +376,49 @@ __device__ __forceinline__ void base_sweep_body(const Args& a, const int64_t s, 
     else
       put3x4(a.T_bt + s * a.tb_ss);
   }
-  if (LEVEL >= 1 && a.J)
+  if constexpr (LEVEL == 1 && STAGED)
   {
-    const bool jst = STAGED && stg;
-    if (jst) sm.init(small_area, 6 * c->n_active, lane);
-    // getJacobian, primitives_impl.h:939-945: column k = spatialTranslation(S_l, p_tool - p_l);
-    // getJacobianLink, primitives_impl.h:951-979: the same referred to the origin of link j_link; only the FIRST
-    // `up` input columns are filled, up = number of input joints upstream of the link (the reference's loop runs over
-    // idx < joints.size() and reads m_active_joints.at(idx), :970-972) -- for the default, chain-ordered input list
-    // these are exactly the link's parent joints.  j_link == NJ is the tool (up = n_active: plain getJacobian).
-    double* __restrict__ jp = a.J + s * a.j_ss;
-    V3 pref = p;
-    int up = 0;
-#pragma unroll
-    for (int l = 0; l < NJ; ++l)
+    if (a.J)
     {
-      if (a.j_link == l + 1) pref = po[l];
-      if (l < a.j_link && c->j[l].in_idx >= 0) ++up;
-    }
-    if (a.j_link == 0) pref = mk(0, 0, 0);
+      // the staged kernel (64-thread workgroups, its waves in flight bounded by the 19 KB record tile, not by registers) keeps every
+      // joint's axis and origin and forms the columns here: the first pass of the two-pass form cost it 98 -> 134 us per 1e6
+      if (jst) smJ.init(small_area, 6 * c->n_active, lane);
+      V3 pr = p;
+      int up = 0;
 #pragma unroll
-    for (int l = 0; l < NJ; ++l)
-    {
-      const int k = c->j[l].in_idx;
-      if (k < 0) continue;
-      const int type = c->j[l].type;
-      V3 jlin = mk(0, 0, 0), jang = mk(0, 0, 0);
-      if (k < up)
+      for (int l = 0; l < NJ; ++l)
       {
-        if (type == RDYN_REVOLUTE)
+        if (a.j_link == l + 1) pr = pos[l];
+        if (l < a.j_link && c->j[l].in_idx >= 0) ++up;
+      }
+      if (a.j_link == 0) pr = mk(0, 0, 0);
+#pragma unroll
+      for (int l = 0; l < NJ; ++l)
+      {
+        const int k = c->j[l].in_idx;
+        if (k < 0) continue;
+        const int ty = c->j[l].type;
+        V3 jlin = mk(0, 0, 0), jang = mk(0, 0, 0);
+        if (k < up)
         {
-          jlin = cross(z[l], pref - po[l]);
-          jang = z[l];
+          if (ty == RDYN_REVOLUTE)
+          {
+            jlin = cross(zs[l], pr - pos[l]);
+            jang = zs[l];
+          }
+          else if (ty == RDYN_PRISMATIC)
+            jlin = zs[l];
         }
-        else if (type == RDYN_PRISMATIC)
-          jlin = z[l];
+        if (jst)
+        {
+          smJ.put(6 * k, jlin.x); smJ.put(6 * k + 1, jlin.y); smJ.put(6 * k + 2, jlin.z);
+          smJ.put(6 * k + 3, jang.x); smJ.put(6 * k + 4, jang.y); smJ.put(6 * k + 5, jang.z);
+        }
+        else
+          put6(a.J + s * a.j_ss + (int64_t)(6 * k) * es, jlin, jang);
       }
-      if (jst)
-      {
-        sm.put(6 * k, jlin.x); sm.put(6 * k + 1, jlin.y); sm.put(6 * k + 2, jlin.z);
-        sm.put(6 * k + 3, jang.x); sm.put(6 * k + 4, jang.y); sm.put(6 * k + 5, jang.z);
-      }
-      else
-        put6(jp + (int64_t)(6 * k) * es, jlin, jang);
+      if (jst) smJ.copy_out(a.J + (s - lane) * a.j_ss, lane);
     }
-    if (jst) sm.copy_out(a.J + (s - lane) * a.j_ss, lane);
   }
 }
 
@@ -529,12 +597,26 @@ hipError_t rdyn_launch_sample_all(int n_joints, const RdynAllArgs& a, hipStream_
 #endif
 
 #if RDYN_KERNELS_PART == 2
-hipError_t rdyn_launch_base_sweep(int n_joints, const RdynKinArgs& a, hipStream_t st)
+static hipError_t launch_base_dispatch(int n_joints, const RdynKinArgs& a, hipStream_t st)
 {
-  if (a.n_samples <= 0) return hipSuccess;
 #define CALL(N) launch_base_nj<N>(a, st)
   RDYN_DISPATCH_NJ(n_joints, CALL)
 #undef CALL
+}
+hipError_t rdyn_launch_base_sweep(int n_joints, const RdynKinArgs& a, hipStream_t st)
+{
+  if (a.n_samples <= 0) return hipSuccess;
+  if (a.J && (a.twists || a.dtwists || a.T_bt || a.T_links))
+  {
+    // the Jacobian is level 1's alone (the twist levels do not keep the screws and origins it needs): two launches
+    RdynKinArgs j = a, rest = a;
+    j.twists = j.dtwists = j.T_bt = j.T_links = nullptr;
+    rest.J = nullptr;
+    const hipError_t e = launch_base_dispatch(n_joints, j, st);
+    if (e != hipSuccess) return e;
+    return launch_base_dispatch(n_joints, rest, st);
+  }
+  return launch_base_dispatch(n_joints, a, st);
 }
 #endif
 

@@ -51,9 +51,14 @@ __device__ __forceinline__ S6 axpy6(S6 a, S6 b, double s)
 // STAGED (a.staged: sample-major records at their natural stride, line-aligned outputs): 64-thread workgroups; the records of a FULL
 // wave leave through wave-private LDS in whole lines (rdyn_record_stage.h) -- one ring per requested split / jerk output, the wrench
 // records from the tile they are parked in anyway (then laid out [sample][6 (NJ + 1) | 1])
-template <int NJ, bool WRENCH, bool STAGED>
+// MASK (split / jerk sweeps): which of the five outputs this instantiation can produce -- bit 0 dtw_lin, 1 dtw_nonlin, 2 ddtw, 3 ddtw_lin,
+// 4 ddtw_nonlin; 31 = any combination.  The reference's getters ask for ONE at a time (primitives.h:468-488) and so do the facade and the
+// Python mirror: with the other four recursions compiled out a call carries a fraction of the 84 registers of running state (203 for
+// the all-outputs kernel: two waves per SIMD on a kernel that is bound by the waves in flight).
+template <int NJ, bool WRENCH, bool STAGED, int MASK = 31>
 __global__ __launch_bounds__((WRENCH || STAGED) ? 64 : 256, RDYN_KIN_EXT_WAVES) void k_base_ext(const RdynKinExtArgs a)
 {
+  constexpr bool W0 = (MASK & 1) != 0, W1 = (MASK & 2) != 0, W2 = (MASK & 4) != 0, W3 = (MASK & 8) != 0, W4 = (MASK & 16) != 0;
   constexpr int BS = (WRENCH || STAGED) ? 64 : 256;
   extern __shared__ __attribute__((aligned(16))) double own_lds[];  // WRENCH: [6 (NJ + 1)][64]; STAGED: the rings / the record tile
   ChainPtr c = as_const(a.chain);
@@ -70,7 +75,8 @@ __global__ __launch_bounds__((WRENCH || STAGED) ? 64 : 256, RDYN_KIN_EXT_WAVES) 
       else
       {
         char* lp = (char*)own_lds;
-        double* const outs[5] = {a.dtw_lin, a.dtw_nonlin, a.ddtw, a.ddtw_lin, a.ddtw_nonlin};
+        double* const outs[5] = {W0 ? a.dtw_lin : nullptr, W1 ? a.dtw_nonlin : nullptr, W2 ? a.ddtw : nullptr, W3 ? a.ddtw_lin : nullptr,
+                                 W4 ? a.ddtw_nonlin : nullptr};
 #pragma unroll
         for (int k = 0; k < 5; ++k)
           if (outs[k])
@@ -123,11 +129,11 @@ __global__ __launch_bounds__((WRENCH || STAGED) ? 64 : 256, RDYN_KIN_EXT_WAVES) 
   };
   if (!WRENCH)
   {
-    out6(0, a.dtw_lin, 0, zero);
-    out6(1, a.dtw_nonlin, 0, zero);
-    out6(2, a.ddtw, 0, zero);
-    out6(3, a.ddtw_lin, 0, zero);
-    out6(4, a.ddtw_nonlin, 0, zero);
+    if (W0) out6(0, a.dtw_lin, 0, zero);
+    if (W1) out6(1, a.dtw_nonlin, 0, zero);
+    if (W2) out6(2, a.ddtw, 0, zero);
+    if (W3) out6(3, a.ddtw_lin, 0, zero);
+    if (W4) out6(4, a.ddtw_nonlin, 0, zero);
   }
   // WRENCH: origins of links 0 .. NJ.  The per-link wrench accumulators do NOT live in registers (6 (NJ + 1) doubles pushed the
   // kernel to 200 VGPRs = 2 waves per SIMD on a streaming kernel): every link's OWN wrench is parked in LDS referred to the base
@@ -238,11 +244,11 @@ __global__ __launch_bounds__((WRENCH || STAGED) ? 64 : 256, RDYN_KIN_EXT_WAVES) 
       jk = axpy6(axpy6(axpy6(shift(jk, d), S, dddqf), vxs, ddqf), cq, dqf);
       jL = axpy6(shift(jL, d), S, dddqf);
       jN = axpy6(axpy6(shift(jN, d), vxs, ddqf), cq, dqf);
-      out6(0, a.dtw_lin, f + 1, aL);
-      out6(1, a.dtw_nonlin, f + 1, aN);
-      out6(2, a.ddtw, f + 1, jk);
-      out6(3, a.ddtw_lin, f + 1, jL);
-      out6(4, a.ddtw_nonlin, f + 1, jN);
+      if (W0) out6(0, a.dtw_lin, f + 1, aL);
+      if (W1) out6(1, a.dtw_nonlin, f + 1, aN);
+      if (W2) out6(2, a.ddtw, f + 1, jk);
+      if (W3) out6(3, a.ddtw_lin, f + 1, jL);
+      if (W4) out6(4, a.ddtw_nonlin, f + 1, jN);
     }
     if (WRENCH)
     {
@@ -297,7 +303,8 @@ __global__ __launch_bounds__((WRENCH || STAGED) ? 64 : 256, RDYN_KIN_EXT_WAVES) 
   }
   else if (STAGED && stg)
   {
-    double* const outs[5] = {a.dtw_lin, a.dtw_nonlin, a.ddtw, a.ddtw_lin, a.ddtw_nonlin};
+    double* const outs[5] = {W0 ? a.dtw_lin : nullptr, W1 ? a.dtw_nonlin : nullptr, W2 ? a.ddtw : nullptr, W3 ? a.ddtw_lin : nullptr,
+                             W4 ? a.ddtw_nonlin : nullptr};
 #pragma unroll
     for (int k = 0; k < 5; ++k)
       if (outs[k]) rings[(STAGED && !WRENCH) ? k : 0].finish();
@@ -313,13 +320,28 @@ hipError_t launch_ext_nj(const RdynKinExtArgs& a, hipStream_t st)
     if (a.staged) hipLaunchKernelGGL((k_base_ext<NJ, true, true>), grid64, dim3(64), (size_t)((6 * (NJ + 1)) | 1) * 64 * sizeof(double), st, a);
     else hipLaunchKernelGGL((k_base_ext<NJ, true, false>), grid64, dim3(64), (size_t)6 * (NJ + 1) * 64 * sizeof(double), st, a);
   }
-  else if (a.staged)
-  {
-    const int rings = (a.dtw_lin ? 1 : 0) + (a.dtw_nonlin ? 1 : 0) + (a.ddtw ? 1 : 0) + (a.ddtw_lin ? 1 : 0) + (a.ddtw_nonlin ? 1 : 0);
-    hipLaunchKernelGGL((k_base_ext<NJ, false, true>), grid64, dim3(64), (size_t)rings * RecordRing<48>::BYTES, st, a);
-  }
   else
-    hipLaunchKernelGGL((k_base_ext<NJ, false, false>), grid, dim3(256), 0, st, a);
+  {
+    const int mask = (a.dtw_lin ? 1 : 0) | (a.dtw_nonlin ? 2 : 0) | (a.ddtw ? 4 : 0) | (a.ddtw_lin ? 8 : 0) | (a.ddtw_nonlin ? 16 : 0);
+    const int rings = __builtin_popcount((unsigned)mask);
+    const size_t lds = (size_t)rings * RecordRing<48>::BYTES;
+#define RDYN_EXT_LAUNCH(M_)                                                                                       \
+  do                                                                                                              \
+  {                                                                                                               \
+    if (a.staged) hipLaunchKernelGGL((k_base_ext<NJ, false, true, M_>), grid64, dim3(64), lds, st, a);           \
+    else hipLaunchKernelGGL((k_base_ext<NJ, false, false, M_>), grid, dim3(256), 0, st, a);                      \
+  } while (0)
+    switch (mask)  // one output: its own instantiation
+    {
+    case 1: RDYN_EXT_LAUNCH(1); break;
+    case 2: RDYN_EXT_LAUNCH(2); break;
+    case 4: RDYN_EXT_LAUNCH(4); break;
+    case 8: RDYN_EXT_LAUNCH(8); break;
+    case 16: RDYN_EXT_LAUNCH(16); break;
+    default: RDYN_EXT_LAUNCH(31); break;
+    }
+#undef RDYN_EXT_LAUNCH
+  }
   return hipGetLastError();
 }
 }  // namespace
