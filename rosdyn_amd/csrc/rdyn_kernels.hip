@@ -509,7 +509,7 @@ hipError_t launch_local_nj(int mode, const RdynSweepArgs& a, hipStream_t st)
     else hipLaunchKernelGGL((k_local_sweep<NJ, MODE_TORQUE>), dim3(grid), dim3(256), 0, st, a);
     break;
   default:
-    if (a.staged) hipLaunchKernelGGL((k_local_sweep_rec<NJ, MODE_INERTIA>), dim3((unsigned)((a.n_samples + 63) / 64)), dim3(64), (size_t)64 * (a.staged | 1) * 8, st, a);
+    if (a.staged) hipLaunchKernelGGL((k_local_sweep_rec<NJ, MODE_INERTIA>), dim3((unsigned)((a.n_samples + 63) / 64)), dim3(64), (size_t)32 * (a.staged | 1) * 8, st, a);  // a half-wave tile
     else hipLaunchKernelGGL((k_local_sweep<NJ, MODE_INERTIA>), dim3(grid), dim3(256), 0, st, a);
     break;
   }

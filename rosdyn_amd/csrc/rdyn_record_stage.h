@@ -136,18 +136,20 @@ struct SmallRecords
     mine = tile + lane * prec;
   }
   __device__ __forceinline__ void put(int e, double v) const { mine[e] = v; }
-  __device__ __forceinline__ void copy_out(void* wave_records, int lane) const
+  // ns = 64: the tile holds the wave's 64 records; ns = 32: a HALF-wave's (the tile is half the size -- twice the waves per CU where the
+  // LDS bounds them -- and the wave stages and copies out its two halves one after the other: 32 rec doubles are whole lines too)
+  __device__ __forceinline__ void copy_out(void* records, int lane, int ns = 64) const
   {
     rs_wave_fence();
     // chunk c = it * 64 + lane holds doubles 2 c, 2 c + 1 of the run; double d belongs to sample d / rec, element d % rec
     int s0 = (int)(((float)(2 * lane) + 0.5f) / (float)rec);
     int e0 = 2 * lane - s0 * rec;
     const int ds = 128 / rec, de = 128 - ds * rec;  // wave-uniform
-    char* dst = (char*)wave_records + lane * 16;
+    char* dst = (char*)records + lane * 16;
 #pragma unroll 4
-    for (int it = 0; it < (rec + 1) / 2; ++it)
+    for (int it = 0; it < (ns * rec + 127) / 128; ++it)
     {
-      if (2 * (it * 64 + lane) < 64 * rec)
+      if (2 * (it * 64 + lane) < ns * rec)
       {
         int s1 = s0, e1 = e0 + 1;
         if (e1 == rec)
