@@ -7,7 +7,7 @@
 // 16 bytes per lane with the lanes running along the bytes of a record, whole 128-byte lines only, nontemporal (written once, never
 // re-read) -- the copy-out of the regressor image kernel (rdyn_image_impl.h) for records that are produced
 //   * link by link (frames, twists, acceleration / jerk twists: PIECE bytes per link)  -> RecordRing<PIECE>
-//   * at once at the end of the sweep (tool frame, Jacobian, joint torque, inertia)     -> stage_small_records
+//   * at once at the end of the sweep (tool frame, Jacobian, joint torque, inertia)     -> SmallRecords
 // Only wave-local ordering is needed (no barrier).  The INPUTS keep their per-lane loads: reading a wave's 64 input records as whole
 // lines into an LDS tile was built and measured (profiles/r6/sweep_sheet_input_tile.txt) -- every kernel the same or slower (getTwist
 // 91 -> 101 us, getWrench with its external wrenches through the record tile 234 -> 262 us): these kernels move 0.3-0.8 KB per sample
@@ -122,7 +122,6 @@ struct RecordRing
 // Records of `rec` doubles that a lane holds complete at the end of its sweep: every lane drops its record into the wave's tile
 // (pitch rec | 1 doubles: consecutive lanes on different banks), then the wave copies the run of 64 rec doubles out, 16 bytes per lane,
 // whole lines.  LDS: 64 (rec | 1) doubles.
-__device__ __forceinline__ size_t small_record_lds_bytes(int rec) { return (size_t)64 * (size_t)(rec | 1) * 8; }
 struct SmallRecords
 {
   double* tile;
