@@ -515,6 +515,7 @@ hipError_t launch_local_nj(int mode, const RdynSweepArgs& a, hipStream_t st)
   }
   return hipGetLastError();
 }
+constexpr size_t kFramesStageLds = 33 * 1024;  // 160 KB / 33 KB: four waves per CU
 template <int NJ>
 hipError_t launch_base_nj(const RdynKinArgs& a, hipStream_t st)
 {
@@ -528,6 +529,13 @@ hipError_t launch_base_nj(const RdynKinArgs& a, hipStream_t st)
     if (a.T_bt) small = (size_t)64 * 13 * 8;
     if (a.J && (size_t)64 * (size_t)((6 * a.n_active) | 1) * 8 > small) small = (size_t)64 * (size_t)((6 * a.n_active) | 1) * 8;
     lds += small;
+    // all frames (720 B per sample at 6 joints): FOUR waves per CU are the optimum -- 118-122 us per 1e6 against 129-133 at five to seven
+    // (tools/build_variant.sh ... -DRDYN_STAGE_LDS_PAD, profiles/r6/stage_occupancy.txt; the twist levels, a third of the bytes per wave
+    // behind a longer recursion, want every wave they can get: 90 / 99 / 122 us at 8 / 6 / 4 waves) -- asked for through the LDS request
+    if (a.T_links && lds < kFramesStageLds) lds = kFramesStageLds;
+#ifdef RDYN_STAGE_LDS_PAD  // timing experiment: fewer waves per CU through the LDS request
+    lds += RDYN_STAGE_LDS_PAD;
+#endif
     const unsigned g64 = (unsigned)((a.n_samples + 63) / 64);
     if (a.dtwists) hipLaunchKernelGGL((k_base_sweep_staged<NJ, 3>), dim3(g64), dim3(64), lds, st, a);
     else if (a.twists) hipLaunchKernelGGL((k_base_sweep_staged<NJ, 2>), dim3(g64), dim3(64), lds, st, a);
@@ -540,7 +548,11 @@ hipError_t launch_base_nj(const RdynKinArgs& a, hipStream_t st)
   if (a.dtwists) hipLaunchKernelGGL((k_base_sweep<NJ, 3>), dim3(grid), dim3(256), 0, st, a);
   else if (a.twists) hipLaunchKernelGGL((k_base_sweep<NJ, 2>), dim3(grid), dim3(256), 0, st, a);
   else if (a.J) hipLaunchKernelGGL((k_base_sweep<NJ, 1>), dim3(grid), dim3(256), 0, st, a);
+#ifdef RDYN_BASE0_LDS_PAD  // timing experiment: fewer waves per CU for the frames-only level through an LDS request
+  else hipLaunchKernelGGL((k_base_sweep<NJ, 0>), dim3(grid), dim3(256), RDYN_BASE0_LDS_PAD, st, a);
+#else
   else hipLaunchKernelGGL((k_base_sweep<NJ, 0>), dim3(grid), dim3(256), 0, st, a);
+#endif
   return hipGetLastError();
 }
 

@@ -317,7 +317,10 @@ hipError_t launch_ext_nj(const RdynKinExtArgs& a, hipStream_t st)
   const dim3 grid((unsigned)((a.n_samples + 255) / 256)), grid64((unsigned)((a.n_samples + 63) / 64));
   if (a.wrench)
   {
-    if (a.staged) hipLaunchKernelGGL((k_base_ext<NJ, true, true>), grid64, dim3(64), (size_t)((6 * (NJ + 1)) | 1) * 64 * sizeof(double), st, a);
+#ifndef RDYN_WRENCH_LDS_PAD
+#define RDYN_WRENCH_LDS_PAD 0  // (timing experiment: fewer waves per CU through the LDS request)
+#endif
+    if (a.staged) hipLaunchKernelGGL((k_base_ext<NJ, true, true>), grid64, dim3(64), (size_t)((6 * (NJ + 1)) | 1) * 64 * sizeof(double) + RDYN_WRENCH_LDS_PAD, st, a);
     else hipLaunchKernelGGL((k_base_ext<NJ, true, false>), grid64, dim3(64), (size_t)6 * (NJ + 1) * 64 * sizeof(double), st, a);
   }
   else
