@@ -36,9 +36,10 @@ __device__ __forceinline__ void rs_wave_fence()
 }
 
 // Records that grow by PIECE bytes per link (PIECE = 96: a 3x4 frame, 48: a 6-vector).  Per sample one LDS slot:
-//   [0, 128)        the record's first 128 bytes, kept to the end: the head of a record shares its line with the tail of the previous
-//                   sample's record (records are rb bytes apart, not a multiple of 128 in general)
-//   [128, 128 + W)  a ring over the rest, addressed by record offset: what a flush has not written yet (< 128 bytes that wait for
+//   [0, 112)        the record's first 112 bytes, kept to the end: the head of a record (at most 112 bytes: misalignments are multiples
+//                   of 16) shares its line with the tail of the previous sample's record (records are rb bytes apart, not a multiple of
+//                   128 in general)
+//   [112, 112 + W)  a ring over the rest, addressed by record offset: what a flush has not written yet (< 128 bytes that wait for
 //                   their line to complete) plus the next piece
 // After every link the lines of every record that are complete by now are written; finish() writes the lines two records share.
 // Sample i of the wave starts at byte i rb of the run; its misalignment m_i = (i rb) mod 128 depends on i mod 8 only (rb is a multiple
@@ -49,7 +50,8 @@ struct RecordRing
 {
   static_assert(PIECE % 16 == 0 && PIECE >= 16 && PIECE <= 128, "a flush completes at most one line per record");
   static constexpr int W = PIECE + 112;
-  static constexpr int SLOT = 128 + W;
+  static constexpr int HEAD = 112;  // a record's head is at most 112 bytes (misalignments are multiples of 16)
+  static constexpr int SLOT = HEAD + W;
   // odd number of 16-byte units: the 8-byte staging writes of consecutive lanes fall into different LDS banks
   static constexpr int PITCH = SLOT + (((SLOT / 16) & 1) ? 0 : 16);
   static constexpr int BYTES = 64 * PITCH;  // LDS per wave
@@ -69,7 +71,7 @@ struct RecordRing
     sub = lane >> 3;
     cj = lane & 7;
   }
-  __device__ static __forceinline__ uint32_t pos(uint32_t x) { return x < 128u ? x : 128u + (x - 128u) % (uint32_t)W; }
+  __device__ static __forceinline__ uint32_t pos(uint32_t x) { return x < (uint32_t)HEAD ? x : (uint32_t)HEAD + (x - (uint32_t)HEAD) % (uint32_t)W; }
   // value at record byte x (a multiple of 8) of the lane's own sample
   __device__ __forceinline__ void put(uint32_t x, double v) const { *(double*)(mine + pos(x)) = v; }
   // every record's bytes [Ep, E) are staged (E - Ep <= PIECE): write the lines this completes
