@@ -145,3 +145,29 @@ def test_staged_records_match_oracle_full_waves(torch_cuda):
         close(chain.getDTwist(tq, tdq, tddq), ref.dtwist(q, dq, ddq), "dtwist")
         close(chain.getJointTorque(tq, tdq, tddq), ref.joint_torque(q, dq, ddq), "tau")
         close(chain.getJointInertia(tq).transpose(-1, -2), ref.joint_inertia(q), "M")
+
+
+@pytest.mark.parametrize("N", [1, 63, 64, 65, 127, 128, 129, 191, 320])
+def test_batch_sizes_around_the_wave(torch_cuda, N):
+    """Batches of less than a wave, exactly one wave, one sample more ... : every sample-major getter equals its element-major twin bit for
+    bit (6- and 9-joint chains; the ragged wave keeps the 8-byte stores, full waves go through the staged copy-out)."""
+    torch = torch_cuda
+    from rosdyn_amd import Chain
+    from rosdyn_amd.samples import uniform_pm1
+    for urdf, base, tool in (("ur10_like.urdf", "base_link", "wrist_3_link"), ("ur10_public.urdf", "base_link", "tool0")):
+        chain = Chain(os.path.join(FIXTURES, urdf), base, tool, GRAV)
+        n, L = chain.getActiveJointsNumber(), chain.getLinksNumber()
+        host = uniform_pm1(0x5EED0800 + N, (4, N, n))
+        xs = {k: torch.from_numpy(np.ascontiguousarray(host[i])).cuda() for i, k in enumerate(("q", "dq", "ddq", "dddq"))}
+        xs["ext"] = torch.from_numpy(uniform_pm1(0x5EED0900 + N, (N, L, 6))).cuda()
+        xe = {k: v.T.contiguous() for k, v in xs.items() if k != "ext"}
+        xe["ext"] = xs["ext"].permute(1, 2, 0).contiguous()
+        for name, (rec, call) in _calls(chain, None, None, None, None, None, chain.getLinksName()[2]).items():
+            ref = torch.empty(rec + (N,), dtype=torch.float64, device="cuda")
+            call("element", xe, ref)
+            want = ref.permute(len(rec), *range(len(rec))).contiguous()
+            out, check = _guarded(torch, (N,) + rec, 0)
+            call("sample", xs, out)
+            torch.cuda.synchronize()
+            check("%s N = %d" % (name, N))
+            assert torch.equal(out, want), "%s N = %d: sample-major differs from element-major" % (name, N)
