@@ -791,6 +791,7 @@ int rdyn_wrench(const rdyn_chain* c, const rdyn_batch* b, const double* ext, dou
   a.ext_ss = a.out_ss;
   a.ext_se = a.out_se;
   a.staged = b->layout == RDYN_LAYOUT_SAMPLE_MAJOR && lines_aligned(wrenches) && !probe_env("RDYN_NO_RECORD_STAGING");
+  a.ext_staged = a.staged && ext && ((uintptr_t)ext & 15u) == 0 && !probe_env("RDYN_NO_EXT_STAGING");
   if (c->long_chain())
     RDYN_HIP_TRY(rdyn_launch_long_ext(c->n_joints(), a, (hipStream_t)b->stream));
   else

@@ -71,6 +71,7 @@ struct RdynKinExtArgs
   double* tau;
   int64_t tau_ss, tau_sj;
   int staged;  // sample-major records through wave-private LDS, whole lines (rdyn_record_stage.h); decided by the host: natural strides, line-aligned outputs
+  int ext_staged;  // ... and the external wrenches read as whole lines into the same tile (16-byte aligned, natural stride)
 };
 hipError_t rdyn_launch_base_ext(int n_joints, const RdynKinExtArgs& a, hipStream_t st);
 hipError_t rdyn_launch_long_ext(int n_joints, const RdynKinExtArgs& a, hipStream_t st);  // a.chain_long; any chain length

@@ -71,7 +71,16 @@ __global__ __launch_bounds__((WRENCH || STAGED) ? 64 : 256, RDYN_KIN_EXT_WAVES) 
     if (stg)
     {
       if constexpr (WRENCH)
+      {
         wtile.init((char*)own_lds, 6 * (NJ + 1), threadIdx.x);
+        // the external wrenches arrive in the tile the link wrenches leave from: ext_of(link) reads the lane's own slot before park6(link)
+        // overwrites it (a.ext_staged: natural stride, 16-byte aligned -- decided by the host)
+        if (a.ext && a.ext_staged)
+        {
+          load_records_into_tile<3 * (NJ + 1)>(wtile.tile, wtile.prec, a.ext + (int64_t)blockIdx.x * BS * a.ext_ss, 6 * (NJ + 1), threadIdx.x);
+          rs_wave_fence();
+        }
+      }
       else
       {
         char* lp = (char*)own_lds;
@@ -171,7 +180,13 @@ __global__ __launch_bounds__((WRENCH || STAGED) ? 64 : 256, RDYN_KIN_EXT_WAVES) 
   const V3 grav = mk(c->g[0], c->g[1], c->g[2]);
   auto ext_of = [&](int link) -> S6 {  // -ext_wrenches_in_link_frame.at(link), :1255
     S6 e = zero;
-    if (a.ext)
+    if (STAGED && stg && a.ext && a.ext_staged)
+    {
+      const double* const o = wtile.mine + 6 * link;
+      e.l = mk(-o[0], -o[1], -o[2]);
+      e.a = mk(-o[3], -o[4], -o[5]);
+    }
+    else if (a.ext)
     {
       const char* const ep = (const char*)(a.ext + (int64_t)blockIdx.x * BS * a.ext_ss + (int64_t)(6 * link) * a.ext_se);  // uniform
       const uint32_t ev = threadIdx.x * (uint32_t)a.ext_ss * 8u;

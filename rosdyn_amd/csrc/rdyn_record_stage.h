@@ -176,5 +176,44 @@ struct SmallRecords
   }
 };
 
+// The INPUT side for records that are not on the wave's critical path (the external wrenches of getWrench: 6 (NJ + 1) doubles per sample,
+// needed link by link behind each link's kinematics): the wave reads its 64 records as ONE run, 16 bytes per lane, all loads in flight
+// before the first LDS write, into the same [sample][rec | 1] tile the wrenches are parked in -- 21 whole-line loads instead of 42
+// loads that touch 64 lines each.  (The joint inputs q, Dq, DDq stay per-lane loads: they feed the first sincos, see above.)
+template <int MAX_IT>
+__device__ __forceinline__ void load_records_into_tile(double* tile, int prec, const double* wave_run, int rec, int lane)
+{
+  const int s_first = (int)(((float)(2 * lane) + 0.5f) / (float)rec);
+  const int e_first = 2 * lane - s_first * rec;
+  const int ds = 128 / rec, de = 128 - ds * rec;  // wave-uniform
+  rs_d2a v[MAX_IT];
+#pragma unroll
+  for (int it = 0; it < MAX_IT; ++it)
+    if (2 * (it * 64 + lane) < 64 * rec) v[it] = __builtin_nontemporal_load((const rs_d2a*)((const char*)wave_run + lane * 16 + it * 1024));
+  int s0 = s_first, e0 = e_first;
+#pragma unroll
+  for (int it = 0; it < MAX_IT; ++it)
+  {
+    if (2 * (it * 64 + lane) < 64 * rec)
+    {
+      int s1 = s0, e1 = e0 + 1;
+      if (e1 == rec)
+      {
+        e1 = 0;
+        ++s1;
+      }
+      tile[s0 * prec + e0] = v[it].x;
+      tile[s1 * prec + e1] = v[it].y;
+    }
+    s0 += ds;
+    e0 += de;
+    if (e0 >= rec)
+    {
+      e0 -= rec;
+      ++s0;
+    }
+  }
+}
+
 }  // namespace
 #endif
