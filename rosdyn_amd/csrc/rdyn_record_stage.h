@@ -179,7 +179,8 @@ struct SmallRecords
 // The INPUT side for records that are not on the wave's critical path (the external wrenches of getWrench: 6 (NJ + 1) doubles per sample,
 // needed link by link behind each link's kinematics): the wave reads its 64 records as ONE run, 16 bytes per lane, all loads in flight
 // before the first LDS write, into the same [sample][rec | 1] tile the wrenches are parked in -- 21 whole-line loads instead of 42
-// loads that touch 64 lines each.  (The joint inputs q, Dq, DDq stay per-lane loads: they feed the first sincos, see above.)
+// loads that touch 64 lines each: getWrench 245 -> 204 us per 1e6.  (The joint inputs stay per-lane loads: q feeds the first sincos, and
+// Dq / DDq through a tile -- made visible behind the first joint's sincos -- cost the torque kernel 83 -> 88 us: measured, not shipped.)
 template <int MAX_IT>
 __device__ __forceinline__ void load_records_into_tile(double* tile, int prec, const double* wave_run, int rec, int lane)
 {
