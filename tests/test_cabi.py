@@ -78,8 +78,9 @@ def test_too_many_joints_is_reported():
         return "<robot name='long'>%s%s</robot>" % (links, joints)
     with pytest.raises(RdynError, match="at most 32"):
         Chain(xml(33), "l0", "l33")
-    # 12 moving joints: ingested (names, limits, parameters), but no kernel sweeps more than 10 input joints -- the workspace queries
-    # say so before anything touches a device; with at most 10 of them as input joints the chain is served
+    # 12 moving joints: ingested (names, limits, parameters); regressor / torque / inertia are served by the run-time-length kernels (round 6,
+    # tests/test_gpu_longkin.py), but the normal equations stop at 111 columns and the R factors at 10 input joints -- the workspace
+    # queries say so before anything touches a device; with at most 10 of them as input joints every entry point serves the chain
     c = Chain(xml(12), "l0", "l12")
     from rosdyn_amd._lib import lib
     assert c.getJointsNumber() == 12 and lib().rdyn_regressor_tsqr_workspace_bytes(c._h) == 0 and lib().rdyn_regressor_gram_workspace_bytes(c._h, 0) == 0
