@@ -821,6 +821,21 @@ def main():
                      "traffic_source": "committed profile (profiles/pmc_latest.json, builder's box), not measured in this run" if traffic else None,
                      "kernel": kernel, "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": b_eval * N},
     }
+    if args.y_layout == "stacked" and world == 1 and not args.no_extras:
+        # side block, never `value`: the same evaluation into the per-sample DROP-IN images (what a rosdyn::Chain caller receives per sample,
+        # primitives_impl.h:1350-1354) -- its own first allocation, same step count, same timing protocol
+        def drop_in():
+            Yp = torch.empty((N, P, n), dtype=torch.float64, device=dev)
+            w_p, ms_p = time_region(step_into(chain, q, dq, ddq, in_layout, "per_sample", Yp, tau), args.steps, args.warmup, world, dist, dev)
+            k_ms = ms_p / args.steps
+            return {"layout": "per-sample column-major n x P images (N, P, n)", "value": N * args.steps / w_p, "unit": "evals/s", "ms_per_step": w_p / args.steps * 1e3,
+                    "roofline": {"bound": "hbm", "achieved": b_eval * N / (k_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                                 "frac": b_eval * N / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "kernel_ms": k_ms,
+                                 "kernel": "void (anonymous namespace)::k_image_sweep<6, 0u, true, false, -1, false>(RdynSweepArgs)",
+                                 "traffic": committed_traffic("regressor_per_sample_n%d_P%d_N%d" % (n, P, N))},
+                    "note": "side block: the headline is the stacked matrix of SURVEY.md section 8(d)"}
+        out["drop_in_layout"] = guarded(drop_in)
+        torch.cuda.empty_cache()
     if args.placements > 1:
         # side block, never `value`: the same launch into the best of a few candidate output allocations (rosdyn_amd/placement.py)
         del Y
