@@ -49,7 +49,10 @@ extern "C" {
  *      rdyn_regressor, rdyn_joint_torque(_nonlinear), rdyn_joint_inertia, rdyn_nominal_parameters, the normal equations, the R factors
  *      and rdyn_local_ik sweep the REDUCED COMPANION -- the input joints (at most RDYN_MAX_SWEPT_JOINTS) with the fixed frames folded
  *      into the neighbouring bodies, rdyn_chain_reduction -- and restore the columns of every folded link exactly (Y_f = Y_body X_f);
- *      with more input joints than that only the kinematic outputs and the joint torques (read off the wrench recursion) are served. */
+ *      with MORE input joints than that (up to RDYN_MAX_JOINTS of them; rdyn_long_local.hip: rolled link and row loops, the per-joint
+ *      state in wave-private LDS) rdyn_regressor (+ its fused torque), rdyn_joint_inertia, the joint torques (read off the wrench
+ *      recursion) and every kinematic output are served, rdyn_regressor_gram for 11 input joints (110 + 1 columns: what the Gram kernel
+ *      holds); the R factors, rdyn_local_ik and wider normal equations answer RDYN_ERR_UNSUPPORTED. */
 #define RDYN_MAX_JOINTS 32
 #define RDYN_MAX_SWEPT_JOINTS 10
 
@@ -166,7 +169,9 @@ typedef enum rdyn_layout
 {
   /* x[s][e] -- every sample's record is contiguous and is exactly the memory image of the Eigen object the
    * reference returns for that sample (VectorXd, column-major MatrixXd / Matrix6Xd, 3x4 column-major
-   * Affine3d::affine()).  Drop-in layout. */
+   * Affine3d::affine()).  Drop-in layout.  Kinematic / torque / inertia outputs that start on a 128-byte line (any
+   * hipMalloc does) are written in whole lines through wave-private LDS (rdyn_record_stage.h) at about the rate of the
+   * element-major layout; other alignments are served correctly by 8-byte stores at 2-3x the time. */
   RDYN_LAYOUT_SAMPLE_MAJOR = 0,
   /* x[e][s] -- one N-vector per record element (structure of arrays).  Fully coalesced on the GPU;
    * for the regressor this IS a column-major (n*N) x P matrix whose row index is j*N + s. */

@@ -483,10 +483,19 @@ __global__ __launch_bounds__(64) void k_long_inertia(const RdynLongLocalArgs a)
   }
 }
 
-hipError_t allow_big_lds(const void* fn, size_t bytes)
+// more than 64 KB of dynamic LDS needs the attribute, once per kernel and device (slot: 0 inertia, 1..3 the regressor's STAGE 0..2)
+hipError_t allow_big_lds(const void* fn, size_t bytes, int slot)
 {
   if (bytes <= 64 * 1024) return hipSuccess;
-  return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  static std::atomic<uint64_t> done[4];
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  const uint64_t bit = 1ull << (dev & 63);
+  if (done[slot].load(std::memory_order_acquire) & bit) return hipSuccess;
+  e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (e == hipSuccess) done[slot].fetch_or(bit, std::memory_order_release);
+  return e;
 }
 }  // namespace
 
@@ -500,7 +509,7 @@ hipError_t rdyn_launch_long_local(int mode, int n_joints, const RdynLongLocalArg
   if (mode == RDYN_MODE_INERTIA)
   {
     if (lds > 160 * 1024) return hipErrorInvalidValue;
-    hipError_t e = allow_big_lds((const void*)k_long_inertia, lds);
+    hipError_t e = allow_big_lds((const void*)k_long_inertia, lds, 0);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_long_inertia, grid, dim3(64), lds, st, a);
     return hipGetLastError();
@@ -511,7 +520,7 @@ hipError_t rdyn_launch_long_local(int mode, int n_joints, const RdynLongLocalArg
   if (stage) lds += tile;
   if (lds > 160 * 1024) return hipErrorInvalidValue;
   const void* fn = stage == 1 ? (const void*)k_long_regressor<1> : (stage == 2 ? (const void*)k_long_regressor<2> : (const void*)k_long_regressor<0>);
-  hipError_t e = allow_big_lds(fn, lds);
+  hipError_t e = allow_big_lds(fn, lds, 1 + stage);
   if (e != hipSuccess) return e;
   if (stage == 1) hipLaunchKernelGGL(k_long_regressor<1>, grid, dim3(64), lds, st, a);
   else if (stage == 2) hipLaunchKernelGGL(k_long_regressor<2>, grid, dim3(64), lds, st, a);
