@@ -86,6 +86,12 @@ def test_too_many_joints_is_reported():
     assert c.getJointsNumber() == 12 and lib().rdyn_regressor_tsqr_workspace_bytes(c._h) == 0 and lib().rdyn_regressor_gram_workspace_bytes(c._h, 0) == 0
     c.setInputJointsName(["j%d" % i for i in range(2, 9)])
     assert c.getActiveJointsNumber() == 7 and lib().rdyn_regressor_tsqr_workspace_bytes(c._h) > 0
+    # 11 input joints: 110 + 1 columns are what the Gram kernel holds -- the normal equations are served through chunk images of the
+    # run-time-length regressor kernel (slabs + one chunk image of 32 768 samples x 11 rows x 111 columns), the R factors are not
+    c11 = Chain(xml(11), "l0", "l11")
+    w = lib().rdyn_regressor_gram_workspace_bytes(c11._h, 0)
+    assert w >= 32768 * 11 * 111 * 8 and lib().rdyn_regressor_tsqr_workspace_bytes(c11._h) == 0
+    assert lib().rdyn_regressor_gram_workspace_bytes(c11._h, 4096) < w   # the caller's chunk size sizes the image
 
 
 def test_generated_chain_variants_ingest_identically():
