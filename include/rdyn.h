@@ -51,8 +51,9 @@ extern "C" {
  *      into the neighbouring bodies, rdyn_chain_reduction -- and restore the columns of every folded link exactly (Y_f = Y_body X_f);
  *      with MORE input joints than that (up to RDYN_MAX_JOINTS of them; rdyn_long_local.hip: rolled link and row loops, the per-joint
  *      state in wave-private LDS) rdyn_regressor (+ its fused torque), rdyn_joint_inertia, the joint torques (read off the wrench
- *      recursion) and every kinematic output are served, rdyn_regressor_gram for 11 input joints (110 + 1 columns: what the Gram kernel
- *      holds); the R factors, rdyn_local_ik and wider normal equations answer RDYN_ERR_UNSUPPORTED. */
+ *      recursion) and every kinematic output are served, rdyn_regressor_gram and rdyn_regressor_tsqr for 11 input joints (110 + 1 columns:
+ *      what the Gram kernel and the widest R factor hold; chunk images); rdyn_local_ik, component columns and wider normal equations /
+ *      factors answer RDYN_ERR_UNSUPPORTED. */
 #define RDYN_MAX_JOINTS 32
 #define RDYN_MAX_SWEPT_JOINTS 10
 

@@ -1786,6 +1786,7 @@ struct TsqrPlan
   // 9 .. 10 input joints (more rows per sample than the tile kernels' sweepers hold): the rows go through a chunk image in the
   // workspace -- swept by the one-thread-per-sample kernel, factored by rdyn_tsqr's kernels, chunk after chunk
   bool image = false;
+  bool long_image = false;    // ... of a chain with 11 input joints (no companion): the chunk image comes from rdyn_long_local.hip
   size_t img_off = 0, rows_off = 0;  // doubles: the chunk image, rdyn_tsqr's own workspace
   RdynLdsGramArgs la, la_sub, la_wide;
   RdynLdsGramArgs la_b;       // pass B's tile: la, or the layout of the one-lane-per-sample sweepers (sweep_lanes set)
@@ -1802,8 +1803,30 @@ static bool tsqr_plan(const rdyn_chain* c, const rdyn_component* comps, int n_co
   p->expand = raw != c;
   if (c->long_chain() && !p->expand)
   {
-    p->why = "a chain of more than 10 joints needs 2 .. 10 input joints";
-    return false;
+    // no companion (more than 10 input joints): served as long as the factor fits the widest one the kernels hold -- 11 input joints
+    // without component columns (110 + 1 columns) -- through chunk images of the run-time-length regressor kernel
+    const int K0 = n_comps > 0 ? rdyn_components_columns(comps, n_comps) : 0;
+    if (K0 != 0 || 10 * c->n_joints() + 1 > rdyn_tsqr_wide_max_cols() || c->n_active() != c->n_joints())
+    {
+      p->why = "a chain of more than 10 joints needs 2 .. 10 input joints (11 without fixed joints and component columns)";
+      return false;
+    }
+    p->cs = c;
+    p->n = c->n_active();
+    p->nJ = c->n_joints();
+    p->K = 0;
+    p->xb = 0;
+    p->n1s = p->n1 = 10 * p->nJ + 1;
+    memset(&p->la, 0, sizeof p->la);
+    memset(&p->la_sub, 0, sizeof p->la_sub);
+    memset(&p->la_wide, 0, sizeof p->la_wide);
+    memset(&p->la_b, 0, sizeof p->la_b);
+    p->image = p->long_image = true;
+    p->L = tsqr_layout(0, p->n1s, 0, 0);
+    p->img_off = (p->L.total_doubles + 31) & ~(size_t)31;
+    p->rows_off = p->img_off + (size_t)kTsqrImageChunk * p->n * p->n1s;
+    p->L.total_doubles = p->rows_off + rdyn_tsqr_workspace_bytes(p->n1s) / sizeof(double);
+    return true;
   }
   const rdyn_chain* cs = p->cs;
   p->n = cs->n_active();
@@ -1915,7 +1938,8 @@ static bool tsqr_plan(const rdyn_chain* c, const rdyn_component* comps, int n_co
 static int regressor_tsqr_run(const rdyn_chain* c, const rdyn_component* comps, int n_comps, const rdyn_batch* b, const double* tau_meas, double* R,
                               int accumulate, void* workspace, size_t workspace_bytes, const char* who, bool swept_only = false)
 {
-  int st = check_batch(c, b, true, true, who, LONG_COMPANION);
+  // (a long chain without a companion: tsqr_plan decides -- 11 input joints are served through chunk images)
+  int st = check_batch(c, b, true, true, who, (c && c->long_chain() && !c->reduced) ? LONG_KERNELS : LONG_COMPANION);
   if (st != RDYN_OK) return st;
   if (!R || !workspace || n_comps < 0 || n_comps > RDYN_MAX_COMPONENTS || (n_comps > 0 && !comps))
   {
@@ -1949,7 +1973,8 @@ static int regressor_tsqr_run(const rdyn_chain* c, const rdyn_component* comps, 
   st = g.enter(b->device);
   if (st != RDYN_OK) return st;
   const RdynChainConst* dc = nullptr;
-  st = device_const(cs, &dc);
+  const RdynLongChainConst* dcl = nullptr;
+  st = p.long_image ? device_const_long(cs, &dcl) : device_const(cs, &dc);
   if (st != RDYN_OK) return st;
   hipStream_t stream = (hipStream_t)b->stream;
   if (b->n_samples == 0)
@@ -1990,7 +2015,29 @@ static int regressor_tsqr_run(const rdyn_chain* c, const rdyn_component* comps, 
       a.y_ss = 1;
       a.y_sr = cnt;
       a.y_sc = (int64_t)n * cnt;
-      RDYN_HIP_TRY(rdyn_launch_local_sweep(nJ, RDYN_MODE_REGRESSOR_GRAM, a, stream));
+      if (p.long_image)
+      {
+        // 11 input joints: the dense image by the run-time-length kernel (rdyn_long_local.hip), the measured torque behind it
+        RdynLongLocalArgs la;
+        memset(&la, 0, sizeof la);
+        la.chain_long = dcl;
+        la.q = a.q;
+        la.dq = a.dq;
+        la.ddq = a.ddq;
+        la.bcol = a.bcol;
+        la.bcol_col = cols;
+        la.n_samples = cnt;
+        la.in_ss = a.in_ss;
+        la.in_sj = a.in_sj;
+        la.Y = img;
+        la.y_ss = 1;
+        la.y_sr = cnt;
+        la.y_sc = (int64_t)n * cnt;
+        la.n_active = n;
+        RDYN_HIP_TRY(rdyn_launch_long_local(RDYN_MODE_REGRESSOR, nJ, la, stream));
+      }
+      else
+        RDYN_HIP_TRY(rdyn_launch_local_sweep(nJ, RDYN_MODE_REGRESSOR_GRAM, a, stream));
       if (K > 0)
       {
         RdynComponentArgs cc = ca;

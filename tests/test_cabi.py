@@ -79,18 +79,18 @@ def test_too_many_joints_is_reported():
     with pytest.raises(RdynError, match="at most 32"):
         Chain(xml(33), "l0", "l33")
     # 12 moving joints: ingested (names, limits, parameters); regressor / torque / inertia are served by the run-time-length kernels (round 6,
-    # tests/test_gpu_longkin.py), but the normal equations stop at 111 columns and the R factors at 10 input joints -- the workspace
+    # tests/test_gpu_longkin.py), but the normal equations and the R factors stop at 111 columns (11 input joints) -- the workspace
     # queries say so before anything touches a device; with at most 10 of them as input joints every entry point serves the chain
     c = Chain(xml(12), "l0", "l12")
     from rosdyn_amd._lib import lib
     assert c.getJointsNumber() == 12 and lib().rdyn_regressor_tsqr_workspace_bytes(c._h) == 0 and lib().rdyn_regressor_gram_workspace_bytes(c._h, 0) == 0
     c.setInputJointsName(["j%d" % i for i in range(2, 9)])
     assert c.getActiveJointsNumber() == 7 and lib().rdyn_regressor_tsqr_workspace_bytes(c._h) > 0
-    # 11 input joints: 110 + 1 columns are what the Gram kernel holds -- the normal equations are served through chunk images of the
-    # run-time-length regressor kernel (slabs + one chunk image of 32 768 samples x 11 rows x 111 columns), the R factors are not
+    # 11 input joints: 110 + 1 columns are what the Gram kernel and the widest R factor hold -- both are served through chunk images of the
+    # run-time-length regressor kernel (slabs + one chunk image of 32 768 samples x 11 rows x 111 columns; 65 536 for the factor)
     c11 = Chain(xml(11), "l0", "l11")
     w = lib().rdyn_regressor_gram_workspace_bytes(c11._h, 0)
-    assert w >= 32768 * 11 * 111 * 8 and lib().rdyn_regressor_tsqr_workspace_bytes(c11._h) == 0
+    assert w >= 32768 * 11 * 111 * 8 and lib().rdyn_regressor_tsqr_workspace_bytes(c11._h) >= 65536 * 11 * 111 * 8
     assert lib().rdyn_regressor_gram_workspace_bytes(c11._h, 4096) < w   # the caller's chunk size sizes the image
 
 

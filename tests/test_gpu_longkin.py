@@ -230,8 +230,8 @@ def test_long_chain_more_than_ten_input_joints_regressor_torque_inertia(case):
     _close(o["T_links"].cpu().numpy().transpose(0, 1, 3, 2), ref.fk(q), "evaluateAll T")
 
 
-def test_eleven_input_joints_normal_equations():
-    """rdyn_regressor_gram of a chain with ELEVEN input joints (110 columns + tau_meas = the 111 the Gram kernel holds): chunk images by
+def test_eleven_input_joints_normal_equations_and_r_factor():
+    """rdyn_regressor_gram / rdyn_regressor_tsqr of a chain with ELEVEN input joints (110 columns + tau_meas = the 111 the Gram kernel holds): chunk images by
     rdyn_long_local.hip contracted by k_gram, several chunks with a ragged last one, accumulation; 12 input joints (121 columns) are
     refused before anything touches the device (the documented limit)."""
     torch = pytest.importorskip("torch")
@@ -255,8 +255,16 @@ def test_eleven_input_joints_normal_equations():
     eq, edq, eddq, et = (torch.from_numpy(np.ascontiguousarray(x.T)).cuda() for x in (q, dq, ddq, tau))
     G, c, bb = chain.getRegressorGram(eq, edq, eddq, et, layout="element", chunk_samples=1000)
     assert np.linalg.norm(G.cpu().numpy() - Gr) <= 1e-10 * np.linalg.norm(Gr) and np.linalg.norm(c.cpu().numpy() - cr) <= 1e-10 * np.linalg.norm(cr)
+    # the R factor of [A | tau] without the normal equations (rdyn_regressor_tsqr: chunk images -> rdyn_tsqr's kernels, 111 columns)
+    M = np.column_stack([A, tau.reshape(-1)])
+    full = M.T @ M
+    R1 = chain.getRegressorTsqr(tq, tdq, tddq, tt).cpu().numpy()
+    assert R1.shape == (P + 1, P + 1) and np.allclose(np.tril(R1, -1), 0.0)
+    assert np.abs(R1.T @ R1 - full).max() <= 1e-10 * np.abs(full).max()
+    R1e = chain.getRegressorTsqr(eq, edq, eddq, et, layout="element").cpu().numpy()
+    assert np.abs(R1e.T @ R1e - full).max() <= 1e-10 * np.abs(full).max()
     twelve = Chain(generated_revolute_chain(12, 1212), "l0", "l12", GRAV)
-    assert lib().rdyn_regressor_gram_workspace_bytes(twelve._h, 0) == 0
+    assert lib().rdyn_regressor_gram_workspace_bytes(twelve._h, 0) == 0 and lib().rdyn_regressor_tsqr_workspace_bytes(twelve._h) == 0
 
 
 @pytest.mark.parametrize("case", ["ur10_long", "gen20_permuted"])
